@@ -1,0 +1,508 @@
+/*
+ * oracle/tm_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, single thread) of the arithmetic the reference's GPU path
+ * performs for one frame pair: decoded frame -> linear RGB -> 6-scale pyramid -> XYB ->
+ * recursive-Gaussian blur (columns, then rows) -> SSIM / edge maps -> 1- and 4-norm sums
+ * -> SSIMULACRA2 score, plus the u8 quantisation that feeds PSNR.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * file's library; the product (turbo-metrics_amd/) never links or calls it.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/crates).  The reference cannot be compiled here (Rust + Rust->PTX +
+ * closed-source NPP/libdevice; no rustc/cargo/nvcc in the image), so this restatement is
+ * pinned on the reference's own known-answer data instead (tests/golden/reference_tables.json
+ * + tests/test_oracle_pins.py): the 256-entry sRGB LUT, the recursive-Gaussian literals,
+ * the 108 weights, "identical inputs -> exactly 100", the NPP sum known answer.  The
+ * end-to-end score is NOT pinned by any reference fixture (the only known answer,
+ * 17.398505 in ssimulacra2-cuda/examples/compare.rs:70-90, is for an image pair that is not
+ * in the repository): "parity unpinned" for the final score.
+ *
+ * Layout convention here: planar f32, 3 planes of w*h each (plane c at p + c*w*h), row-major,
+ * no padding.  The reference uses packed C3; every operation on the path is per-sample or
+ * per-pixel, so planar vs packed changes no arithmetic.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "tm_math.h"
+#include "tm_oracle_tables.inc"
+
+#define TMO_SCALES 6
+
+/* ------------------------------------------------------------------------------------------
+ * data tables
+ * ---------------------------------------------------------------------------------------- */
+static const uint32_t k_srgb_lut_bits[256] = {TM_SRGB_LUT_BITS};
+static const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
+
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+void tmo_srgb8_lut(float out[256])
+{
+    for (int i = 0; i < 256; ++i) out[i] = u2f(k_srgb_lut_bits[i]);
+}
+
+void tmo_weights(double out[108]) { memcpy(out, k_weights, sizeof k_weights); }
+
+/* exported scalar math so tests can pin it */
+float tmo_math_cbrtf(float a) { return tmo_cbrtf(a); }
+float tmo_math_powf(float x, float y) { return tmo_powf(x, (double)y); }
+
+/* ------------------------------------------------------------------------------------------
+ * sRGB / RGB inputs -> linear   (cuda-colorspace-kernel/src/srgb.rs:40-127)
+ * ---------------------------------------------------------------------------------------- */
+/* srgb_inverse_oetf, srgb.rs:40-48 (powf_fast restated by tmo_powf) */
+static inline float srgb_inverse_oetf(float x)
+{
+    const float SRGB_ALPHA = 1.0550107f;
+    const float SRGB_BETA = 0.0030412825f;
+    if (x < 12.92f * SRGB_BETA) return x / 12.92f;
+    return tmo_powf((x + (SRGB_ALPHA - 1.0f)) / SRGB_ALPHA, (double)2.4f);
+}
+float tmo_srgb_inverse_oetf(float x) { return srgb_inverse_oetf(x); }
+
+/* srgb_to_linear_u8_lookup, srgb.rs:51-66. rgb: packed C3, pitch in bytes. */
+void tmo_rgb8_to_linear(const uint8_t *rgb, size_t pitch, int w, int h, float *lin)
+{
+    const size_t n = (size_t)w * h;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c)
+                lin[c * n + (size_t)y * w + x] = u2f(k_srgb_lut_bits[rgb[y * pitch + 3 * x + c]]);
+}
+
+/* srgb_to_linear_u16, srgb.rs:68-113 + Sample::conv_to_f lib.rs:19-21 */
+void tmo_rgb16_to_linear(const uint16_t *rgb, size_t pitch, int w, int h, float *lin)
+{
+    const size_t n = (size_t)w * h;
+    for (int y = 0; y < h; ++y) {
+        const uint16_t *row = (const uint16_t *)((const char *)rgb + y * pitch);
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c)
+                lin[c * n + (size_t)y * w + x] = srgb_inverse_oetf((float)row[3 * x + c] / 65535.0f);
+    }
+}
+
+/* srgb_to_linear_f32, srgb.rs:115-127 */
+void tmo_rgbf32_to_linear(const float *rgb, size_t pitch, int w, int h, float *lin)
+{
+    const size_t n = (size_t)w * h;
+    for (int y = 0; y < h; ++y) {
+        const float *row = (const float *)((const char *)rgb + y * pitch);
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c)
+                lin[c * n + (size_t)y * w + x] = srgb_inverse_oetf(row[3 * x + c]);
+    }
+}
+
+/* packed linear f32 C3 -> planar (the Ssimulacra2::new input, ssimulacra2-cuda/src/lib.rs:48-52) */
+void tmo_linear_packed_to_planar(const float *rgb, size_t pitch, int w, int h, float *lin)
+{
+    const size_t n = (size_t)w * h;
+    for (int y = 0; y < h; ++y) {
+        const float *row = (const float *)((const char *)rgb + y * pitch);
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) lin[c * n + (size_t)y * w + x] = row[3 * x + c];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * NV12 / P016 -> linear RGB
+ *   kernel body   cuda-colorspace-kernel/src/biplanar.rs:8-70
+ *   coefficients  cuda-colorspace-kernel/src/lib.rs:186-200 (MatrixCoefficients::coefficients)
+ *   Kr,Kb         cuda-colorspace-kernel/src/lib.rs:203-218 (constants_from_primaries),
+ *                 const_algebra.rs (f32 vector algebra), constants.rs (chromaticities)
+ *   range         cuda-colorspace-kernel/src/lib.rs:103-132 (Limited)
+ *   EOTF          cuda-colorspace-kernel/src/lib.rs:221-236 (BT709::eotf; identical for the
+ *                 two BT601 structs :247-262, :273-288)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } v3;
+static inline v3 xy_to_xyz(float x, float y) { v3 r = {x / y, 1.0f, (1.0f - x - y) / y}; return r; }
+static inline float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b)
+{
+    v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return r;
+}
+
+/* matrix: 0 BT709, 1 BT601_525, 2 BT601_625 (constants.rs:3-18) */
+void tmo_kr_kb(int matrix, float *kr, float *kb)
+{
+    static const float prim[3][8] = {
+        {0.640f, 0.330f, 0.300f, 0.600f, 0.150f, 0.060f, 0.3127f, 0.3290f},
+        {0.630f, 0.340f, 0.310f, 0.595f, 0.155f, 0.070f, 0.3127f, 0.3290f},
+        {0.640f, 0.330f, 0.290f, 0.600f, 0.150f, 0.060f, 0.3127f, 0.3290f},
+    };
+    const float *p = prim[matrix];
+    v3 r = xy_to_xyz(p[0], p[1]), g = xy_to_xyz(p[2], p[3]), b = xy_to_xyz(p[4], p[5]),
+       w = xy_to_xyz(p[6], p[7]);
+    v3 x_rgb = {r.x, g.x, b.x}, y_rgb = {r.y, g.y, b.y}, z_rgb = {r.z, g.z, b.z};
+    const float mul = 1.0f / dot3(x_rgb, cross3(y_rgb, z_rgb));
+    *kr = dot3(w, cross3(g, b)) * mul;
+    *kb = dot3(w, cross3(r, g)) * mul;
+}
+
+/* coefficients(): bits = 8 or 16 (the reference only instantiates those two, biplanar.rs:74-161) */
+void tmo_yuv_coefficients(int matrix, int bits, float out[5])
+{
+    float kr, kb;
+    tmo_kr_kb(matrix, &kr, &kb);
+    const float luma_range = (float)((235u - 16u) << (bits - 8));
+    const float chroma_range = (float)((240u - 16u) << (bits - 8));
+    const float kg = 1.0f - kr - kb;
+    out[0] = 1.0f / luma_range;                                        /* y_coeff  */
+    out[1] = 2.0f * (1.0f - kr) * 1.0f / chroma_range;                 /* r_coeff  */
+    out[2] = 2.0f * (1.0f - kb) * 1.0f / chroma_range;                 /* b_coeff  */
+    out[3] = -2.0f * (1.0f - kb) * kb / kg * 1.0f / chroma_range;      /* g_coeff1 */
+    out[4] = -2.0f * (1.0f - kr) * kr / kg * 1.0f / chroma_range;      /* g_coeff2 */
+}
+
+static inline float bt709_eotf(float v)
+{
+    const float BETA = 0.018053968510807f;
+    const float ALPHA = 1.0f + 5.5f * BETA;
+    const float THRESHOLD = 0.08124285829863521110029445797874f;
+    if (v >= THRESHOLD) return tmo_powf((v + (ALPHA - 1.0f)) / ALPHA, (double)(1.0f / 0.45f));
+    return v / 4.5f;
+}
+float tmo_bt709_eotf(float v) { return bt709_eotf(v); }
+
+static inline float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+/* One launch thread per 2x2 luma quad over (w/2, h/2); an odd last column/row is never
+ * written by the reference (cuda-colorspace/src/kernel.rs:64-65) -- here those samples are 0. */
+int tmo_yuv420_biplanar_to_linear(const void *ybase, const void *uvbase, size_t pitch, int w, int h,
+                                  int bits, int matrix, float *lin)
+{
+    if ((bits != 8 && bits != 16) || matrix < 0 || matrix > 2) return 1;
+    float k[5];
+    tmo_yuv_coefficients(matrix, bits, k);
+    const size_t n = (size_t)w * h;
+    memset(lin, 0, 3 * n * sizeof(float));
+    const int32_t neutral = 1 << (bits - 1);
+    const uint32_t ymin = 16u << (bits - 8);
+    for (int qy = 0; qy < h / 2; ++qy)
+        for (int qx = 0; qx < w / 2; ++qx) {
+            uint32_t ucb, ucr;
+            if (bits == 8) {
+                const uint8_t *uv = (const uint8_t *)uvbase + qy * pitch + 2 * qx;
+                ucb = uv[0]; ucr = uv[1];
+            } else {
+                const uint16_t *uv = (const uint16_t *)((const char *)uvbase + qy * pitch) + 2 * qx;
+                ucb = uv[0]; ucr = uv[1];
+            }
+            const float cb = (float)((int32_t)ucb - neutral);
+            const float cr = (float)((int32_t)ucr - neutral);
+            const float r_ = k[1] * cr;
+            const float g_ = fmaf(k[3], cb, k[4] * cr);
+            const float b_ = k[2] * cb;
+            for (int iy = 0; iy < 2; ++iy)
+                for (int ix = 0; ix < 2; ++ix) {
+                    const int x = 2 * qx + ix, y = 2 * qy + iy;
+                    uint32_t ys;
+                    if (bits == 8) ys = ((const uint8_t *)ybase)[y * pitch + x];
+                    else ys = ((const uint16_t *)((const char *)ybase + y * pitch))[x];
+                    const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
+                    const size_t o = (size_t)y * w + x;
+                    lin[o] = clamp01(bt709_eotf(luma + r_));
+                    lin[n + o] = clamp01(bt709_eotf(luma + g_));
+                    lin[2 * n + o] = clamp01(bt709_eotf(luma + b_));
+                }
+        }
+    return 0;
+}
+
+/* f32_to_8bit: u8 = float2uint_rn(v*255)  (cuda-colorspace-kernel/src/sample_conv.rs:6-35) */
+void tmo_quantize_u8(const float *lin, size_t count, uint8_t *out)
+{
+    for (size_t i = 0; i < count; ++i) out[i] = (uint8_t)(uint32_t)nearbyintf(lin[i] * 255.0f);
+}
+
+/* PSNR on the u8-quantised linear RGB pair (turbo-metrics/src/lib.rs:296-318 -> nppiPSNR_8u_C3R).
+ * NPP is closed source: BUILD-DEFINED as 10 log10(255^2 / MSE), MSE = exact integer SSE over all
+ * 3*w*h samples / (3*w*h), evaluated in f64, rounded to f32 (NPP returns Npp32f,
+ * cudarse-npp/src/image/ist.rs:118) and widened (lib.rs:355). */
+uint64_t tmo_sse_u8(const uint8_t *a, const uint8_t *b, size_t count)
+{
+    uint64_t s = 0;
+    for (size_t i = 0; i < count; ++i) { const int d = (int)a[i] - (int)b[i]; s += (uint64_t)(d * d); }
+    return s;
+}
+double tmo_psnr_from_sse(uint64_t sse, size_t count)
+{
+    const double mse = (double)sse / (double)count;
+    return (double)(float)(10.0 * log10(255.0 * 255.0 / mse));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pyramid + XYB
+ * ---------------------------------------------------------------------------------------- */
+/* downscale_by_2, ssimulacra2-cuda-kernel/src/downscale.rs:5-35 (one plane) */
+void tmo_downscale_by_2(const float *src, int sw, int sh, float *dst)
+{
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    for (int oy = 0; oy < dh; ++oy)
+        for (int ox = 0; ox < dw; ++ox) {
+            float sum = 0.0f;
+            for (int iy = 0; iy < 2; ++iy)
+                for (int ix = 0; ix < 2; ++ix) {
+                    int x = ox * 2 + ix; if (x > sw - 1) x = sw - 1;
+                    int y = oy * 2 + iy; if (y > sh - 1) y = sh - 1;
+                    sum += src[(size_t)y * sw + x];
+                }
+            dst[(size_t)oy * dw + ox] = sum * 0.25f;
+        }
+}
+
+/* px_linear_rgb_to_positive_xyb + opsin_absorbance, ssimulacra2-cuda-kernel/src/xyb.rs:3-79 */
+void tmo_linear_to_xyb(const float *lin, size_t n, float *xyb)
+{
+    const float K_M02 = 0.078f, K_M00 = 0.30f, K_M01 = 1.0f - K_M02 - K_M00;
+    const float K_M12 = 0.078f, K_M10 = 0.23f, K_M11 = 1.0f - K_M12 - K_M10;
+    const float K_M20 = 0.24342269f, K_M21 = 0.20476745f, K_M22 = 1.0f - K_M20 - K_M21;
+    const float K_B0 = 0.0037930734f;
+    const float K_B0_ROOT = 0.1559542025327239180319220163705f;
+    for (size_t i = 0; i < n; ++i) {
+        const float r = lin[i], g = lin[n + i], b = lin[2 * n + i];
+        float rg = fmaf(K_M00, r, fmaf(K_M01, g, fmaf(K_M02, b, K_B0)));
+        float gr = fmaf(K_M10, r, fmaf(K_M11, g, fmaf(K_M12, b, K_B0)));
+        float bb = fmaf(K_M20, r, fmaf(K_M21, g, fmaf(K_M22, b, K_B0)));
+        rg = tmo_cbrtf(fmaxf(rg, 0.0f)) - K_B0_ROOT;
+        gr = tmo_cbrtf(fmaxf(gr, 0.0f)) - K_B0_ROOT;
+        bb = tmo_cbrtf(fmaxf(bb, 0.0f)) - K_B0_ROOT;
+        const float x = 0.5f * (rg - gr);
+        const float y = 0.5f * (rg + gr);
+        xyb[i] = fmaf(x, 14.0f, 0.42f);
+        xyb[n + i] = y + 0.01f;
+        xyb[2 * n + i] = bb - y + 0.55f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * recursive Gaussian, one pass down the columns of one plane
+ *   ssimulacra2-cuda-kernel/src/blur.rs:34-137; constants build.rs:28-145 (sigma 1.5 -> N = 5),
+ *   literals pinned against ssimulacra2-cuda/examples/cpu.rs:931-948.
+ * The kernel's shared-memory ring (blur.rs:25, :104-106, :135) returns src[y-N-1] for every read it
+ * serves (slot left%11 is rewritten only 11 iterations later), so it is restated as a direct read.
+ * ---------------------------------------------------------------------------------------- */
+static const float MUL_IN_1 = 0.055295236f, MUL_IN_3 = -0.058836687f, MUL_IN_5 = 0.012955819f;
+static const float MUL_PREV_1 = 1.9021131f, MUL_PREV_3 = 1.1755705f, MUL_PREV_5 = 1.2246469e-16f;
+static const float MUL_PREV2 = -1.0f;
+
+void tmo_gaussian_constants(float out[7])
+{
+    out[0] = MUL_IN_1; out[1] = MUL_IN_3; out[2] = MUL_IN_5;
+    out[3] = MUL_PREV_1; out[4] = MUL_PREV_3; out[5] = MUL_PREV_5; out[6] = MUL_PREV2;
+}
+
+void tmo_blur_columns(const float *src, int w, int h, float *dst)
+{
+    const int N = 5;
+    for (int x = 0; x < w; ++x) {
+        float prev_1 = 0, prev_3 = 0, prev_5 = 0, prev2_1 = 0, prev2_3 = 0, prev2_5 = 0;
+        for (int y = -N + 1; y < h; ++y) {
+            const int right = y + N - 1;
+            const float right_val = right < h ? src[(size_t)right * w + x] : 0.0f;
+            const int left = y - N - 1;
+            const float left_val = left >= 0 ? src[(size_t)left * w + x] : 0.0f;
+            const float sum = left_val + right_val;
+            float out_1 = sum * MUL_IN_1, out_3 = sum * MUL_IN_3, out_5 = sum * MUL_IN_5;
+            out_1 = fmaf(MUL_PREV2, prev2_1, out_1);
+            out_3 = fmaf(MUL_PREV2, prev2_3, out_3);
+            out_5 = fmaf(MUL_PREV2, prev2_5, out_5);
+            prev2_1 = prev_1; prev2_3 = prev_3; prev2_5 = prev_5;
+            out_1 = fmaf(MUL_PREV_1, prev_1, out_1);
+            out_3 = fmaf(MUL_PREV_3, prev_3, out_3);
+            out_5 = fmaf(MUL_PREV_5, prev_5, out_5);
+            prev_1 = out_1; prev_3 = out_3; prev_5 = out_5;
+            if (y >= 0) dst[(size_t)y * w + x] = out_1 + out_3 + out_5;
+        }
+    }
+}
+
+/* nppiTranspose_32f_C3R (ssimulacra2-cuda/src/lib.rs:342-361,383-390): dst is h wide, w tall */
+void tmo_transpose(const float *src, int w, int h, float *dst)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) dst[(size_t)x * h + y] = src[(size_t)y * w + x];
+}
+
+/* compute_error_maps, ssimulacra2-cuda-kernel/src/error_maps.rs:5-60 (count samples) */
+void tmo_error_maps(const float *source, const float *distorted, const float *mu1p, const float *mu2p,
+                    const float *s11p, const float *s22p, const float *s12p, size_t count, float *ssim,
+                    float *artifact, float *detail_loss)
+{
+    const float C2 = 0.0009f;
+    for (size_t i = 0; i < count; ++i) {
+        const float mu1 = mu1p[i], mu2 = mu2p[i];
+        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+        const float mu_diff = mu1 - mu2;
+        const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
+        const float num_s = fmaf(2.0f, s12p[i] - mu12, C2);
+        const float denom_s = (s11p[i] - mu11) + (s22p[i] - mu22) + C2;
+        ssim[i] = fmaxf(1.0f - (num_m * num_s) / denom_s, 0.0f);
+        const float denom = 1.0f / (1.0f + fabsf(source[i] - mu1));
+        const float numer = 1.0f + fabsf(distorted[i] - mu2);
+        const float d1 = fmaf(numer, denom, -1.0f);
+        artifact[i] = fmaxf(d1, 0.0f);
+        detail_loss[i] = fmaxf(-d1, 0.0f);
+    }
+}
+
+/* reduce(): sum and sum of (x^2)^2, the squares rounded to f32, the sum in f64
+ * (ssimulacra2-cuda/src/lib.rs:417-447; NPP Sum accumulates into Npp64f, order unspecified --
+ * row-major sequential here). */
+static void sum_1_4(const float *m, size_t count, double *s1, double *s4)
+{
+    double a = 0.0, b = 0.0;
+    for (size_t i = 0; i < count; ++i) {
+        float t = m[i] * m[i];
+        t = t * t;
+        a += (double)m[i];
+        b += (double)t;
+    }
+    *s1 = a; *s4 = b;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * one scale: process_scale, ssimulacra2-cuda/src/lib.rs:293-415.
+ *   ref_xyb/dis_xyb : 3 planes w*h (normal orientation)
+ *   sums18          : [kind 0..5][channel] = S ssim, S artifact, S detail, S ssim^4, ... (lib.rs:410-447)
+ *   cap (optional)  : captured intermediates, all in TRANSPOSED orientation (h wide, w tall), as the
+ *                     reference holds them in imgt[]: 5 pass-1 planes (sigma11,sigma22,sigma12,mu1,mu2)
+ *                     x3 channels, 5 pass-2 planes x3, 3 maps x3; each plane w*h floats:
+ *                     cap[(group*5 + p)*3 + c] for group 0 (pass1, transposed), 1 (pass2),
+ *                     cap[(10 + m)*3 + c] for the maps.
+ * ---------------------------------------------------------------------------------------- */
+void tmo_process_scale(const float *ref_xyb, const float *dis_xyb, int w, int h, double sums18[18],
+                       float *cap)
+{
+    const size_t n = (size_t)w * h;
+    float *in = malloc(n * sizeof(float));
+    float *v = malloc(n * sizeof(float));
+    float *vt[5], *ht[5];
+    for (int p = 0; p < 5; ++p) { vt[p] = malloc(n * sizeof(float)); ht[p] = malloc(n * sizeof(float)); }
+    float *srct = malloc(n * sizeof(float)), *dist = malloc(n * sizeof(float));
+    float *m0 = malloc(n * sizeof(float)), *m1 = malloc(n * sizeof(float)), *m2 = malloc(n * sizeof(float));
+    for (int c = 0; c < 3; ++c) {
+        const float *r = ref_xyb + c * n, *d = dis_xyb + c * n;
+        for (int p = 0; p < 5; ++p) {
+            /* products by nppiMul (lib.rs:299-317): plain f32 multiply */
+            for (size_t i = 0; i < n; ++i)
+                in[i] = p == 0 ? r[i] * r[i] : p == 1 ? d[i] * d[i] : p == 2 ? r[i] * d[i] : p == 3 ? r[i] : d[i];
+            tmo_blur_columns(in, w, h, v);          /* pass 1, lib.rs:322-335 */
+            tmo_transpose(v, w, h, vt[p]);          /* lib.rs:342-361 */
+            tmo_blur_columns(vt[p], h, w, ht[p]);   /* pass 2 on the transposed image, lib.rs:368-379 */
+        }
+        tmo_transpose(r, w, h, srct);               /* lib.rs:383-390 */
+        tmo_transpose(d, w, h, dist);
+        /* (src, dis, mu1=ht[3], mu2=ht[4], s11=ht[0], s22=ht[1], s12=ht[2]), lib.rs:396-401 */
+        tmo_error_maps(srct, dist, ht[3], ht[4], ht[0], ht[1], ht[2], n, m0, m1, m2);
+        sum_1_4(m0, n, &sums18[0 * 3 + c], &sums18[3 * 3 + c]);
+        sum_1_4(m1, n, &sums18[1 * 3 + c], &sums18[4 * 3 + c]);
+        sum_1_4(m2, n, &sums18[2 * 3 + c], &sums18[5 * 3 + c]);
+        if (cap) {
+            for (int p = 0; p < 5; ++p) {
+                memcpy(cap + ((size_t)(0 * 5 + p) * 3 + c) * n, vt[p], n * sizeof(float));
+                memcpy(cap + ((size_t)(1 * 5 + p) * 3 + c) * n, ht[p], n * sizeof(float));
+            }
+            memcpy(cap + ((size_t)(10 + 0) * 3 + c) * n, m0, n * sizeof(float));
+            memcpy(cap + ((size_t)(10 + 1) * 3 + c) * n, m1, n * sizeof(float));
+            memcpy(cap + ((size_t)(10 + 2) * 3 + c) * n, m2, n * sizeof(float));
+        }
+    }
+    free(in); free(v);
+    for (int p = 0; p < 5; ++p) { free(vt[p]); free(ht[p]); }
+    free(srct); free(dist); free(m0); free(m1); free(m2);
+}
+
+void tmo_scale_sizes(int w, int h, int ws[TMO_SCALES], int hs[TMO_SCALES])
+{
+    ws[0] = w; hs[0] = h;
+    for (int s = 1; s < TMO_SCALES; ++s) { ws[s] = (ws[s - 1] + 1) / 2; hs[s] = (hs[s - 1] + 1) / 2; }
+}
+
+/* Full graph: Ssimulacra2::record, ssimulacra2-cuda/src/lib.rs:140-229.  The pyramid is built on
+ * LINEAR RGB (scale s from scale s-1), XYB recomputed at every scale; always 6 scales.
+ * sums: [scale][kind][channel] = the reference's `scores` before post-processing.
+ * xyb_out (optional): per scale, ref XYB then dis XYB (3 planes each), concatenated. */
+void tmo_ssimulacra2_sums(const float *ref_lin, const float *dis_lin, int w, int h, double sums[108],
+                          float *xyb_out)
+{
+    int ws[TMO_SCALES], hs[TMO_SCALES];
+    tmo_scale_sizes(w, h, ws, hs);
+    const size_t n0 = (size_t)w * h;
+    float *cur[2], *nxt[2], *xyb[2];
+    for (int i = 0; i < 2; ++i) {
+        cur[i] = malloc(3 * n0 * sizeof(float));
+        nxt[i] = malloc(3 * n0 * sizeof(float));
+        xyb[i] = malloc(3 * n0 * sizeof(float));
+    }
+    memcpy(cur[0], ref_lin, 3 * n0 * sizeof(float));
+    memcpy(cur[1], dis_lin, 3 * n0 * sizeof(float));
+    size_t xo = 0;
+    for (int s = 0; s < TMO_SCALES; ++s) {
+        const size_t n = (size_t)ws[s] * hs[s];
+        if (s > 0) {
+            const size_t np = (size_t)ws[s - 1] * hs[s - 1];
+            for (int i = 0; i < 2; ++i) {
+                for (int c = 0; c < 3; ++c) tmo_downscale_by_2(cur[i] + c * np, ws[s - 1], hs[s - 1], nxt[i] + c * n);
+                float *t = cur[i]; cur[i] = nxt[i]; nxt[i] = t;
+            }
+        }
+        tmo_linear_to_xyb(cur[0], n, xyb[0]);
+        tmo_linear_to_xyb(cur[1], n, xyb[1]);
+        if (xyb_out) {
+            memcpy(xyb_out + xo, xyb[0], 3 * n * sizeof(float)); xo += 3 * n;
+            memcpy(xyb_out + xo, xyb[1], 3 * n * sizeof(float)); xo += 3 * n;
+        }
+        tmo_process_scale(xyb[0], xyb[1], ws[s], hs[s], sums + 18 * s, NULL);
+    }
+    for (int i = 0; i < 2; ++i) { free(cur[i]); free(nxt[i]); free(xyb[i]); }
+}
+
+/* post_process_scores, ssimulacra2-cuda/src/lib.rs:449-623 (operates on a copy) */
+double tmo_score_from_sums(const double sums_in[108], int w, int h)
+{
+    double sc[108];
+    memcpy(sc, sums_in, sizeof sc);
+    int ws[TMO_SCALES], hs[TMO_SCALES];
+    tmo_scale_sizes(w, h, ws, hs);
+    for (int scale = 0; scale < TMO_SCALES; ++scale) {
+        /* NppiRect::norm of the transposed size, cudarse-npp-sys/src/lib.rs:19-21 (i32 product) */
+        const double opp = 1.0 / (double)(hs[scale] * ws[scale]);
+        const int offset0 = 3 * 6 * scale;
+        for (int c = 0; c < 3; ++c) {
+            const int o = offset0 + c, ow = c * 6 * 6 + 6 * scale;
+            sc[o] = fabs(sc[o] * opp) * k_weights[ow];
+            sc[o + 3] = fabs(sc[o + 3] * opp) * k_weights[ow + 1];
+            sc[o + 6] = fabs(sc[o + 6] * opp) * k_weights[ow + 2];
+            sc[o + 9] = sqrt(sqrt(sc[o + 9] * opp)) * k_weights[ow + 3];
+            sc[o + 12] = sqrt(sqrt(sc[o + 12] * opp)) * k_weights[ow + 4];
+            sc[o + 15] = sqrt(sqrt(sc[o + 15] * opp)) * k_weights[ow + 5];
+        }
+    }
+    double score = 0.0;
+    for (int i = 0; i < 108; ++i) score += sc[i];
+    score *= 0.9562382616834844;
+    score = fma(6.248496625763138e-5 * score * score, score,
+                fma(2.326765642916932, score, -0.020884521182843837 * score * score));
+    if (score > 0.0) score = fma(pow(score, 0.6276336467831387), -10.0, 100.0);
+    else score = 100.0;
+    return score;
+}
+
+/* convenience: linear planar pair -> score */
+double tmo_ssimulacra2_from_linear(const float *ref_lin, const float *dis_lin, int w, int h, double sums_out[108])
+{
+    double sums[108];
+    tmo_ssimulacra2_sums(ref_lin, dis_lin, w, h, sums, NULL);
+    if (sums_out) memcpy(sums_out, sums, sizeof sums);
+    return tmo_score_from_sums(sums, w, h);
+}
