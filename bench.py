@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- SSIMULACRA2 frame-pairs/s on synthetic decoded streams, one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p_nv12|4k_p016] [--batch B]
+
+A "step" is one pass of the hot path (ingest -> XYB pyramid -> column pass -> row pass + error maps +
+reductions -> 108 sums per pair -> scores) over one batch of B frame pairs whose decoded surfaces are
+already resident in HBM.  value = pairs processed by all ranks / wall time of the K timed steps
+(barrier + device sync on both sides, max over ranks).  Prints ONE JSON line on rank 0.
+
+Extra objects on the line:
+  roofline      the dominant kernel against the HBM roofline: algorithmic bytes per launch (SURVEY 8d:
+                7 f32 per pixel-channel per blur pass = 84 B/px per pass) / its mean launch duration,
+                measured with HIP events on the engine's own stream inside the timed region.
+  cpu_baseline  the CPU oracle (oracle/tm_oracle.c, a single-thread C restatement of the same
+                arithmetic) timed on this host on a bounded sample of the same workload (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (w, h, kind, default batch, BASELINE.json config it implements)
+    "1080p_nv12": (1920, 1080, "nv12", 32, "configs[1]: synthetic 1080p yuv420p frame-pair stream, SSIMULACRA2"),
+    "4k_p016": (3840, 2160, "p016", 8, "configs[2]: synthetic 4K yuv420p10 stream, SSIMULACRA2"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec; 6.29 TB/s measured copy ceiling)
+
+
+def scale_pixels(w, h):
+    tot = 0
+    for _ in range(6):
+        tot += w * h
+        w, h = (w + 1) // 2, (h + 1) // 2
+    return tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="1080p_nv12", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled over the batch)")
+    ap.add_argument("--metrics", default="ssimulacra2", help="comma list: ssimulacra2,psnr")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed for cpu_baseline (0 = auto, ~15 s)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+
+    import torch
+    from tm_pkg import tm
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    tm.init_hip(local_rank)
+
+    w, h, kind, default_b, cfg_name = WORKLOADS[args.workload]
+    B = args.batch or default_b
+    mets = set(args.metrics.split(","))
+    metrics = tm.Metrics(ssimulacra2="ssimulacra2" in mets, psnr="psnr" in mets)
+    eng = tm.TurboMetrics(w, h, metrics, batch=B)
+
+    # ---- synthetic decoded surfaces, resident in HBM before the timed region (weak scaling: every rank
+    # owns its own shard of the stream: pair index = rank*B + slot, cycled over `distinct` generated pairs)
+    gen = tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair
+    distinct = max(1, min(args.distinct, B))
+    surfaces = []
+    for n in range(distinct):
+        (rs, rp, rch), (ds, dp, dch) = gen(w, h, rank * distinct + n)
+        surfaces.append(((torch.from_numpy(rs).cuda(), rp, rch), (torch.from_numpy(ds).cuda(), dp, dch)))
+    mk = tm.HwFrame.nv12 if kind == "nv12" else tm.HwFrame.p016
+    for slot in range(B):
+        (rt, rp, rch), (dt, dp, dch) = surfaces[slot % distinct]
+        eng.set_pair(slot, mk(rt, rp, rch), mk(dt, dp, dch))
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        eng.compute_async(B)
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_profiling(True)
+    eng.stage_ms(reset=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage_ms, n_meas = eng.stage_ms(reset=True)
+    eng.set_profiling(False)
+
+    # ---- the single collective of the path: per-frame scores reduced (sum) to rank 0
+    scores_local = np.array([eng.scores(i).ssimulacra2 or 0.0 for i in range(B)], np.float64)
+    if dist is not None:
+        t = torch.zeros(world * B, dtype=torch.float64, device="cuda")
+        t[rank * B:(rank + 1) * B] = torch.from_numpy(scores_local).cuda()
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        all_scores = t.cpu().numpy()
+    else:
+        all_scores = scores_local
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        spx = scale_pixels(w, h)
+        pass_bytes = 84 * spx * B  # 7 f32 per pixel-channel x 3 channels, per blur pass, per launch (B pairs)
+        ms_v = stage_ms[tm.ffi.TM_STAGE_BLUR_V] / max(n_meas, 1)
+        ms_h = stage_ms[tm.ffi.TM_STAGE_BLUR_H] / max(n_meas, 1)
+        ms_i = stage_ms[tm.ffi.TM_STAGE_INGEST] / max(n_meas, 1)
+        dom_name, dom_ms = ("k_blur_h", ms_h) if ms_h >= ms_v else ("k_blur_v", ms_v)
+        ach = pass_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        stage_ach = 2 * pass_bytes / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
+        out = {
+            "metric": "ssimulacra2_frame_pairs_per_sec",
+            "value": pairs / elapsed,
+            "unit": "frame-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "baseline_config": cfg_name, "width": w, "height": h, "input": kind,
+                       "pairs_per_step_per_gpu": B, "metrics": sorted(mets), "inputs_resident_in_hbm": True,
+                       "parallelism": f"frame-pair sharding x{world}, one RCCL reduce of scores"},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": pass_bytes, "avg_launch_ms": dom_ms},
+            "stages": {"ingest_ms": ms_i, "blur_v_ms": ms_v, "blur_h_ms": ms_h,
+                       "blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
+                       "full_pipeline_GBs": (pairs / elapsed) * (168 * spx + 24 * spx + (w * h * 3 * (1 if kind == "nv12" else 2))) / 1e9 / world},
+            "score_mean": float(np.mean(all_scores)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tm, w, h, kind, args.cpu_pairs)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tm, w, h, kind, n_pairs):
+    """Time the CPU oracle (test infrastructure, here only as the reported baseline) on a bounded sample
+    of the same workload: same synthetic pairs, same stages (YUV -> linear -> ... -> score), one thread."""
+    from oracle import oracle as O
+    gen = tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair
+    if n_pairs <= 0:
+        n_pairs = 8 if w * h <= 1920 * 1080 else 2
+    pairs = [gen(w, h, n) for n in range(min(n_pairs, 2))]
+    bits = 8 if kind == "nv12" else 16
+    t0 = time.perf_counter()
+    for i in range(n_pairs):
+        (rs, rp, rch), (ds, dp, dch) = pairs[i % len(pairs)]
+        lr = O.yuv420_biplanar_to_linear(rs, rp, rch, w, h, bits, 0)
+        ld = O.yuv420_biplanar_to_linear(ds, dp, dch, w, h, bits, 0)
+        O.ssimulacra2_from_linear(lr, ld)
+    dt = time.perf_counter() - t0
+    return {"value": n_pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n_pairs} {w}x{h} {kind} pairs, single thread, oracle/tm_oracle.c (C restatement of the reference GPU arithmetic)",
+            "seconds": dt, "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

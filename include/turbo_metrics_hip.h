@@ -1,0 +1,152 @@
+/*
+ * turbo_metrics_hip.h -- C ABI of the MI355X (gfx950) SSIMULACRA2 / PSNR frame-pair engine.
+ *
+ * This is the drop-in boundary for the hot path of Gui-Yom/turbo-metrics: everything the
+ * reference does between "a decoded frame pair is in device memory" and "FrameScores".
+ * It replaces, as one fused engine, the reference's Rust->cudarse FFI for this path:
+ *
+ *   reference interface (file:line, relative to crates/)               entry point here
+ *   -----------------------------------------------------------------  -------------------------------
+ *   turbo-metrics/src/lib.rs:438-456  init_cuda()                      tm_init
+ *   turbo-metrics/src/lib.rs:201-249  TurboMetrics::new(w,h,&Metrics)  tm_engine_create
+ *   ssimulacra2-cuda/src/lib.rs:48-107 Ssimulacra2::new (buffers)      tm_engine_create
+ *   ssimulacra2-cuda/src/lib.rs:110   Ssimulacra2::mem_usage           tm_engine_mem_usage
+ *   turbo-metrics/src/color.rs:96-116 convert_frame_to_linearrgb       tm_engine_set_frame_{nv12,p016,
+ *     + cuda-colorspace/src/lib.rs:33-170 ColorspaceConversion::*        rgb8,rgb16,rgbf32}
+ *   ssimulacra2-cuda/src/lib.rs:48-52 (linear f32 C3 inputs of
+ *     Ssimulacra2::new / compute)                                      tm_engine_set_frame_linear_f32
+ *   turbo-metrics/src/lib.rs:268-345  compute_one (launch part)        tm_engine_compute_async
+ *   ssimulacra2-cuda/src/lib.rs:283-286 Ssimulacra2::compute           tm_engine_compute_async
+ *   turbo-metrics/src/lib.rs:347-359  compute_one (sync + FrameScores) tm_engine_sync, tm_engine_get_scores
+ *   ssimulacra2-cuda/src/lib.rs:271-291 compute_sync / get_score       tm_engine_sync, tm_engine_get_scores
+ *   ssimulacra2-cuda/src/lib.rs:44 `scores: [f64;108]` (pre post-proc) tm_engine_get_raw_sums
+ *   cudarse-driver-sys/src/lib.rs:12-31 CuError Display                tm_strerror
+ *
+ * Differences from the reference that are part of the contract:
+ *   - One engine holds `batch_capacity` frame-pair SLOTS.  set_frame fills (slot, side);
+ *     compute_async runs the whole pipeline for slots [0, n_slots) in a handful of launches.
+ *     batch_capacity = 1 reproduces the reference's one-pair-at-a-time `compute_one`.
+ *   - No panics / exceptions cross the ABI: every call returns a TM_* code.  The combinations the
+ *     reference leaves as `todo!()` (full-range YUV, non-BT.709 transfer:
+ *     cuda-colorspace/src/lib.rs:45-52) return TM_ERR_UNSUPPORTED.
+ *   - One engine = one device = one host thread at a time (same as the reference, lib.rs:438-456).
+ *
+ * Plain C types only, so a Rust `extern "C"` block, cgo, JNI or ctypes can bind it unchanged
+ * (INTEGRATION.md shows the Rust binding).
+ */
+#ifndef TURBO_METRICS_HIP_H
+#define TURBO_METRICS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tm_engine tm_engine;
+
+/* return codes */
+enum {
+    TM_OK = 0,
+    TM_ERR_INVALID_ARG = 1,
+    TM_ERR_UNSUPPORTED = 2, /* reference `todo!()` territory */
+    TM_ERR_HIP = 3,         /* a HIP runtime call failed; see tm_last_hip_error() */
+    TM_ERR_OOM = 4,
+    TM_ERR_STATE = 5        /* e.g. get_scores before compute, slot not filled */
+};
+
+/* metrics_mask bits == the reference's `Metrics` struct (turbo-metrics/src/lib.rs:27-37) */
+enum { TM_METRIC_PSNR = 1, TM_METRIC_SSIM = 2, TM_METRIC_MSSSIM = 4, TM_METRIC_SSIMULACRA2 = 8 };
+
+/* cuda_colorspace::ColorMatrix / Transfer (cuda-colorspace/src/lib.rs) */
+enum { TM_MATRIX_BT709 = 0, TM_MATRIX_BT601_525 = 1, TM_MATRIX_BT601_625 = 2 };
+enum { TM_TRANSFER_BT709 = 0 };
+
+enum { TM_SIDE_REF = 0, TM_SIDE_DIS = 1 };
+
+/* where the frame bytes live.  TM_MEM_DEVICE is zero-copy: the pointers are read by the
+ * ingest kernel at compute time and must stay valid until tm_engine_sync returns (the
+ * reference has the same rule for mapped NVDEC surfaces). TM_MEM_HOST is copied into an
+ * engine-owned device surface on the engine's stream before the call returns control. */
+enum { TM_MEM_HOST = 0, TM_MEM_DEVICE = 1 };
+
+/* == turbo_metrics::FrameScores (lib.rs:112-123); `valid` has the TM_METRIC_* bits of the
+ * Option<> fields that are Some(). */
+typedef struct tm_frame_scores {
+    double psnr;
+    double ssim;
+    double msssim;
+    double ssimulacra2;
+    uint32_t valid;
+} tm_frame_scores;
+
+/* Bind the calling process to `device` (hipSetDevice) and make sure a gfx950 device is there.
+ * Fails loudly (TM_ERR_HIP / TM_ERR_UNSUPPORTED) when no usable GPU exists: there is no CPU path. */
+int tm_init(int device);
+
+int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t metrics_mask,
+                     uint32_t batch_capacity);
+void tm_engine_destroy(tm_engine *e);
+
+/* bytes of device memory held by the engine */
+size_t tm_engine_mem_usage(const tm_engine *e);
+
+/* NV12: 8-bit luma plane `y` (rows at `pitch` bytes) + interleaved CbCr plane `uv` (same pitch);
+ * layout of an NVDEC mapping, cudarse-video/src/dec.rs:299-346.  Visible window starts at the origin. */
+int tm_engine_set_frame_nv12(tm_engine *e, uint32_t slot, int side, const void *y, const void *uv,
+                             size_t pitch, int matrix, int transfer, int full_range, int mem);
+/* P016: 16-bit samples, 10-bit values MSB aligned (dec.rs:348-403). `pitch` in bytes.
+ * For TM_MEM_HOST the engine copies `height` luma rows and ceil(height/2) chroma rows. */
+int tm_engine_set_frame_p016(tm_engine *e, uint32_t slot, int side, const void *y, const void *uv,
+                             size_t pitch, int matrix, int transfer, int full_range, int mem);
+/* packed RGB, 3 samples per pixel (HwFrame::Npp8 / Npp16 / Npp32, turbo-metrics/src/lib.rs:125-130);
+ * sRGB transfer: 8-bit through the LUT, 16-bit / f32 through the formula (color.rs:112-114). */
+int tm_engine_set_frame_rgb8(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem);
+int tm_engine_set_frame_rgb16(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem);
+int tm_engine_set_frame_rgbf32(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem);
+/* already-linear packed RGB f32: the input of ssimulacra2_cuda::Ssimulacra2 itself */
+int tm_engine_set_frame_linear_f32(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem);
+
+/* Enqueue the whole pipeline for slots [0, n_slots) on the engine's stream; returns immediately. */
+int tm_engine_compute_async(tm_engine *e, uint32_t n_slots);
+/* Block until the last compute_async has finished and its results are on the host. */
+int tm_engine_sync(tm_engine *e);
+/* FrameScores of one slot of the last completed compute (host-side post-processing happens here) */
+int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out);
+/* the 108 raw sums [scale][kind][channel] == the reference's `scores` before post_process_scores */
+int tm_engine_get_raw_sums(tm_engine *e, uint32_t slot, double out[108]);
+/* PSNR input: exact integer sum of squared differences of the u8-quantised linear RGB pair */
+int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out);
+
+/* SSIMULACRA2 post-processing (ssimulacra2-cuda/src/lib.rs:449-623) as a pure host function */
+double tm_ssimulacra2_score_from_sums(const double sums[108], uint32_t width, uint32_t height);
+
+/* ---- measurement hooks -------------------------------------------------------------- */
+enum { TM_STAGE_INGEST = 0, TM_STAGE_BLUR_V = 1, TM_STAGE_BLUR_H = 2, TM_STAGE_COUNT = 3 };
+/* When on, HIP events bracket each stage of every compute_async on the engine's own stream. */
+int tm_engine_set_profiling(tm_engine *e, int on);
+/* Accumulated since the last reset: milliseconds per stage and number of computes measured. */
+int tm_engine_get_stage_ms(tm_engine *e, double ms[TM_STAGE_COUNT], uint64_t *n_computes, int reset);
+/* select the kernel generation (0 = simple reference kernels, 1 = tuned); for A/B tests */
+int tm_engine_set_variant(tm_engine *e, int variant);
+
+/* ---- test hooks: read back intermediate planes of one slot (blocking) ------------------ */
+enum {
+    TM_PLANE_LINEAR = 0, /* index = side,            channel = R,G,B  ; scale 0..5 ; w x h   */
+    TM_PLANE_XYB = 1,    /* index = side,            channel = X,Y,B  ; w x h                 */
+    TM_PLANE_XYB_T = 2,  /* index = side,            transposed: h wide, w tall               */
+    TM_PLANE_PASS1_T = 3 /* index = 0..4 (s11,s22,s12,mu1,mu2), transposed: h wide, w tall    */
+};
+int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale, int index, int channel,
+                               float *out, size_t out_count);
+
+const char *tm_strerror(int code);
+/* text of the last HIP error seen by this thread's calls ("" if none) */
+const char *tm_last_hip_error(void);
+const char *tm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

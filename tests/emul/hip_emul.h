@@ -1,0 +1,35 @@
+// tests/emul/hip_emul.h -- TEST INFRASTRUCTURE ONLY.
+// A minimal host-side stand-in for the HIP device environment so that the kernel SOURCE in
+// turbo-metrics_amd/csrc/tm_kernels.h can be executed lane by lane on the CPU inside the
+// `-m "not gpu"` test tier (index/ordering logic is checked against the oracle before GPU time is
+// spent).  It is compiled only into tests/emul/libtm_emul.so; the product library never sees it.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint3_ { unsigned x, y, z; };
+extern thread_local uint3_ threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
+
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float2 make_float2(float a, float b) { return {a, b}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+using std::min;
+using std::max;
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+
+// lanes of one wave run back to back (x fastest), so a running total per wave is enough
+bool tm_wave_sum6(double (&a)[6]);
+bool tm_wave_sum_u32(unsigned &v);

@@ -1,0 +1,69 @@
+// tests/emul/tm_emul.cpp -- TEST INFRASTRUCTURE ONLY: runs the product's kernel source on the CPU,
+// one lane at a time, over host buffers laid out exactly like the engine's HBM arenas.
+#define TM_EMULATE 1
+#include "hip_emul.h"
+thread_local uint3_ threadIdx, blockIdx;
+thread_local dim3 blockDim, gridDim;
+
+static double g_acc6[6];
+static unsigned g_accu;
+static inline unsigned lane_id() { return (threadIdx.x + threadIdx.y * blockDim.x) & 63; }
+bool tm_wave_sum6(double (&a)[6])
+{
+    if (lane_id() == 0) for (int k = 0; k < 6; ++k) g_acc6[k] = 0.0;
+    for (int k = 0; k < 6; ++k) g_acc6[k] += a[k];
+    if (lane_id() == 63) { for (int k = 0; k < 6; ++k) a[k] = g_acc6[k]; return true; }
+    return false;
+}
+bool tm_wave_sum_u32(unsigned &v)
+{
+    if (lane_id() == 0) g_accu = 0;
+    g_accu += v;
+    if (lane_id() == 63) { v = g_accu; return true; }
+    return false;
+}
+
+#include "../../turbo-metrics_amd/csrc/tm_kernels.h"
+
+template <typename F> static void launch(dim3 grid, dim3 block, F f)
+{
+    gridDim = grid; blockDim = block;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx = {bx, by, bz};
+                for (unsigned tz = 0; tz < block.z; ++tz)
+                    for (unsigned ty = 0; ty < block.y; ++ty)
+                        for (unsigned tx = 0; tx < block.x; ++tx) { threadIdx = {tx, ty, tz}; f(); }
+            }
+}
+
+extern "C" {
+
+void emul_geom(int w, int h, TmGeom *g) { tm_make_geom(g, w, h); }
+size_t emul_geom_size(void) { return sizeof(TmGeom); }
+
+// counts (in elements) the caller must allocate: LIN, XYB (floats), XYBT, V, PART (doubles), SUMS, SSE
+void emul_sizes(int w, int h, int n, unsigned long long out[7])
+{
+    TmGeom g; tm_make_geom(&g, w, h);
+    out[0] = (unsigned long long)n * 2 * g.pyr; out[1] = out[0];
+    out[2] = (unsigned long long)n * 2 * g.pyr_t; out[3] = (unsigned long long)n * 5 * g.pyr_t;
+    out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = n;
+}
+
+void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, int want_sse,
+                   float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE)
+{
+    TmGeom g; tm_make_geom(&g, w, h);
+    const int qw = (w + 1) / 2, qh = (h + 1) / 2;
+    launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, LIN, SSE, want_sse); });
+    for (int s = 1; s < TM_SCALES; ++s)
+        launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 6), dim3(64), [&] { tmk::k_downscale(g, s, LIN); });
+    for (int s = 0; s < TM_SCALES; ++s)
+        launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
+    launch(dim3(g.vblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_v(g, XYB, XYBT, V); });
+    launch(dim3(g.hblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_h(g, XYBT, V, PART); });
+    launch(dim3(n), dim3(128), [&] { tmk::k_finish(g, PART, SUMS); });
+}
+}

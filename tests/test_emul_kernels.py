@@ -1,0 +1,73 @@
+"""No-GPU tier: execute the product's kernel source lane by lane on the CPU (tests/emul) and demand
+bit equality with the oracle for every plane of every scale, and 1e-12 agreement of the sums.
+The same comparisons run against the real device in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.emul import emul as E
+from tm_pkg import tm
+
+
+def coef_table():
+    return np.stack([np.stack([O.yuv_coefficients(m, 8), O.yuv_coefficients(m, 16)]) for m in range(3)]).astype(np.float32)
+
+
+def oracle_linear(f, w, h):
+    k = f["kind"]
+    if k in ("nv12", "p016"):
+        return O.yuv420_biplanar_to_linear(f["data"], f["pitch"], f["coded_height"], w, h, 8 if k == "nv12" else 16, int(f.get("matrix", 0)))
+    return {"rgb8": O.rgb8_to_linear, "rgb16": O.rgb16_to_linear, "rgbf32": O.rgbf32_to_linear, "linear_f32": O.linear_packed_to_planar}[k](f["data"])
+
+
+def check_against_oracle(em, frames, w, h):
+    for slot, (fr, fd) in enumerate(frames):
+        lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+        sums, pyr = O.ssimulacra2_sums(lin[0], lin[1], want_xyb=True)
+        for side in range(2):
+            for c in range(3):
+                assert np.array_equal(em.plane(em.LIN, slot, 0, side, c), lin[side][c]), ("linear", slot, side, c)
+        for s, (ws, hs) in enumerate(O.scale_sizes(w, h)):
+            for side in range(2):
+                for c in range(3):
+                    got = em.plane(em.XYB, slot, s, side, c)
+                    assert np.array_equal(got, pyr[s][side][c]), ("xyb", slot, s, side, c)
+                    got_t = em.plane(em.XYBT, slot, s, side, c, transposed=True)
+                    assert np.array_equal(got_t, pyr[s][side][c].T), ("xybt", slot, s, side, c)
+            _, cap = O.process_scale(pyr[s][0], pyr[s][1], capture=True)
+            for p in range(5):
+                for c in range(3):
+                    got = em.plane(em.V, slot, s, p, c, transposed=True, per_slot=5)
+                    assert np.array_equal(got, cap["pass1"][p][c]), ("pass1", slot, s, p, c)
+        np.testing.assert_allclose(em.sums(slot), sums, rtol=1e-12, atol=1e-300)
+        sse, _ = O.psnr(lin[0], lin[1])
+        assert int(em.SSE[slot]) == sse
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20)])
+def test_nv12_pipeline_matches_oracle(w, h):
+    frames = []
+    for n in range(2):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
+        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=n % 3),
+                       dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table())
+    check_against_oracle(em, frames, w, h)
+
+
+def test_p016_and_rgb_kinds_match_oracle():
+    w, h = 46, 30
+    (rs, rp, rch), (ds, dp, dch) = tm.synth.p016_pair(w, h, 3)
+    r8, d8 = tm.synth.rgb8_pair(w, h)
+    rng = np.random.default_rng(5)
+    r16 = (r8.astype(np.uint16) * 257); d16 = (d8.astype(np.uint16) * 257 + rng.integers(0, 200, d8.shape)).astype(np.uint16)
+    rf = rng.random((h, w, 3), dtype=np.float32); df = np.clip(rf + rng.normal(0, 0.03, rf.shape).astype(np.float32), 0, 1)
+    frames = [
+        (dict(kind="p016", data=rs, pitch=rp, coded_height=rch, matrix=0), dict(kind="p016", data=ds, pitch=dp, coded_height=dch, matrix=0)),
+        (dict(kind="rgb8", data=r8), dict(kind="rgb8", data=d8)),
+        (dict(kind="rgb16", data=r16), dict(kind="rgb16", data=d16)),
+        (dict(kind="rgbf32", data=rf), dict(kind="rgbf32", data=df)),
+        (dict(kind="linear_f32", data=rf), dict(kind="linear_f32", data=df)),
+    ]
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table())
+    check_against_oracle(em, frames, w, h)

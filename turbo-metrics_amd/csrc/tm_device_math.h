@@ -1,0 +1,173 @@
+// tm_device_math.h -- gfx950 device-side scalar math for the SSIMULACRA2 path.
+//
+// The reference kernels call two libdevice routines whose bit-level behaviour is NVIDIA's:
+//   __nv_cbrtf     in linear_to_xyb            (ssimulacra2-cuda-kernel/src/xyb.rs:44-46)
+//   __nv_fast_powf in the BT.709 / sRGB EOTFs  (cuda-colorspace-kernel/src/lib.rs:228, srgb.rs:46)
+// Here both are evaluated as a fixed sequence of IEEE-754 binary64 operations (v_fma_f64,
+// v_mul_f64, v_add_f64, one correctly rounded f64 division, v_rndne_f64, integer ops on the
+// exponent field) followed by one rounding to f32.  The result is the correctly rounded f32
+// value (no observed exception), deterministic, and reproducible on any IEEE machine --
+// which is what lets the parity tests demand bit equality for every plane.
+// MI355X runs f64 FMA at half the f32 rate, so the ~25 / ~45 f64 operations per call stay
+// far below the HBM time of the ingest kernel ("ingest").
+//
+// Must be compiled with -ffp-contract=off: the fma() calls are the only fused operations.
+#pragma once
+#ifdef TM_EMULATE /* CPU lane-by-lane execution of this source for the no-GPU test tier (tests/emul) */
+#include "hip_emul.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+namespace tmdev {
+
+__device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
+
+// cube root of a >= 0
+__device__ __forceinline__ float cbrt_pos(float a)
+{
+    if (!(a > 0.0f)) return a;
+    const double x = (double)a;
+    const uint32_t hi = (uint32_t)(d2u(x) >> 32);
+    // r ~ x^(-1/3) from the exponent field (|rel err| < 3.5 %), then 4 division-free Newton steps
+    double r = u2d((uint64_t)(0x553EF000u - hi / 3u) << 32);
+    const double third = 0x1.5555555555555p-2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double r3 = (r * r) * r;
+        const double e = __builtin_fma(-x, r3, 1.0);
+        r = __builtin_fma(r * third, e, r);
+    }
+    return (float)(x * (r * r));
+}
+
+// x^y, finite x > 0
+__device__ __forceinline__ float pow_pos(float xf, double y)
+{
+    if (!(xf > 0.0f)) return xf != xf ? xf : 0.0f;
+    const double x = (double)xf;
+    const uint64_t b = d2u(x);
+    int e = (int)(b >> 52) - 1023;
+    double m = u2d((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; e += 1; }
+    const double t = (m - 1.0) / (m + 1.0);
+    const double t2 = t * t;
+    double s = 0x1.8618618618618p-5;
+    s = __builtin_fma(s, t2, 0x1.af286bca1af28p-5);
+    s = __builtin_fma(s, t2, 0x1.e1e1e1e1e1e1ep-5);
+    s = __builtin_fma(s, t2, 0x1.1111111111111p-4);
+    s = __builtin_fma(s, t2, 0x1.3b13b13b13b14p-4);
+    s = __builtin_fma(s, t2, 0x1.745d1745d1746p-4);
+    s = __builtin_fma(s, t2, 0x1.c71c71c71c71cp-4);
+    s = __builtin_fma(s, t2, 0x1.2492492492492p-3);
+    s = __builtin_fma(s, t2, 0x1.999999999999ap-3);
+    s = __builtin_fma(s, t2, 0x1.5555555555555p-2);
+    s = __builtin_fma(s, t2, 1.0);
+    const double ln2 = 0x1.62e42fefa39efp-1;
+    const double lnx = __builtin_fma((double)e, ln2, (2.0 * t) * s);
+    const double z = y * lnx;
+    const double n = __builtin_rint(z * 0x1.71547652b82fep+0);
+    const double r = __builtin_fma(-n, ln2, z);
+    double p = 0x1.6124613a86d09p-33;
+    p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);
+    p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);
+    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const long long ni = (long long)n;
+    return (float)u2d(d2u(p) + ((uint64_t)ni << 52));
+}
+
+// BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs)
+__device__ __forceinline__ float bt709_eotf(float v)
+{
+    const float BETA = 0.018053968510807f;
+    const float ALPHA = 1.0f + 5.5f * BETA;
+    const float THRESHOLD = 0.08124285829863521110029445797874f;
+    if (v >= THRESHOLD) return pow_pos((v + (ALPHA - 1.0f)) / ALPHA, (double)(1.0f / 0.45f));
+    return v / 4.5f;
+}
+
+// srgb_inverse_oetf, cuda-colorspace-kernel/src/srgb.rs:40-48
+__device__ __forceinline__ float srgb_inverse_oetf(float x)
+{
+    const float SRGB_ALPHA = 1.0550107f;
+    const float SRGB_BETA = 0.0030412825f;
+    if (x < 12.92f * SRGB_BETA) return x / 12.92f;
+    return pow_pos((x + (SRGB_ALPHA - 1.0f)) / SRGB_ALPHA, (double)2.4f);
+}
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+// px_linear_rgb_to_positive_xyb, ssimulacra2-cuda-kernel/src/xyb.rs:42-79
+__device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float &X, float &Y, float &B)
+{
+    const float K_M02 = 0.078f, K_M00 = 0.30f, K_M01 = 1.0f - K_M02 - K_M00;
+    const float K_M12 = 0.078f, K_M10 = 0.23f, K_M11 = 1.0f - K_M12 - K_M10;
+    const float K_M20 = 0.24342269f, K_M21 = 0.20476745f, K_M22 = 1.0f - K_M20 - K_M21;
+    const float K_B0 = 0.0037930734f;
+    const float K_B0_ROOT = 0.1559542025327239180319220163705f;
+    float rg = __builtin_fmaf(K_M00, r, __builtin_fmaf(K_M01, g, __builtin_fmaf(K_M02, b, K_B0)));
+    float gr = __builtin_fmaf(K_M10, r, __builtin_fmaf(K_M11, g, __builtin_fmaf(K_M12, b, K_B0)));
+    float bb = __builtin_fmaf(K_M20, r, __builtin_fmaf(K_M21, g, __builtin_fmaf(K_M22, b, K_B0)));
+    rg = cbrt_pos(fmaxf(rg, 0.0f)) - K_B0_ROOT;
+    gr = cbrt_pos(fmaxf(gr, 0.0f)) - K_B0_ROOT;
+    bb = cbrt_pos(fmaxf(bb, 0.0f)) - K_B0_ROOT;
+    const float x = 0.5f * (rg - gr);
+    const float y = 0.5f * (rg + gr);
+    X = __builtin_fmaf(x, 14.0f, 0.42f);
+    Y = y + 0.01f;
+    B = bb - y + 0.55f;
+}
+
+// One step of the three second-order sections of the truncated-cosine recursive Gaussian,
+// ssimulacra2-cuda-kernel/src/blur.rs:112-131; constants = build.rs:28-145 for sigma 1.5.
+struct Iir {
+    float p1a, p1b, p1c, p2a, p2b, p2c;
+};
+__device__ __forceinline__ float iir_step(Iir &s, float sum)
+{
+    const float MUL_IN_1 = 0.055295236f, MUL_IN_3 = -0.058836687f, MUL_IN_5 = 0.012955819f;
+    const float MUL_PREV_1 = 1.9021131f, MUL_PREV_3 = 1.1755705f, MUL_PREV_5 = 1.2246469e-16f;
+    float o1 = sum * MUL_IN_1, o3 = sum * MUL_IN_3, o5 = sum * MUL_IN_5;
+    o1 = __builtin_fmaf(-1.0f, s.p2a, o1);
+    o3 = __builtin_fmaf(-1.0f, s.p2b, o3);
+    o5 = __builtin_fmaf(-1.0f, s.p2c, o5);
+    s.p2a = s.p1a; s.p2b = s.p1b; s.p2c = s.p1c;
+    o1 = __builtin_fmaf(MUL_PREV_1, s.p1a, o1);
+    o3 = __builtin_fmaf(MUL_PREV_3, s.p1b, o3);
+    o5 = __builtin_fmaf(MUL_PREV_5, s.p1c, o5);
+    s.p1a = o1; s.p1b = o3; s.p1c = o5;
+    return (o1 + o3) + o5;
+}
+
+// compute_error_maps, ssimulacra2-cuda-kernel/src/error_maps.rs:5-60
+__device__ __forceinline__ void error_maps(float source, float distorted, float mu1, float mu2, float sigma11,
+                                           float sigma22, float sigma12, float &ssim, float &artifact,
+                                           float &detail_loss)
+{
+    const float C2 = 0.0009f;
+    const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+    const float mu_diff = mu1 - mu2;
+    const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
+    const float num_s = __builtin_fmaf(2.0f, sigma12 - mu12, C2);
+    const float denom_s = (sigma11 - mu11) + (sigma22 - mu22) + C2;
+    ssim = fmaxf(1.0f - (num_m * num_s) / denom_s, 0.0f);
+    const float denom = 1.0f / (1.0f + fabsf(source - mu1));
+    const float numer = 1.0f + fabsf(distorted - mu2);
+    const float d1 = __builtin_fmaf(numer, denom, -1.0f);
+    artifact = fmaxf(d1, 0.0f);
+    detail_loss = fmaxf(-d1, 0.0f);
+}
+
+} // namespace tmdev

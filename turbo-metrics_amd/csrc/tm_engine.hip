@@ -1,0 +1,525 @@
+// tm_engine.hip -- host side of libturbometrics_hip.so: the C ABI of include/turbo_metrics_hip.h
+// over the gfx950 kernels in tm_kernels.h.  No CPU compute path exists here: every entry point that
+// needs the GPU returns TM_ERR_HIP / TM_ERR_UNSUPPORTED when there is none.
+//
+// Reference counterparts (paths relative to /root/reference/crates):
+//   engine object        turbo-metrics/src/lib.rs:188-249 (TurboMetrics) + ssimulacra2-cuda/src/lib.rs:27-107
+//   per-pair dataflow    turbo-metrics/src/lib.rs:268-360 (compute_one), ssimulacra2-cuda/src/lib.rs:140-229
+//   post-processing      ssimulacra2-cuda/src/lib.rs:449-623
+//   colour coefficients  cuda-colorspace-kernel/src/lib.rs:186-218
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/turbo_metrics_hip.h"
+#include "tm_geom.h"
+#include "tm_kernels.h"
+#include "tm_tables.inc"
+
+namespace {
+
+thread_local char g_hip_err[256] = "";
+
+int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+    return TM_ERR_HIP;
+}
+#define HIPCHK(call)                                        \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+    } while (0)
+
+const uint32_t k_lut_bits[256] = {TM_SRGB_LUT_BITS};
+const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
+
+// ---- colour coefficients: same f32 operation order as the reference's const evaluation -----------
+struct V3 { float x, y, z; };
+V3 xy_to_xyz(float x, float y) { return {x / y, 1.0f, (1.0f - x - y) / y}; } // const_algebra.rs:30-32
+float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+void kr_kb(int matrix, float *kr, float *kb) // lib.rs:203-218 + constants.rs:3-18
+{
+    static const float prim[3][8] = {
+        {0.640f, 0.330f, 0.300f, 0.600f, 0.150f, 0.060f, 0.3127f, 0.3290f}, // BT709
+        {0.630f, 0.340f, 0.310f, 0.595f, 0.155f, 0.070f, 0.3127f, 0.3290f}, // BT601_525
+        {0.640f, 0.330f, 0.290f, 0.600f, 0.150f, 0.060f, 0.3127f, 0.3290f}, // BT601_625
+    };
+    const float *p = prim[matrix];
+    const V3 r = xy_to_xyz(p[0], p[1]), g = xy_to_xyz(p[2], p[3]), b = xy_to_xyz(p[4], p[5]),
+             w = xy_to_xyz(p[6], p[7]);
+    const V3 xr = {r.x, g.x, b.x}, yr = {r.y, g.y, b.y}, zr = {r.z, g.z, b.z};
+    const float mul = 1.0f / dot3(xr, cross3(yr, zr));
+    *kr = dot3(w, cross3(g, b)) * mul;
+    *kb = dot3(w, cross3(r, g)) * mul;
+}
+
+void yuv_coefficients(int matrix, int bits, float out[5]) // lib.rs:186-200, Limited range :103-132
+{
+    float kr, kb;
+    kr_kb(matrix, &kr, &kb);
+    const float luma_range = (float)((235u - 16u) << (bits - 8));
+    const float chroma_range = (float)((240u - 16u) << (bits - 8));
+    const float kg = 1.0f - kr - kb;
+    out[0] = 1.0f / luma_range;
+    out[1] = 2.0f * (1.0f - kr) * 1.0f / chroma_range;
+    out[2] = 2.0f * (1.0f - kb) * 1.0f / chroma_range;
+    out[3] = -2.0f * (1.0f - kb) * kb / kg * 1.0f / chroma_range;
+    out[4] = -2.0f * (1.0f - kr) * kr / kg * 1.0f / chroma_range;
+}
+
+} // namespace
+
+struct tm_engine {
+    int device = 0;
+    uint32_t w = 0, h = 0, mask = 0, cap = 0;
+    TmGeom g{};
+    hipStream_t stream = nullptr;
+    float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr;
+    double *PART = nullptr, *SUMS = nullptr;
+    unsigned long long *SSE = nullptr;
+    TmFrameDesc *d_desc = nullptr, *h_desc = nullptr;
+    double *h_sums = nullptr;
+    unsigned long long *h_sse = nullptr;
+    float *d_lut = nullptr, *d_coef = nullptr;
+    std::vector<void *> staging;      // [slot*2+side], lazily allocated
+    std::vector<size_t> staging_size;
+    size_t mem_bytes = 0;
+    bool profiling = false, ev_pending = false;
+    hipEvent_t ev[TM_STAGE_COUNT + 1] = {};
+    double stage_ms[TM_STAGE_COUNT] = {0, 0, 0};
+    uint64_t n_prof = 0;
+    uint32_t last_n = 0;
+    bool in_flight = false, have_results = false;
+    int variant = 0;
+};
+
+namespace {
+
+template <typename T> int dev_alloc(tm_engine *e, T **p, size_t count, bool zero)
+{
+    const size_t bytes = count * sizeof(T);
+    hipError_t r = hipMalloc((void **)p, bytes ? bytes : 1);
+    if (r == hipErrorOutOfMemory) { snprintf(g_hip_err, sizeof g_hip_err, "hipMalloc(%zu): out of memory", bytes); return TM_ERR_OOM; }
+    if (r != hipSuccess) return hip_fail(r, "hipMalloc");
+    e->mem_bytes += bytes;
+    if (zero) HIPCHK(hipMemset(*p, 0, bytes ? bytes : 1));
+    return TM_OK;
+}
+
+int check_slot_side(const tm_engine *e, uint32_t slot, int side)
+{
+    if (!e || slot >= e->cap || (side != TM_SIDE_REF && side != TM_SIDE_DIS)) return TM_ERR_INVALID_ARG;
+    return TM_OK;
+}
+
+// copy `rows` rows of `row_bytes` from host memory (pitch `src_pitch`) into the staging surface
+int stage_rows(tm_engine *e, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, size_t rows)
+{
+    if (rows == 0 || row_bytes == 0) return TM_OK;
+    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, e->stream));
+    return TM_OK;
+}
+
+int ensure_staging(tm_engine *e, size_t idx, size_t bytes)
+{
+    if (e->staging_size[idx] >= bytes) return TM_OK;
+    if (e->staging[idx]) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipFree(e->staging[idx]));
+        e->mem_bytes -= e->staging_size[idx];
+        e->staging[idx] = nullptr; e->staging_size[idx] = 0;
+    }
+    hipError_t r = hipMalloc(&e->staging[idx], bytes);
+    if (r == hipErrorOutOfMemory) return TM_ERR_OOM;
+    if (r != hipSuccess) return hip_fail(r, "hipMalloc(staging)");
+    e->staging_size[idx] = bytes; e->mem_bytes += bytes;
+    return TM_OK;
+}
+
+int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void *p0, const void *p1, size_t pitch,
+                     int matrix, int mem)
+{
+    int rc = check_slot_side(e, slot, side);
+    if (rc) return rc;
+    if (!p0 || (mem != TM_MEM_HOST && mem != TM_MEM_DEVICE)) return TM_ERR_INVALID_ARG;
+    const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016;
+    if (yuv && !p1) return TM_ERR_INVALID_ARG;
+    const size_t bps = kind == TM_KIND_NV12 || kind == TM_KIND_RGB8 ? 1 : (kind == TM_KIND_P016 || kind == TM_KIND_RGB16 ? 2 : 4);
+    const size_t row_bytes = yuv ? (size_t)e->w * bps : (size_t)e->w * 3 * bps;
+    if (pitch < row_bytes) return TM_ERR_INVALID_ARG;
+    TmFrameDesc &d = e->h_desc[slot * 2 + side];
+    if (e->in_flight) { // descriptors are read by an async copy; do not race with it
+        rc = tm_engine_sync(e);
+        if (rc) return rc;
+    }
+    if (mem == TM_MEM_DEVICE) {
+        d.p0 = p0; d.p1 = p1; d.pitch = pitch;
+    } else {
+        const size_t idx = slot * 2 + side;
+        const size_t spitch = (row_bytes + 255) / 256 * 256;
+        const size_t chroma_rows = (e->h + 1) / 2;
+        const size_t need = yuv ? spitch * (e->h + chroma_rows) : spitch * e->h;
+        rc = ensure_staging(e, idx, need);
+        if (rc) return rc;
+        char *s = (char *)e->staging[idx];
+        rc = stage_rows(e, s, spitch, p0, pitch, row_bytes, e->h);
+        if (rc) return rc;
+        if (yuv) {
+            const size_t uv_bytes = (size_t)((e->w + 1) / 2) * 2 * bps;
+            rc = stage_rows(e, s + spitch * e->h, spitch, p1, pitch, uv_bytes <= pitch ? uv_bytes : pitch, chroma_rows);
+            if (rc) return rc;
+            d.p1 = s + spitch * e->h;
+        } else d.p1 = nullptr;
+        // pageable source: make sure the bytes have left the caller's buffer before returning
+        HIPCHK(hipStreamSynchronize(e->stream));
+        d.p0 = s; d.pitch = spitch;
+    }
+    d.kind = kind; d.matrix = matrix;
+    return TM_OK;
+}
+
+int check_yuv_args(int matrix, int transfer, int full_range)
+{
+    if (matrix < 0 || matrix > 2) return TM_ERR_INVALID_ARG;
+    // cuda-colorspace/src/lib.rs:45-52: full range and non-BT709 transfer are todo!() in the reference
+    if (transfer != TM_TRANSFER_BT709 || full_range) return TM_ERR_UNSUPPORTED;
+    return TM_OK;
+}
+
+dim3 grid2(int w, int h, int z) { return dim3((unsigned)((w + 63) / 64), (unsigned)h, (unsigned)z); }
+
+} // namespace
+
+extern "C" {
+
+const char *tm_version(void) { return "turbo-metrics-hip 0.1 (gfx950)"; }
+
+const char *tm_last_hip_error(void) { return g_hip_err; }
+
+const char *tm_strerror(int code)
+{
+    switch (code) {
+    case TM_OK: return "ok";
+    case TM_ERR_INVALID_ARG: return "invalid argument";
+    case TM_ERR_UNSUPPORTED: return "unsupported (todo!() in the reference: full-range YUV / non-BT.709 transfer, or no gfx950 device)";
+    case TM_ERR_HIP: return "HIP runtime error (see tm_last_hip_error)";
+    case TM_ERR_OOM: return "out of device memory";
+    case TM_ERR_STATE: return "invalid state (compute before all frames set, or results not ready)";
+    default: return "unknown error";
+    }
+}
+
+int tm_init(int device)
+{
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { snprintf(g_hip_err, sizeof g_hip_err, "device %d of %d", device, n); return TM_ERR_INVALID_ARG; }
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_hip_err, sizeof g_hip_err, "device %d is %s, this library carries gfx950 code only", device, prop.gcnArchName);
+        return TM_ERR_UNSUPPORTED;
+    }
+    return TM_OK;
+}
+
+int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t metrics_mask, uint32_t batch_capacity)
+{
+    if (!out) return TM_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 16384 || height > 16384 || batch_capacity == 0 || batch_capacity > 4096)
+        return TM_ERR_INVALID_ARG;
+    if ((metrics_mask & ~15u) || metrics_mask == 0) return TM_ERR_INVALID_ARG;
+    if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
+        // NPP's SSIM / MS-SSIM arithmetic is closed source and pinned by no reference test:
+        // not built yet rather than built to a guess.
+        return TM_ERR_UNSUPPORTED;
+    }
+    tm_engine *e = new (std::nothrow) tm_engine();
+    if (!e) return TM_ERR_OOM;
+    int rc = TM_OK;
+    auto fail = [&](int code) { tm_engine_destroy(e); return code; };
+    if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
+    e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
+    tm_make_geom(&e->g, (int)width, (int)height);
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
+    const size_t B = batch_capacity;
+    const TmGeom &g = e->g;
+    if ((rc = dev_alloc(e, &e->LIN, B * 2 * g.pyr, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->XYBT, B * 2 * g.pyr_t, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->SSE, B, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->d_desc, B * 2, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->d_lut, 256, false))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->d_coef, 3 * 2 * 5, false))) return fail(rc);
+    float coef[3][2][5];
+    for (int m = 0; m < 3; ++m) { yuv_coefficients(m, 8, coef[m][0]); yuv_coefficients(m, 16, coef[m][1]); }
+    if ((he = hipMemcpy(e->d_coef, coef, sizeof coef, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(coef)"));
+    if ((he = hipMemcpy(e->d_lut, k_lut_bits, sizeof k_lut_bits, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(lut)"));
+    if ((he = hipHostMalloc((void **)&e->h_desc, B * 2 * sizeof(TmFrameDesc), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
+    if ((he = hipHostMalloc((void **)&e->h_sums, B * 108 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
+    if ((he = hipHostMalloc((void **)&e->h_sse, B * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
+    for (size_t i = 0; i < B * 2; ++i) { e->h_desc[i] = TmFrameDesc{nullptr, nullptr, 0, TM_KIND_NONE, 0}; }
+    e->staging.assign(B * 2, nullptr);
+    e->staging_size.assign(B * 2, 0);
+    for (int i = 0; i <= TM_STAGE_COUNT; ++i)
+        if ((he = hipEventCreate(&e->ev[i])) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
+    *out = e;
+    return TM_OK;
+}
+
+void tm_engine_destroy(tm_engine *e)
+{
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->staging) if (p) (void)hipFree(p);
+    (void)hipFree(e->LIN); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
+    (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
+    (void)hipFree(e->d_lut); (void)hipFree(e->d_coef);
+    if (e->h_desc) (void)hipHostFree(e->h_desc);
+    if (e->h_sums) (void)hipHostFree(e->h_sums);
+    if (e->h_sse) (void)hipHostFree(e->h_sse);
+    for (int i = 0; i <= TM_STAGE_COUNT; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+size_t tm_engine_mem_usage(const tm_engine *e) { return e ? e->mem_bytes : 0; }
+
+int tm_engine_set_frame_nv12(tm_engine *e, uint32_t slot, int side, const void *y, const void *uv, size_t pitch,
+                             int matrix, int transfer, int full_range, int mem)
+{
+    int rc = check_yuv_args(matrix, transfer, full_range);
+    if (rc) return rc;
+    return set_frame_common(e, slot, side, TM_KIND_NV12, y, uv, pitch, matrix, mem);
+}
+
+int tm_engine_set_frame_p016(tm_engine *e, uint32_t slot, int side, const void *y, const void *uv, size_t pitch,
+                             int matrix, int transfer, int full_range, int mem)
+{
+    int rc = check_yuv_args(matrix, transfer, full_range);
+    if (rc) return rc;
+    return set_frame_common(e, slot, side, TM_KIND_P016, y, uv, pitch, matrix, mem);
+}
+
+int tm_engine_set_frame_rgb8(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
+{
+    return set_frame_common(e, slot, side, TM_KIND_RGB8, rgb, nullptr, pitch, 0, mem);
+}
+int tm_engine_set_frame_rgb16(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
+{
+    return set_frame_common(e, slot, side, TM_KIND_RGB16, rgb, nullptr, pitch, 0, mem);
+}
+int tm_engine_set_frame_rgbf32(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
+{
+    return set_frame_common(e, slot, side, TM_KIND_RGBF32, rgb, nullptr, pitch, 0, mem);
+}
+int tm_engine_set_frame_linear_f32(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
+{
+    return set_frame_common(e, slot, side, TM_KIND_LINEARF32, rgb, nullptr, pitch, 0, mem);
+}
+
+int tm_engine_set_profiling(tm_engine *e, int on)
+{
+    if (!e) return TM_ERR_INVALID_ARG;
+    e->profiling = on != 0;
+    return TM_OK;
+}
+
+int tm_engine_set_variant(tm_engine *e, int variant)
+{
+    if (!e || variant < 0 || variant > 0) return TM_ERR_INVALID_ARG;
+    e->variant = variant;
+    return TM_OK;
+}
+
+int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
+{
+    if (!e || n_slots == 0 || n_slots > e->cap) return TM_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n_slots * 2; ++i)
+        if (e->h_desc[i].kind == TM_KIND_NONE) return TM_ERR_STATE;
+    if (e->ev_pending) { // fold the previous compute's timings before the events are reused
+        int rc = tm_engine_sync(e);
+        if (rc) return rc;
+    }
+    const TmGeom &g = e->g;
+    hipStream_t st = e->stream;
+    const int n = (int)n_slots;
+    HIPCHK(hipMemcpyAsync(e->d_desc, e->h_desc, (size_t)n * 2 * sizeof(TmFrameDesc), hipMemcpyHostToDevice, st));
+    const int want_sse = (e->mask & TM_METRIC_PSNR) ? 1 : 0;
+    if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * sizeof(unsigned long long), st));
+    if (e->profiling) HIPCHK(hipEventRecord(e->ev[0], st));
+    // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
+    {
+        const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
+        dim3 grid((unsigned)((qw + 63) / 64), (unsigned)((qh + 3) / 4), (unsigned)n), block(64, 4, 1);
+        hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->LIN, e->SSE, want_sse);
+    }
+    if (e->mask & TM_METRIC_SSIMULACRA2) {
+        for (int s = 1; s < TM_SCALES; ++s)
+            hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, e->LIN);
+        for (int s = 0; s < TM_SCALES; ++s)
+            hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, e->LIN, e->XYB);
+    }
+    if (e->profiling) HIPCHK(hipEventRecord(e->ev[1], st));
+    if (e->mask & TM_METRIC_SSIMULACRA2) {
+        // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
+        hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, e->XYB, e->XYBT, e->V);
+        if (e->profiling) HIPCHK(hipEventRecord(e->ev[2], st));
+        // ---- stage BLUR_H: row pass + error maps + reductions
+        hipLaunchKernelGGL(tmk::k_blur_h, dim3((unsigned)g.hblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, e->XYBT, e->V, e->PART);
+        if (e->profiling) HIPCHK(hipEventRecord(e->ev[3], st));
+        hipLaunchKernelGGL(tmk::k_finish, dim3((unsigned)n), dim3(128), 0, st, g, e->PART, e->SUMS);
+        HIPCHK(hipMemcpyAsync(e->h_sums, e->SUMS, (size_t)n * 108 * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else if (e->profiling) {
+        HIPCHK(hipEventRecord(e->ev[2], st));
+        HIPCHK(hipEventRecord(e->ev[3], st));
+    }
+    if (want_sse) HIPCHK(hipMemcpyAsync(e->h_sse, e->SSE, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    e->ev_pending = e->profiling;
+    e->last_n = n_slots;
+    e->in_flight = true;
+    e->have_results = false;
+    return TM_OK;
+}
+
+int tm_engine_sync(tm_engine *e)
+{
+    if (!e) return TM_ERR_INVALID_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->ev_pending) {
+        for (int i = 0; i < TM_STAGE_COUNT; ++i) {
+            float ms = 0.0f;
+            HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+            e->stage_ms[i] += (double)ms;
+        }
+        e->n_prof += 1;
+        e->ev_pending = false;
+    }
+    if (e->in_flight) { e->in_flight = false; e->have_results = true; }
+    return TM_OK;
+}
+
+int tm_engine_get_stage_ms(tm_engine *e, double ms[TM_STAGE_COUNT], uint64_t *n_computes, int reset)
+{
+    if (!e || !ms) return TM_ERR_INVALID_ARG;
+    for (int i = 0; i < TM_STAGE_COUNT; ++i) ms[i] = e->stage_ms[i];
+    if (n_computes) *n_computes = e->n_prof;
+    if (reset) { for (int i = 0; i < TM_STAGE_COUNT; ++i) e->stage_ms[i] = 0.0; e->n_prof = 0; }
+    return TM_OK;
+}
+
+double tm_ssimulacra2_score_from_sums(const double sums[108], uint32_t width, uint32_t height)
+{
+    // post_process_scores, ssimulacra2-cuda/src/lib.rs:586-622
+    double sc[108];
+    memcpy(sc, sums, sizeof sc);
+    int w = (int)width, h = (int)height;
+    for (int scale = 0; scale < TM_SCALES; ++scale) {
+        const double opp = 1.0 / (double)(h * w); // NppiRect::norm, cudarse-npp-sys/src/lib.rs:19-21
+        for (int c = 0; c < 3; ++c) {
+            const int o = 18 * scale + c, ow = c * 36 + 6 * scale;
+            sc[o] = std::fabs(sc[o] * opp) * k_weights[ow];
+            sc[o + 3] = std::fabs(sc[o + 3] * opp) * k_weights[ow + 1];
+            sc[o + 6] = std::fabs(sc[o + 6] * opp) * k_weights[ow + 2];
+            sc[o + 9] = std::sqrt(std::sqrt(sc[o + 9] * opp)) * k_weights[ow + 3];
+            sc[o + 12] = std::sqrt(std::sqrt(sc[o + 12] * opp)) * k_weights[ow + 4];
+            sc[o + 15] = std::sqrt(std::sqrt(sc[o + 15] * opp)) * k_weights[ow + 5];
+        }
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    double score = 0.0;
+    for (int i = 0; i < 108; ++i) score += sc[i];
+    score *= 0.9562382616834844;
+    score = std::fma(6.248496625763138e-5 * score * score, score,
+                     std::fma(2.326765642916932, score, -0.020884521182843837 * score * score));
+    if (score > 0.0) score = std::fma(std::pow(score, 0.6276336467831387), -10.0, 100.0);
+    else score = 100.0;
+    return score;
+}
+
+int tm_engine_get_raw_sums(tm_engine *e, uint32_t slot, double out[108])
+{
+    if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
+    if (!e->have_results || slot >= e->last_n || !(e->mask & TM_METRIC_SSIMULACRA2)) return TM_ERR_STATE;
+    memcpy(out, e->h_sums + (size_t)slot * 108, 108 * sizeof(double));
+    return TM_OK;
+}
+
+int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out)
+{
+    if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
+    if (!e->have_results || slot >= e->last_n || !(e->mask & TM_METRIC_PSNR)) return TM_ERR_STATE;
+    *out = e->h_sse[slot];
+    return TM_OK;
+}
+
+int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out)
+{
+    if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
+    if (!e->have_results || slot >= e->last_n) return TM_ERR_STATE;
+    memset(out, 0, sizeof *out);
+    if (e->mask & TM_METRIC_SSIMULACRA2) {
+        out->ssimulacra2 = tm_ssimulacra2_score_from_sums(e->h_sums + (size_t)slot * 108, e->w, e->h);
+        out->valid |= TM_METRIC_SSIMULACRA2;
+    }
+    if (e->mask & TM_METRIC_PSNR) {
+        // PSNR of the u8-quantised linear RGB pair (turbo-metrics/src/lib.rs:296-318); NPP returns one
+        // Npp32f (cudarse-npp/src/image/ist.rs:118) which the engine widens (lib.rs:355).
+        const double count = 3.0 * (double)e->w * (double)e->h;
+        const double mse = (double)e->h_sse[slot] / count;
+        out->psnr = (double)(float)(10.0 * std::log10(255.0 * 255.0 / mse));
+        out->valid |= TM_METRIC_PSNR;
+    }
+    return TM_OK;
+}
+
+int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale, int index, int channel, float *out,
+                               size_t out_count)
+{
+    if (!e || !out || slot >= e->cap || scale < 0 || scale >= TM_SCALES || channel < 0 || channel > 2) return TM_ERR_INVALID_ARG;
+    const TmGeom &g = e->g;
+    const TmScaleGeom &sg = g.s[scale];
+    if (out_count < (size_t)sg.w * sg.h) return TM_ERR_INVALID_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const float *src = nullptr;
+    size_t pitch = 0, width = 0, rows = 0;
+    switch (kind) {
+    case TM_PLANE_LINEAR:
+    case TM_PLANE_XYB:
+        if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
+        src = (kind == TM_PLANE_LINEAR ? e->LIN : e->XYB) + (size_t)(slot * 2 + index) * g.pyr + sg.off + channel * sg.plane;
+        pitch = sg.pitch; width = sg.w; rows = sg.h;
+        break;
+    case TM_PLANE_XYB_T:
+        if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
+        src = e->XYBT + (size_t)(slot * 2 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
+        pitch = sg.pitch_t; width = sg.h; rows = sg.w;
+        break;
+    case TM_PLANE_PASS1_T:
+        if (index < 0 || index > 4) return TM_ERR_INVALID_ARG;
+        src = e->V + (size_t)(slot * 5 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
+        pitch = sg.pitch_t; width = sg.h; rows = sg.w;
+        break;
+    default: return TM_ERR_INVALID_ARG;
+    }
+    HIPCHK(hipMemcpy2D(out, width * sizeof(float), src, pitch * sizeof(float), width * sizeof(float), rows, hipMemcpyDeviceToHost));
+    return TM_OK;
+}
+
+} // extern "C"

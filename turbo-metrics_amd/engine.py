@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference's operator interface for the frame-pair path, over the C ABI.
+
+Reference types mirrored (paths relative to /root/reference/crates):
+  Metrics, Options, FrameScores      turbo-metrics/src/lib.rs:27-54,112-123
+  HwFrame                            turbo-metrics/src/lib.rs:125-130
+  TurboMetrics::{new,compute_one,compute_all}   turbo-metrics/src/lib.rs:201-433
+  Ssimulacra2::{new,compute_sync,mem_usage}     ssimulacra2-cuda/src/lib.rs:48-138,271-291
+  ColorMatrix                        cuda-colorspace/src/lib.rs
+  init_cuda                          turbo-metrics/src/lib.rs:438-456  (here: init_hip)
+
+The reference is Rust; this image has no Rust toolchain, so the mirror is Python (tests and the
+benchmark read like the reference's call sites).  All arithmetic happens in libturbometrics_hip.so.
+"""
+import ctypes as C
+import enum
+from dataclasses import dataclass
+from typing import Iterable, List, Optional
+
+import numpy as np
+
+from . import ffi
+
+
+class TmError(RuntimeError):
+    def __init__(self, code, where):
+        L = ffi.lib()
+        msg = L.tm_strerror(code).decode()
+        hip = L.tm_last_hip_error().decode()
+        super().__init__(f"{where}: {msg}" + (f" [{hip}]" if code == ffi.TM_ERR_HIP and hip else ""))
+        self.code = code
+
+
+def _chk(code, where):
+    if code != ffi.TM_OK:
+        raise TmError(code, where)
+
+
+def init_hip(device: int = 0):
+    """Counterpart of init_cuda(): bind this process to `device`; raises when no gfx950 GPU exists."""
+    _chk(ffi.lib().tm_init(int(device)), "tm_init")
+
+
+class ColorMatrix(enum.IntEnum):
+    BT709 = ffi.TM_MATRIX_BT709
+    BT601_525 = ffi.TM_MATRIX_BT601_525
+    BT601_625 = ffi.TM_MATRIX_BT601_625
+
+
+def color_matrix_fallback(height: int) -> ColorMatrix:
+    """turbo-metrics/src/color.rs:51-78: unspecified metadata falls back by frame height."""
+    if height <= 525:
+        return ColorMatrix.BT601_525
+    if height <= 625:
+        return ColorMatrix.BT601_625
+    return ColorMatrix.BT709
+
+
+@dataclass
+class Metrics:
+    psnr: bool = False
+    ssim: bool = False
+    msssim: bool = False
+    ssimulacra2: bool = False
+
+    def mask(self) -> int:
+        return ((ffi.TM_METRIC_PSNR if self.psnr else 0) | (ffi.TM_METRIC_SSIM if self.ssim else 0)
+                | (ffi.TM_METRIC_MSSSIM if self.msssim else 0) | (ffi.TM_METRIC_SSIMULACRA2 if self.ssimulacra2 else 0))
+
+
+@dataclass
+class Options:
+    every: int = 0
+    skip: int = 0
+    skip_ref: int = 0
+    skip_dis: int = 0
+    frames: int = 0
+
+
+@dataclass
+class FrameScores:
+    psnr: Optional[float] = None
+    ssim: Optional[float] = None
+    msssim: Optional[float] = None
+    ssimulacra2: Optional[float] = None
+
+
+@dataclass
+class HwFrame:
+    """One decoded frame.  kind: 'nv12' | 'p016' | 'rgb8' | 'rgb16' | 'rgbf32' | 'linear_f32'.
+    data: numpy array (host memory) or any object with .data_ptr() (device memory, e.g. a torch
+    tensor on the GPU).  For the biplanar kinds `data` is the whole surface (luma rows, then the CbCr
+    plane at pitch*coded_height); for RGB kinds it is (h, w, 3)."""
+    kind: str
+    data: object
+    pitch: int = 0
+    coded_height: int = 0
+    matrix: ColorMatrix = ColorMatrix.BT709
+    full_range: bool = False
+    transfer: int = ffi.TM_TRANSFER_BT709
+
+    @staticmethod
+    def nv12(surface, pitch, coded_height, matrix=ColorMatrix.BT709, full_range=False):
+        return HwFrame("nv12", surface, pitch, coded_height, matrix, full_range)
+
+    @staticmethod
+    def p016(surface, pitch, coded_height, matrix=ColorMatrix.BT709, full_range=False):
+        return HwFrame("p016", surface, pitch, coded_height, matrix, full_range)
+
+    @staticmethod
+    def rgb(arr):
+        a = np.asarray(arr) if not hasattr(arr, "data_ptr") else arr
+        dt = str(a.dtype).replace("torch.", "")
+        kind = {"uint8": "rgb8", "uint16": "rgb16", "float32": "rgbf32"}[dt]
+        return HwFrame(kind, a)
+
+    @staticmethod
+    def linear(arr):
+        return HwFrame("linear_f32", arr)
+
+
+def _ptr_and_mem(data):
+    if hasattr(data, "data_ptr"):  # torch tensor
+        mem = ffi.TM_MEM_DEVICE if getattr(data, "is_cuda", False) else ffi.TM_MEM_HOST
+        return int(data.data_ptr()), mem, data
+    a = np.ascontiguousarray(data)
+    return a.ctypes.data, ffi.TM_MEM_HOST, a
+
+
+class TurboMetrics:
+    """Mirror of turbo_metrics::TurboMetrics with `batch` frame-pair slots (batch=1 == reference)."""
+
+    def __init__(self, width: int, height: int, metrics: Metrics, batch: int = 1):
+        self._L = ffi.lib()
+        self.width, self.height, self.batch = int(width), int(height), int(batch)
+        self._metrics = metrics
+        h = C.c_void_p()
+        _chk(self._L.tm_engine_create(C.byref(h), self.width, self.height, metrics.mask(), self.batch), "tm_engine_create")
+        self._h = h
+        self._keep = {}
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tm_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def metrics(self) -> Metrics:
+        return self._metrics
+
+    def mem_usage(self) -> int:
+        return int(self._L.tm_engine_mem_usage(self._h))
+
+    # -- frames -------------------------------------------------------------------------------
+    def set_frame(self, slot: int, side: int, f: HwFrame):
+        ptr, mem, keep = _ptr_and_mem(f.data)
+        self._keep[(slot, side)] = keep  # device pointers must outlive the compute
+        L, h = self._L, self._h
+        if f.kind in ("nv12", "p016"):
+            fn = L.tm_engine_set_frame_nv12 if f.kind == "nv12" else L.tm_engine_set_frame_p016
+            uv = ptr + f.pitch * f.coded_height
+            _chk(fn(h, slot, side, ptr, uv, f.pitch, int(f.matrix), int(f.transfer), int(bool(f.full_range)), mem),
+                 f"tm_engine_set_frame_{f.kind}")
+        else:
+            shape = tuple(f.data.shape)
+            if len(shape) != 3 or shape[2] != 3 or shape[0] != self.height or shape[1] != self.width:
+                raise ValueError(f"expected ({self.height}, {self.width}, 3), got {shape}")
+            bps = {"rgb8": 1, "rgb16": 2, "rgbf32": 4, "linear_f32": 4}[f.kind]
+            fn = getattr(L, "tm_engine_set_frame_" + f.kind)
+            _chk(fn(h, slot, side, ptr, self.width * 3 * bps, mem), f"tm_engine_set_frame_{f.kind}")
+
+    def set_pair(self, slot: int, fref: HwFrame, fdis: HwFrame):
+        self.set_frame(slot, ffi.TM_SIDE_REF, fref)
+        self.set_frame(slot, ffi.TM_SIDE_DIS, fdis)
+
+    # -- compute ------------------------------------------------------------------------------
+    def compute_async(self, n_slots: Optional[int] = None):
+        _chk(self._L.tm_engine_compute_async(self._h, self.batch if n_slots is None else int(n_slots)), "tm_engine_compute_async")
+
+    def sync(self):
+        _chk(self._L.tm_engine_sync(self._h), "tm_engine_sync")
+
+    def scores(self, slot: int) -> FrameScores:
+        s = ffi.FrameScoresC()
+        _chk(self._L.tm_engine_get_scores(self._h, slot, C.byref(s)), "tm_engine_get_scores")
+        v = s.valid
+        return FrameScores(
+            psnr=s.psnr if v & ffi.TM_METRIC_PSNR else None, ssim=s.ssim if v & ffi.TM_METRIC_SSIM else None,
+            msssim=s.msssim if v & ffi.TM_METRIC_MSSSIM else None,
+            ssimulacra2=s.ssimulacra2 if v & ffi.TM_METRIC_SSIMULACRA2 else None)
+
+    def raw_sums(self, slot: int) -> np.ndarray:
+        out = np.zeros(108, np.float64)
+        _chk(self._L.tm_engine_get_raw_sums(self._h, slot, out.ctypes.data_as(C.POINTER(C.c_double))), "tm_engine_get_raw_sums")
+        return out.reshape(6, 6, 3)
+
+    def sse(self, slot: int) -> int:
+        v = C.c_uint64()
+        _chk(self._L.tm_engine_get_sse(self._h, slot, C.byref(v)), "tm_engine_get_sse")
+        return int(v.value)
+
+    def compute_one(self, fref: HwFrame, fdis: HwFrame) -> FrameScores:
+        """== TurboMetrics::compute_one: convert, compute, block, return FrameScores."""
+        self.set_pair(0, fref, fdis)
+        self.compute_async(1)
+        self.sync()
+        return self.scores(0)
+
+    def compute_all(self, frames_ref: Iterable[HwFrame], frames_dis: Iterable[HwFrame], opts: Options = Options()) -> List[FrameScores]:
+        """== TurboMetrics::compute_all frame selection (lib.rs:385-404), batched over the slots."""
+        it_r, it_d = iter(frames_ref), iter(frames_dis)
+        for _ in range(opts.skip_ref + opts.skip):
+            next(it_r, None)
+        for _ in range(opts.skip_dis + opts.skip):
+            next(it_d, None)
+        out: List[FrameScores] = []
+        decode_count, filled = 0, 0
+
+        def flush():
+            nonlocal filled
+            if filled:
+                self.compute_async(filled)
+                self.sync()
+                out.extend(self.scores(i) for i in range(filled))
+                filled = 0
+
+        for fr, fd in zip(it_r, it_d):
+            if opts.every > 1 and decode_count != 0 and decode_count % opts.every != 0:
+                decode_count += 1
+                continue
+            if opts.frames > 0 and decode_count >= opts.frames:
+                break
+            decode_count += 1
+            self.set_pair(filled, fr, fd)
+            filled += 1
+            if filled == self.batch:
+                flush()
+        flush()
+        return out
+
+    # -- measurement / test hooks -------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        _chk(self._L.tm_engine_set_profiling(self._h, int(on)), "tm_engine_set_profiling")
+
+    def stage_ms(self, reset: bool = False):
+        ms = (C.c_double * ffi.TM_STAGE_COUNT)()
+        n = C.c_uint64()
+        _chk(self._L.tm_engine_get_stage_ms(self._h, ms, C.byref(n), int(reset)), "tm_engine_get_stage_ms")
+        return list(ms), int(n.value)
+
+    def set_variant(self, v: int):
+        _chk(self._L.tm_engine_set_variant(self._h, int(v)), "tm_engine_set_variant")
+
+    def read_plane(self, slot: int, kind: int, scale: int, index: int, channel: int) -> np.ndarray:
+        w, h = self.width, self.height
+        for _ in range(scale):
+            w, h = (w + 1) // 2, (h + 1) // 2
+        transposed = kind in (ffi.TM_PLANE_XYB_T, ffi.TM_PLANE_PASS1_T)
+        out = np.zeros((w, h) if transposed else (h, w), np.float32)
+        _chk(self._L.tm_engine_debug_read_plane(self._h, slot, kind, scale, index, channel,
+                                                out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "tm_engine_debug_read_plane")
+        return out
+
+
+class Ssimulacra2:
+    """Mirror of ssimulacra2_cuda::Ssimulacra2: inputs are LINEAR RGB f32 images (h, w, 3)."""
+
+    def __init__(self, width: int, height: int):
+        self._tm = TurboMetrics(width, height, Metrics(ssimulacra2=True), batch=1)
+
+    def compute_sync(self, ref_linear, dis_linear) -> float:
+        return self._tm.compute_one(HwFrame.linear(ref_linear), HwFrame.linear(dis_linear)).ssimulacra2
+
+    def compute_srgb_sync(self, ref_srgb8, dis_srgb8) -> float:
+        """== compute_from_cpu_srgb_sync (lib.rs:232-266): packed sRGB u8 through the LUT."""
+        return self._tm.compute_one(HwFrame.rgb(np.asarray(ref_srgb8, np.uint8)), HwFrame.rgb(np.asarray(dis_srgb8, np.uint8))).ssimulacra2
+
+    def mem_usage(self) -> int:
+        return self._tm.mem_usage()
+
+    def close(self):
+        self._tm.close()
+
+
+def score_from_sums(sums, width, height) -> float:
+    s = np.ascontiguousarray(np.asarray(sums, np.float64).ravel())
+    return float(ffi.lib().tm_ssimulacra2_score_from_sums(s.ctypes.data_as(C.POINTER(C.c_double)), int(width), int(height)))

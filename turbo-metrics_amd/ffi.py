@@ -1,0 +1,69 @@
+"""ctypes binding of the C ABI (include/turbo_metrics_hip.h).  Loads the in-tree
+libturbometrics_hip.so; raises loudly if it is missing -- there is no fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libturbometrics_hip.so")
+
+TM_OK, TM_ERR_INVALID_ARG, TM_ERR_UNSUPPORTED, TM_ERR_HIP, TM_ERR_OOM, TM_ERR_STATE = range(6)
+TM_METRIC_PSNR, TM_METRIC_SSIM, TM_METRIC_MSSSIM, TM_METRIC_SSIMULACRA2 = 1, 2, 4, 8
+TM_MATRIX_BT709, TM_MATRIX_BT601_525, TM_MATRIX_BT601_625 = 0, 1, 2
+TM_TRANSFER_BT709 = 0
+TM_SIDE_REF, TM_SIDE_DIS = 0, 1
+TM_MEM_HOST, TM_MEM_DEVICE = 0, 1
+TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_COUNT = 0, 1, 2, 3
+TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
+
+
+class FrameScoresC(C.Structure):
+    _fields_ = [("psnr", C.c_double), ("ssim", C.c_double), ("msssim", C.c_double),
+                ("ssimulacra2", C.c_double), ("valid", C.c_uint32)]
+
+
+# every symbol include/turbo_metrics_hip.h declares: name -> (restype, argtypes)
+_vp, _u32, _i, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
+SYMBOLS = {
+    "tm_init": (_i, [_i]),
+    "tm_engine_create": (_i, [C.POINTER(_vp), _u32, _u32, _u32, _u32]),
+    "tm_engine_destroy": (None, [_vp]),
+    "tm_engine_mem_usage": (_sz, [_vp]),
+    "tm_engine_set_frame_nv12": (_i, [_vp, _u32, _i, _vp, _vp, _sz, _i, _i, _i, _i]),
+    "tm_engine_set_frame_p016": (_i, [_vp, _u32, _i, _vp, _vp, _sz, _i, _i, _i, _i]),
+    "tm_engine_set_frame_rgb8": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
+    "tm_engine_set_frame_rgb16": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
+    "tm_engine_set_frame_rgbf32": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
+    "tm_engine_set_frame_linear_f32": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
+    "tm_engine_compute_async": (_i, [_vp, _u32]),
+    "tm_engine_sync": (_i, [_vp]),
+    "tm_engine_get_scores": (_i, [_vp, _u32, C.POINTER(FrameScoresC)]),
+    "tm_engine_get_raw_sums": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
+    "tm_engine_get_sse": (_i, [_vp, _u32, C.POINTER(C.c_uint64)]),
+    "tm_ssimulacra2_score_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
+    "tm_engine_set_profiling": (_i, [_vp, _i]),
+    "tm_engine_get_stage_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), _i]),
+    "tm_engine_set_variant": (_i, [_vp, _i]),
+    "tm_engine_debug_read_plane": (_i, [_vp, _u32, _i, _i, _i, _i, C.POINTER(C.c_float), _sz]),
+    "tm_strerror": (C.c_char_p, [_i]),
+    "tm_last_hip_error": (C.c_char_p, []),
+    "tm_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library with typed entry points."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
