@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first serves the whole process, so load
+# torch's before libturbometrics_hip.so pulls in /opt/rocm's (bench.py does the same).  Tests only use torch
+# as a device allocator for the "frames already in HBM" case.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

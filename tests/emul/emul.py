@@ -18,7 +18,7 @@ def build():
     if os.path.exists(_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(_LIB) for s in _SRCS):
         return _LIB
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-march=x86-64-v3", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
-                           "-shared", "-Wno-unknown-pragmas", "-I", _HERE, "-o", _LIB, _SRCS[0]])
+                           "-shared", "-pthread", "-Wno-unknown-pragmas", "-I", _HERE, "-o", _LIB, _SRCS[0]])
     return _LIB
 
 
@@ -41,10 +41,9 @@ KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 
 class Emulated:
     """Runs the whole generation-0 pipeline for n slots; keeps the arenas for plane inspection."""
 
-    def __init__(self, w, h, frames, lut, coef, want_sse=True):
+    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0):
         """frames: list of (ref, dis) where each is dict(kind=, data=np.ndarray, pitch=, coded_height=, matrix=)."""
         L = C.CDLL(build())
-        assert L.emul_geom_size() == C.sizeof(Geom) or True
         L.emul_geom_size.restype = C.c_size_t
         assert L.emul_geom_size() == C.sizeof(Geom), (L.emul_geom_size(), C.sizeof(Geom))
         self.g = Geom()
@@ -70,7 +69,7 @@ class Emulated:
         lut = np.ascontiguousarray(lut, np.float32); coef = np.ascontiguousarray(coef, np.float32)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         L.emul_pipeline(w, h, n, desc, vp(lut), vp(coef), int(want_sse), vp(self.LIN), vp(self.XYB), vp(self.XYBT), vp(self.V),
-                        vp(self.PART), vp(self.SUMS), vp(self.SSE))
+                        vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant))
         self.w, self.h, self.n = w, h, n
 
     def plane(self, arena, slot, scale, index, channel, transposed=False, per_slot=2):

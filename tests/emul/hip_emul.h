@@ -14,6 +14,11 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __shared__ static
+// a wavefront executes in lockstep on the device; here its 64 lanes are 64 host threads and this is the
+// rendezvous that stands in for that lockstep wherever lanes exchange data through LDS
+void tm_emul_wave_barrier();
+#define __builtin_amdgcn_wave_barrier() tm_emul_wave_barrier()
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct uint3_ { unsigned x, y, z; };

@@ -23,7 +23,37 @@ bool tm_wave_sum_u32(unsigned &v)
     return false;
 }
 
+#include <pthread.h>
+#include <thread>
+#include <vector>
+static pthread_barrier_t g_wave_bar;
+static bool g_lockstep = false;
+void tm_emul_wave_barrier() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
+
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
+
+// one workgroup == one wavefront of 64 lanes running as 64 host threads in lockstep-by-barrier
+template <typename F> static void launch_wave_lockstep(dim3 grid, F f)
+{
+    pthread_barrier_init(&g_wave_bar, nullptr, 64);
+    g_lockstep = true;
+    std::vector<std::thread> th;
+    for (unsigned lane = 0; lane < 64; ++lane)
+        th.emplace_back([=] {
+            gridDim = grid; blockDim = dim3(64);
+            for (unsigned bz = 0; bz < grid.z; ++bz)
+                for (unsigned by = 0; by < grid.y; ++by)
+                    for (unsigned bx = 0; bx < grid.x; ++bx) {
+                        blockIdx = {bx, by, bz}; threadIdx = {lane, 0, 0};
+                        pthread_barrier_wait(&g_wave_bar);
+                        f();
+                        pthread_barrier_wait(&g_wave_bar);
+                    }
+        });
+    for (auto &t : th) t.join();
+    g_lockstep = false;
+    pthread_barrier_destroy(&g_wave_bar);
+}
 
 template <typename F> static void launch(dim3 grid, dim3 block, F f)
 {
@@ -53,7 +83,8 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
 }
 
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, int want_sse,
-                   float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE)
+                   float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
+                   int variant)
 {
     TmGeom g; tm_make_geom(&g, w, h);
     const int qw = (w + 1) / 2, qh = (h + 1) / 2;
@@ -62,7 +93,14 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 6), dim3(64), [&] { tmk::k_downscale(g, s, LIN); });
     for (int s = 0; s < TM_SCALES; ++s)
         launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
-    launch(dim3(g.vblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_v(g, XYB, XYBT, V); });
+    const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
+    switch (variant) {
+    case 0: launch(vgrid, dim3(64), [&] { tmk::k_blur_v(g, XYB, XYBT, V); }); break;
+    case 2: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<32, 32>(g, XYB, XYBT, V); }); break;
+    case 3: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<8, 16>(g, XYB, XYBT, V); }); break;
+    case 4: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 16>(g, XYB, XYBT, V); }); break;
+    default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
+    }
     launch(dim3(g.hblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_h(g, XYBT, V, PART); });
     launch(dim3(n), dim3(128), [&] { tmk::k_finish(g, PART, SUMS); });
 }

@@ -44,14 +44,15 @@ def check_against_oracle(em, frames, w, h):
         assert int(em.SSE[slot]) == sse
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20)])
-def test_nv12_pipeline_matches_oracle(w, h):
+def test_nv12_pipeline_matches_oracle(w, h, variant):
     frames = []
     for n in range(2):
         (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
         frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=n % 3),
                        dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table())
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant)
     check_against_oracle(em, frames, w, h)
 
 

@@ -77,6 +77,22 @@ def test_nv12_planes_and_scores_match_oracle(w, h):
     eng.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_column_pass_generations_are_bit_identical(variant):
+    w, h = 333, 203
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=2)
+    eng.set_variant(variant)
+    frames = [nv12_frames(w, h, n) for n in range(2)]
+    for slot, (fr, fd) in enumerate(frames):
+        eng.set_pair(slot, fr, fd)
+    eng.compute_async()
+    eng.sync()
+    for slot, (fr, fd) in enumerate(frames):
+        lin, sums = check_planes(eng, slot, fr, fd, w, h)
+        check_scores(eng, slot, lin, sums, w, h)
+    eng.close()
+
+
 def test_every_input_kind_matches_oracle():
     w, h = 94, 58
     rng = np.random.default_rng(5)

@@ -99,7 +99,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = 0;
+    int variant = 1;
 };
 
 namespace {
@@ -342,7 +342,7 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || variant < 0 || variant > 0) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || variant > 4) return TM_ERR_INVALID_ARG;
     e->variant = variant;
     return TM_OK;
 }
@@ -378,7 +378,16 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     if (e->profiling) HIPCHK(hipEventRecord(e->ev[1], st));
     if (e->mask & TM_METRIC_SSIMULACRA2) {
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
-        hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, e->XYB, e->XYBT, e->V);
+        {
+            const dim3 vgrid((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n);
+            switch (e->variant) { // column-pass generations; all bit-identical (tests/test_gpu_parity.py)
+            case 0: hipLaunchKernelGGL(tmk::k_blur_v, vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 2: hipLaunchKernelGGL((tmk::k_blur_v_lds<32, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 3: hipLaunchKernelGGL((tmk::k_blur_v_lds<8, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 4: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            }
+        }
         if (e->profiling) HIPCHK(hipEventRecord(e->ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
         hipLaunchKernelGGL(tmk::k_blur_h, dim3((unsigned)g.hblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, e->XYBT, e->V, e->PART);

@@ -281,6 +281,118 @@ __global__ void __launch_bounds__(64) k_blur_v(TmGeom g, const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column pass, generation 1: same arithmetic and same per-lane IIR state as k_blur_v, but the
+// transposition goes through LDS so that HBM only ever sees whole 64-B / 128-B segments.
+// gen 0 stores one float4 (4 rows of one column) per lane: 16-B pieces scattered at pitch_t stride,
+// which the memory side has to merge (measured 0.98 TB/s).  Here every lane drops its 7 per-step values
+// (5 blurred planes + the ref/dis copies) into a [plane][row % R][column] LDS tile (row stride S floats,
+// S chosen so that both the row-wise writes and the column-wise read-back are bank-conflict free:
+// S = 65 / 66 / 68 for R = 32 / 16 / 8); every R steps the wave reads the tile back transposed and
+// stores, per column, R contiguous floats (R*4 bytes: one or half a cache line) with R/4 lanes per column.
+// A wave is its own workgroup and only touches its own tile, so no barrier is needed: LDS operations of
+// one wave execute in issue order.
+// W = register window per input (rows t-10 .. t+W-11): the reference's 11-deep ring plus a W-10 row
+// load prefetch.  The body is unrolled max(W, R) steps so that every window slot and flush point is static.
+// ------------------------------------------------------------------------------------------------
+template <int R> struct BlurVTile {
+    static constexpr int S = R == 32 ? 65 : (R == 16 ? 66 : 68);
+    static constexpr int LPC = R / 4;   // lanes per column in the read-back
+    static constexpr int CPI = 64 / LPC; // columns per store instruction
+};
+
+template <int R, int P0, int NP>
+__device__ __forceinline__ void blur_v_flush(const float *__restrict__ tile, float *const (&dst)[7], int x0, int w,
+                                             int pitch_t, int y0)
+{
+    using TT = BlurVTile<R>;
+    const int lane = threadIdx.x;
+    const int xl = lane / TT::LPC, yq = lane % TT::LPC;
+#pragma unroll
+    for (int p = P0; p < P0 + NP; ++p) {
+        const float *tp = tile + p * R * TT::S + (4 * yq) * TT::S;
+#pragma unroll
+        for (int i = 0; i < 64 / TT::CPI; ++i) {
+            const int xc = i * TT::CPI + xl;
+            const float4 v = make_float4(tp[xc], tp[TT::S + xc], tp[2 * TT::S + xc], tp[3 * TT::S + xc]);
+            if (x0 + xc < w) *(float4 *)(dst[p] + (size_t)(x0 + xc) * pitch_t + y0 + 4 * yq) = v;
+        }
+    }
+}
+
+template <int R, int W>
+__global__ void __launch_bounds__(64) k_blur_v_lds(TmGeom g, const float *__restrict__ XYB, float *__restrict__ XYBT,
+                                                   float *__restrict__ V)
+{
+    using TT = BlurVTile<R>;
+    constexpr int P = W - 10;          // prefetch distance in rows
+    constexpr int U = W > R ? W : R;   // unroll
+    __shared__ float tile[7 * R * TT::S];
+    int b = blockIdx.x, s = 0;
+#pragma unroll
+    for (int i = 1; i < TM_SCALES; ++i)
+        if (b >= g.vblk[i]) s = i;
+    const TmScaleGeom sg = g.s[s];
+    const int x0 = (b - g.vblk[s]) * 64;
+    const int lane = threadIdx.x;
+    const int x = min(x0 + lane, sg.w - 1); // lanes past the right edge shadow the last column; never stored
+    const int c = blockIdx.y, slot = blockIdx.z;
+    const int h = sg.h, pitch = sg.pitch, w = sg.w, pitch_t = sg.pitch_t;
+    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane + x;
+    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane + x;
+    const size_t to = sg.off_t + c * sg.plane_t;
+    float *const dst[7] = {V + (size_t)(slot * 5 + 0) * g.pyr_t + to, V + (size_t)(slot * 5 + 1) * g.pyr_t + to,
+                           V + (size_t)(slot * 5 + 2) * g.pyr_t + to, V + (size_t)(slot * 5 + 3) * g.pyr_t + to,
+                           V + (size_t)(slot * 5 + 4) * g.pyr_t + to, XYBT + (size_t)(slot * 2 + 0) * g.pyr_t + to,
+                           XYBT + (size_t)(slot * 2 + 1) * g.pyr_t + to};
+
+    float wr[W], wd[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        wr[j] = j < P ? ld_row(ref, j, h, pitch) : 0.0f;
+        wd[j] = j < P ? ld_row(dis, j, h, pitch) : 0.0f;
+    }
+    tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
+    const int T = (h + R - 1) / R * R + 4; // run until the last R-row group of outputs is complete
+    for (int t0 = 0; t0 < T; t0 += U) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 + j;
+            const float r = wr[j % W], d = wd[j % W];
+            const float rold = wr[(j + P) % W], dold = wd[(j + P) % W];
+            wr[(j + P) % W] = ld_row(ref, t + P, h, pitch);
+            wd[(j + P) % W] = ld_row(dis, t + P, h, pitch);
+            const float o0 = tmdev::iir_step(f0, rold * rold + r * r);
+            const float o1 = tmdev::iir_step(f1, dold * dold + d * d);
+            const float o2 = tmdev::iir_step(f2, rold * dold + r * d);
+            const float o3 = tmdev::iir_step(f3, rold + r);
+            const float o4 = tmdev::iir_step(f4, dold + d);
+            // output row y = t-4 -> tile row (y mod R); input row t -> tile row (t mod R)
+            float *to_ = tile + (((j + R - 4) % R) * TT::S) + lane;
+            to_[0 * R * TT::S] = o0;
+            to_[1 * R * TT::S] = o1;
+            to_[2 * R * TT::S] = o2;
+            to_[3 * R * TT::S] = o3;
+            to_[4 * R * TT::S] = o4;
+            float *ti_ = tile + ((j % R) * TT::S) + lane;
+            ti_[5 * R * TT::S] = r;
+            ti_[6 * R * TT::S] = d;
+            if ((j + R - 4) % R == R - 1) { // rows y0 .. y0+R-1 of the five blurred planes are complete
+                const int y0 = t - 4 - (R - 1);
+                __builtin_amdgcn_wave_barrier();
+                if (y0 >= 0 && y0 < h) blur_v_flush<R, 0, 5>(tile, dst, x0, w, pitch_t, y0);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (j % R == R - 1) { // input rows r0 .. r0+R-1
+                const int r0 = t - (R - 1);
+                __builtin_amdgcn_wave_barrier();
+                if (r0 < h) blur_v_flush<R, 5, 2>(tile, dst, x0, w, pitch_t, r0);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row pass ("pass 2") fused with the error maps and the reductions: the reference's second
 // blur_plane_pass_fused on the transposed images (lib.rs:368-379), compute_error_maps
 // (error_maps.rs:5-60) and the six nppiSum / two nppiSqr per map (lib.rs:417-447) in one kernel.
