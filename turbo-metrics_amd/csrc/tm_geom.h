@@ -23,7 +23,7 @@ struct TmScaleGeom {
     int pitch;   // floats
     int pitch_t; // floats
     unsigned long long plane;   // h * pitch
-    unsigned long long plane_t; // w * pitch_t
+    unsigned long long plane_t; // round_up(w,64) * pitch_t
     unsigned long long off;     // float offset of this scale inside a normal pyramid
     unsigned long long off_t;   // float offset inside a transposed pyramid
 };
@@ -61,7 +61,7 @@ static inline void tm_make_geom(TmGeom *g, int w, int h)
         s->pitch = tm_round_up(w, 64);
         s->pitch_t = tm_round_up(h, 64);
         s->plane = (unsigned long long)h * s->pitch;
-        s->plane_t = (unsigned long long)w * s->pitch_t;
+        s->plane_t = (unsigned long long)tm_round_up(w, 64) * s->pitch_t; // rows padded: see blur_v_flush
         s->off = off; s->off_t = off_t;
         off += 3 * s->plane; off_t += 3 * s->plane_t;
         g->vblk[i + 1] = g->vblk[i] + (w + 63) / 64;

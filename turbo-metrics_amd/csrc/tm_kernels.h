@@ -301,9 +301,13 @@ template <int R> struct BlurVTile {
 };
 
 template <int R, int P0, int NP>
-__device__ __forceinline__ void blur_v_flush(const float *__restrict__ tile, float *const (&dst)[7], int x0, int w,
+__device__ __forceinline__ void blur_v_flush(const float *__restrict__ tile, float *const (&dst)[7], int x0,
                                              int pitch_t, int y0)
 {
+    // No predicate on purpose: columns past the right edge land in the plane's padding rows (plane_t is
+    // allocated for round_up(w,64) rows) and rows past the bottom in the pitch padding.  Keeping the stores
+    // unconditional keeps the whole loop body one basic block, so the compiler can give every later load an
+    // exact s_waitcnt vmcnt(N) instead of draining the 20+ stores of a flush with vmcnt(0).
     using TT = BlurVTile<R>;
     const int lane = threadIdx.x;
     const int xl = lane / TT::LPC, yq = lane % TT::LPC;
@@ -314,7 +318,7 @@ __device__ __forceinline__ void blur_v_flush(const float *__restrict__ tile, flo
         for (int i = 0; i < 64 / TT::CPI; ++i) {
             const int xc = i * TT::CPI + xl;
             const float4 v = make_float4(tp[xc], tp[TT::S + xc], tp[2 * TT::S + xc], tp[3 * TT::S + xc]);
-            if (x0 + xc < w) *(float4 *)(dst[p] + (size_t)(x0 + xc) * pitch_t + y0 + 4 * yq) = v;
+            *(float4 *)(dst[p] + (size_t)(x0 + xc) * pitch_t + y0 + 4 * yq) = v;
         }
     }
 }
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(64) k_blur_v_lds(TmGeom g, const float *__rest
 {
     using TT = BlurVTile<R>;
     constexpr int P = W - 10;          // prefetch distance in rows
-    constexpr int U = W > R ? W : R;   // unroll
+    constexpr int U = W > R ? W : R;   // unroll (W and R are powers of two, so U is a multiple of both)
     __shared__ float tile[7 * R * TT::S];
     int b = blockIdx.x, s = 0;
 #pragma unroll
@@ -334,9 +338,9 @@ __global__ void __launch_bounds__(64) k_blur_v_lds(TmGeom g, const float *__rest
     const TmScaleGeom sg = g.s[s];
     const int x0 = (b - g.vblk[s]) * 64;
     const int lane = threadIdx.x;
-    const int x = min(x0 + lane, sg.w - 1); // lanes past the right edge shadow the last column; never stored
+    const int x = min(x0 + lane, sg.w - 1); // lanes past the right edge shadow the last column
     const int c = blockIdx.y, slot = blockIdx.z;
-    const int h = sg.h, pitch = sg.pitch, w = sg.w, pitch_t = sg.pitch_t;
+    const int h = sg.h, pitch = sg.pitch, pitch_t = sg.pitch_t;
     const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane + x;
     const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane + x;
     const size_t to = sg.off_t + c * sg.plane_t;
@@ -352,40 +356,54 @@ __global__ void __launch_bounds__(64) k_blur_v_lds(TmGeom g, const float *__rest
         wd[j] = j < P ? ld_row(dis, j, h, pitch) : 0.0f;
     }
     tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
-    const int T = (h + R - 1) / R * R + 4; // run until the last R-row group of outputs is complete
-    for (int t0 = 0; t0 < T; t0 += U) {
+
+    // steps 0..3 have no output row yet (row t-4 < 0): run the recurrences, keep the input copies
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float r = wr[t], d = wd[t];
+        const float rold = wr[(t + P) % W], dold = wd[(t + P) % W];
+        wr[(t + P) % W] = ld_row(ref, t + P, h, pitch);
+        wd[(t + P) % W] = ld_row(dis, t + P, h, pitch);
+        (void)tmdev::iir_step(f0, rold * rold + r * r);
+        (void)tmdev::iir_step(f1, dold * dold + d * d);
+        (void)tmdev::iir_step(f2, rold * dold + r * d);
+        (void)tmdev::iir_step(f3, rold + r);
+        (void)tmdev::iir_step(f4, dold + d);
+        float *ti_ = tile + (t * TT::S) + lane;
+        ti_[5 * R * TT::S] = r;
+        ti_[6 * R * TT::S] = d;
+    }
+    const int T = (h + U - 1) / U * U + 4; // whole U-row groups of outputs; overshoot lands in padding
+    for (int t0 = 4; t0 < T; t0 += U) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int t = t0 + j;
-            const float r = wr[j % W], d = wd[j % W];
-            const float rold = wr[(j + P) % W], dold = wd[(j + P) % W];
-            wr[(j + P) % W] = ld_row(ref, t + P, h, pitch);
-            wd[(j + P) % W] = ld_row(dis, t + P, h, pitch);
+            const int t = t0 + j; // t mod W == (j+4) mod W, (t-4) mod R == j mod R
+            const float r = wr[(j + 4) % W], d = wd[(j + 4) % W];
+            const float rold = wr[(j + 4 + P) % W], dold = wd[(j + 4 + P) % W];
+            wr[(j + 4 + P) % W] = ld_row(ref, t + P, h, pitch);
+            wd[(j + 4 + P) % W] = ld_row(dis, t + P, h, pitch);
             const float o0 = tmdev::iir_step(f0, rold * rold + r * r);
             const float o1 = tmdev::iir_step(f1, dold * dold + d * d);
             const float o2 = tmdev::iir_step(f2, rold * dold + r * d);
             const float o3 = tmdev::iir_step(f3, rold + r);
             const float o4 = tmdev::iir_step(f4, dold + d);
-            // output row y = t-4 -> tile row (y mod R); input row t -> tile row (t mod R)
-            float *to_ = tile + (((j + R - 4) % R) * TT::S) + lane;
+            float *to_ = tile + ((j % R) * TT::S) + lane; // output row y = t-4
             to_[0 * R * TT::S] = o0;
             to_[1 * R * TT::S] = o1;
             to_[2 * R * TT::S] = o2;
             to_[3 * R * TT::S] = o3;
             to_[4 * R * TT::S] = o4;
-            float *ti_ = tile + ((j % R) * TT::S) + lane;
+            float *ti_ = tile + (((j + 4) % R) * TT::S) + lane; // input row t
             ti_[5 * R * TT::S] = r;
             ti_[6 * R * TT::S] = d;
-            if ((j + R - 4) % R == R - 1) { // rows y0 .. y0+R-1 of the five blurred planes are complete
-                const int y0 = t - 4 - (R - 1);
+            if (j % R == R - 1) { // output rows y0 .. y0+R-1 complete
                 __builtin_amdgcn_wave_barrier();
-                if (y0 >= 0 && y0 < h) blur_v_flush<R, 0, 5>(tile, dst, x0, w, pitch_t, y0);
+                blur_v_flush<R, 0, 5>(tile, dst, x0, pitch_t, t - 4 - (R - 1));
                 __builtin_amdgcn_wave_barrier();
             }
-            if (j % R == R - 1) { // input rows r0 .. r0+R-1
-                const int r0 = t - (R - 1);
+            if ((j + 4) % R == R - 1) { // input rows r0 .. r0+R-1 complete
                 __builtin_amdgcn_wave_barrier();
-                if (r0 < h) blur_v_flush<R, 5, 2>(tile, dst, x0, w, pitch_t, r0);
+                blur_v_flush<R, 5, 2>(tile, dst, x0, pitch_t, t - (R - 1));
                 __builtin_amdgcn_wave_barrier();
             }
         }
