@@ -76,7 +76,7 @@ class Emulated:
         sg = self.g.s[scale]
         if transposed:
             base = (slot * per_slot + index) * self.g.pyr_t + sg.off_t + channel * sg.plane_t
-            return arena[base:base + sg.plane_t].reshape(sg.w, sg.pitch_t)[:, :sg.h]
+            return arena[base:base + sg.plane_t].reshape(-1, sg.pitch_t)[:sg.w, :sg.h]
         base = (slot * per_slot + index) * self.g.pyr + sg.off + channel * sg.plane
         return arena[base:base + sg.plane].reshape(sg.h, sg.pitch)[:, :sg.w]
 

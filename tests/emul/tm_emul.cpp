@@ -33,22 +33,23 @@ void tm_emul_wave_barrier() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar);
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
 
 // one workgroup == one wavefront of 64 lanes running as 64 host threads in lockstep-by-barrier
-template <typename F> static void launch_wave_lockstep(dim3 grid, F f)
+template <typename F> static void launch_wave_lockstep(dim3 grid, F f, unsigned nwaves = 1)
 {
     pthread_barrier_init(&g_wave_bar, nullptr, 64);
     g_lockstep = true;
     std::vector<std::thread> th;
     for (unsigned lane = 0; lane < 64; ++lane)
         th.emplace_back([=] {
-            gridDim = grid; blockDim = dim3(64);
+            gridDim = grid; blockDim = dim3(64 * nwaves);
             for (unsigned bz = 0; bz < grid.z; ++bz)
                 for (unsigned by = 0; by < grid.y; ++by)
-                    for (unsigned bx = 0; bx < grid.x; ++bx) {
-                        blockIdx = {bx, by, bz}; threadIdx = {lane, 0, 0};
-                        pthread_barrier_wait(&g_wave_bar);
-                        f();
-                        pthread_barrier_wait(&g_wave_bar);
-                    }
+                    for (unsigned bx = 0; bx < grid.x; ++bx)
+                        for (unsigned wv = 0; wv < nwaves; ++wv) { // waves of a workgroup that never talk: one after the other
+                            blockIdx = {bx, by, bz}; threadIdx = {wv * 64 + lane, 0, 0};
+                            pthread_barrier_wait(&g_wave_bar);
+                            f();
+                            pthread_barrier_wait(&g_wave_bar);
+                        }
         });
     for (auto &t : th) t.join();
     g_lockstep = false;
@@ -99,6 +100,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     case 2: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<32, 32>(g, XYB, XYBT, V); }); break;
     case 3: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<8, 16>(g, XYB, XYBT, V); }); break;
     case 4: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 16>(g, XYB, XYBT, V); }); break;
+    case 5: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 32>(g, XYB, XYBT, V); }, 5); break;
+    case 6: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16>(g, XYB, XYBT, V); }, 5); break;
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
     launch(dim3(g.hblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_h(g, XYBT, V, PART); });

@@ -44,7 +44,7 @@ def check_against_oracle(em, frames, w, h):
         assert int(em.SSE[slot]) == sse
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20)])
 def test_nv12_pipeline_matches_oracle(w, h, variant):
     frames = []

@@ -77,7 +77,7 @@ def test_nv12_planes_and_scores_match_oracle(w, h):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_column_pass_generations_are_bit_identical(variant):
     w, h = 333, 203
     eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=2)

@@ -342,7 +342,7 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || variant < 0 || variant > 4) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || variant > 6) return TM_ERR_INVALID_ARG;
     e->variant = variant;
     return TM_OK;
 }
@@ -385,6 +385,8 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
             case 2: hipLaunchKernelGGL((tmk::k_blur_v_lds<32, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
             case 3: hipLaunchKernelGGL((tmk::k_blur_v_lds<8, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
             case 4: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 5: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 32>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
             }
         }

@@ -411,6 +411,149 @@ __global__ void __launch_bounds__(64) k_blur_v_lds(TmGeom g, const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column pass, generation 2 ("split"): one workgroup = 5 wavefronts = the five blurred planes of one
+// 64-column block; wave `role` runs ONE recurrence (6 state registers) and owns one [32][65] LDS tile
+// (roles mu1/mu2 own a second tile for the transposed ref/dis copy).  Compared with generation 1 this
+//   * flushes R = 32 rows at a time: every store instruction writes whole 128-B lines, which is what the
+//     memory side needs for full write bandwidth (tools/microbench/wrpattern.hip: 64-B runs 3.3 TB/s,
+//     128-B runs 5.4 TB/s, plain fill 5.2 TB/s);
+//   * keeps 10 light waves per CU in flight (2 workgroups x 58 KB LDS) instead of 2-4 heavy ones, each with
+//     its own W-10 row load prefetch;
+//   * re-reads ref/dis from L1/L2 in the waves that share them (3 readers each) -- HBM still sees them once.
+// The five waves never exchange data, so there is no barrier; arithmetic is unchanged (bit-identical).
+// ------------------------------------------------------------------------------------------------
+// row `row` of a plane whose base pointer is wave-uniform: the row address stays in SGPRs and the load uses
+// the scalar-base + per-lane-offset form, so a whole window of in-flight loads costs one VGPR of addressing
+#ifdef TM_EMULATE
+#define TM_GLOBAL_AS
+struct alignas(16) tm_f4 { float x, y, z, w; };
+#else
+#define TM_GLOBAL_AS __attribute__((address_space(1)))
+typedef float tm_f4 __attribute__((ext_vector_type(4))); // plain vector: assignable through address_space(1)
+#endif
+__device__ __forceinline__ tm_f4 tm_make_f4(float a, float b, float c, float d) { tm_f4 v = {a, b, c, d}; return v; }
+template <typename T> __device__ __forceinline__ TM_GLOBAL_AS T *tm_uniform_ptr(T *p)
+{
+    // Pin a wave-uniform pointer into an SGPR pair (and keep it in the global address space).  The empty asm
+    // is opaque to LLVM, which otherwise re-associates base + row*pitch + lane into a per-lane 64-bit address
+    // for every load of the window (2 VGPRs and a v_lshl_add_u64 each) instead of selecting the
+    // scalar-base + 32-bit-lane-offset form of global_load / global_store.
+    unsigned long long v = (unsigned long long)p;
+#ifndef TM_EMULATE
+    asm("" : "+s"(v));
+#endif
+    return (TM_GLOBAL_AS T *)v;
+}
+
+__device__ __forceinline__ float ld_row_u(const float *__restrict__ plane, unsigned xb, int row, int nrows, int pitch)
+{
+    // xb = this lane's BYTE offset inside the row (a zero-extended 32-bit VGPR offset is what the
+    // scalar-base form of global_load takes)
+    const int rc = row < nrows ? row : nrows - 1;
+    TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(plane + (size_t)rc * pitch);
+    const float v = *(TM_GLOBAL_AS const float *)(rowp + xb);
+    return row < nrows ? v : 0.0f;
+}
+
+template <int R, int W, bool TWO, bool COPY>
+__device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, float *__restrict__ tile_copy,
+                                                  const float *__restrict__ pa, const float *__restrict__ pb, unsigned x,
+                                                  float *__restrict__ dst, float *__restrict__ dst_copy, int h, int pitch,
+                                                  int pitch_t, bool product)
+{
+    // pa/pb: wave-uniform input plane bases; x: this lane's column as a BYTE offset; dst/dst_copy: wave-uniform pointers to
+    // transposed row x0 of the output planes
+    using TT = BlurVTile<R>;
+    constexpr int P = W - 10;
+    constexpr int U = W > R ? W : R;
+    const int lane = threadIdx.x & 63;
+    const int xl = lane / TT::LPC, yq = lane % TT::LPC;
+    const unsigned voff = (unsigned)(xl * pitch_t + 4 * yq) * 4u; // per-lane BYTE part of every flush address
+    float wa[W], wb[TWO ? W : 1];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        wa[j] = j < P ? ld_row_u(pa, x, j, h, pitch) : 0.0f;
+        if (TWO) wb[j] = j < P ? ld_row_u(pb, x, j, h, pitch) : 0.0f;
+    }
+    tmdev::Iir f = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { // no output row yet
+        const float a = wa[t], aold = wa[(t + P) % W];
+        const float b = TWO ? wb[t] : a, bold = TWO ? wb[(t + P) % W] : aold;
+        wa[(t + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
+        if (TWO) wb[(t + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+        (void)tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
+    }
+    const int T = (h + U - 1) / U * U + 4;
+    for (int t0 = 4; t0 < T; t0 += U) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int t = t0 + j;
+            const float a = wa[(j + 4) % W], aold = wa[(j + 4 + P) % W];
+            const float b = TWO ? wb[(j + 4) % W] : a, bold = TWO ? wb[(j + 4 + P) % W] : aold;
+            const float a4 = wa[j % W]; // input row t-4 == output row: its transposed copy rides along
+            wa[(j + 4 + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
+            if (TWO) wb[(j + 4 + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+            const float o = tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
+            tile[(j % R) * TT::S + lane] = o;
+            if (COPY) tile_copy[(j % R) * TT::S + lane] = a4;
+            if (j % R == R - 1) {
+                const int y0 = t - 4 - (R - 1);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 64 / TT::CPI; ++i) {
+                    const int xc = i * TT::CPI + xl;
+                    const float *tp = tile + (4 * yq) * TT::S + xc;
+                    TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst + (size_t)(i * TT::CPI) * pitch_t + y0);
+                    *(TM_GLOBAL_AS tm_f4 *)(ub + voff) = tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]);
+                    if (COPY) {
+                        const float *tc = tile_copy + (4 * yq) * TT::S + xc;
+                        TM_GLOBAL_AS char *uc = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst_copy + (size_t)(i * TT::CPI) * pitch_t + y0);
+                        *(TM_GLOBAL_AS tm_f4 *)(uc + voff) = tm_make_f4(tc[0], tc[TT::S], tc[2 * TT::S], tc[3 * TT::S]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+template <int R, int W>
+__global__ void __launch_bounds__(320, 3) k_blur_v_split(TmGeom g, const float *__restrict__ XYB, float *__restrict__ XYBT,
+                                                      float *__restrict__ V)
+{
+    using TT = BlurVTile<R>;
+    __shared__ float tiles[7 * R * TT::S];
+    int b = blockIdx.x, s = 0;
+#pragma unroll
+    for (int i = 1; i < TM_SCALES; ++i)
+        if (b >= g.vblk[i]) s = i;
+    const TmScaleGeom sg = g.s[s];
+    const int x0 = (b - g.vblk[s]) * 64;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u; // byte offset; lanes past the right edge shadow the last column
+    const int c = blockIdx.y, slot = blockIdx.z;
+    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
+    float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
+    float *tile = tiles + role * R * TT::S;
+    // planes (ssimulacra2-cuda/src/lib.rs:299-335): 0 ref*ref, 1 dis*dis, 2 ref*dis, 3 ref, 4 dis
+    if (role == 2) {
+        blur_v_split_role<R, W, true, false>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+    } else if (role < 2) {
+        blur_v_split_role<R, W, false, false>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
+                                              sg.pitch_t, true);
+    } else {
+        const int side = role - 3;
+        float *cdst = XYBT + (size_t)(slot * 2 + side) * g.pyr_t + to;
+        blur_v_split_role<R, W, false, true>(tile, tiles + (5 + side) * R * TT::S, side == 0 ? ref : dis, nullptr, x, vdst, cdst,
+                                             sg.h, sg.pitch, sg.pitch_t, false);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row pass ("pass 2") fused with the error maps and the reductions: the reference's second
 // blur_plane_pass_fused on the transposed images (lib.rs:368-379), compute_error_maps
 // (error_maps.rs:5-60) and the six nppiSum / two nppiSqr per map (lib.rs:417-447) in one kernel.
