@@ -20,6 +20,8 @@
 void tm_emul_wave_barrier();
 #define __builtin_amdgcn_wave_barrier() tm_emul_wave_barrier()
 #define __builtin_amdgcn_readfirstlane(x) (x)
+void tm_emul_syncthreads();
+#define __syncthreads() tm_emul_syncthreads()
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct uint3_ { unsigned x, y, z; };

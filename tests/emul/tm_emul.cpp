@@ -29,8 +29,32 @@ bool tm_wave_sum_u32(unsigned &v)
 static pthread_barrier_t g_wave_bar;
 static bool g_lockstep = false;
 void tm_emul_wave_barrier() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
+void tm_emul_syncthreads() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
 
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
+
+// a whole workgroup of `nthreads` host threads; __syncthreads() is a real barrier
+template <typename F> static void launch_wg_lockstep(dim3 grid, unsigned nthreads, F f)
+{
+    pthread_barrier_init(&g_wave_bar, nullptr, nthreads);
+    g_lockstep = true;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; ++t)
+        th.emplace_back([=] {
+            gridDim = grid; blockDim = dim3(nthreads);
+            for (unsigned bz = 0; bz < grid.z; ++bz)
+                for (unsigned by = 0; by < grid.y; ++by)
+                    for (unsigned bx = 0; bx < grid.x; ++bx) {
+                        blockIdx = {bx, by, bz}; threadIdx = {t, 0, 0};
+                        pthread_barrier_wait(&g_wave_bar);
+                        f();
+                        pthread_barrier_wait(&g_wave_bar);
+                    }
+        });
+    for (auto &x : th) x.join();
+    g_lockstep = false;
+    pthread_barrier_destroy(&g_wave_bar);
+}
 
 // one workgroup == one wavefront of 64 lanes running as 64 host threads in lockstep-by-barrier
 template <typename F> static void launch_wave_lockstep(dim3 grid, F f, unsigned nwaves = 1)
@@ -87,21 +111,28 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
                    int variant)
 {
+    const int ingest_gen = variant >> 8;
+    variant &= 255;
     TmGeom g; tm_make_geom(&g, w, h);
     const int qw = (w + 1) / 2, qh = (h + 1) / 2;
-    launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, LIN, SSE, want_sse); });
-    for (int s = 1; s < TM_SCALES; ++s)
-        launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 6), dim3(64), [&] { tmk::k_downscale(g, s, LIN); });
-    for (int s = 0; s < TM_SCALES; ++s)
-        launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
+    if (ingest_gen == 0) {
+        launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, LIN, SSE, want_sse); });
+        for (int s = 1; s < TM_SCALES; ++s)
+            launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 6), dim3(64), [&] { tmk::k_downscale(g, s, LIN); });
+        for (int s = 0; s < TM_SCALES; ++s)
+            launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
+    } else {
+        launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, XYB, XYBT, SSE, want_sse); });
+    }
     const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
     switch (variant) {
     case 0: launch(vgrid, dim3(64), [&] { tmk::k_blur_v(g, XYB, XYBT, V); }); break;
     case 2: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<32, 32>(g, XYB, XYBT, V); }); break;
     case 3: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<8, 16>(g, XYB, XYBT, V); }); break;
     case 4: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 16>(g, XYB, XYBT, V); }); break;
-    case 5: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 32>(g, XYB, XYBT, V); }, 5); break;
-    case 6: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16>(g, XYB, XYBT, V); }, 5); break;
+    case 5: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 32, true>(g, XYB, XYBT, V); }, 5); break;
+    case 6: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, true>(g, XYB, XYBT, V); }, 5); break;
+    case 7: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false>(g, XYB, XYBT, V); }, 5); break;
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
     launch(dim3(g.hblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_h(g, XYBT, V, PART); });

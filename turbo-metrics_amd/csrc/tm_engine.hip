@@ -99,7 +99,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = 1;
+    int variant = (1 << 8) | 7; // fused ingest + split column pass without copies
 };
 
 namespace {
@@ -256,7 +256,6 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
     const size_t B = batch_capacity;
     const TmGeom &g = e->g;
-    if ((rc = dev_alloc(e, &e->LIN, B * 2 * g.pyr, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->XYBT, B * 2 * g.pyr_t, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
@@ -342,7 +341,13 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || variant < 0 || variant > 6) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || (variant & 255) > 7 || (variant >> 8) > 1) return TM_ERR_INVALID_ARG;
+    if ((variant & 255) == 7 && (variant >> 8) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
+    if ((variant >> 8) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
+        if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+        int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
+        if (rc) return rc;
+    }
     e->variant = variant;
     return TM_OK;
 }
@@ -364,29 +369,33 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * sizeof(unsigned long long), st));
     if (e->profiling) HIPCHK(hipEventRecord(e->ev[0], st));
     // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
-    {
+    if ((e->variant >> 8) == 0) { // generation 0: separate kernels, linear pyramid in HBM (kept as the on-device reference)
         const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
         dim3 grid((unsigned)((qw + 63) / 64), (unsigned)((qh + 3) / 4), (unsigned)n), block(64, 4, 1);
         hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->LIN, e->SSE, want_sse);
-    }
-    if (e->mask & TM_METRIC_SSIMULACRA2) {
-        for (int s = 1; s < TM_SCALES; ++s)
-            hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, e->LIN);
-        for (int s = 0; s < TM_SCALES; ++s)
-            hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, e->LIN, e->XYB);
+        if (e->mask & TM_METRIC_SSIMULACRA2) {
+            for (int s = 1; s < TM_SCALES; ++s)
+                hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, e->LIN);
+            for (int s = 0; s < TM_SCALES; ++s)
+                hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, e->LIN, e->XYB);
+        }
+    } else { // generation 1: one kernel, linear RGB never leaves the CU
+        dim3 grid((unsigned)((e->w + 63) / 64), (unsigned)((e->h + 63) / 64), (unsigned)n);
+        hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->XYB, e->XYBT, e->SSE, want_sse);
     }
     if (e->profiling) HIPCHK(hipEventRecord(e->ev[1], st));
     if (e->mask & TM_METRIC_SSIMULACRA2) {
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         {
             const dim3 vgrid((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n);
-            switch (e->variant) { // column-pass generations; all bit-identical (tests/test_gpu_parity.py)
+            switch (e->variant & 255) { // column-pass generations; all bit-identical (tests/test_gpu_parity.py)
             case 0: hipLaunchKernelGGL(tmk::k_blur_v, vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
             case 2: hipLaunchKernelGGL((tmk::k_blur_v_lds<32, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
             case 3: hipLaunchKernelGGL((tmk::k_blur_v_lds<8, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
             case 4: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 5: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 32>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 5: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 32, true>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
+            case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
             }
         }
@@ -514,6 +523,7 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     case TM_PLANE_LINEAR:
     case TM_PLANE_XYB:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
+        if (kind == TM_PLANE_LINEAR && (!e->LIN || (e->variant >> 8) != 0)) return TM_ERR_STATE; // only the gen-0 ingest stores it
         src = (kind == TM_PLANE_LINEAR ? e->LIN : e->XYB) + (size_t)(slot * 2 + index) * g.pyr + sg.off + channel * sg.plane;
         pitch = sg.pitch; width = sg.w; rows = sg.h;
         break;

@@ -165,6 +165,240 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused ingest (generation 1): decoded frame pair -> linear RGB -> 6-level pyramid -> XYB, in one kernel.
+// Replaces gen 0's k_ingest + 5 x k_downscale + 6 x k_xyb and the whole linear-RGB arena: linear RGB only
+// ever lives in registers / LDS.  HBM traffic is the algorithmic minimum for this stage: the frame surfaces
+// are read once, the XYB pyramid is written once in the normal orientation (for the column pass) and once
+// transposed (for the row pass' edge terms).
+//
+//   workgroup = one 64x64 tile of scale 0 of one slot, both sides (so the PSNR SSE needs no second pass);
+//               64-aligned tiles keep every 2x2 parent block of every level inside the tile
+//   wave      = one 32x32 quadrant;  lane = one 4x4 pixel block:  in BOTH orientations 8 neighbouring lanes
+//               write 8 x 16 B = one full 128-B line
+//   levels 1,2 come straight from the lane's registers (4x4 -> 2x2 -> 1), levels 3..5 (8x8, 4x4, 2x2 per
+//   tile) go through a few hundred bytes of LDS.
+// Arithmetic per pixel is exactly gen 0's (same helper functions); the downscale clamp
+// min(2o+i, size-1) (downscale.rs:24-25) becomes "take the in-range neighbour of the 2x2 block".
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ds4(float v00, float v01, float v10, float v11, bool okx, bool oky)
+{
+    // sum order of downscale.rs:22-30: (iy,ix) = (0,0),(0,1),(1,0),(1,1), starting from 0.0
+    const float b = okx ? v01 : v00;
+    const float c = oky ? v10 : v00;
+    const float d = okx ? (oky ? v11 : v01) : (oky ? v10 : v00);
+    float sum = 0.0f;
+    sum += v00; sum += b; sum += c; sum += d;
+    return sum * 0.25f;
+}
+
+__global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDesc *__restrict__ desc,
+                                                      const float *__restrict__ lut, const float *__restrict__ coef,
+                                                      float *__restrict__ XYB, float *__restrict__ XYBT,
+                                                      unsigned long long *__restrict__ SSE, int want_sse)
+{
+    __shared__ float l2s[3][16][17];
+    __shared__ float l3s[3][8][9];
+    __shared__ float l4s[3][4][5];
+    __shared__ unsigned sse_s[256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bx = (wave & 1) * 8 + (lane & 7), by = (wave >> 1) * 8 + (lane >> 3); // 4x4-block coords in the tile
+    const int slot = blockIdx.z;
+    const int X0 = blockIdx.x * 64 + bx * 4, Y0 = blockIdx.y * 64 + by * 4;
+    const int w = g.s[0].w, h = g.s[0].h;
+    unsigned qref[12];
+    unsigned sse = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) qref[i] = 0;
+
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const TmFrameDesc d = desc[slot * 2 + side];
+        float l0[4][4][3];
+#pragma unroll
+        for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 4; ++ix)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) l0[iy][ix][c] = 0.0f;
+        // ---- level 0: decoded samples -> linear RGB (registers)
+        if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016) {
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                for (int qx = 0; qx < 2; ++qx) {
+                    const int gx = X0 / 2 + qx, gy = Y0 / 2 + qy; // quad coordinates in the image
+                    if (2 * gx + 1 < w && 2 * gy + 1 < h) {
+                        float px[2][2][3];
+                        if (d.kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, gx, gy, px);
+                        else ingest_yuv_quad<unsigned short, 16>(d, coef, gx, gy, px);
+#pragma unroll
+                        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                            for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) l0[2 * qy + iy][2 * qx + ix][c] = px[iy][ix][c];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 4; ++ix) {
+                    const int x = X0 + ix, y = Y0 + iy;
+                    if (x < w && y < h) {
+                        const char *row = (const char *)d.p0 + (size_t)y * d.pitch;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float v;
+                            if (d.kind == TM_KIND_RGB8) v = lut[((const unsigned char *)row)[3 * x + c]];
+                            else if (d.kind == TM_KIND_RGB16)
+                                v = tmdev::srgb_inverse_oetf((float)((const unsigned short *)row)[3 * x + c] / 65535.0f);
+                            else if (d.kind == TM_KIND_RGBF32) v = tmdev::srgb_inverse_oetf(((const float *)row)[3 * x + c]);
+                            else v = ((const float *)row)[3 * x + c];
+                            l0[iy][ix][c] = v;
+                        }
+                    }
+                }
+        }
+        if (want_sse) { // sample_conv.rs:6-35 quantisation; out-of-image samples are 0 on both sides
+#pragma unroll
+            for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 4; ++ix)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int k = (iy * 4 + ix) * 3 + c;
+                        const unsigned q = (unsigned)(int)rintf(l0[iy][ix][c] * 255.0f) & 255u;
+                        if (side == 0) qref[k >> 2] |= q << (8 * (k & 3));
+                        else {
+                            const int dlt = (int)((qref[k >> 2] >> (8 * (k & 3))) & 255u) - (int)q;
+                            sse += (unsigned)(dlt * dlt);
+                        }
+                    }
+        }
+        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
+        float *xybt = XYBT + (size_t)(slot * 2 + side) * g.pyr_t;
+        // ---- level 0 XYB: normal rows (float4 per row) and transposed rows (float4 per column)
+        {
+            const TmScaleGeom sg = g.s[0];
+            float xv[4][4][3];
+#pragma unroll
+            for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 4; ++ix)
+                    tmdev::linear_to_xyb(l0[iy][ix][0], l0[iy][ix][1], l0[iy][ix][2], xv[iy][ix][0], xv[iy][ix][1], xv[iy][ix][2]);
+            if (X0 < w && Y0 < h) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int iy = 0; iy < 4; ++iy)
+                        if (Y0 + iy < h)
+                            *(float4 *)(xyb + sg.off + c * sg.plane + (size_t)(Y0 + iy) * sg.pitch + X0) =
+                                make_float4(xv[iy][0][c], xv[iy][1][c], xv[iy][2][c], xv[iy][3][c]);
+#pragma unroll
+                    for (int ix = 0; ix < 4; ++ix)
+                        if (X0 + ix < w)
+                            *(float4 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(X0 + ix) * sg.pitch_t + Y0) =
+                                make_float4(xv[0][ix][c], xv[1][ix][c], xv[2][ix][c], xv[3][ix][c]);
+                }
+            }
+        }
+        // ---- level 1 (2x2 per lane)
+        float l1[2][2][3];
+        {
+            const TmScaleGeom sg = g.s[1];
+            const int X1 = X0 / 2, Y1 = Y0 / 2;
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    const bool okx = X0 + 2 * ix + 1 < w, oky = Y0 + 2 * iy + 1 < h;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        l1[iy][ix][c] = ds4(l0[2 * iy][2 * ix][c], l0[2 * iy][2 * ix + 1][c], l0[2 * iy + 1][2 * ix][c],
+                                            l0[2 * iy + 1][2 * ix + 1][c], okx, oky);
+                }
+            if (X1 < sg.w && Y1 < sg.h) {
+                float xv[2][2][3];
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix)
+                        tmdev::linear_to_xyb(l1[iy][ix][0], l1[iy][ix][1], l1[iy][ix][2], xv[iy][ix][0], xv[iy][ix][1], xv[iy][ix][2]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int iy = 0; iy < 2; ++iy)
+                        if (Y1 + iy < sg.h)
+                            *(float2 *)(xyb + sg.off + c * sg.plane + (size_t)(Y1 + iy) * sg.pitch + X1) = make_float2(xv[iy][0][c], xv[iy][1][c]);
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix)
+                        if (X1 + ix < sg.w)
+                            *(float2 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(X1 + ix) * sg.pitch_t + Y1) = make_float2(xv[0][ix][c], xv[1][ix][c]);
+                }
+            }
+        }
+        // ---- level 2 (one pixel per lane) -> LDS for the upper levels
+        {
+            const TmScaleGeom sg = g.s[2];
+            const int X2 = X0 / 4, Y2 = Y0 / 4;
+            const bool okx = X0 / 2 + 1 < g.s[1].w, oky = Y0 / 2 + 1 < g.s[1].h;
+            float l2[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                l2[c] = ds4(l1[0][0][c], l1[0][1][c], l1[1][0][c], l1[1][1][c], okx, oky);
+                l2s[c][by][bx] = l2[c];
+            }
+            if (X2 < sg.w && Y2 < sg.h) {
+                float X, Y, B;
+                tmdev::linear_to_xyb(l2[0], l2[1], l2[2], X, Y, B);
+                const size_t o = sg.off + (size_t)Y2 * sg.pitch + X2, ot = sg.off_t + (size_t)X2 * sg.pitch_t + Y2;
+                xyb[o] = X; xyb[o + sg.plane] = Y; xyb[o + 2 * sg.plane] = B;
+                xybt[ot] = X; xybt[ot + sg.plane_t] = Y; xybt[ot + 2 * sg.plane_t] = B;
+            }
+        }
+        __syncthreads();
+        // ---- levels 3, 4, 5: 8x8, 4x4, 2x2 pixels per tile
+#pragma unroll
+        for (int lv = 3; lv < TM_SCALES; ++lv) {
+            const int n = 64 >> lv; // tile edge at this level
+            if (tid < n * n) {
+                const TmScaleGeom sg = g.s[lv], sp = g.s[lv - 1];
+                const int ox = tid % n, oy = tid / n;
+                const int XL = (int)(blockIdx.x * 64 >> lv) + ox, YL = (int)(blockIdx.y * 64 >> lv) + oy;
+                const bool okx = 2 * XL + 1 < sp.w, oky = 2 * YL + 1 < sp.h;
+                float v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (lv == 3) v[c] = ds4(l2s[c][2 * oy][2 * ox], l2s[c][2 * oy][2 * ox + 1], l2s[c][2 * oy + 1][2 * ox], l2s[c][2 * oy + 1][2 * ox + 1], okx, oky);
+                    else if (lv == 4) v[c] = ds4(l3s[c][2 * oy][2 * ox], l3s[c][2 * oy][2 * ox + 1], l3s[c][2 * oy + 1][2 * ox], l3s[c][2 * oy + 1][2 * ox + 1], okx, oky);
+                    else v[c] = ds4(l4s[c][2 * oy][2 * ox], l4s[c][2 * oy][2 * ox + 1], l4s[c][2 * oy + 1][2 * ox], l4s[c][2 * oy + 1][2 * ox + 1], okx, oky);
+                    if (lv == 3) l3s[c][oy][ox] = v[c];
+                    if (lv == 4) l4s[c][oy][ox] = v[c];
+                }
+                if (XL < sg.w && YL < sg.h) {
+                    float X, Y, B;
+                    tmdev::linear_to_xyb(v[0], v[1], v[2], X, Y, B);
+                    const size_t o = sg.off + (size_t)YL * sg.pitch + XL, ot = sg.off_t + (size_t)XL * sg.pitch_t + YL;
+                    xyb[o] = X; xyb[o + sg.plane] = Y; xyb[o + 2 * sg.plane] = B;
+                    xybt[ot] = X; xybt[ot + sg.plane_t] = Y; xybt[ot + 2 * sg.plane_t] = B;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (want_sse) {
+        sse_s[tid] = sse;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 256; ++i) tot += sse_s[i];
+            atomicAdd(&SSE[slot], tot);
+        }
+    }
+}
+
 // downscale_by_2, ssimulacra2-cuda-kernel/src/downscale.rs:5-35, one plane per blockIdx.z
 __global__ void __launch_bounds__(64) k_downscale(TmGeom g, int s, float *__restrict__ LIN)
 {
@@ -518,12 +752,14 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
     }
 }
 
-template <int R, int W>
-__global__ void __launch_bounds__(320, 3) k_blur_v_split(TmGeom g, const float *__restrict__ XYB, float *__restrict__ XYBT,
-                                                      float *__restrict__ V)
+// COPIES = false: the transposed ref/dis copies are already written by k_ingest_fused; 5 tiles (41.6 KB) per
+// workgroup -> 3 workgroups = 15 waves per CU, and the kernel moves exactly the algorithmic 2R + 5W planes.
+template <int R, int W, bool COPIES>
+__global__ void __launch_bounds__(320, COPIES ? 3 : 4) k_blur_v_split(TmGeom g, const float *__restrict__ XYB,
+                                                                      float *__restrict__ XYBT, float *__restrict__ V)
 {
     using TT = BlurVTile<R>;
-    __shared__ float tiles[7 * R * TT::S];
+    __shared__ float tiles[(COPIES ? 7 : 5) * R * TT::S];
     int b = blockIdx.x, s = 0;
 #pragma unroll
     for (int i = 1; i < TM_SCALES; ++i)
@@ -547,9 +783,14 @@ __global__ void __launch_bounds__(320, 3) k_blur_v_split(TmGeom g, const float *
                                               sg.pitch_t, true);
     } else {
         const int side = role - 3;
-        float *cdst = XYBT + (size_t)(slot * 2 + side) * g.pyr_t + to;
-        blur_v_split_role<R, W, false, true>(tile, tiles + (5 + side) * R * TT::S, side == 0 ? ref : dis, nullptr, x, vdst, cdst,
-                                             sg.h, sg.pitch, sg.pitch_t, false);
+        if (COPIES) {
+            float *cdst = XYBT + (size_t)(slot * 2 + side) * g.pyr_t + to;
+            blur_v_split_role<R, W, false, true>(tile, tiles + (COPIES ? 5 + side : 0) * R * TT::S, side == 0 ? ref : dis, nullptr, x,
+                                                 vdst, cdst, sg.h, sg.pitch, sg.pitch_t, false);
+        } else {
+            blur_v_split_role<R, W, false, false>(tile, nullptr, side == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
+                                                  sg.pitch_t, false);
+        }
     }
 }
 
