@@ -15,7 +15,7 @@ SCALES = 6
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("tm_oracle.c", "tm_cpu_path.c", "tm_math.h", "tm_oracle_tables.inc", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("tm_oracle.c", "tm_cpu_path.c", "tm_math.h", "tm_oracle_tables.inc", "tm_math_tables.inc", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if force or stale:

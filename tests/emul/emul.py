@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _LIB = os.path.join(_HERE, "libtm_emul.so")
 _SRCS = [os.path.join(_HERE, "tm_emul.cpp"), os.path.join(_HERE, "hip_emul.h")] + [
-    os.path.join(_ROOT, "turbo-metrics_amd", "csrc", f) for f in ("tm_kernels.h", "tm_device_math.h", "tm_geom.h")]
+    os.path.join(_ROOT, "turbo-metrics_amd", "csrc", f) for f in ("tm_kernels.h", "tm_device_math.h", "tm_geom.h", "tm_math_tables.inc")]
 
 
 def build():
@@ -20,6 +20,15 @@ def build():
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-march=x86-64-v3", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
                            "-shared", "-pthread", "-Wno-unknown-pragmas", "-I", _HERE, "-o", _LIB, _SRCS[0]])
     return _LIB
+
+
+def product_pow_tables():
+    """the 96 doubles of turbo-metrics_amd/csrc/tm_math_tables.inc (rcp, nlog, exp2)"""
+    import re
+    txt = open(os.path.join(_ROOT, "turbo-metrics_amd", "csrc", "tm_math_tables.inc")).read()
+    vals = [float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[-+]?[0-9]+", txt)]
+    assert len(vals) == 96
+    return np.array(vals, np.float64)
 
 
 class ScaleGeom(C.Structure):
@@ -41,7 +50,7 @@ KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 
 class Emulated:
     """Runs the whole generation-0 pipeline for n slots; keeps the arenas for plane inspection."""
 
-    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0):
+    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None):
         """frames: list of (ref, dis) where each is dict(kind=, data=np.ndarray, pitch=, coded_height=, matrix=)."""
         L = C.CDLL(build())
         L.emul_geom_size.restype = C.c_size_t
@@ -67,8 +76,9 @@ class Emulated:
                 else:
                     d.pitch = a.strides[0]; d.p1 = None
         lut = np.ascontiguousarray(lut, np.float32); coef = np.ascontiguousarray(coef, np.float32)
+        powtab = np.ascontiguousarray(product_pow_tables() if powtab is None else powtab, np.float64)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        L.emul_pipeline(w, h, n, desc, vp(lut), vp(coef), int(want_sse), vp(self.LIN), vp(self.XYB), vp(self.XYBT), vp(self.V),
+        L.emul_pipeline(w, h, n, desc, vp(lut), vp(coef), vp(powtab), int(want_sse), vp(self.LIN), vp(self.XYB), vp(self.XYBT), vp(self.V),
                         vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant))
         self.w, self.h, self.n = w, h, n
 

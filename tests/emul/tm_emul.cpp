@@ -107,7 +107,7 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
     out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = n;
 }
 
-void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, int want_sse,
+void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
                    int variant)
 {
@@ -116,13 +116,13 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     TmGeom g; tm_make_geom(&g, w, h);
     const int qw = (w + 1) / 2, qh = (h + 1) / 2;
     if (ingest_gen == 0) {
-        launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, LIN, SSE, want_sse); });
+        launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, tab, LIN, SSE, want_sse); });
         for (int s = 1; s < TM_SCALES; ++s)
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 6), dim3(64), [&] { tmk::k_downscale(g, s, LIN); });
         for (int s = 0; s < TM_SCALES; ++s)
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
     } else {
-        launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, XYB, XYBT, SSE, want_sse); });
+        launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, tab, XYB, XYBT, SSE, want_sse); });
     }
     const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
     switch (variant) {

@@ -3,13 +3,12 @@
 // The reference kernels call two libdevice routines whose bit-level behaviour is NVIDIA's:
 //   __nv_cbrtf     in linear_to_xyb            (ssimulacra2-cuda-kernel/src/xyb.rs:44-46)
 //   __nv_fast_powf in the BT.709 / sRGB EOTFs  (cuda-colorspace-kernel/src/lib.rs:228, srgb.rs:46)
-// Here both are evaluated as a fixed sequence of IEEE-754 binary64 operations (v_fma_f64,
-// v_mul_f64, v_add_f64, one correctly rounded f64 division, v_rndne_f64, integer ops on the
-// exponent field) followed by one rounding to f32.  The result is the correctly rounded f32
-// value (no observed exception), deterministic, and reproducible on any IEEE machine --
-// which is what lets the parity tests demand bit equality for every plane.
-// MI355X runs f64 FMA at half the f32 rate, so the ~25 / ~45 f64 operations per call stay
-// far below the HBM time of the ingest kernel ("ingest").
+// Here both are evaluated as a fixed sequence of IEEE-754 operations (v_fma_f64 / v_mul_f64 / v_add_f64,
+// v_rndne_f64, a few v_fma_f32, integer ops on the exponent field, three 32-entry tables) followed by one
+// rounding to f32.  The result is within 0.50001 ulp of the exact value, deterministic, and reproducible on
+// any IEEE machine -- which is what lets the parity tests demand bit equality for every plane.
+// Cost matters: the ingest kernel is ALU bound (MI355X runs f64 FMA at half the f32 rate), so both
+// routines avoid division and keep the f64 operation count low (pow ~20, cbrt 7 + 15 f32).
 //
 // Must be compiled with -ffp-contract=off: the fma() calls are the only fused operations.
 #pragma once
@@ -25,86 +24,88 @@ namespace tmdev {
 __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
 
-// cube root of a >= 0
+// cube root of a >= 0: exponent-trick seed (3.4 %), three Newton steps on r = a^(-1/3) in f32 (full-rate
+// VALU, -> ~1e-7), one in f64 (-> ~2e-14), a*r^2 rounded once to f32.  7 f64 + 15 f32 operations.
 __device__ __forceinline__ float cbrt_pos(float a)
 {
     if (!(a > 0.0f)) return a;
     const double x = (double)a;
     const uint32_t hi = (uint32_t)(d2u(x) >> 32);
-    // r ~ x^(-1/3) from the exponent field (|rel err| < 3.5 %), then 4 division-free Newton steps
     double r = u2d((uint64_t)(0x553EF000u - hi / 3u) << 32);
     const double third = 0x1.5555555555555p-2;
+    if (a > 1e-18f && a < 1e18f) {
+        float rf = (float)r;
+        const float thirdf = 0x1.555556p-2f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 3; ++i) {
+            const float r3 = (rf * rf) * rf;
+            const float e = __builtin_fmaf(-a, r3, 1.0f);
+            rf = __builtin_fmaf(rf * thirdf, e, rf);
+        }
+        r = (double)rf;
         const double r3 = (r * r) * r;
         const double e = __builtin_fma(-x, r3, 1.0);
         r = __builtin_fma(r * third, e, r);
+    } else { // the f32 steps would overflow out here
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double r3 = (r * r) * r;
+            const double e = __builtin_fma(-x, r3, 1.0);
+            r = __builtin_fma(r * third, e, r);
+        }
     }
     return (float)(x * (r * r));
 }
 
-// x^y, finite x > 0
-__device__ __forceinline__ float pow_pos(float xf, double y)
+// x^y, finite x > 0.  tab: 96 doubles {rcp[32], nlog[32], exp2[32]} (tm_math_tables.inc), normally in LDS.
+// ln x = e ln2 - ln(rcp_i) + log1p(m rcp_i - 1), |r| <= 2^-6, degree-6 series; exp z = 2^n 2^(j/32) exp(rr),
+// |rr| <= ln2/64, degree-5 series.  ~20 f64 operations, no division.
+__device__ __forceinline__ float pow_pos(float xf, double y, const double *__restrict__ tab)
 {
     if (!(xf > 0.0f)) return xf != xf ? xf : 0.0f;
     const double x = (double)xf;
     const uint64_t b = d2u(x);
-    int e = (int)(b >> 52) - 1023;
-    double m = u2d((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
-    if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; e += 1; }
-    const double t = (m - 1.0) / (m + 1.0);
-    const double t2 = t * t;
-    double s = 0x1.8618618618618p-5;
-    s = __builtin_fma(s, t2, 0x1.af286bca1af28p-5);
-    s = __builtin_fma(s, t2, 0x1.e1e1e1e1e1e1ep-5);
-    s = __builtin_fma(s, t2, 0x1.1111111111111p-4);
-    s = __builtin_fma(s, t2, 0x1.3b13b13b13b14p-4);
-    s = __builtin_fma(s, t2, 0x1.745d1745d1746p-4);
-    s = __builtin_fma(s, t2, 0x1.c71c71c71c71cp-4);
-    s = __builtin_fma(s, t2, 0x1.2492492492492p-3);
-    s = __builtin_fma(s, t2, 0x1.999999999999ap-3);
-    s = __builtin_fma(s, t2, 0x1.5555555555555p-2);
-    s = __builtin_fma(s, t2, 1.0);
+    const int e = (int)(b >> 52) - 1023;
+    const int i = (int)(b >> 47) & 31;
+    const double m = u2d((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    const double r = __builtin_fma(m, tab[i], -1.0);
+    double p = __builtin_fma(r, -0x1.5555555555555p-3, 0x1.999999999999ap-3);
+    p = __builtin_fma(p, r, -0.25);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-2);
+    p = __builtin_fma(p, r, -0.5);
+    p = __builtin_fma(p, r, 1.0);
     const double ln2 = 0x1.62e42fefa39efp-1;
-    const double lnx = __builtin_fma((double)e, ln2, (2.0 * t) * s);
+    const double lnx = __builtin_fma((double)e, ln2, tab[32 + i] + r * p);
     const double z = y * lnx;
-    const double n = __builtin_rint(z * 0x1.71547652b82fep+0);
-    const double r = __builtin_fma(-n, ln2, z);
-    double p = 0x1.6124613a86d09p-33;
-    p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);
-    p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);
-    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
-    p = __builtin_fma(p, r, 0x1.1111111111111p-7);
-    p = __builtin_fma(p, r, 0x1.5555555555555p-5);
-    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const long long ni = (long long)n;
-    return (float)u2d(d2u(p) + ((uint64_t)ni << 52));
+    const double k = __builtin_rint(z * 0x1.71547652b82fep+5);
+    const double rr = __builtin_fma(-k, 0x1.62e42fefa39efp-6, z);
+    double q = __builtin_fma(rr, 0x1.1111111111111p-7, 0x1.5555555555555p-5);
+    q = __builtin_fma(q, rr, 0x1.5555555555555p-3);
+    q = __builtin_fma(q, rr, 0.5);
+    q = __builtin_fma(q, rr, 1.0);
+    q = __builtin_fma(q, rr, 1.0);
+    const int ki = (int)k;
+    const double res = q * tab[64 + (ki & 31)];
+    return (float)u2d(d2u(res) + ((uint64_t)(long long)(ki >> 5) << 52));
 }
 
 // BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs)
-__device__ __forceinline__ float bt709_eotf(float v)
+__device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ tab)
 {
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
     const float THRESHOLD = 0.08124285829863521110029445797874f;
-    if (v >= THRESHOLD) return pow_pos((v + (ALPHA - 1.0f)) / ALPHA, (double)(1.0f / 0.45f));
+    if (v >= THRESHOLD) return pow_pos((v + (ALPHA - 1.0f)) / ALPHA, (double)(1.0f / 0.45f), tab);
     return v / 4.5f;
 }
 
 // srgb_inverse_oetf, cuda-colorspace-kernel/src/srgb.rs:40-48
-__device__ __forceinline__ float srgb_inverse_oetf(float x)
+__device__ __forceinline__ float srgb_inverse_oetf(float x, const double *__restrict__ tab)
 {
     const float SRGB_ALPHA = 1.0550107f;
     const float SRGB_BETA = 0.0030412825f;
     if (x < 12.92f * SRGB_BETA) return x / 12.92f;
-    return pow_pos((x + (SRGB_ALPHA - 1.0f)) / SRGB_ALPHA, (double)2.4f);
+    return pow_pos((x + (SRGB_ALPHA - 1.0f)) / SRGB_ALPHA, (double)2.4f, tab);
 }
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }

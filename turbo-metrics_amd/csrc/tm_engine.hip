@@ -21,6 +21,7 @@
 #include "tm_geom.h"
 #include "tm_kernels.h"
 #include "tm_tables.inc"
+#include "tm_math_tables.inc"
 
 namespace {
 
@@ -39,6 +40,7 @@ int hip_fail(hipError_t e, const char *what)
 
 const uint32_t k_lut_bits[256] = {TM_SRGB_LUT_BITS};
 const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
+const double k_powtab[96] = {TM_POW_RCP, TM_POW_NLOG, TM_POW_EXP2};
 
 // ---- colour coefficients: same f32 operation order as the reference's const evaluation -----------
 struct V3 { float x, y, z; };
@@ -90,6 +92,7 @@ struct tm_engine {
     double *h_sums = nullptr;
     unsigned long long *h_sse = nullptr;
     float *d_lut = nullptr, *d_coef = nullptr;
+    double *d_powtab = nullptr;
     std::vector<void *> staging;      // [slot*2+side], lazily allocated
     std::vector<size_t> staging_size;
     size_t mem_bytes = 0;
@@ -253,6 +256,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
     tm_make_geom(&e->g, (int)width, (int)height);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
     const size_t B = batch_capacity;
     const TmGeom &g = e->g;
@@ -265,6 +269,8 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((rc = dev_alloc(e, &e->d_desc, B * 2, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->d_lut, 256, false))) return fail(rc);
     if ((rc = dev_alloc(e, &e->d_coef, 3 * 2 * 5, false))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->d_powtab, 96, false))) return fail(rc);
+    if ((he = hipMemcpy(e->d_powtab, k_powtab, sizeof k_powtab, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(powtab)"));
     float coef[3][2][5];
     for (int m = 0; m < 3; ++m) { yuv_coefficients(m, 8, coef[m][0]); yuv_coefficients(m, 16, coef[m][1]); }
     if ((he = hipMemcpy(e->d_coef, coef, sizeof coef, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(coef)"));
@@ -288,7 +294,7 @@ void tm_engine_destroy(tm_engine *e)
     for (void *p : e->staging) if (p) (void)hipFree(p);
     (void)hipFree(e->LIN); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
-    (void)hipFree(e->d_lut); (void)hipFree(e->d_coef);
+    (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab);
     if (e->h_desc) (void)hipHostFree(e->h_desc);
     if (e->h_sums) (void)hipHostFree(e->h_sums);
     if (e->h_sse) (void)hipHostFree(e->h_sse);
@@ -372,7 +378,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     if ((e->variant >> 8) == 0) { // generation 0: separate kernels, linear pyramid in HBM (kept as the on-device reference)
         const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
         dim3 grid((unsigned)((qw + 63) / 64), (unsigned)((qh + 3) / 4), (unsigned)n), block(64, 4, 1);
-        hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->LIN, e->SSE, want_sse);
+        hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->d_powtab, e->LIN, e->SSE, want_sse);
         if (e->mask & TM_METRIC_SSIMULACRA2) {
             for (int s = 1; s < TM_SCALES; ++s)
                 hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, e->LIN);
@@ -381,7 +387,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
         }
     } else { // generation 1: one kernel, linear RGB never leaves the CU
         dim3 grid((unsigned)((e->w + 63) / 64), (unsigned)((e->h + 63) / 64), (unsigned)n);
-        hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->XYB, e->XYBT, e->SSE, want_sse);
+        hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->d_powtab, e->XYB, e->XYBT, e->SSE, want_sse);
     }
     if (e->profiling) HIPCHK(hipEventRecord(e->ev[1], st));
     if (e->mask & TM_METRIC_SSIMULACRA2) {

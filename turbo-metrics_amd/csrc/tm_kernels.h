@@ -55,8 +55,8 @@ __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, in
 // coef: [matrix 0..2][bits 8|16][5] = y, r, b, g1, g2 coefficients (lib.rs:186-200), host computed.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BITS>
-__device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const float *__restrict__ coef, int qx,
-                                                int qy, float (&px)[2][2][3])
+__device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const float *__restrict__ coef,
+                                                const double *__restrict__ tab, int qx, int qy, float (&px)[2][2][3])
 {
     const float *k = coef + (d.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
     const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
@@ -74,17 +74,17 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
         for (int ix = 0; ix < 2; ++ix) {
             const unsigned ys = yrow[ix];
             const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
-            px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_));
-            px[iy][ix][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_));
-            px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_));
+            px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
+            px[iy][ix][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
+            px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
         }
     }
 }
 
 __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__restrict__ desc,
                                                 const float *__restrict__ lut, const float *__restrict__ coef,
-                                                float *__restrict__ LIN, unsigned long long *__restrict__ SSE,
-                                                int want_sse)
+                                                const double *__restrict__ tab, float *__restrict__ LIN,
+                                                unsigned long long *__restrict__ SSE, int want_sse)
 {
     const int qx = blockIdx.x * 64 + threadIdx.x;
     const int qy = blockIdx.y * 4 + threadIdx.y;
@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
         if (inside) {
             if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016) {
                 if (2 * qx + 1 < w && 2 * qy + 1 < h) {
-                    if (d.kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, qx, qy, px);
-                    else ingest_yuv_quad<unsigned short, 16>(d, coef, qx, qy, px);
+                    if (d.kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, qx, qy, px);
+                    else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, qx, qy, px);
                 }
             } else {
 #pragma unroll
@@ -121,9 +121,9 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
                                 float v;
                                 if (d.kind == TM_KIND_RGB8) v = lut[((const unsigned char *)row)[3 * x + c]];
                                 else if (d.kind == TM_KIND_RGB16)
-                                    v = tmdev::srgb_inverse_oetf((float)((const unsigned short *)row)[3 * x + c] / 65535.0f);
+                                    v = tmdev::srgb_inverse_oetf((float)((const unsigned short *)row)[3 * x + c] / 65535.0f, tab);
                                 else if (d.kind == TM_KIND_RGBF32)
-                                    v = tmdev::srgb_inverse_oetf(((const float *)row)[3 * x + c]);
+                                    v = tmdev::srgb_inverse_oetf(((const float *)row)[3 * x + c], tab);
                                 else v = ((const float *)row)[3 * x + c];
                                 px[iy][ix][c] = v;
                             }
@@ -194,9 +194,11 @@ __device__ __forceinline__ float ds4(float v00, float v01, float v10, float v11,
 
 __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDesc *__restrict__ desc,
                                                       const float *__restrict__ lut, const float *__restrict__ coef,
-                                                      float *__restrict__ XYB, float *__restrict__ XYBT,
-                                                      unsigned long long *__restrict__ SSE, int want_sse)
+                                                      const double *__restrict__ gtab, float *__restrict__ XYB,
+                                                      float *__restrict__ XYBT, unsigned long long *__restrict__ SSE,
+                                                      int want_sse)
 {
+    __shared__ double tab[96]; // pow tables: 32 entries x 8 B = one LDS bank row each, conflict-free for any index mix
     __shared__ float l2s[3][16][17];
     __shared__ float l3s[3][8][9];
     __shared__ float l4s[3][4][5];
@@ -210,6 +212,8 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
     unsigned sse = 0;
 #pragma unroll
     for (int i = 0; i < 12; ++i) qref[i] = 0;
+    if (tid < 96) tab[tid] = gtab[tid];
+    __syncthreads();
 
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
@@ -230,8 +234,8 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
                     const int gx = X0 / 2 + qx, gy = Y0 / 2 + qy; // quad coordinates in the image
                     if (2 * gx + 1 < w && 2 * gy + 1 < h) {
                         float px[2][2][3];
-                        if (d.kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, gx, gy, px);
-                        else ingest_yuv_quad<unsigned short, 16>(d, coef, gx, gy, px);
+                        if (d.kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, gx, gy, px);
+                        else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, gx, gy, px);
 #pragma unroll
                         for (int iy = 0; iy < 2; ++iy)
 #pragma unroll
@@ -253,8 +257,8 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
                             float v;
                             if (d.kind == TM_KIND_RGB8) v = lut[((const unsigned char *)row)[3 * x + c]];
                             else if (d.kind == TM_KIND_RGB16)
-                                v = tmdev::srgb_inverse_oetf((float)((const unsigned short *)row)[3 * x + c] / 65535.0f);
-                            else if (d.kind == TM_KIND_RGBF32) v = tmdev::srgb_inverse_oetf(((const float *)row)[3 * x + c]);
+                                v = tmdev::srgb_inverse_oetf((float)((const unsigned short *)row)[3 * x + c] / 65535.0f, tab);
+                            else if (d.kind == TM_KIND_RGBF32) v = tmdev::srgb_inverse_oetf(((const float *)row)[3 * x + c], tab);
                             else v = ((const float *)row)[3 * x + c];
                             l0[iy][ix][c] = v;
                         }
