@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (w, h, kind, default batch, BASELINE.json config it implements)
     "1080p_nv12": (1920, 1080, "nv12", 32, "configs[1]: synthetic 1080p yuv420p frame-pair stream, SSIMULACRA2"),
-    "4k_p016": (3840, 2160, "p016", 8, "configs[2]: synthetic 4K yuv420p10 stream, SSIMULACRA2"),
+    "4k_p016": (3840, 2160, "p016", 16, "configs[2]: synthetic 4K yuv420p10 stream, SSIMULACRA2"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec; 6.29 TB/s measured copy ceiling)
 
