@@ -119,16 +119,12 @@ def main():
 
     # ---- the single collective of the path: per-frame scores reduced (sum) to rank 0
     scores_local = np.array([eng.scores(i).ssimulacra2 or 0.0 for i in range(B)], np.float64)
+    lo, hi = tm.shard.shard_range(world * B, rank, world)  # this rank's block of the stream: [rank*B, (rank+1)*B)
+    all_scores = tm.shard.reduce_scores(scores_local, lo, world * B, 1, dist, "cuda" if dist is not None else "cpu")
     if dist is not None:
-        t = torch.zeros(world * B, dtype=torch.float64, device="cuda")
-        t[rank * B:(rank + 1) * B] = torch.from_numpy(scores_local).cuda()
-        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        all_scores = t.cpu().numpy()
-    else:
-        all_scores = scores_local
 
     if rank == 0:
         pairs = world * B * args.steps

@@ -724,6 +724,11 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
     }
     const int T = (h + U - 1) / U * U + 4;
     for (int t0 = 4; t0 < T; t0 += U) {
+        // Keep the five role-waves of the workgroup within one iteration of each other: they read the same
+        // ref/dis rows (3 readers each), and only while they stay close do the 2nd and 3rd reader hit L1/L2
+        // (rocprofv3 FETCH_SIZE showed ~2.6x the algorithmic read bytes without this).  A bare s_barrier: no
+        // data is exchanged, so nothing has to be drained (no vmcnt(0) as __syncthreads would add).
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int t = t0 + j;
