@@ -42,6 +42,10 @@ def lib():
         L.tmo_score_from_sums.restype = C.c_double; L.tmo_score_from_sums.argtypes = [dp, C.c_int, C.c_int]
         L.tmo_ssimulacra2_from_linear.restype = C.c_double
         L.tmo_ssimulacra2_from_linear.argtypes = [fp, fp, C.c_int, C.c_int, dp]
+        L.tmo_cpu_path_score_linear.restype = C.c_double
+        L.tmo_cpu_path_score_linear.argtypes = [fp, fp, C.c_int, C.c_int]
+        L.tmo_cpu_path_score_srgb8.restype = C.c_double
+        L.tmo_cpu_path_score_srgb8.argtypes = [vp, vp, C.c_int, C.c_int]
         L.tmo_yuv420_biplanar_to_linear.restype = C.c_int
         L.tmo_yuv420_biplanar_to_linear.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, fp]
     return _lib
@@ -243,3 +247,19 @@ def ssimulacra2_from_linear(ref_lin, dis_lin):
     sums = np.zeros(108, np.float64)
     s = lib().tmo_ssimulacra2_from_linear(_fp(ref_lin), _fp(dis_lin), w, h, _dp(sums))
     return float(s), sums.reshape(6, 6, 3)
+
+
+def cpu_path_score_linear(ref_lin, dis_lin):
+    """Restated reference CPU path (examples/cpu.rs) on planar linear RGB (3, h, w)."""
+    ref_lin = np.ascontiguousarray(ref_lin, np.float32)
+    dis_lin = np.ascontiguousarray(dis_lin, np.float32)
+    _, h, w = ref_lin.shape
+    return float(lib().tmo_cpu_path_score_linear(_fp(ref_lin), _fp(dis_lin), w, h))
+
+
+def cpu_path_score_srgb8(ref_rgb, dis_rgb):
+    """Restated reference CPU path on packed sRGB u8 images (h, w, 3): CpuImg::from_srgb + compute_frame_ssimulacra2."""
+    ref_rgb = np.ascontiguousarray(ref_rgb, np.uint8)
+    dis_rgb = np.ascontiguousarray(dis_rgb, np.uint8)
+    h, w, _ = ref_rgb.shape
+    return float(lib().tmo_cpu_path_score_srgb8(ref_rgb.ctypes.data_as(C.c_void_p), dis_rgb.ctypes.data_as(C.c_void_p), w, h))

@@ -114,3 +114,15 @@ def test_yuv_matrix_constants():
 def test_oracle_header_declares_role():
     src = open(os.path.join(ROOT, "oracle", "tm_oracle.c")).read()
     assert "TEST INFRASTRUCTURE ONLY" in src and "parity unpinned" in src
+
+
+def test_cpu_path_restatement_properties():
+    # examples/cpu.rs restated (oracle/tm_cpu_path.c): identical inputs -> exactly 100 (f64 maps, unlike the GPU
+    # arithmetic), and it agrees with the GPU-arithmetic oracle within the reference's own 0.25 band
+    # (examples/compare.rs:72) on an image large enough for all six scales
+    from tm_pkg import tm
+    r8, d8 = tm.synth.rgb8_pair(320, 256)
+    assert O.cpu_path_score_srgb8(r8, r8) == 100.0
+    c = O.cpu_path_score_srgb8(r8, d8)
+    g, _ = O.ssimulacra2_from_linear(O.rgb8_to_linear(r8), O.rgb8_to_linear(d8))
+    assert 0.0 < c < 100.0 and abs(c - g) < 0.25
