@@ -26,9 +26,15 @@ bool tm_wave_sum_u32(unsigned &v)
 #include <pthread.h>
 #include <thread>
 #include <vector>
-static pthread_barrier_t g_wave_bar;
-static bool g_lockstep = false;
-void tm_emul_wave_barrier() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
+static pthread_barrier_t g_wave_bar;       // all host threads of the workgroup (__syncthreads)
+static pthread_barrier_t g_per_wave_bar[16]; // the 64 host threads of one wavefront (wave-synchronous code)
+static bool g_lockstep = false, g_per_wave = false;
+void tm_emul_wave_barrier()
+{
+    if (!g_lockstep) return;
+    if (g_per_wave) pthread_barrier_wait(&g_per_wave_bar[threadIdx.x >> 6]);
+    else pthread_barrier_wait(&g_wave_bar);
+}
 void tm_emul_syncthreads() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
 
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
@@ -37,7 +43,8 @@ void tm_emul_syncthreads() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); 
 template <typename F> static void launch_wg_lockstep(dim3 grid, unsigned nthreads, F f)
 {
     pthread_barrier_init(&g_wave_bar, nullptr, nthreads);
-    g_lockstep = true;
+    for (unsigned i = 0; i < nthreads / 64; ++i) pthread_barrier_init(&g_per_wave_bar[i], nullptr, 64);
+    g_lockstep = true; g_per_wave = true;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nthreads; ++t)
         th.emplace_back([=] {
@@ -52,8 +59,9 @@ template <typename F> static void launch_wg_lockstep(dim3 grid, unsigned nthread
                     }
         });
     for (auto &x : th) x.join();
-    g_lockstep = false;
+    g_lockstep = false; g_per_wave = false;
     pthread_barrier_destroy(&g_wave_bar);
+    for (unsigned i = 0; i < nthreads / 64; ++i) pthread_barrier_destroy(&g_per_wave_bar[i]);
 }
 
 // one workgroup == one wavefront of 64 lanes running as 64 host threads in lockstep-by-barrier
@@ -121,8 +129,16 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 6), dim3(64), [&] { tmk::k_downscale(g, s, LIN); });
         for (int s = 0; s < TM_SCALES; ++s)
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
-    } else {
+    } else if (ingest_gen == 1) {
         launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, tab, XYB, XYBT, SSE, want_sse); });
+    } else {
+        std::vector<float> yuvlut((size_t)3 * 2 * 65536);
+        launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
+        launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n), 256, [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
+          switch (kind) {
+          case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, SSE, want_sse); break;
+          case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, SSE, want_sse); break;
+          default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, SSE, want_sse); break; } } });
     }
     const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
     switch (variant) {

@@ -57,18 +57,19 @@ def test_nv12_pipeline_matches_oracle(w, h, variant):
     check_against_oracle(em, frames, w, h)
 
 
+@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (127, 63)])
-def test_fused_ingest_matches_oracle(w, h):
+def test_fused_ingest_matches_oracle(w, h, gen):
     frames = []
     for n in range(2):
         (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
         frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=n % 3),
                        dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=256 + 7)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 7)
     check_against_oracle(em, frames, w, h, have_linear=False)
 
 
-@pytest.mark.parametrize("variant", [0, 256 + 7])
+@pytest.mark.parametrize("variant", [0, 256 + 7, 512 + 7])
 def test_p016_and_rgb_kinds_match_oracle(variant):
     w, h = 46, 30
     (rs, rp, rch), (ds, dp, dch) = tm.synth.p016_pair(w, h, 3)

@@ -21,13 +21,22 @@
 
 namespace tmdev {
 
+#ifdef TM_EXP_NOINLINE
+#define TM_MATH_INLINE __attribute__((noinline))
+#else
+#define TM_MATH_INLINE __forceinline__
+#endif
+
 __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
 
 // cube root of a >= 0: exponent-trick seed (3.4 %), three Newton steps on r = a^(-1/3) in f32 (full-rate
 // VALU, -> ~1e-7), one in f64 (-> ~2e-14), a*r^2 rounded once to f32.  7 f64 + 15 f32 operations.
-__device__ __forceinline__ float cbrt_pos(float a)
+__device__ TM_MATH_INLINE float cbrt_pos(float a)
 {
+#ifdef TM_EXP_NOCBRT
+    return a * 0.5f + 0.1f;
+#endif
     if (!(a > 0.0f)) return a;
     const double x = (double)a;
     const uint32_t hi = (uint32_t)(d2u(x) >> 32);
@@ -60,8 +69,11 @@ __device__ __forceinline__ float cbrt_pos(float a)
 // x^y, finite x > 0.  tab: 96 doubles {rcp[32], nlog[32], exp2[32]} (tm_math_tables.inc), normally in LDS.
 // ln x = e ln2 - ln(rcp_i) + log1p(m rcp_i - 1), |r| <= 2^-6, degree-6 series; exp z = 2^n 2^(j/32) exp(rr),
 // |rr| <= ln2/64, degree-5 series.  ~20 f64 operations, no division.
-__device__ __forceinline__ float pow_pos(float xf, double y, const double *__restrict__ tab)
+__device__ TM_MATH_INLINE float pow_pos(float xf, double y, const double *__restrict__ tab)
 {
+#ifdef TM_EXP_NOPOW
+    return xf * xf;
+#endif
     if (!(xf > 0.0f)) return xf != xf ? xf : 0.0f;
     const double x = (double)xf;
     const uint64_t b = d2u(x);

@@ -84,7 +84,8 @@ struct tm_engine {
     int device = 0;
     uint32_t w = 0, h = 0, mask = 0, cap = 0;
     TmGeom g{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_pipe[4] = {};
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr;
     double *PART = nullptr, *SUMS = nullptr;
     unsigned long long *SSE = nullptr;
@@ -93,6 +94,7 @@ struct tm_engine {
     unsigned long long *h_sse = nullptr;
     float *d_lut = nullptr, *d_coef = nullptr;
     double *d_powtab = nullptr;
+    float *d_yuvlut = nullptr; // [matrix 3][R|B][Y<<8|C]: memoised 8-bit YUV -> linear R,B (k_build_yuv_lut)
     std::vector<void *> staging;      // [slot*2+side], lazily allocated
     std::vector<size_t> staging_size;
     size_t mem_bytes = 0;
@@ -102,7 +104,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = (1 << 8) | 7; // fused ingest + split column pass without copies
+    int variant = (2 << 8) | 7; // tile32 fused ingest + split column pass without copies
 };
 
 namespace {
@@ -275,6 +277,9 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     for (int m = 0; m < 3; ++m) { yuv_coefficients(m, 8, coef[m][0]); yuv_coefficients(m, 16, coef[m][1]); }
     if ((he = hipMemcpy(e->d_coef, coef, sizeof coef, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(coef)"));
     if ((he = hipMemcpy(e->d_lut, k_lut_bits, sizeof k_lut_bits, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(lut)"));
+    if ((rc = dev_alloc(e, &e->d_yuvlut, (size_t)3 * 2 * 65536, false))) return fail(rc);
+    hipLaunchKernelGGL(tmk::k_build_yuv_lut, dim3(256, 2, 3), dim3(256), 0, e->stream, e->d_coef, e->d_powtab, e->d_yuvlut);
+    if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(hip_fail(he, "k_build_yuv_lut"));
     if ((he = hipHostMalloc((void **)&e->h_desc, B * 2 * sizeof(TmFrameDesc), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     if ((he = hipHostMalloc((void **)&e->h_sums, B * 108 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     if ((he = hipHostMalloc((void **)&e->h_sse, B * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
@@ -283,6 +288,9 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     e->staging_size.assign(B * 2, 0);
     for (int i = 0; i <= TM_STAGE_COUNT; ++i)
         if ((he = hipEventCreate(&e->ev[i])) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
+    if ((he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
+    for (int i = 0; i < 4; ++i)
+        if ((he = hipEventCreateWithFlags(&e->ev_pipe[i], hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     *out = e;
     return TM_OK;
 }
@@ -291,10 +299,12 @@ void tm_engine_destroy(tm_engine *e)
 {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
+    for (int i = 0; i < 4; ++i) if (e->ev_pipe[i]) (void)hipEventDestroy(e->ev_pipe[i]);
     for (void *p : e->staging) if (p) (void)hipFree(p);
     (void)hipFree(e->LIN); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
-    (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab);
+    (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab); (void)hipFree(e->d_yuvlut);
     if (e->h_desc) (void)hipHostFree(e->h_desc);
     if (e->h_sums) (void)hipHostFree(e->h_sums);
     if (e->h_sse) (void)hipHostFree(e->h_sse);
@@ -347,14 +357,88 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || variant < 0 || (variant & 255) > 7 || (variant >> 8) > 1) return TM_ERR_INVALID_ARG;
-    if ((variant & 255) == 7 && (variant >> 8) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
-    if ((variant >> 8) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
+    // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off)
+    if (!e || variant < 0 || (variant & 255) > 7 || (variant >> 8 & 255) > 2 || (variant >> 20) != 0) return TM_ERR_INVALID_ARG;
+    if ((variant & 255) == 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
+    if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
         int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
         if (rc) return rc;
     }
     e->variant = variant;
+    return TM_OK;
+}
+
+// Launch the whole pipeline for slots [slot0, slot0 + n) on stream `st`.  Every arena is slot-major, so a
+// chunk is just the same kernels on offset base pointers.  ev (optional): 4 events bracketing the 3 stages.
+// ev_ingest_done (optional): recorded right after the ingest stage (lets the next chunk's ingest start).
+static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want_sse, hipEvent_t *ev, hipEvent_t ev_ingest_done)
+{
+    const TmGeom &g = e->g;
+    const TmFrameDesc *h_desc = e->h_desc + (size_t)slot0 * 2;
+    const TmFrameDesc *d_desc = e->d_desc + (size_t)slot0 * 2;
+    float *XYB = e->XYB + (size_t)slot0 * 2 * g.pyr, *XYBT = e->XYBT + (size_t)slot0 * 2 * g.pyr_t;
+    float *V = e->V + (size_t)slot0 * 5 * g.pyr_t;
+    float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
+    double *PART = e->PART + (size_t)slot0 * 3 * g.hblk[TM_SCALES] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
+    unsigned long long *SSE = e->SSE + slot0;
+    if (ev) HIPCHK(hipEventRecord(ev[0], st));
+    // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
+    if ((e->variant >> 8 & 255) == 0) { // generation 0: separate kernels, linear pyramid in HBM (kept as the on-device reference)
+        const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
+        dim3 grid((unsigned)((qw + 63) / 64), (unsigned)((qh + 3) / 4), (unsigned)n), block(64, 4, 1);
+        hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, LIN, SSE, want_sse);
+        if (e->mask & TM_METRIC_SSIMULACRA2) {
+            for (int s = 1; s < TM_SCALES; ++s)
+                hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, LIN);
+            for (int s = 0; s < TM_SCALES; ++s)
+                hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, LIN, XYB);
+        }
+    } else if ((e->variant >> 8 & 255) == 1) { // generation 1: one kernel, 64x64 tiles, 4x4 pixels per lane
+        dim3 grid((unsigned)((e->w + 63) / 64), (unsigned)((e->h + 63) / 64), (unsigned)n);
+        hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, XYB, XYBT, SSE, want_sse);
+    } else { // generation 2: 32x32 tiles, one quad per lane, LDS-staged stores
+        dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
+        int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
+        for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
+#define TM_LAUNCH_T32(K) hipLaunchKernelGGL((tmk::k_ingest_tile32<K>), grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, XYBT, SSE, want_sse)
+        switch (kind) {
+        case TM_KIND_NV12: TM_LAUNCH_T32(TM_KIND_NV12); break;
+        case TM_KIND_P016: TM_LAUNCH_T32(TM_KIND_P016); break;
+        case TM_KIND_RGB8: TM_LAUNCH_T32(TM_KIND_RGB8); break;
+        case TM_KIND_RGB16: TM_LAUNCH_T32(TM_KIND_RGB16); break;
+        case TM_KIND_RGBF32: TM_LAUNCH_T32(TM_KIND_RGBF32); break;
+        case TM_KIND_LINEARF32: TM_LAUNCH_T32(TM_KIND_LINEARF32); break;
+        default: TM_LAUNCH_T32(-1); break;
+        }
+#undef TM_LAUNCH_T32
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[1], st));
+    if (ev_ingest_done) HIPCHK(hipEventRecord(ev_ingest_done, st));
+    if (e->mask & TM_METRIC_SSIMULACRA2) {
+        // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
+        {
+            const dim3 vgrid((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n);
+            switch (e->variant & 255) { // column-pass generations; all bit-identical (tests/test_gpu_parity.py)
+            case 0: hipLaunchKernelGGL(tmk::k_blur_v, vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
+            case 2: hipLaunchKernelGGL((tmk::k_blur_v_lds<32, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
+            case 3: hipLaunchKernelGGL((tmk::k_blur_v_lds<8, 16>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
+            case 4: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 16>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
+            case 5: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 32, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
+            case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
+            case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
+            default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
+            }
+        }
+        if (ev) HIPCHK(hipEventRecord(ev[2], st));
+        // ---- stage BLUR_H: row pass + error maps + reductions
+        hipLaunchKernelGGL(tmk::k_blur_h, dim3((unsigned)g.hblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYBT, V, PART);
+        if (ev) HIPCHK(hipEventRecord(ev[3], st));
+        hipLaunchKernelGGL(tmk::k_finish, dim3((unsigned)n), dim3(128), 0, st, g, PART, SUMS);
+    } else if (ev) {
+        HIPCHK(hipEventRecord(ev[2], st));
+        HIPCHK(hipEventRecord(ev[3], st));
+    }
     return TM_OK;
 }
 
@@ -367,57 +451,39 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
         int rc = tm_engine_sync(e);
         if (rc) return rc;
     }
-    const TmGeom &g = e->g;
     hipStream_t st = e->stream;
     const int n = (int)n_slots;
     HIPCHK(hipMemcpyAsync(e->d_desc, e->h_desc, (size_t)n * 2 * sizeof(TmFrameDesc), hipMemcpyHostToDevice, st));
     const int want_sse = (e->mask & TM_METRIC_PSNR) ? 1 : 0;
     if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * sizeof(unsigned long long), st));
-    if (e->profiling) HIPCHK(hipEventRecord(e->ev[0], st));
-    // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
-    if ((e->variant >> 8) == 0) { // generation 0: separate kernels, linear pyramid in HBM (kept as the on-device reference)
-        const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
-        dim3 grid((unsigned)((qw + 63) / 64), (unsigned)((qh + 3) / 4), (unsigned)n), block(64, 4, 1);
-        hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->d_powtab, e->LIN, e->SSE, want_sse);
-        if (e->mask & TM_METRIC_SSIMULACRA2) {
-            for (int s = 1; s < TM_SCALES; ++s)
-                hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, e->LIN);
-            for (int s = 0; s < TM_SCALES; ++s)
-                hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, e->LIN, e->XYB);
+    int chunks = (e->variant >> 16) & 15;
+    if (chunks < 1) chunks = 1;
+    if (chunks > n) chunks = n;
+    if (chunks == 1) {
+        int rc = launch_chunk(e, st, 0, n, want_sse, e->profiling ? e->ev : nullptr, nullptr);
+        if (rc) return rc;
+    } else {
+        // Software pipeline over chunks of slots on two streams: chunk i+1's ingest (ALU bound) starts as soon as
+        // chunk i's ingest is done and runs beside chunk i's blur passes (HBM bound).  Stage events are not
+        // recorded in this mode (stages overlap).
+        HIPCHK(hipEventRecord(e->ev_pipe[0], st)); // descriptors + SSE reset are visible
+        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_pipe[0], 0));
+        const int per = (n + chunks - 1) / chunks;
+        int i = 0;
+        for (int s0 = 0; s0 < n; s0 += per, ++i) {
+            hipStream_t cs = (i & 1) ? e->stream2 : st;
+            if (i > 0) HIPCHK(hipStreamWaitEvent(cs, e->ev_pipe[1 + ((i - 1) & 1)], 0));
+            int rc = launch_chunk(e, cs, s0, (s0 + per <= n) ? per : n - s0, want_sse, nullptr, e->ev_pipe[1 + (i & 1)]);
+            if (rc) return rc;
         }
-    } else { // generation 1: one kernel, linear RGB never leaves the CU
-        dim3 grid((unsigned)((e->w + 63) / 64), (unsigned)((e->h + 63) / 64), (unsigned)n);
-        hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, e->d_desc, e->d_lut, e->d_coef, e->d_powtab, e->XYB, e->XYBT, e->SSE, want_sse);
+        HIPCHK(hipEventRecord(e->ev_pipe[3], e->stream2));
+        HIPCHK(hipStreamWaitEvent(st, e->ev_pipe[3], 0));
     }
-    if (e->profiling) HIPCHK(hipEventRecord(e->ev[1], st));
-    if (e->mask & TM_METRIC_SSIMULACRA2) {
-        // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
-        {
-            const dim3 vgrid((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n);
-            switch (e->variant & 255) { // column-pass generations; all bit-identical (tests/test_gpu_parity.py)
-            case 0: hipLaunchKernelGGL(tmk::k_blur_v, vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 2: hipLaunchKernelGGL((tmk::k_blur_v_lds<32, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 3: hipLaunchKernelGGL((tmk::k_blur_v_lds<8, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 4: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 16>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 5: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 32, true>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, e->XYB, e->XYBT, e->V); break;
-            }
-        }
-        if (e->profiling) HIPCHK(hipEventRecord(e->ev[2], st));
-        // ---- stage BLUR_H: row pass + error maps + reductions
-        hipLaunchKernelGGL(tmk::k_blur_h, dim3((unsigned)g.hblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, e->XYBT, e->V, e->PART);
-        if (e->profiling) HIPCHK(hipEventRecord(e->ev[3], st));
-        hipLaunchKernelGGL(tmk::k_finish, dim3((unsigned)n), dim3(128), 0, st, g, e->PART, e->SUMS);
+    if (e->mask & TM_METRIC_SSIMULACRA2)
         HIPCHK(hipMemcpyAsync(e->h_sums, e->SUMS, (size_t)n * 108 * sizeof(double), hipMemcpyDeviceToHost, st));
-    } else if (e->profiling) {
-        HIPCHK(hipEventRecord(e->ev[2], st));
-        HIPCHK(hipEventRecord(e->ev[3], st));
-    }
     if (want_sse) HIPCHK(hipMemcpyAsync(e->h_sse, e->SSE, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
-    e->ev_pending = e->profiling;
+    e->ev_pending = e->profiling && chunks == 1;
     e->last_n = n_slots;
     e->in_flight = true;
     e->have_results = false;
@@ -529,7 +595,7 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     case TM_PLANE_LINEAR:
     case TM_PLANE_XYB:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
-        if (kind == TM_PLANE_LINEAR && (!e->LIN || (e->variant >> 8) != 0)) return TM_ERR_STATE; // only the gen-0 ingest stores it
+        if (kind == TM_PLANE_LINEAR && (!e->LIN || (e->variant >> 8 & 255) != 0)) return TM_ERR_STATE; // only the gen-0 ingest stores it
         src = (kind == TM_PLANE_LINEAR ? e->LIN : e->XYB) + (size_t)(slot * 2 + index) * g.pyr + sg.off + channel * sg.plane;
         pitch = sg.pitch; width = sg.w; rows = sg.h;
         break;

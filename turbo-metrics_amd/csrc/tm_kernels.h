@@ -35,6 +35,15 @@ __device__ __forceinline__ bool tm_wave_sum_u32(unsigned &v)
 }
 #endif
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding GLOBAL
+// store of the wave (s_waitcnt vmcnt(0)); the ingest kernel only ever exchanges data through LDS, and
+// waiting ~2 us for store acknowledgements at each of its 12 barriers was most of a workgroup's lifetime.
+#ifdef TM_EMULATE
+#define TM_LDS_BARRIER() __syncthreads()
+#else
+#define TM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 namespace tmk {
 
 __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, int nrows, int pitch)
@@ -54,31 +63,59 @@ __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, in
 //   quantise   sample_conv.rs:6-35 (float2uint_rn(v*255))
 // coef: [matrix 0..2][bits 8|16][5] = y, r, b, g1, g2 coefficients (lib.rs:186-200), host computed.
 // ------------------------------------------------------------------------------------------------
+// R and B of an 8-bit frame depend on two 8-bit samples each ((Y,Cr) and (Y,Cb)): k_build_yuv_lut memoises
+// clamp01(eotf(luma(Y) + coeff*(C-128))) -- evaluated by the very same device functions, so the values are
+// bit-identical -- in two 256x256 f32 tables per matrix (512 KB, L2 resident).  Two gathers replace two
+// pow + two IEEE divisions per pixel; G (three samples) is still evaluated.  rb == nullptr: no table.
 template <typename T, int BITS>
 __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const float *__restrict__ coef,
-                                                const double *__restrict__ tab, int qx, int qy, float (&px)[2][2][3])
+                                                const double *__restrict__ tab, int qx, int qy, float (&px)[2][2][3],
+                                                const float *__restrict__ rb = nullptr)
 {
     const float *k = coef + (d.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
     const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
     const int neutral = 1 << (BITS - 1);
     const unsigned ymin = 16u << (BITS - 8);
-    const float cb = (float)((int)uv[0] - neutral);
-    const float cr = (float)((int)uv[1] - neutral);
+    // all six samples of the quad are fetched before any is used: one exposed latency instead of six
+    const T *yrow0 = (const T *)((const char *)d.p0 + (size_t)(2 * qy) * d.pitch) + 2 * qx;
+    const T *yrow1 = (const T *)((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch) + 2 * qx;
+    const unsigned ucb = uv[0], ucr = uv[1];
+    const unsigned yv[2][2] = {{yrow0[0], yrow0[1]}, {yrow1[0], yrow1[1]}};
+    const float cb = (float)((int)ucb - neutral);
+    const float cr = (float)((int)ucr - neutral);
     const float r_ = k[1] * cr;
     const float g_ = __builtin_fmaf(k[3], cb, k[4] * cr);
     const float b_ = k[2] * cb;
 #pragma unroll
     for (int iy = 0; iy < 2; ++iy) {
-        const T *yrow = (const T *)((const char *)d.p0 + (size_t)(2 * qy + iy) * d.pitch) + 2 * qx;
 #pragma unroll
         for (int ix = 0; ix < 2; ++ix) {
-            const unsigned ys = yrow[ix];
+            const unsigned ys = yv[iy][ix];
             const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
-            px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
             px[iy][ix][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
-            px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
+            if (BITS == 8 && rb != nullptr) {
+                const float *t = rb + (size_t)d.matrix * 2 * 65536;
+                px[iy][ix][0] = t[(ys << 8) | ucr];
+                px[iy][ix][2] = t[65536 + ((ys << 8) | ucb)];
+            } else {
+                px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
+                px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
+            }
         }
     }
+}
+
+// out[matrix][0][Y<<8|Cr] = R, out[matrix][1][Y<<8|Cb] = B of an 8-bit limited-range sample pair; grid (256, 2, 3) x 256
+__global__ void __launch_bounds__(256) k_build_yuv_lut(const float *__restrict__ coef, const double *__restrict__ tab,
+                                                       float *__restrict__ out)
+{
+    const int c = threadIdx.x, y = blockIdx.x, which = blockIdx.y, matrix = blockIdx.z;
+    const float *k = coef + (matrix * 2 + 0) * 5;
+    const unsigned ys = (unsigned)y, ymin = 16u;
+    const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
+    const float ch = (float)(c - 128);
+    const float add = (which == 0 ? k[1] : k[2]) * ch; // r_ = r_coeff*cr, b_ = b_coeff*cb (biplanar.rs:36-38)
+    out[((size_t)matrix * 2 + which) * 65536 + ((y << 8) | c)] = tmdev::clamp01(tmdev::bt709_eotf(luma + add, tab));
 }
 
 __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__restrict__ desc,
@@ -395,6 +432,207 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
     if (want_sse) {
         sse_s[tid] = sse;
         __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 256; ++i) tot += sse_s[i];
+            atomicAdd(&SSE[slot], tot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused ingest, generation 2 ("tile32"): same job and same arithmetic as k_ingest_fused, restructured
+// after measuring it: generation 1 keeps a 4x4 pixel block per lane in registers, which unrolls into
+// ~27 000 instructions (~190 KB of code: several times the instruction cache, and 5x more instruction
+// bytes than data bytes per wave) at 238 VGPRs / 2 waves per SIMD.  Here a lane owns ONE 2x2 quad (the
+// unit the reference's NV12 kernel works on), the workgroup a 32x32 tile; XYB goes through a 12 KB LDS
+// tile so that both orientations are stored as float4 with 8 lanes per 128-B line; levels 1..5 of the
+// pyramid (16, 8, 4, 2, 1 pixels per tile edge) go through a few KB of LDS.  ~3 000 instructions, < 100
+// VGPRs, so 5+ workgroups per CU hide each other's load latency, barriers and the thin upper levels.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, const float *__restrict__ lut,
+                                              const double *__restrict__ tab, int x, int y, float (&v)[3])
+{
+    const char *row = (const char *)d.p0 + (size_t)y * d.pitch;
+    if (kind == TM_KIND_RGB8) { // all three samples first, then the LUT gathers: one wait instead of three
+        const unsigned char *p = (const unsigned char *)row + 3 * x;
+        const unsigned a = p[0], b = p[1], c = p[2];
+        v[0] = lut[a]; v[1] = lut[b]; v[2] = lut[c];
+    } else if (kind == TM_KIND_RGB16) {
+        const unsigned short *p = (const unsigned short *)row + 3 * x;
+        const float a = (float)p[0], b = (float)p[1], c = (float)p[2];
+        v[0] = tmdev::srgb_inverse_oetf(a / 65535.0f, tab);
+        v[1] = tmdev::srgb_inverse_oetf(b / 65535.0f, tab);
+        v[2] = tmdev::srgb_inverse_oetf(c / 65535.0f, tab);
+    } else {
+        const float *p = (const float *)row + 3 * x;
+        const float a = p[0], b = p[1], c = p[2];
+        if (kind == TM_KIND_RGBF32) {
+            v[0] = tmdev::srgb_inverse_oetf(a, tab); v[1] = tmdev::srgb_inverse_oetf(b, tab); v[2] = tmdev::srgb_inverse_oetf(c, tab);
+        } else { v[0] = a; v[1] = b; v[2] = c; }
+    }
+}
+
+__device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__restrict__ xybt, const TmScaleGeom &sg,
+                                             int X, int Y, const float (&lin)[3])
+{
+    if (X < sg.w && Y < sg.h) {
+        float a, b, c;
+        tmdev::linear_to_xyb(lin[0], lin[1], lin[2], a, b, c);
+        const size_t o = sg.off + (size_t)Y * sg.pitch + X, ot = sg.off_t + (size_t)X * sg.pitch_t + Y;
+        xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c;
+        xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c;
+    }
+}
+
+// LDS working set of k_ingest_tile32 (one side at a time; double buffering it and finishing the upper levels on a
+// designated wave was measured slower: 42 KB per workgroup cost a workgroup of occupancy)
+struct IngestSideLds {
+    float t0[3][32][33];   // level-0 XYB tile
+    float t1[3][16][17];   // level-1 XYB tile
+    float lin1[3][16][17]; // level-1 .. level-4 linear RGB
+    float lin2[3][8][9];
+    float lin3[3][4][5];
+    float lin4[3][2][3];
+};
+
+// KIND >= 0: every frame of the launch has this TM_KIND_* (the normal case; the host checks), so all format
+// branches fold away and the sample loads of a quad are issued back to back; KIND = -1: per-frame dispatch.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_ingest_tile32(TmGeom g, const TmFrameDesc *__restrict__ desc,
+                                                       const float *__restrict__ lut, const float *__restrict__ coef,
+                                                       const double *__restrict__ gtab, const float *__restrict__ yuvlut,
+                                                       float *__restrict__ XYB, float *__restrict__ XYBT,
+                                                       unsigned long long *__restrict__ SSE, int want_sse)
+{
+    __shared__ double tab[96];
+    __shared__ IngestSideLds L;
+    __shared__ unsigned sse_s[256];
+    const int tid = threadIdx.x;
+    const int qx = tid & 15, qy = tid >> 4; // quad inside the tile
+    const int slot = blockIdx.z;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+    const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
+    const int w = g.s[0].w, h = g.s[0].h;
+    unsigned qref[3] = {0, 0, 0};
+    unsigned sse = 0;
+    if (tid < 96) tab[tid] = gtab[tid];
+    TM_LDS_BARRIER();
+
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const TmFrameDesc d = desc[slot * 2 + side];
+        const int kind = KIND >= 0 ? KIND : d.kind;
+        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
+        float *xybt = XYBT + (size_t)(slot * 2 + side) * g.pyr_t;
+        // ---- the lane's quad -> linear RGB
+        float px[2][2][3];
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
+        if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
+            if (X0 + 1 < w && Y0 + 1 < h) { // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
+                if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px, yuvlut);
+                else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
+            }
+        } else {
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix)
+                    if (X0 + ix < w && Y0 + iy < h) ingest_px_rgb(d, kind, lut, tab, X0 + ix, Y0 + iy, px[iy][ix]);
+        }
+        if (want_sse) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const unsigned q = (unsigned)(int)rintf(px[k / 6][(k / 3) & 1][k % 3] * 255.0f) & 255u;
+                if (side == 0) qref[k >> 2] |= q << (8 * (k & 3));
+                else {
+                    const int dlt = (int)((qref[k >> 2] >> (8 * (k & 3))) & 255u) - (int)q;
+                    sse += (unsigned)(dlt * dlt);
+                }
+            }
+        }
+        // ---- level-0 XYB into the LDS tile, level-1 linear pixel of this quad and its XYB
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                float a, b, c;
+                tmdev::linear_to_xyb(px[iy][ix][0], px[iy][ix][1], px[iy][ix][2], a, b, c);
+                L.t0[0][2 * qy + iy][2 * qx + ix] = a;
+                L.t0[1][2 * qy + iy][2 * qx + ix] = b;
+                L.t0[2][2 * qy + iy][2 * qx + ix] = c;
+            }
+        {
+            const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
+            float l1[3], a, b, c;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                l1[ch] = ds4(px[0][0][ch], px[0][1][ch], px[1][0][ch], px[1][1][ch], okx, oky);
+                L.lin1[ch][qy][qx] = l1[ch];
+            }
+            tmdev::linear_to_xyb(l1[0], l1[1], l1[2], a, b, c);
+            L.t1[0][qy][qx] = a; L.t1[1][qy][qx] = b; L.t1[2][qy][qx] = c;
+        }
+        TM_LDS_BARRIER();
+        // ---- level 0 out of the tile: float4 per lane, 8 lanes per 128-B line, both orientations
+        {
+            const TmScaleGeom sg = g.s[0];
+            const int r = tid >> 3, q4 = (tid & 7) * 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (ty0 + r < h && tx0 + q4 < w)
+                    *(float4 *)(xyb + sg.off + c * sg.plane + (size_t)(ty0 + r) * sg.pitch + tx0 + q4) =
+                        make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
+                if (tx0 + r < w && ty0 + q4 < h)
+                    *(float4 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(tx0 + r) * sg.pitch_t + ty0 + q4) =
+                        make_float4(L.t0[c][q4][r], L.t0[c][q4 + 1][r], L.t0[c][q4 + 2][r], L.t0[c][q4 + 3][r]);
+            }
+        }
+        // ---- level 1 out of its tile (16 px = 64 B per row of the tile)
+        if (tid < 192) {
+            const TmScaleGeom sg = g.s[1];
+            const int c = tid >> 6, r = (tid & 63) >> 2, q4 = (tid & 3) * 4;
+            const int x1 = tx0 / 2, y1 = ty0 / 2;
+            if (y1 + r < sg.h && x1 + q4 < sg.w)
+                *(float4 *)(xyb + sg.off + c * sg.plane + (size_t)(y1 + r) * sg.pitch + x1 + q4) =
+                    make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
+            if (x1 + r < sg.w && y1 + q4 < sg.h)
+                *(float4 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(x1 + r) * sg.pitch_t + y1 + q4) =
+                    make_float4(L.t1[c][q4][r], L.t1[c][q4 + 1][r], L.t1[c][q4 + 2][r], L.t1[c][q4 + 3][r]);
+        }
+        // ---- levels 2..5: 8x8, 4x4, 2x2, 1 pixel(s) per tile
+#pragma unroll
+        for (int lv = 2; lv < TM_SCALES; ++lv) {
+            const int n = 32 >> lv;
+            if (tid < n * n) {
+                const TmScaleGeom sp = g.s[lv - 1];
+                const int ox = tid % n, oy = tid / n;
+                const int XL = (tx0 >> lv) + ox, YL = (ty0 >> lv) + oy;
+                const bool okx = 2 * XL + 1 < sp.w, oky = 2 * YL + 1 < sp.h;
+                float v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (lv == 2) v[c] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox], L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
+                    else if (lv == 3) v[c] = ds4(L.lin2[c][2 * oy][2 * ox], L.lin2[c][2 * oy][2 * ox + 1], L.lin2[c][2 * oy + 1][2 * ox], L.lin2[c][2 * oy + 1][2 * ox + 1], okx, oky);
+                    else if (lv == 4) v[c] = ds4(L.lin3[c][2 * oy][2 * ox], L.lin3[c][2 * oy][2 * ox + 1], L.lin3[c][2 * oy + 1][2 * ox], L.lin3[c][2 * oy + 1][2 * ox + 1], okx, oky);
+                    else v[c] = ds4(L.lin4[c][0][0], L.lin4[c][0][1], L.lin4[c][1][0], L.lin4[c][1][1], okx, oky);
+                    if (lv == 2) L.lin2[c][oy][ox] = v[c];
+                    if (lv == 3) L.lin3[c][oy][ox] = v[c];
+                    if (lv == 4) L.lin4[c][oy][ox] = v[c];
+                }
+                store_xyb_px(xyb, xybt, g.s[lv], XL, YL, v);
+            }
+            TM_LDS_BARRIER();
+        }
+    }
+    if (want_sse) {
+        sse_s[tid] = sse;
+        TM_LDS_BARRIER();
         if (tid == 0) {
             unsigned long long tot = 0;
             for (int i = 0; i < 256; ++i) tot += sse_s[i];

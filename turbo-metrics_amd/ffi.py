@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libturbometrics_hip.so")
+LIB_PATH = os.environ.get("TM_HIP_LIB") or os.path.join(_HERE, "libturbometrics_hip.so")  # override: experiment builds only
 
 TM_OK, TM_ERR_INVALID_ARG, TM_ERR_UNSUPPORTED, TM_ERR_HIP, TM_ERR_OOM, TM_ERR_STATE = range(6)
 TM_METRIC_PSNR, TM_METRIC_SSIM, TM_METRIC_MSSSIM, TM_METRIC_SSIMULACRA2 = 1, 2, 4, 8
