@@ -39,7 +39,7 @@ static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v
 static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 using std::min;
 using std::max;
-static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // lanes of one wave run back to back (x fastest), so a running total per wave is enough
 bool tm_wave_sum6(double (&a)[6]);

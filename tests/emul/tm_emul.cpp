@@ -133,12 +133,14 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, tab, XYB, XYBT, SSE, want_sse); });
     } else {
         std::vector<float> yuvlut((size_t)3 * 2 * 65536);
+        std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
         launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
         launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n), 256, [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
           switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, SSE, want_sse); break;
-          case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, SSE, want_sse); break;
-          default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, SSE, want_sse); break; } } });
+          case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse); break;
+          case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse); break;
+          default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse); break; } } });
+        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, XYBT); });
     }
     const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
     switch (variant) {

@@ -87,6 +87,7 @@ struct tm_engine {
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_pipe[4] = {};
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr;
+    float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_tile32 -> k_ingest_upper
     double *PART = nullptr, *SUMS = nullptr;
     unsigned long long *SSE = nullptr;
     TmFrameDesc *d_desc = nullptr, *h_desc = nullptr;
@@ -263,6 +264,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     const size_t B = batch_capacity;
     const TmGeom &g = e->g;
     if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->LIN2, B * 2 * 3 * g.s[2].plane, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->XYBT, B * 2 * g.pyr_t, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
@@ -302,7 +304,7 @@ void tm_engine_destroy(tm_engine *e)
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
     for (int i = 0; i < 4; ++i) if (e->ev_pipe[i]) (void)hipEventDestroy(e->ev_pipe[i]);
     for (void *p : e->staging) if (p) (void)hipFree(p);
-    (void)hipFree(e->LIN); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
+    (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
     (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab); (void)hipFree(e->d_yuvlut);
     if (e->h_desc) (void)hipHostFree(e->h_desc);
@@ -380,6 +382,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     float *XYB = e->XYB + (size_t)slot0 * 2 * g.pyr, *XYBT = e->XYBT + (size_t)slot0 * 2 * g.pyr_t;
     float *V = e->V + (size_t)slot0 * 5 * g.pyr_t;
     float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
+    float *LIN2 = e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane;
     double *PART = e->PART + (size_t)slot0 * 3 * g.hblk[TM_SCALES] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
     unsigned long long *SSE = e->SSE + slot0;
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
@@ -401,7 +404,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_T32(K) hipLaunchKernelGGL((tmk::k_ingest_tile32<K>), grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, XYBT, SSE, want_sse)
+#define TM_LAUNCH_T32(K) hipLaunchKernelGGL((tmk::k_ingest_tile32<K>), grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, XYBT, LIN2, SSE, want_sse)
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_T32(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_T32(TM_KIND_P016); break;
@@ -412,6 +415,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         default: TM_LAUNCH_T32(-1); break;
         }
 #undef TM_LAUNCH_T32
+        hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     if (ev_ingest_done) HIPCHK(hipEventRecord(ev_ingest_done, st));

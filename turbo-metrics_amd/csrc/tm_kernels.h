@@ -490,10 +490,7 @@ __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__r
 struct IngestSideLds {
     float t0[3][32][33];   // level-0 XYB tile
     float t1[3][16][17];   // level-1 XYB tile
-    float lin1[3][16][17]; // level-1 .. level-4 linear RGB
-    float lin2[3][8][9];
-    float lin3[3][4][5];
-    float lin4[3][2][3];
+    float lin1[3][16][17]; // level-1 linear RGB
 };
 
 // KIND >= 0: every frame of the launch has this TM_KIND_* (the normal case; the host checks), so all format
@@ -503,7 +500,8 @@ __global__ void __launch_bounds__(256) k_ingest_tile32(TmGeom g, const TmFrameDe
                                                        const float *__restrict__ lut, const float *__restrict__ coef,
                                                        const double *__restrict__ gtab, const float *__restrict__ yuvlut,
                                                        float *__restrict__ XYB, float *__restrict__ XYBT,
-                                                       unsigned long long *__restrict__ SSE, int want_sse)
+                                                       float *__restrict__ LIN2, unsigned long long *__restrict__ SSE,
+                                                       int want_sse)
 {
     __shared__ double tab[96];
     __shared__ IngestSideLds L;
@@ -605,39 +603,95 @@ __global__ void __launch_bounds__(256) k_ingest_tile32(TmGeom g, const TmFrameDe
                 *(float4 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(x1 + r) * sg.pitch_t + y1 + q4) =
                     make_float4(L.t1[c][q4][r], L.t1[c][q4 + 1][r], L.t1[c][q4 + 2][r], L.t1[c][q4 + 3][r]);
         }
-        // ---- levels 2..5: 8x8, 4x4, 2x2, 1 pixel(s) per tile
+        // ---- level-2 LINEAR pixels of this tile (8x8) go to HBM: levels 2..5 are finished by k_ingest_upper.
+        // (Doing them here cost four more barriers per side with 3/4 .. 255/256 of the workgroup idle.)
+        if (tid < 64) {
+            const TmScaleGeom s1 = g.s[1], s2 = g.s[2];
+            const int ox = tid & 7, oy = tid >> 3;
+            const int XL = (tx0 >> 2) + ox, YL = (ty0 >> 2) + oy;
+            if (XL < s2.w && YL < s2.h) {
+                const bool okx = 2 * XL + 1 < s1.w, oky = 2 * YL + 1 < s1.h;
+                float *l2 = LIN2 + (size_t)(slot * 2 + side) * 3 * s2.plane + (size_t)YL * s2.pitch + XL;
 #pragma unroll
-        for (int lv = 2; lv < TM_SCALES; ++lv) {
-            const int n = 32 >> lv;
-            if (tid < n * n) {
-                const TmScaleGeom sp = g.s[lv - 1];
-                const int ox = tid % n, oy = tid / n;
-                const int XL = (tx0 >> lv) + ox, YL = (ty0 >> lv) + oy;
-                const bool okx = 2 * XL + 1 < sp.w, oky = 2 * YL + 1 < sp.h;
-                float v[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (lv == 2) v[c] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox], L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
-                    else if (lv == 3) v[c] = ds4(L.lin2[c][2 * oy][2 * ox], L.lin2[c][2 * oy][2 * ox + 1], L.lin2[c][2 * oy + 1][2 * ox], L.lin2[c][2 * oy + 1][2 * ox + 1], okx, oky);
-                    else if (lv == 4) v[c] = ds4(L.lin3[c][2 * oy][2 * ox], L.lin3[c][2 * oy][2 * ox + 1], L.lin3[c][2 * oy + 1][2 * ox], L.lin3[c][2 * oy + 1][2 * ox + 1], okx, oky);
-                    else v[c] = ds4(L.lin4[c][0][0], L.lin4[c][0][1], L.lin4[c][1][0], L.lin4[c][1][1], okx, oky);
-                    if (lv == 2) L.lin2[c][oy][ox] = v[c];
-                    if (lv == 3) L.lin3[c][oy][ox] = v[c];
-                    if (lv == 4) L.lin4[c][oy][ox] = v[c];
-                }
-                store_xyb_px(xyb, xybt, g.s[lv], XL, YL, v);
+                for (int c = 0; c < 3; ++c)
+                    l2[c * s2.plane] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox],
+                                           L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
             }
-            TM_LDS_BARRIER();
         }
+        TM_LDS_BARRIER(); // the tile is reused by the next side
     }
-    if (want_sse) {
+    if (want_sse) { // per-wave sum through LDS (wave-synchronous), one 64-bit integer atomic per wave: exact, order-free
         sse_s[tid] = sse;
-        TM_LDS_BARRIER();
-        if (tid == 0) {
+        __builtin_amdgcn_wave_barrier();
+        if ((tid & 63) == 0) {
             unsigned long long tot = 0;
-            for (int i = 0; i < 256; ++i) tot += sse_s[i];
+            for (int i = 0; i < 64; ++i) tot += sse_s[tid + i];
             atomicAdd(&SSE[slot], tot);
         }
+    }
+}
+
+// Levels 2..5 of the pyramid from the level-2 linear RGB that k_ingest_tile32 leaves in LIN2 (1/16 of the
+// pixels): XYB of level 2, then 2x2 box downscales (downscale.rs:5-35) and XYB for levels 3, 4, 5.
+// Workgroup = 32x32 tile of level 2 (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad.
+// grid (ceil(w2/32), ceil(h2/32), slots*2), block 256.
+__global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB,
+                                                      float *__restrict__ XYBT)
+{
+    __shared__ float lin3[3][16][17];
+    __shared__ float lin4[3][8][9];
+    const int tid = threadIdx.x, qx = tid & 15, qy = tid >> 4;
+    const int img = blockIdx.z; // slot*2 + side
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+    const TmScaleGeom s2 = g.s[2];
+    float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT + (size_t)img * g.pyr_t;
+    const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
+    const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
+    float px[2][2][3];
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+            const bool in = X0 + ix < s2.w && Y0 + iy < s2.h;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[iy][ix][c] = in ? l2[c * s2.plane + (size_t)(Y0 + iy) * s2.pitch + X0 + ix] : 0.0f;
+            store_xyb_px(xyb, xybt, s2, X0 + ix, Y0 + iy, px[iy][ix]);
+        }
+    {
+        const bool okx = X0 + 1 < s2.w, oky = Y0 + 1 < s2.h;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = ds4(px[0][0][c], px[0][1][c], px[1][0][c], px[1][1][c], okx, oky);
+            lin3[c][qy][qx] = v[c];
+        }
+        store_xyb_px(xyb, xybt, g.s[3], X0 / 2, Y0 / 2, v);
+    }
+    TM_LDS_BARRIER();
+    if (tid < 64) {
+        const TmScaleGeom s3 = g.s[3];
+        const int ox = tid & 7, oy = tid >> 3;
+        const int XL = (tx0 >> 2) + ox, YL = (ty0 >> 2) + oy;
+        const bool okx = 2 * XL + 1 < s3.w, oky = 2 * YL + 1 < s3.h;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v[c] = ds4(lin3[c][2 * oy][2 * ox], lin3[c][2 * oy][2 * ox + 1], lin3[c][2 * oy + 1][2 * ox], lin3[c][2 * oy + 1][2 * ox + 1], okx, oky);
+            lin4[c][oy][ox] = v[c];
+        }
+        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v);
+    }
+    TM_LDS_BARRIER();
+    if (tid < 16) {
+        const TmScaleGeom s4 = g.s[4];
+        const int ox = tid & 3, oy = tid >> 2;
+        const int XL = (tx0 >> 3) + ox, YL = (ty0 >> 3) + oy;
+        const bool okx = 2 * XL + 1 < s4.w, oky = 2 * YL + 1 < s4.h;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            v[c] = ds4(lin4[c][2 * oy][2 * ox], lin4[c][2 * oy][2 * ox + 1], lin4[c][2 * oy + 1][2 * ox], lin4[c][2 * oy + 1][2 * ox + 1], okx, oky);
+        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v);
     }
 }
 
