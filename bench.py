@@ -129,13 +129,25 @@ def main():
     if rank == 0:
         pairs = world * B * args.steps
         spx = scale_pixels(w, h)
-        pass_bytes = 84 * spx * B  # 7 f32 per pixel-channel x 3 channels, per blur pass, per launch (B pairs)
-        ms_v = stage_ms[tm.ffi.TM_STAGE_BLUR_V] / max(n_meas, 1)
-        ms_h = stage_ms[tm.ffi.TM_STAGE_BLUR_H] / max(n_meas, 1)
-        ms_i = stage_ms[tm.ffi.TM_STAGE_INGEST] / max(n_meas, 1)
-        dom_name, dom_ms = ("k_blur_h", ms_h) if ms_h >= ms_v else ("k_blur_v", ms_v)
-        ach = pass_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        stage_ach = 2 * pass_bytes / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
+        n = max(n_meas, 1)
+        in_bytes = w * h * 3 // 2 * (1 if kind == "nv12" else 2) * 2  # both frames of a pair
+        # ALGORITHMIC bytes per launch (B pairs), SURVEY 8d: each blur pass moves 7 f32 per pixel-channel
+        # (= 84 B/px summed over the 6 scales); ingest reads the two surfaces and writes the planar XYB pyramid once
+        # (24 B/px; the kernel additionally writes a transposed copy, which shows up in `traffic`, not here).
+        kernels = {
+            "k_ingest_tile32": (stage_ms[tm.ffi.TM_STAGE_INGEST] / n, (in_bytes + 24 * spx) * B),
+            "k_blur_v_split": (stage_ms[tm.ffi.TM_STAGE_BLUR_V] / n, 84 * spx * B),
+            "k_blur_h": (stage_ms[tm.ffi.TM_STAGE_BLUR_H] / n, 84 * spx * B),
+        }
+        traffic = load_pmc_traffic(args.workload, B)
+        per_kernel = {}
+        for name, (ms, nbytes) in kernels.items():
+            ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            per_kernel[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": ach,
+                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name)}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_launch_ms"])
+        ms_v, ms_h = per_kernel["k_blur_v_split"]["avg_launch_ms"], per_kernel["k_blur_h"]["avg_launch_ms"]
+        stage_ach = 2 * 84 * spx * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
         out = {
             "metric": "ssimulacra2_frame_pairs_per_sec",
             "value": pairs / elapsed,
@@ -152,12 +164,13 @@ def main():
             "config": {"workload": args.workload, "baseline_config": cfg_name, "width": w, "height": h, "input": kind,
                        "pairs_per_step_per_gpu": B, "metrics": sorted(mets), "inputs_resident_in_hbm": True,
                        "parallelism": f"frame-pair sharding x{world}, one RCCL reduce of scores"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": pass_bytes, "avg_launch_ms": dom_ms},
-            "stages": {"ingest_ms": ms_i, "blur_v_ms": ms_v, "blur_h_ms": ms_h,
-                       "blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
-                       "full_pipeline_GBs": (pairs / elapsed) * (168 * spx + 24 * spx + (w * h * 3 * (1 if kind == "nv12" else 2))) / 1e9 / world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
+                         "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
+                         "avg_launch_ms": per_kernel[dom]["avg_launch_ms"]},
+            "kernels": per_kernel,
+            "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
+                       "full_pipeline_GBs": (pairs / elapsed) * (168 * spx + 24 * spx + in_bytes) / 1e9 / world},
             "score_mean": float(np.mean(all_scores)),
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -166,6 +179,23 @@ def main():
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def load_pmc_traffic(workload, batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_<workload>_b<B>.json, made by
+    tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md, which the row pass' known read volume confirms).  Empty when no matching profile exists."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}_b{batch}.json")
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    out = {}
+    for k, v in d.get("kernels", {}).items():
+        name = k.replace("void ", "").replace("tmk::", "").split("<")[0]
+        f, wr = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
+        if f is not None and wr is not None:
+            out[name] = int((2 * f + wr) * 1024)
+    return out
 
 
 def cpu_baseline(tm, w, h, kind, n_pairs):

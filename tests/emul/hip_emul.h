@@ -23,6 +23,7 @@ void tm_emul_wave_barrier();
 // role-waves of the split column pass share no data; the emulator runs them one after the other, so the
 // drift-limiting barrier has nothing to do here
 #define __builtin_amdgcn_s_barrier() ((void)0)
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 void tm_emul_syncthreads();
 #define __syncthreads() tm_emul_syncthreads()
 

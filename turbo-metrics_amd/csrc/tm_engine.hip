@@ -105,7 +105,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = (2 << 8) | 7; // tile32 fused ingest + split column pass without copies
+    int variant = (2 << 8) | 8; // tile32 fused ingest + split column pass without copies, non-temporal stores
 };
 
 namespace {
@@ -360,8 +360,8 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
     // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off)
-    if (!e || variant < 0 || (variant & 255) > 7 || (variant >> 8 & 255) > 2 || (variant >> 20) != 0) return TM_ERR_INVALID_ARG;
-    if ((variant & 255) == 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
+    if (!e || variant < 0 || (variant & 255) > 8 || (variant >> 8 & 255) > 2 || (variant >> 20) != 0) return TM_ERR_INVALID_ARG;
+    if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
         int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
@@ -431,6 +431,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
             case 5: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 32, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
+            case 8: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
             }
         }

@@ -985,7 +985,7 @@ __device__ __forceinline__ float ld_row_u(const float *__restrict__ plane, unsig
     return row < nrows ? v : 0.0f;
 }
 
-template <int R, int W, bool TWO, bool COPY>
+template <int R, int W, bool TWO, bool COPY, bool NT = false>
 __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, float *__restrict__ tile_copy,
                                                   const float *__restrict__ pa, const float *__restrict__ pb, unsigned x,
                                                   float *__restrict__ dst, float *__restrict__ dst_copy, int h, int pitch,
@@ -1040,7 +1040,8 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
                     const int xc = i * TT::CPI + xl;
                     const float *tp = tile + (4 * yq) * TT::S + xc;
                     TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst + (size_t)(i * TT::CPI) * pitch_t + y0);
-                    *(TM_GLOBAL_AS tm_f4 *)(ub + voff) = tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]);
+                    if (NT) __builtin_nontemporal_store(tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]), (TM_GLOBAL_AS tm_f4 *)(ub + voff));
+                    else *(TM_GLOBAL_AS tm_f4 *)(ub + voff) = tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]);
                     if (COPY) {
                         const float *tc = tile_copy + (4 * yq) * TT::S + xc;
                         TM_GLOBAL_AS char *uc = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst_copy + (size_t)(i * TT::CPI) * pitch_t + y0);
@@ -1055,7 +1056,7 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
 
 // COPIES = false: the transposed ref/dis copies are already written by k_ingest_fused; 5 tiles (41.6 KB) per
 // workgroup -> 3 workgroups = 15 waves per CU, and the kernel moves exactly the algorithmic 2R + 5W planes.
-template <int R, int W, bool COPIES>
+template <int R, int W, bool COPIES, bool NT = false>
 __global__ void __launch_bounds__(320, COPIES ? 3 : 4) k_blur_v_split(TmGeom g, const float *__restrict__ XYB,
                                                                       float *__restrict__ XYBT, float *__restrict__ V)
 {
@@ -1078,10 +1079,10 @@ __global__ void __launch_bounds__(320, COPIES ? 3 : 4) k_blur_v_split(TmGeom g, 
     float *tile = tiles + role * R * TT::S;
     // planes (ssimulacra2-cuda/src/lib.rs:299-335): 0 ref*ref, 1 dis*dis, 2 ref*dis, 3 ref, 4 dis
     if (role == 2) {
-        blur_v_split_role<R, W, true, false>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, true, false, NT>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
     } else if (role < 2) {
-        blur_v_split_role<R, W, false, false>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
-                                              sg.pitch_t, true);
+        blur_v_split_role<R, W, false, false, NT>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
+                                                  sg.pitch_t, true);
     } else {
         const int side = role - 3;
         if (COPIES) {
@@ -1089,8 +1090,8 @@ __global__ void __launch_bounds__(320, COPIES ? 3 : 4) k_blur_v_split(TmGeom g, 
             blur_v_split_role<R, W, false, true>(tile, tiles + (COPIES ? 5 + side : 0) * R * TT::S, side == 0 ? ref : dis, nullptr, x,
                                                  vdst, cdst, sg.h, sg.pitch, sg.pitch_t, false);
         } else {
-            blur_v_split_role<R, W, false, false>(tile, nullptr, side == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
-                                                  sg.pitch_t, false);
+            blur_v_split_role<R, W, false, false, NT>(tile, nullptr, side == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
+                                                      sg.pitch_t, false);
         }
     }
 }
