@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled over the batch)")
     ap.add_argument("--metrics", default="ssimulacra2", help="comma list: ssimulacra2,psnr")
+    ap.add_argument("--full-sums", action="store_true", help="compute all 108 per-scale sums like the reference (default: only the 52 with a non-zero weight; same score)")
+    ap.add_argument("--no-compare", action="store_true", help="skip the short extra run with the other full_sums setting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed for cpu_baseline (0 = auto, ~15 s)")
     args = ap.parse_args()
@@ -102,20 +104,26 @@ def main():
         eng.compute_async(B)
         eng.sync()
 
+    def timed(steps):
+        eng.set_profiling(True)
+        eng.stage_ms(reset=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        ms, n = eng.stage_ms(reset=True)
+        eng.set_profiling(False)
+        return dt, [m / max(n, 1) for m in ms]
+
+    eng.set_full_sums(args.full_sums)
     for _ in range(args.warmup):
         step()
-    eng.set_profiling(True)
-    eng.stage_ms(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stage_ms, n_meas = eng.stage_ms(reset=True)
-    eng.set_profiling(False)
+    elapsed, stage_ms = timed(args.steps)
+    modes = eng.job_modes()
 
     # ---- the single collective of the path: per-frame scores reduced (sum) to rank 0
     scores_local = np.array([eng.scores(i).ssimulacra2 or 0.0 for i in range(B)], np.float64)
@@ -126,28 +134,54 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- the same batch with the other setting of full_sums (a few steps, outside the headline timing): by default the
+    # engine skips the 56 of 108 per-scale sums whose weight in the reference's table is 0.0; --full-sums computes all
+    other = None
+    if world == 1 and not args.no_compare:
+        eng.set_full_sums(not args.full_sums)
+        step()
+        k = max(2, min(5, args.steps))
+        dt_o, ms_o = timed(k)
+        modes_o = eng.job_modes()
+        scores_o = np.array([eng.scores(i).ssimulacra2 or 0.0 for i in range(B)], np.float64)
+        other = {"full_sums": not args.full_sums, "value": B * k / dt_o, "ms_per_step": dt_o / k * 1e3,
+                 "stage_ms": {"ingest": ms_o[0], "blur_v": ms_o[1], "blur_h": ms_o[2]},
+                 "scores_bit_identical": bool(np.array_equal(scores_o, scores_local)), "_modes": modes_o}
+        eng.set_full_sums(args.full_sums)
+
     if rank == 0:
         pairs = world * B * args.steps
         spx = scale_pixels(w, h)
-        n = max(n_meas, 1)
         in_bytes = w * h * 3 // 2 * (1 if kind == "nv12" else 2) * 2  # both frames of a pair
-        # ALGORITHMIC bytes per launch (B pairs), SURVEY 8d: each blur pass moves 7 f32 per pixel-channel
-        # (= 84 B/px summed over the 6 scales); ingest reads the two surfaces and writes the planar XYB pyramid once
-        # (24 B/px; the kernel additionally writes a transposed copy, which shows up in `traffic`, not here).
-        kernels = {
-            "k_ingest_tile32": (stage_ms[tm.ffi.TM_STAGE_INGEST] / n, (in_bytes + 24 * spx) * B),
-            "k_blur_v_split": (stage_ms[tm.ffi.TM_STAGE_BLUR_V] / n, 84 * spx * B),
-            "k_blur_h": (stage_ms[tm.ffi.TM_STAGE_BLUR_H] / n, 84 * spx * B),
-        }
-        traffic = load_pmc_traffic(args.workload, B)
-        per_kernel = {}
-        for name, (ms, nbytes) in kernels.items():
+        # ALGORITHMIC bytes per launch (B pairs).  SURVEY 8d model: each blur pass moves 7 f32 per pixel-channel
+        # (= 84 B/px summed over the 6 scales) when all five blurred planes of every channel are computed (full_sums).
+        # With the zero-weight sums skipped a (scale, channel) image costs 7 (all maps), 4 (edge terms only: mu1, mu2 +
+        # ref, dis) or 0 f32 per pixel and pass -- `job_bytes` is what THIS configuration must move.
+        # Ingest reads the two surfaces and writes the planar XYB pyramid once (24 B/px; the kernel additionally writes a
+        # transposed copy, which shows up in `traffic`, not here).
+        sizes, ww, hh = [], w, h
+        for _ in range(6):
+            sizes.append(ww * hh)
+            ww, hh = (ww + 1) // 2, (hh + 1) // 2
+        units = {0: 0, 1: 4, 2: 7}
+        job_bytes = sum(4 * units[int(modes[sc, c])] * sizes[sc] for sc in range(6) for c in range(3))
+        model_bytes = 84 * spx
+
+        def roof(ms, nbytes):
             ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            per_kernel[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": ach,
-                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name)}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_launch_ms"])
-        ms_v, ms_h = per_kernel["k_blur_v_split"]["avg_launch_ms"], per_kernel["k_blur_h"]["avg_launch_ms"]
-        stage_ach = 2 * 84 * spx * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
+            return {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": ach, "frac": ach / HBM_PEAK_GBS}
+
+        traffic = load_pmc_traffic(args.workload, B, args.full_sums)
+        per_kernel = {
+            "k_ingest_tile32": roof(stage_ms[tm.ffi.TM_STAGE_INGEST], (in_bytes + 24 * spx) * B),
+            "k_blur_v_jobs": roof(stage_ms[tm.ffi.TM_STAGE_BLUR_V], job_bytes * B),
+            "k_blur_h_jobs": roof(stage_ms[tm.ffi.TM_STAGE_BLUR_H], job_bytes * B),
+        }
+        for name in per_kernel:
+            per_kernel[name]["traffic"] = traffic.get(name)
+        dom = max(("k_blur_v_jobs", "k_blur_h_jobs"), key=lambda k: per_kernel[k]["avg_launch_ms"])
+        ms_v, ms_h = per_kernel["k_blur_v_jobs"]["avg_launch_ms"], per_kernel["k_blur_h_jobs"]["avg_launch_ms"]
+        stage_ach = 2 * job_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
         out = {
             "metric": "ssimulacra2_frame_pairs_per_sec",
             "value": pairs / elapsed,
@@ -163,16 +197,29 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "baseline_config": cfg_name, "width": w, "height": h, "input": kind,
                        "pairs_per_step_per_gpu": B, "metrics": sorted(mets), "inputs_resident_in_hbm": True,
+                       "full_sums": bool(args.full_sums),
                        "parallelism": f"frame-pair sharding x{world}, one RCCL reduce of scores"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
                          "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
-                         "avg_launch_ms": per_kernel[dom]["avg_launch_ms"]},
+                         "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
+                         "bytes_model": "SURVEY 8d (84 B/px/pass)" if args.full_sums else
+                                        "SURVEY 8d restricted to the planes that carry weight (job table)"},
             "kernels": per_kernel,
             "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
-                       "full_pipeline_GBs": (pairs / elapsed) * (168 * spx + 24 * spx + in_bytes) / 1e9 / world},
+                       "blur_reduce_stage_bytes_per_pair": 2 * job_bytes,
+                       "survey_8d_model_bytes_per_pair": 2 * model_bytes,
+                       "survey_8d_model_frac": 2 * model_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_v + ms_h > 0 else 0.0,
+                       "full_pipeline_GBs": (pairs / elapsed) * (2 * job_bytes + 24 * spx + in_bytes) / 1e9 / world},
             "score_mean": float(np.mean(all_scores)),
         }
+        if other is not None:
+            mv, mh = other["stage_ms"]["blur_v"], other["stage_ms"]["blur_h"]
+            modes_o = other.pop("_modes")
+            ob = sum(4 * units[int(modes_o[sc, c])] * sizes[sc] for sc in range(6) for c in range(3))
+            other["blur_reduce_stage_bytes_per_pair"] = 2 * ob
+            other["blur_reduce_stage_frac"] = 2 * ob * B / ((mv + mh) * 1e-3) / 1e9 / HBM_PEAK_GBS if mv + mh > 0 else 0.0
+            out["compare"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tm, w, h, kind, args.cpu_pairs)
         print(json.dumps(out), flush=True)
@@ -181,11 +228,11 @@ def main():
         dist.destroy_process_group()
 
 
-def load_pmc_traffic(workload, batch):
+def load_pmc_traffic(workload, batch, full_sums=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_<workload>_b<B>.json, made by
     tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md, which the row pass' known read volume confirms).  Empty when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}_b{batch}.json")
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}_b{batch}{'_full' if full_sums else ''}.json")
     if not os.path.exists(path):
         return {}
     d = json.load(open(path))

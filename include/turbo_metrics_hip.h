@@ -114,8 +114,14 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots);
 int tm_engine_sync(tm_engine *e);
 /* FrameScores of one slot of the last completed compute (host-side post-processing happens here) */
 int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out);
-/* the 108 raw sums [scale][kind][channel] == the reference's `scores` before post_process_scores */
+/* the 108 raw sums [scale][kind][channel] == the reference's `scores` before post_process_scores
+ * (ssimulacra2-cuda/src/lib.rs:417-447).  By default the 56 sums whose weight in the reference's table is
+ * exactly 0.0 (lib.rs:454-584; they are multiplied away at lib.rs:592-602) are not computed and read 0.0;
+ * the score is bit-identical either way.  tm_engine_set_full_sums(e, 1) computes all 108. */
 int tm_engine_get_raw_sums(tm_engine *e, uint32_t slot, double out[108]);
+int tm_engine_set_full_sums(tm_engine *e, int on);
+/* what the blur passes compute per [scale*3 + channel]: 0 nothing, 1 edge terms only (mu1, mu2), 2 everything */
+int tm_engine_get_job_modes(const tm_engine *e, int out[18]);
 /* PSNR input: exact integer sum of squared differences of the u8-quantised linear RGB pair */
 int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out);
 

@@ -50,7 +50,7 @@ KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 
 class Emulated:
     """Runs the whole generation-0 pipeline for n slots; keeps the arenas for plane inspection."""
 
-    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None):
+    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True):
         """frames: list of (ref, dis) where each is dict(kind=, data=np.ndarray, pitch=, coded_height=, matrix=)."""
         L = C.CDLL(build())
         L.emul_geom_size.restype = C.c_size_t
@@ -78,8 +78,12 @@ class Emulated:
         lut = np.ascontiguousarray(lut, np.float32); coef = np.ascontiguousarray(coef, np.float32)
         powtab = np.ascontiguousarray(product_pow_tables() if powtab is None else powtab, np.float64)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        if weights is None:  # [channel][scale][6]; all non-zero -> every job FULL
+            weights = np.ones(108)
+        weights = np.ascontiguousarray(weights, np.float64).ravel()
+        assert weights.size == 108
         L.emul_pipeline(w, h, n, desc, vp(lut), vp(coef), vp(powtab), int(want_sse), vp(self.LIN), vp(self.XYB), vp(self.XYBT), vp(self.V),
-                        vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant))
+                        vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant), vp(weights), int(full_sums))
         self.w, self.h, self.n = w, h, n
 
     def plane(self, arena, slot, scale, index, channel, transposed=False, per_slot=2):

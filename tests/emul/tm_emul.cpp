@@ -117,11 +117,12 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
 
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
-                   int variant)
+                   int variant, const double *weights, int full_sums)
 {
     const int ingest_gen = variant >> 8;
     variant &= 255;
     TmGeom g; tm_make_geom(&g, w, h);
+    TmJobs jobs; tm_make_jobs(&jobs, &g, weights, full_sums);
     const int qw = (w + 1) / 2, qh = (h + 1) / 2;
     if (ingest_gen == 0) {
         launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, tab, LIN, SSE, want_sse); });
@@ -152,9 +153,12 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     case 6: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, true>(g, XYB, XYBT, V); }, 5); break;
     case 7: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false>(g, XYB, XYBT, V); }, 5); break;
     case 8: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false, true>(g, XYB, XYBT, V); }, 5); break;
+    case 9: launch_wave_lockstep(dim3(jobs.vstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 0); }, 5); break;
+    case 10: launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 1); }, 5); break;
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
-    launch(dim3(g.hblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_h(g, XYBT, V, PART); });
-    launch(dim3(n), dim3(128), [&] { tmk::k_finish(g, PART, SUMS); });
+    if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
+    else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });
+    launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });
 }
 }

@@ -86,3 +86,30 @@ def test_p016_and_rgb_kinds_match_oracle(variant):
     ]
     em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant)
     check_against_oracle(em, frames, w, h, have_linear=variant < 256)
+
+
+def weight_mask():
+    """(6 scales, 6 kinds, 3 channels) bool: sums that carry a non-zero weight (table layout [channel][scale][kind])"""
+    return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (1, 1), (129, 20), (200, 9)])
+def test_job_driven_blur_passes_full_and_pruned(w, h):
+    """variant 9 = job-table column pass.  full_sums: every plane and all 108 sums equal the oracle.  Pruned (the
+    default of the engine): the sums that carry weight are bit-identical to the full run, the others read 0, and
+    the score is bit-identical."""
+    frames = []
+    for n in range(2):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
+        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=0),
+                       dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0)))
+    full = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 9, weights=O.weights(), full_sums=True)
+    check_against_oracle(full, frames, w, h, have_linear=False)
+    pruned = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 10, weights=O.weights(), full_sums=False)  # 10: slot-major grid
+    m = weight_mask()
+    assert m.sum() == 52
+    for slot in range(2):
+        a, b = full.sums(slot), pruned.sums(slot)
+        assert np.array_equal(a[m], b[m])
+        assert np.all(b[~m] == 0.0) or np.array_equal(a[~m & (b != 0)], b[~m & (b != 0)])  # EDGE jobs still report all four edge sums
+        assert O.score_from_sums(a, w, h) == O.score_from_sums(b, w, h)

@@ -66,7 +66,7 @@ def check_scores(eng, slot, lin, sums, w, h):
 
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (257, 131)])
 def test_nv12_planes_and_scores_match_oracle(w, h):
-    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=3)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=3, full_sums=True)
     frames = [nv12_frames(w, h, n, tm.ColorMatrix(n % 3)) for n in range(3)]
     for slot, (fr, fd) in enumerate(frames):
         eng.set_pair(slot, fr, fd)
@@ -78,11 +78,11 @@ def test_nv12_planes_and_scores_match_oracle(w, h):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 256, 256 + 2, 256 + 6, 256 + 7, 512 + 6, 512 + 7, 512 + 8, 2 * 65536 + 512 + 7, 3 * 65536 + 512 + 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 256, 256 + 2, 256 + 6, 256 + 7, 512 + 6, 512 + 7, 512 + 8, 512 + 9, (1 << 20) + 512 + 9, 2 * 65536 + 512 + 7, 3 * 65536 + 512 + 9])
 def test_kernel_generations_are_bit_identical(variant):
     # low byte: column-pass generation, bit 8: fused ingest.  Every combination must reproduce the oracle bit for bit.
     w, h = 333, 203
-    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=2)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=2, full_sums=True)
     eng.set_variant(variant)
     frames = [nv12_frames(w, h, n) for n in range(2)]
     for slot, (fr, fd) in enumerate(frames):
@@ -105,7 +105,7 @@ def test_every_input_kind_matches_oracle():
     df = np.clip(rf + rng.normal(0, 0.03, rf.shape).astype(np.float32), 0, 1)
     frames = [p016_frames(w, h, 3), (tm.HwFrame.rgb(r8), tm.HwFrame.rgb(d8)), (tm.HwFrame.rgb(r16), tm.HwFrame.rgb(d16)),
               (tm.HwFrame.rgb(rf), tm.HwFrame.rgb(df)), (tm.HwFrame.linear(rf), tm.HwFrame.linear(df))]
-    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=len(frames))
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=len(frames), full_sums=True)
     for slot, (fr, fd) in enumerate(frames):
         eng.set_pair(slot, fr, fd)
     eng.compute_async()
@@ -142,12 +142,42 @@ def test_device_resident_frames_and_slot_independence():
     eng.close(); solo.close()
 
 
+def weight_mask():
+    """(6 scales, 6 kinds, 3 channels) bool: sums with a non-zero weight in the reference's table [channel][scale][kind]"""
+    return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (333, 203), (1, 1), (129, 20), (640, 360)])
+def test_weight_pruned_sums_equal_full_sums(w, h):
+    """Default mode skips the 56 sums whose weight is 0.0: the 52 weighted sums and the score must be bit-identical
+    to the full computation, and the full computation must match the oracle."""
+    frames = [nv12_frames(w, h, n) for n in range(3)]
+    res = []
+    for full in (False, True):
+        eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=3, full_sums=full)
+        for slot, (fr, fd) in enumerate(frames):
+            eng.set_pair(slot, fr, fd)
+        eng.compute_async()
+        eng.sync()
+        res.append([(eng.raw_sums(i).copy(), eng.scores(i).ssimulacra2) for i in range(3)])
+        eng.close()
+    m = weight_mask()
+    assert m.sum() == 52
+    for slot, (fr, fd) in enumerate(frames):
+        (sp, scp), (sf, scf) = res[0][slot], res[1][slot]
+        assert np.array_equal(sp[m], sf[m])
+        assert scp == scf
+        want, sums = O.ssimulacra2_from_linear(oracle_linear(fr, w, h), oracle_linear(fd, w, h))
+        np.testing.assert_allclose(sf, sums, rtol=1e-12, atol=1e-300)
+        assert abs(scp - want) <= 1e-9
+
+
 def test_identical_frames_property_full_hd():
     # size-independent property at BASELINE's full size: identical inputs -> SSIM map exactly 0 at every
     # scale/channel, PSNR = +inf, score just below 100 (edge-term rounding residue, see oracle pins)
     w, h = 1920, 1080
     fr, _ = nv12_frames(w, h, 5)
-    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=1)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=1, full_sums=True)
     s = eng.compute_one(fr, fr)
     sums = eng.raw_sums(0)
     assert np.all(sums[:, 0, :] == 0.0) and np.all(sums[:, 3, :] == 0.0)
@@ -159,7 +189,7 @@ def test_identical_frames_property_full_hd():
 def test_full_hd_pair_against_oracle():
     w, h = 1920, 1080
     fr, fd = nv12_frames(w, h, 2)
-    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2, full_sums=True)
     eng.set_pair(0, fr, fd)
     eng.set_pair(1, fd, fr)  # swapped roles in the neighbouring slot
     eng.compute_async()
@@ -173,12 +203,17 @@ def test_full_hd_pair_against_oracle():
 def test_4k_p016_pair_against_oracle():
     w, h = 3840, 2160
     fr, fd = p016_frames(w, h, 1)
-    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)  # default: only the sums that carry weight
     got = eng.compute_one(fr, fd)
     lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
     want, sums = O.ssimulacra2_from_linear(lin[0], lin[1])
-    np.testing.assert_allclose(eng.raw_sums(0), sums, rtol=1e-12, atol=1e-300)
+    m = weight_mask()
+    np.testing.assert_allclose(eng.raw_sums(0)[m], sums[m], rtol=1e-12, atol=1e-300)
     assert abs(got.ssimulacra2 - want) <= 1e-9
+    eng.set_full_sums(True)
+    got_full = eng.compute_one(fr, fd)
+    np.testing.assert_allclose(eng.raw_sums(0), sums, rtol=1e-12, atol=1e-300)
+    assert got_full.ssimulacra2 == got.ssimulacra2
     eng.close()
 
 

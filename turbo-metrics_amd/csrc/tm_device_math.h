@@ -164,6 +164,17 @@ __device__ __forceinline__ float iir_step(Iir &s, float sum)
     return (o1 + o3) + o5;
 }
 
+// the edge-difference half of compute_error_maps (error_maps.rs:45-59): needs mu1, mu2 only
+__device__ __forceinline__ void edge_maps(float source, float distorted, float mu1, float mu2, float &artifact,
+                                          float &detail_loss)
+{
+    const float denom = 1.0f / (1.0f + fabsf(source - mu1));
+    const float numer = 1.0f + fabsf(distorted - mu2);
+    const float d1 = __builtin_fmaf(numer, denom, -1.0f);
+    artifact = fmaxf(d1, 0.0f);
+    detail_loss = fmaxf(-d1, 0.0f);
+}
+
 // compute_error_maps, ssimulacra2-cuda-kernel/src/error_maps.rs:5-60
 __device__ __forceinline__ void error_maps(float source, float distorted, float mu1, float mu2, float sigma11,
                                            float sigma22, float sigma12, float &ssim, float &artifact,
@@ -176,11 +187,7 @@ __device__ __forceinline__ void error_maps(float source, float distorted, float 
     const float num_s = __builtin_fmaf(2.0f, sigma12 - mu12, C2);
     const float denom_s = (sigma11 - mu11) + (sigma22 - mu22) + C2;
     ssim = fmaxf(1.0f - (num_m * num_s) / denom_s, 0.0f);
-    const float denom = 1.0f / (1.0f + fabsf(source - mu1));
-    const float numer = 1.0f + fabsf(distorted - mu2);
-    const float d1 = __builtin_fmaf(numer, denom, -1.0f);
-    artifact = fmaxf(d1, 0.0f);
-    detail_loss = fmaxf(-d1, 0.0f);
+    edge_maps(source, distorted, mu1, mu2, artifact, detail_loss);
 }
 
 } // namespace tmdev

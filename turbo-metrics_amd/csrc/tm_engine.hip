@@ -84,6 +84,8 @@ struct tm_engine {
     int device = 0;
     uint32_t w = 0, h = 0, mask = 0, cap = 0;
     TmGeom g{};
+    TmJobs jobs{};
+    bool full_sums = false;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_pipe[4] = {};
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr;
@@ -105,7 +107,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = (2 << 8) | 8; // tile32 fused ingest + split column pass without copies, non-temporal stores
+    int variant = (2 << 8) | 9; // tile32 fused ingest + job-driven split column pass, non-temporal stores
 };
 
 namespace {
@@ -258,6 +260,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
     tm_make_geom(&e->g, (int)width, (int)height);
+    tm_make_jobs(&e->jobs, &e->g, k_weights, 0);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
@@ -359,8 +362,9 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off)
-    if (!e || variant < 0 || (variant & 255) > 8 || (variant >> 8 & 255) > 2 || (variant >> 20) != 0) return TM_ERR_INVALID_ARG;
+    // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
+    // dispatch order of the two blur passes (default: slot-major)
+    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 2 || (variant >> 21) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
@@ -368,6 +372,23 @@ int tm_engine_set_variant(tm_engine *e, int variant)
         if (rc) return rc;
     }
     e->variant = variant;
+    return TM_OK;
+}
+
+int tm_engine_set_full_sums(tm_engine *e, int on)
+{
+    if (!e) return TM_ERR_INVALID_ARG;
+    if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+    e->full_sums = on != 0;
+    tm_make_jobs(&e->jobs, &e->g, k_weights, on != 0);
+    e->have_results = false;
+    return TM_OK;
+}
+
+int tm_engine_get_job_modes(const tm_engine *e, int out[18])
+{
+    if (!e || !out) return TM_ERR_INVALID_ARG;
+    for (int i = 0; i < TM_SCALES * 3; ++i) out[i] = e->jobs.job_of[i] < 0 ? TM_MODE_NONE : e->jobs.mode[e->jobs.job_of[i]];
     return TM_OK;
 }
 
@@ -383,7 +404,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     float *V = e->V + (size_t)slot0 * 5 * g.pyr_t;
     float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
     float *LIN2 = e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane;
-    double *PART = e->PART + (size_t)slot0 * 3 * g.hblk[TM_SCALES] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
+    double *PART = e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
     unsigned long long *SSE = e->SSE + slot0;
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
@@ -419,6 +440,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     if (ev_ingest_done) HIPCHK(hipEventRecord(ev_ingest_done, st));
+    const int sm = (e->variant >> 20) & 1 ? 0 : 1; // bit 20 set: slot-minor dispatch order (A/B)
     if (e->mask & TM_METRIC_SSIMULACRA2) {
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         {
@@ -432,14 +454,15 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
             case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 8: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
+            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
             }
         }
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
-        hipLaunchKernelGGL(tmk::k_blur_h, dim3((unsigned)g.hblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYBT, V, PART);
+        hipLaunchKernelGGL(tmk::k_blur_h_jobs, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART, sm);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(tmk::k_finish, dim3((unsigned)n), dim3(128), 0, st, g, PART, SUMS);
+        hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, e->jobs, PART, SUMS);
     } else if (ev) {
         HIPCHK(hipEventRecord(ev[2], st));
         HIPCHK(hipEventRecord(ev[3], st));

@@ -48,6 +48,26 @@ struct TmFrameDesc {
     int matrix;
 };
 
+// ---- job table of the two blur passes ---------------------------------------------------------------
+// One job = one (scale, channel) image.  52 of the reference's 108 weights are non-zero
+// (ssimulacra2-cuda/src/lib.rs:454-584), and a term with weight 0.0 contributes exactly 0.0 to the score
+// (lib.rs:592-602 multiplies it away), so a job only has to produce the sums that carry weight:
+//   TM_MODE_FULL  all five blurred planes (s11,s22,s12,mu1,mu2) -> ssim, artifact, detail_loss sums
+//   TM_MODE_EDGE  mu1, mu2 only -> artifact, detail_loss sums (the ssim sums are reported as 0)
+//   TM_MODE_NONE  nothing (every weight of this scale/channel is 0)
+// With `full` set every job is TM_MODE_FULL: all 108 sums, exactly the reference's `scores` array.
+#define TM_MAX_JOBS 18
+enum { TM_MODE_NONE = 0, TM_MODE_EDGE = 1, TM_MODE_FULL = 2 };
+
+struct TmJobs {
+    int n;                        // jobs with mode != NONE
+    int vstart[TM_MAX_JOBS + 1];  // prefix sums: workgroups of the column pass (FULL: one per 64-column block,
+                                  // EDGE: one per two 64-column blocks)
+    int hstart[TM_MAX_JOBS + 1];  // prefix sums: 64-row blocks (= waves) of the row pass; also indexes PART
+    int scale[TM_MAX_JOBS], chan[TM_MAX_JOBS], mode[TM_MAX_JOBS];
+    int job_of[TM_SCALES * 3];    // [scale*3 + channel] -> job index, -1 for TM_MODE_NONE
+};
+
 static inline int tm_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static inline void tm_make_geom(TmGeom *g, int w, int h)
@@ -70,4 +90,32 @@ static inline void tm_make_geom(TmGeom *g, int w, int h)
         w = (w + 1) / 2; h = (h + 1) / 2;
     }
     g->pyr = off; g->pyr_t = off_t;
+}
+
+// weights: the reference's table [channel][scale][ssim1, art1, det1, ssim4, art4, det4]
+static inline void tm_make_jobs(TmJobs *j, const TmGeom *g, const double *weights, int full)
+{
+    j->n = 0;
+    j->vstart[0] = 0; j->hstart[0] = 0;
+    for (int i = 0; i < TM_SCALES * 3; ++i) j->job_of[i] = -1;
+    // longest columns/rows first (scale 0), FULL before EDGE inside a scale
+    for (int s = 0; s < TM_SCALES; ++s)
+        for (int pass = TM_MODE_FULL; pass >= TM_MODE_EDGE; --pass)
+            for (int c = 0; c < 3; ++c) {
+                const double *wt = weights + c * 36 + 6 * s;
+                const int ssim = wt[0] != 0.0 || wt[3] != 0.0;
+                const int edge = wt[1] != 0.0 || wt[2] != 0.0 || wt[4] != 0.0 || wt[5] != 0.0;
+                const int mode = full || ssim ? TM_MODE_FULL : (edge ? TM_MODE_EDGE : TM_MODE_NONE);
+                if (mode != pass) continue;
+                const int k = j->n++;
+                const int cb = (g->s[s].w + 63) / 64, rb = (g->s[s].h + 63) / 64;
+                j->scale[k] = s; j->chan[k] = c; j->mode[k] = mode;
+                j->vstart[k + 1] = j->vstart[k] + (mode == TM_MODE_FULL ? cb : (cb + 1) / 2);
+                j->hstart[k + 1] = j->hstart[k] + rb;
+                j->job_of[s * 3 + c] = k;
+            }
+    for (int k = j->n; k < TM_MAX_JOBS; ++k) {
+        j->scale[k] = 0; j->chan[k] = 0; j->mode[k] = TM_MODE_NONE;
+        j->vstart[k + 1] = j->vstart[k]; j->hstart[k + 1] = j->hstart[k];
+    }
 }

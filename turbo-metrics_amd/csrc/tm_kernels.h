@@ -7,8 +7,9 @@
 //   k_downscale  grid (ceil(dw/64), dh, slots*2*3)                     block 64
 //   k_xyb        grid (ceil(w/64), h, slots*2)                         block 64
 //   k_blur_v     grid (vblk[6], 3, slots)   one lane per image COLUMN, all 6 scales in one launch
-//   k_blur_h     grid (hblk[6], 3, slots)   one lane per image ROW,    all 6 scales in one launch
-//   k_finish     grid (slots)                                          block 128
+//   k_blur_v_jobs grid (jobs.vstart[n], 1, slots) block 320   the tuned column pass, job table driven
+//   k_blur_h_jobs grid (jobs.hstart[n], 1, slots) block 64    one lane per image ROW, job table driven
+//   k_finish_jobs grid (slots)                                          block 128
 //
 // Arithmetic follows the reference kernels operation for operation (cited per function); the
 // file must be compiled with -ffp-contract=off so that only the explicit fmaf calls fuse.
@@ -1097,27 +1098,149 @@ __global__ void __launch_bounds__(320, COPIES ? 3 : 4) k_blur_v_split(TmGeom g, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column pass, generation 3 ("jobs"): the split kernel driven by the job table (tm_geom.h).  A FULL job's
+// workgroup is the five role-waves of one 64-column block, as above.  An EDGE job (only mu1, mu2 carry weight:
+// scale 0 of the X and B channels, i.e. half of all pixels) runs waves 0..3 as {mu1, mu2} x two neighbouring
+// 64-column blocks and retires wave 4 at once, so it reads 2 and writes 2 planes instead of 2 + 5.
+// grid (jobs.vstart[n], 1, slots), block 320.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], int b)
+{
+    int j = 0; // padding entries hold the total, so they never match
+#pragma unroll
+    for (int i = 1; i < TM_MAX_JOBS; ++i)
+        if (b >= start[i]) j = i;
+    return j;
+}
+
+template <int R, int W>
+__global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V,
+                                                        int slot_major)
+{
+    // slot_major: grid (slots, blocks) instead of (blocks, 1, slots) -- workgroups are dispatched x-fastest, so the
+    // long jobs (scale 0) of ALL slots start first and the short scales fill the tail (longest-processing-time order)
+    using TT = BlurVTile<R>;
+    __shared__ float tiles[5 * R * TT::S];
+    const int b = slot_major ? blockIdx.y : blockIdx.x;
+    const int j = tm_find_job(jobs.vstart, b);
+    const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
+    const TmScaleGeom sg = g.s[s];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
+    int role = wave, blk = b - jobs.vstart[j];
+    if (mode != TM_MODE_FULL) {
+        if (wave == 4) return; // a retired wave no longer counts at s_barrier
+        role = 3 + (wave & 1);
+        blk = blk * 2 + (wave >> 1);
+        if (blk * 64 >= sg.w) return;
+    }
+    const int x0 = blk * 64;
+    const int lane = threadIdx.x & 63;
+    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u;
+    const int slot = slot_major ? blockIdx.x : blockIdx.z;
+    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
+    float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
+    float *tile = tiles + wave * R * TT::S;
+    if (role == 2)
+        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+    else if (role < 2)
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+    else
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, false);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row pass ("pass 2") fused with the error maps and the reductions: the reference's second
 // blur_plane_pass_fused on the transposed images (lib.rs:368-379), compute_error_maps
 // (error_maps.rs:5-60) and the six nppiSum / two nppiSqr per map (lib.rs:417-447) in one kernel.
 // One lane owns one image ROW and walks x = 0..w-1 through the transposed planes (coalesced: lanes
 // are consecutive y).  The blurred planes and the three maps never reach HBM; each lane keeps
 // Sum(x) and Sum((x^2)^2) (squares rounded to f32, accumulation in f64, as NPP's Npp64f sums) and
-// the wave total goes to PART[slot][channel][block][6].
+// the wave total goes to PART; k_finish_jobs adds the partials of a job in a fixed order.
+//
+// Job driven: one wave = one 64-row block of one job.  FULL runs all five recurrences; EDGE runs only the
+// mu1 / mu2 recurrences and the edge half of compute_error_maps, reading 4 planes instead of 7 (its freed
+// registers go into a deeper load window: WN = 16 -> rows t+1 .. t+6 in flight).
+// WN = window slots of the pass-1 planes (rows t-10 .. t+WN-11), WS = slots of the ref/dis windows
+// (rows t-4 .. t+WN-11 need WN-6 slots; WS must divide WN).  PART[slot][row block over all jobs][6].
+// grid (jobs.hstart[n], 1, slots), block 64.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_blur_h(TmGeom g, const float *__restrict__ XYBT, const float *__restrict__ V,
-                                               double *__restrict__ PART)
+template <bool FULL, int WN, int WS>
+__device__ __forceinline__ void blur_h_job(const float *__restrict__ reft, const float *__restrict__ dist,
+                                           const float *__restrict__ v0, const float *__restrict__ v1,
+                                           const float *__restrict__ v2, const float *__restrict__ v3,
+                                           const float *__restrict__ v4, int w, int pt, bool valid, double (&acc)[6])
 {
-    int b = blockIdx.x, s = 0;
+    static_assert(WN % WS == 0 && WS >= WN - 6, "window sizes");
+    constexpr int P = WN - 10; // load distance in rows
+    constexpr int NF = FULL ? WN : 1;
+    float w0[NF], w1[NF], w2[NF], w3[WN], w4[WN], ws[WS], wq[WS];
 #pragma unroll
-    for (int i = 1; i < TM_SCALES; ++i)
-        if (b >= g.hblk[i]) s = i;
+    for (int j = 0; j < WN; ++j) {
+        w3[j] = j < P ? ld_row(v3, j, w, pt) : 0.0f;
+        w4[j] = j < P ? ld_row(v4, j, w, pt) : 0.0f;
+        if (FULL) {
+            w0[j] = j < P ? ld_row(v0, j, w, pt) : 0.0f;
+            w1[j] = j < P ? ld_row(v1, j, w, pt) : 0.0f;
+            w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WS; ++j) {
+        ws[j] = j < P ? ld_row(reft, j, w, pt) : 0.0f;
+        wq[j] = j < P ? ld_row(dist, j, w, pt) : 0.0f;
+    }
+    tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
+    const int T = w + 4;
+    for (int t0 = 0; t0 < T; t0 += WN) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int t = t0 + j; // row t lives in slot j, row t-10 in slot (j+P) % WN, which row t+P then takes over
+            float s11 = 0.0f, s22 = 0.0f, s12 = 0.0f;
+            if (FULL) {
+                s11 = tmdev::iir_step(f0, w0[(j + P) % NF] + w0[j % NF]);
+                s22 = tmdev::iir_step(f1, w1[(j + P) % NF] + w1[j % NF]);
+                s12 = tmdev::iir_step(f2, w2[(j + P) % NF] + w2[j % NF]);
+            }
+            const float mu1 = tmdev::iir_step(f3, w3[(j + P) % WN] + w3[j]);
+            const float mu2 = tmdev::iir_step(f4, w4[(j + P) % WN] + w4[j]);
+            const float src = ws[(j + WS - 4) % WS], dsv = wq[(j + WS - 4) % WS]; // row t-4
+            if (FULL) {
+                w0[(j + P) % NF] = ld_row(v0, t + P, w, pt);
+                w1[(j + P) % NF] = ld_row(v1, t + P, w, pt);
+                w2[(j + P) % NF] = ld_row(v2, t + P, w, pt);
+            }
+            w3[(j + P) % WN] = ld_row(v3, t + P, w, pt);
+            w4[(j + P) % WN] = ld_row(v4, t + P, w, pt);
+            ws[(j + P) % WS] = ld_row(reft, t + P, w, pt);
+            wq[(j + P) % WS] = ld_row(dist, t + P, w, pt);
+            if (t >= 4 && t < T) {
+                float ssim = 0.0f, art, det;
+                if (FULL) tmdev::error_maps(src, dsv, mu1, mu2, s11, s22, s12, ssim, art, det);
+                else tmdev::edge_maps(src, dsv, mu1, mu2, art, det);
+                if (valid) {
+                    float q;
+                    if (FULL) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
+                    acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
+                    acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYBT,
+                                                    const float *__restrict__ V, double *__restrict__ PART, int slot_major)
+{
+    const int b = slot_major ? blockIdx.y : blockIdx.x;
+    const int j = tm_find_job(jobs.hstart, b);
+    const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
     const TmScaleGeom sg = g.s[s];
-    const int y = (b - g.hblk[s]) * 64 + threadIdx.x;
+    const int y = (b - jobs.hstart[j]) * 64 + threadIdx.x;
     const bool valid = y < sg.h;
     const int yy = valid ? y : sg.h - 1;
-    const int c = blockIdx.y, slot = blockIdx.z;
-    const int w = sg.w, pt = sg.pitch_t;
+    const int slot = slot_major ? blockIdx.x : blockIdx.z;
     const size_t to = sg.off_t + c * sg.plane_t + yy;
     const float *reft = XYBT + (size_t)(slot * 2 + 0) * g.pyr_t + to;
     const float *dist = XYBT + (size_t)(slot * 2 + 1) * g.pyr_t + to;
@@ -1126,68 +1249,28 @@ __global__ void __launch_bounds__(64) k_blur_h(TmGeom g, const float *__restrict
     const float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
     const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
     const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
-
-    // 12-slot windows: rows t-10 .. t+1 of each pass-1 plane; 6-slot windows for ref/dis (row t-4 .. t+1)
-    float w0[12], w1[12], w2[12], w3[12], w4[12], ws[6], wq[6];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) { w0[j] = 0; w1[j] = 0; w2[j] = 0; w3[j] = 0; w4[j] = 0; }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) { ws[j] = 0; wq[j] = 0; }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        w0[j] = ld_row(v0, j, w, pt); w1[j] = ld_row(v1, j, w, pt); w2[j] = ld_row(v2, j, w, pt);
-        w3[j] = ld_row(v3, j, w, pt); w4[j] = ld_row(v4, j, w, pt);
-        ws[j] = ld_row(reft, j, w, pt); wq[j] = ld_row(dist, j, w, pt);
-    }
-    tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    const int T = w + 4;
-    for (int t0 = 0; t0 < T; t0 += 12) {
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const int t = t0 + j;
-            const float s11 = tmdev::iir_step(f0, w0[(j + 2) % 12] + w0[j]);
-            const float s22 = tmdev::iir_step(f1, w1[(j + 2) % 12] + w1[j]);
-            const float s12 = tmdev::iir_step(f2, w2[(j + 2) % 12] + w2[j]);
-            const float mu1 = tmdev::iir_step(f3, w3[(j + 2) % 12] + w3[j]);
-            const float mu2 = tmdev::iir_step(f4, w4[(j + 2) % 12] + w4[j]);
-            const float src = ws[(j + 2) % 6], dsv = wq[(j + 2) % 6]; // row t-4
-            w0[(j + 2) % 12] = ld_row(v0, t + 2, w, pt);
-            w1[(j + 2) % 12] = ld_row(v1, t + 2, w, pt);
-            w2[(j + 2) % 12] = ld_row(v2, t + 2, w, pt);
-            w3[(j + 2) % 12] = ld_row(v3, t + 2, w, pt);
-            w4[(j + 2) % 12] = ld_row(v4, t + 2, w, pt);
-            ws[(j + 2) % 6] = ld_row(reft, t + 2, w, pt);
-            wq[(j + 2) % 6] = ld_row(dist, t + 2, w, pt);
-            if (t >= 4 && t < T) {
-                float ssim, art, det;
-                tmdev::error_maps(src, dsv, mu1, mu2, s11, s22, s12, ssim, art, det);
-                if (valid) {
-                    float q;
-                    acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q;
-                    acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
-                    acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
-                }
-            }
-        }
-    }
+    if (mode == TM_MODE_FULL) blur_h_job<true, 12, 6>(reft, dist, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
+    else blur_h_job<false, 16, 16>(reft, dist, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
     if (tm_wave_sum6(acc)) {
-        double *o = PART + ((size_t)(slot * 3 + c) * g.hblk[TM_SCALES] + b) * 6;
+        double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = acc[k];
     }
 }
 
-// fixed-order sum of the per-wave partials -> SUMS[slot][scale*18 + kind*3 + channel]
-// (the layout of the reference's `scores`, lib.rs:417-447)
-__global__ void __launch_bounds__(128) k_finish(TmGeom g, const double *__restrict__ PART, double *__restrict__ SUMS)
+// fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no
+// job produces (weight 0.0 in the reference's table) are written as 0
+__global__ void __launch_bounds__(128) k_finish_jobs(TmJobs jobs, const double *__restrict__ PART, double *__restrict__ SUMS)
 {
     const int i = threadIdx.x, slot = blockIdx.x;
     if (i >= 108) return;
     const int s = i / 18, kind = (i % 18) / 3, c = i % 3;
+    const int j = jobs.job_of[s * 3 + c];
     double sum = 0.0;
-    for (int b = g.hblk[s]; b < g.hblk[s + 1]; ++b)
-        sum += PART[((size_t)(slot * 3 + c) * g.hblk[TM_SCALES] + b) * 6 + kind];
+    if (j >= 0 && (jobs.mode[j] == TM_MODE_FULL || (kind != 0 && kind != 3)))
+        for (int b = jobs.hstart[j]; b < jobs.hstart[j + 1]; ++b)
+            sum += PART[((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6 + kind];
     SUMS[(size_t)slot * 108 + i] = sum;
 }
 

@@ -129,7 +129,9 @@ def _ptr_and_mem(data):
 class TurboMetrics:
     """Mirror of turbo_metrics::TurboMetrics with `batch` frame-pair slots (batch=1 == reference)."""
 
-    def __init__(self, width: int, height: int, metrics: Metrics, batch: int = 1):
+    def __init__(self, width: int, height: int, metrics: Metrics, batch: int = 1, full_sums: bool = False):
+        """full_sums: also compute the 56 of the 108 per-scale sums whose weight in the reference's table is 0.0
+        (raw_sums() then equals the reference's `scores` array entry for entry; the score is the same either way)."""
         self._L = ffi.lib()
         self.width, self.height, self.batch = int(width), int(height), int(batch)
         self._metrics = metrics
@@ -137,6 +139,8 @@ class TurboMetrics:
         _chk(self._L.tm_engine_create(C.byref(h), self.width, self.height, metrics.mask(), self.batch), "tm_engine_create")
         self._h = h
         self._keep = {}
+        if full_sums:
+            self.set_full_sums(True)
 
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
@@ -252,6 +256,15 @@ class TurboMetrics:
         n = C.c_uint64()
         _chk(self._L.tm_engine_get_stage_ms(self._h, ms, C.byref(n), int(reset)), "tm_engine_get_stage_ms")
         return list(ms), int(n.value)
+
+    def set_full_sums(self, on: bool):
+        _chk(self._L.tm_engine_set_full_sums(self._h, int(bool(on))), "tm_engine_set_full_sums")
+
+    def job_modes(self) -> np.ndarray:
+        """(6 scales, 3 channels): 0 = nothing computed, 1 = edge terms only, 2 = all three error maps"""
+        out = (C.c_int * 18)()
+        _chk(self._L.tm_engine_get_job_modes(self._h, out), "tm_engine_get_job_modes")
+        return np.array(out, np.int32).reshape(6, 3)
 
     def set_variant(self, v: int):
         _chk(self._L.tm_engine_set_variant(self._h, int(v)), "tm_engine_set_variant")

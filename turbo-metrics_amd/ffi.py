@@ -38,6 +38,8 @@ SYMBOLS = {
     "tm_engine_sync": (_i, [_vp]),
     "tm_engine_get_scores": (_i, [_vp, _u32, C.POINTER(FrameScoresC)]),
     "tm_engine_get_raw_sums": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
+    "tm_engine_set_full_sums": (_i, [_vp, _i]),
+    "tm_engine_get_job_modes": (_i, [_vp, C.POINTER(C.c_int)]),
     "tm_engine_get_sse": (_i, [_vp, _u32, C.POINTER(C.c_uint64)]),
     "tm_ssimulacra2_score_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
     "tm_engine_set_profiling": (_i, [_vp, _i]),
