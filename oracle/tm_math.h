@@ -9,9 +9,9 @@
  *                    crates/cuda-colorspace-kernel/src/lib.rs:221-236 and the sRGB EOTF
  *                    crates/cuda-colorspace-kernel/src/srgb.rs:40-48)
  * libdevice is closed NVIDIA bitcode that is not under /root/reference, so its exact
- * rounding cannot be reproduced.  Both functions are restated as "the correctly rounded
- * f32 result" computed through a fixed sequence of IEEE-754 binary64 operations
- * (+, -, *, /, fma, rint and integer bit manipulation only).  The HIP kernels execute
+ * rounding cannot be reproduced.  Both functions are restated as "the f32 value nearest the exact
+ * result" computed through a fixed sequence of IEEE-754 operations (powf: binary64 +, -, *, fma, rint and
+ * integer bit manipulation; cbrtf: binary32 *, -, fma).  The HIP kernels execute
  * the same sequence (turbo-metrics_amd/csrc/tm_device_math.h, written separately), and
  * because every step is an exactly specified IEEE operation the two agree bit for bit.
  * Accuracy: |error| <= 0.50001 ulp(f32) (tests/test_oracle_pins.py); libdevice documents 1 ulp for
@@ -29,36 +29,37 @@
 static inline uint64_t tmo_d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 static inline double tmo_u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 
-/* cube root of a >= 0 (the caller applies max(.,0) as xyb.rs:44 does).
- * r ~ a^(-1/3): exponent trick (3.4 %), three Newton steps in f32 (-> ~1e-7), one in f64 (-> ~2e-14),
- * result a * r^2 rounded once to f32.  Outside [1e-18, 1e18] the f32 steps would overflow: all four in f64. */
+static inline uint32_t tmo_f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float tmo_u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+
+/* cube root (the caller applies max(.,0) as xyb.rs:44 does), in f32 operations only:
+ * r ~ a^(-1/3) from an exponent-trick seed (3.4 %) and two third-order steps r <- r(1 + e/3 + 2e^2/9), e = 1 - a r^3;
+ * y0 = (a r) r; one Newton step on y with the residual a - y0^3 formed exactly (error-free products, Sterbenz) and
+ * 1/(3y^2) ~ r^2/3.  The last fma is the only rounding that matters: |error| <= 0.500001 ulp.
+ * +0, negatives, NaN, inf come back unchanged; arguments outside [2^-100, 2^100] are scaled by 8^(+-32) (exact). */
 static inline float tmo_cbrtf(float a)
 {
-    if (!(a > 0.0f)) return a; /* +0 -> +0; NaN -> NaN */
-    const double x = (double)a;
-    const uint32_t hi = (uint32_t)(tmo_d2u(x) >> 32);
-    double r = tmo_u2d((uint64_t)(0x553EF000u - hi / 3u) << 32);
-    const double third = 0x1.5555555555555p-2;
-    if (a > 1e-18f && a < 1e18f) {
-        float rf = (float)r;
-        const float thirdf = 0x1.555556p-2f;
-        for (int i = 0; i < 3; ++i) {
-            const float r3 = (rf * rf) * rf;
-            const float e = fmaf(-a, r3, 1.0f);
-            rf = fmaf(rf * thirdf, e, rf);
-        }
-        r = (double)rf;
-        const double r3 = (r * r) * r;
-        const double e = fma(-x, r3, 1.0);
-        r = fma(r * third, e, r);
-    } else {
-        for (int i = 0; i < 4; ++i) {
-            const double r3 = (r * r) * r;
-            const double e = fma(-x, r3, 1.0);
-            r = fma(r * third, e, r);
-        }
+    if (!(a > 0.0f) || !(a < INFINITY)) return a;
+    float sc = 1.0f;
+    if (a < 0x1p-100f) { a *= 0x1p96f; sc = 0x1p-32f; }
+    else if (a > 0x1p100f) { a *= 0x1p-96f; sc = 0x1p32f; }
+    float r = tmo_u2f(0x54a23400u - tmo_f2u(a) / 3u);
+    for (int i = 0; i < 2; ++i) {
+        float t = r * r;
+        t = t * r;
+        const float e = fmaf(-a, t, 1.0f);
+        float p = fmaf(e, 0x1.c71c72p-3f, 0x1.555556p-2f); /* 2/9, 1/3 */
+        p = p * e;
+        r = fmaf(r, p, r);
     }
-    return (float)(x * (r * r));
+    const float y0 = (a * r) * r;
+    const float s = y0 * y0, se = fmaf(y0, y0, -s);
+    const float p = s * y0, pe = fmaf(s, y0, -p);
+    const float d = a - p;
+    float res = d - pe;
+    res = fmaf(-se, y0, res);
+    const float c = (r * r) * 0x1.555556p-2f;
+    return fmaf(res, c, y0) * sc;
 }
 
 #include "tm_math_tables.inc"

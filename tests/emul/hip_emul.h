@@ -36,6 +36,8 @@ struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 static inline float2 make_float2(float a, float b) { return {a, b}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+static inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
 static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 using std::min;

@@ -3,12 +3,12 @@
 // The reference kernels call two libdevice routines whose bit-level behaviour is NVIDIA's:
 //   __nv_cbrtf     in linear_to_xyb            (ssimulacra2-cuda-kernel/src/xyb.rs:44-46)
 //   __nv_fast_powf in the BT.709 / sRGB EOTFs  (cuda-colorspace-kernel/src/lib.rs:228, srgb.rs:46)
-// Here both are evaluated as a fixed sequence of IEEE-754 operations (v_fma_f64 / v_mul_f64 / v_add_f64,
-// v_rndne_f64, a few v_fma_f32, integer ops on the exponent field, three 32-entry tables) followed by one
-// rounding to f32.  The result is within 0.50001 ulp of the exact value, deterministic, and reproducible on
-// any IEEE machine -- which is what lets the parity tests demand bit equality for every plane.
+// Here both are evaluated as a fixed sequence of IEEE-754 operations (pow: v_fma_f64 / v_mul_f64 / v_add_f64,
+// v_rndne_f64, integer ops on the exponent field, three 32-entry tables, one rounding to f32; cbrt: f32 mul / sub /
+// fma only).  The result is within 0.50001 ulp of the exact value, deterministic, and reproducible on any IEEE
+// machine -- which is what lets the parity tests demand bit equality for every plane.
 // Cost matters: the ingest kernel is ALU bound (MI355X runs f64 FMA at half the f32 rate), so both
-// routines avoid division and keep the f64 operation count low (pow ~20, cbrt 7 + 15 f32).
+// routines avoid division; pow is ~20 f64 operations, cbrt 27 f32 operations evaluated on pairs (v_pk_*_f32).
 //
 // Must be compiled with -ffp-contract=off: the fma() calls are the only fused operations.
 #pragma once
@@ -30,40 +30,95 @@ namespace tmdev {
 __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
 
-// cube root of a >= 0: exponent-trick seed (3.4 %), three Newton steps on r = a^(-1/3) in f32 (full-rate
-// VALU, -> ~1e-7), one in f64 (-> ~2e-14), a*r^2 rounded once to f32.  7 f64 + 15 f32 operations.
+// ---- two-lane f32 vectors: gfx950 executes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on two floats per lane at the
+// rate of one scalar VALU instruction, so everything below that can be said on pairs is said on pairs ----------------
+#ifdef TM_EMULATE
+struct tm_f2 { float x, y; };
+static inline tm_f2 operator*(tm_f2 a, tm_f2 b) { return {a.x * b.x, a.y * b.y}; }
+static inline tm_f2 operator-(tm_f2 a, tm_f2 b) { return {a.x - b.x, a.y - b.y}; }
+static inline tm_f2 operator-(tm_f2 a) { return {-a.x, -a.y}; }
+static inline tm_f2 f2_fma(tm_f2 a, tm_f2 b, tm_f2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float tm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tm_f2 f2_fma(tm_f2 a, tm_f2 b, tm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+__device__ __forceinline__ tm_f2 f2_make(float a, float b) { tm_f2 v; v.x = a; v.y = b; return v; }
+__device__ __forceinline__ tm_f2 f2_splat(float a) { return f2_make(a, a); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// Cube root, f32 only (no f64, no division): 27 IEEE operations.
+//   r ~ a^(-1/3): exponent-trick seed (3.4 %), two third-order steps r <- r (1 + e/3 + 2 e^2/9), e = 1 - a r^3
+//                 (3.4e-2 -> 1.7e-4 -> f32 precision);
+//   y0 = (a r) r, then ONE Newton step on y whose residual a - y0^3 is formed exactly with error-free products
+//   (s + se = y0^2, p + pe = s y0, a - p exact by Sterbenz), correction factor 1/(3 y^2) ~ r^2/3:
+//   y = fma(res, r^2/3, y0) is the only rounding that matters -> |error| <= 0.500001 ulp.  Checked exhaustively over
+//   [1, 64) and the whole range of pixel values [0.0037, 1]: two mantissas per three octaves (0x1.06a76ap+1,
+//   0x1.f5fa26p+1 and their 8^k multiples, whose cube roots sit within 1e-6 ulp of a rounding boundary) come out one ulp
+//   off the correctly rounded value, all others are correctly rounded.  Valid for normal a in [2^-100, 2^100].
+__device__ __forceinline__ tm_f2 cbrt_core2(tm_f2 a)
+{
+    tm_f2 r = f2_make(u2f(0x54a23400u - f2u(a.x) / 3u), u2f(0x54a23400u - f2u(a.y) / 3u));
+    const tm_f2 one = f2_splat(1.0f), c29 = f2_splat(0x1.c71c72p-3f), c13 = f2_splat(0x1.555556p-2f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        tm_f2 t = r * r;
+        t = t * r;
+        const tm_f2 e = f2_fma(-a, t, one);
+        tm_f2 p = f2_fma(e, c29, c13);
+        p = p * e;
+        r = f2_fma(r, p, r);
+    }
+    const tm_f2 y0 = (a * r) * r;
+    const tm_f2 s = y0 * y0, se = f2_fma(y0, y0, -s);
+    const tm_f2 p = s * y0, pe = f2_fma(s, y0, -p);
+    const tm_f2 d = a - p;
+    tm_f2 res = d - pe;
+    res = f2_fma(-se, y0, res);
+    const tm_f2 c = (r * r) * c13;
+    return f2_fma(res, c, y0);
+}
+
+// any a: +0 / negative / NaN / inf are returned unchanged (the callers pass max(mixed, 0), xyb.rs:44); values outside
+// [2^-100, 2^100] are brought into range by an exact power-of-eight scaling
 __device__ TM_MATH_INLINE float cbrt_pos(float a)
 {
 #ifdef TM_EXP_NOCBRT
     return a * 0.5f + 0.1f;
 #endif
-    if (!(a > 0.0f)) return a;
-    const double x = (double)a;
-    const uint32_t hi = (uint32_t)(d2u(x) >> 32);
-    double r = u2d((uint64_t)(0x553EF000u - hi / 3u) << 32);
-    const double third = 0x1.5555555555555p-2;
-    if (a > 1e-18f && a < 1e18f) {
-        float rf = (float)r;
-        const float thirdf = 0x1.555556p-2f;
+    if (!(a > 0.0f) || !(a < __builtin_inff())) return a;
+    float sc = 1.0f;
+    if (a < 0x1p-100f) { a *= 0x1p96f; sc = 0x1p-32f; }
+    else if (a > 0x1p100f) { a *= 0x1p-96f; sc = 0x1p32f; }
+    return cbrt_core2(f2_splat(a)).x * sc;
+}
+
+// N cube roots in place; pixel data is always inside [2^-100, 2^100], so the pairs go through cbrt_core2 directly
+// (same operations as cbrt_pos with sc = 1 -> same bits) and the general routine is only a fallback
+template <int N> __device__ __forceinline__ void cbrt_pos_n(float (&v)[N])
+{
+#ifdef TM_EXP_NOCBRT
+    for (int i = 0; i < N; ++i) v[i] = v[i] * 0.5f + 0.1f;
+    return;
+#endif
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float r3 = (rf * rf) * rf;
-            const float e = __builtin_fmaf(-a, r3, 1.0f);
-            rf = __builtin_fmaf(rf * thirdf, e, rf);
-        }
-        r = (double)rf;
-        const double r3 = (r * r) * r;
-        const double e = __builtin_fma(-x, r3, 1.0);
-        r = __builtin_fma(r * third, e, r);
-    } else { // the f32 steps would overflow out here
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double r3 = (r * r) * r;
-            const double e = __builtin_fma(-x, r3, 1.0);
-            r = __builtin_fma(r * third, e, r);
-        }
+    for (int i = 0; i < N; ++i) {
+        const uint32_t u = f2u(v[i]);
+        lo = u < lo ? u : lo;
+        hi = u > hi ? u : hi;
     }
-    return (float)(x * (r * r));
+    if (lo >= 0x0D800000u && hi <= 0x71800000u) { // all in [2^-100, 2^100]: positive, normal, finite
+#pragma unroll
+        for (int i = 0; i + 1 < N; i += 2) {
+            const tm_f2 y = cbrt_core2(f2_make(v[i], v[i + 1]));
+            v[i] = y.x; v[i + 1] = y.y;
+        }
+        if (N & 1) v[N - 1] = cbrt_core2(f2_splat(v[N - 1])).x;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = cbrt_pos(v[i]);
+    }
 }
 
 // x^y, finite x > 0.  tab: 96 doubles {rcp[32], nlog[32], exp2[32]} (tm_math_tables.inc), normally in LDS.
@@ -122,25 +177,42 @@ __device__ __forceinline__ float srgb_inverse_oetf(float x, const double *__rest
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
-// px_linear_rgb_to_positive_xyb, ssimulacra2-cuda-kernel/src/xyb.rs:42-79
-__device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float &X, float &Y, float &B)
+// px_linear_rgb_to_positive_xyb, ssimulacra2-cuda-kernel/src/xyb.rs:42-79, for N pixels at once (the 3N cube roots
+// are evaluated pairwise)
+template <int N>
+__device__ __forceinline__ void linear_to_xyb_n(const float (&r)[N], const float (&g)[N], const float (&b)[N], float (&X)[N],
+                                                float (&Y)[N], float (&B)[N])
 {
     const float K_M02 = 0.078f, K_M00 = 0.30f, K_M01 = 1.0f - K_M02 - K_M00;
     const float K_M12 = 0.078f, K_M10 = 0.23f, K_M11 = 1.0f - K_M12 - K_M10;
     const float K_M20 = 0.24342269f, K_M21 = 0.20476745f, K_M22 = 1.0f - K_M20 - K_M21;
     const float K_B0 = 0.0037930734f;
     const float K_B0_ROOT = 0.1559542025327239180319220163705f;
-    float rg = __builtin_fmaf(K_M00, r, __builtin_fmaf(K_M01, g, __builtin_fmaf(K_M02, b, K_B0)));
-    float gr = __builtin_fmaf(K_M10, r, __builtin_fmaf(K_M11, g, __builtin_fmaf(K_M12, b, K_B0)));
-    float bb = __builtin_fmaf(K_M20, r, __builtin_fmaf(K_M21, g, __builtin_fmaf(K_M22, b, K_B0)));
-    rg = cbrt_pos(fmaxf(rg, 0.0f)) - K_B0_ROOT;
-    gr = cbrt_pos(fmaxf(gr, 0.0f)) - K_B0_ROOT;
-    bb = cbrt_pos(fmaxf(bb, 0.0f)) - K_B0_ROOT;
-    const float x = 0.5f * (rg - gr);
-    const float y = 0.5f * (rg + gr);
-    X = __builtin_fmaf(x, 14.0f, 0.42f);
-    Y = y + 0.01f;
-    B = bb - y + 0.55f;
+    float m[3 * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        m[3 * i + 0] = fmaxf(__builtin_fmaf(K_M00, r[i], __builtin_fmaf(K_M01, g[i], __builtin_fmaf(K_M02, b[i], K_B0))), 0.0f);
+        m[3 * i + 1] = fmaxf(__builtin_fmaf(K_M10, r[i], __builtin_fmaf(K_M11, g[i], __builtin_fmaf(K_M12, b[i], K_B0))), 0.0f);
+        m[3 * i + 2] = fmaxf(__builtin_fmaf(K_M20, r[i], __builtin_fmaf(K_M21, g[i], __builtin_fmaf(K_M22, b[i], K_B0))), 0.0f);
+    }
+    cbrt_pos_n<3 * N>(m);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float rg = m[3 * i + 0] - K_B0_ROOT, gr = m[3 * i + 1] - K_B0_ROOT, bb = m[3 * i + 2] - K_B0_ROOT;
+        const float x = 0.5f * (rg - gr);
+        const float y = 0.5f * (rg + gr);
+        X[i] = __builtin_fmaf(x, 14.0f, 0.42f);
+        Y[i] = y + 0.01f;
+        B[i] = bb - y + 0.55f;
+    }
+}
+
+__device__ __forceinline__ void linear_to_xyb(float r, float g, float b, float &X, float &Y, float &B)
+{
+    const float ra[1] = {r}, ga[1] = {g}, ba[1] = {b};
+    float xa[1], ya[1], za[1];
+    linear_to_xyb_n<1>(ra, ga, ba, xa, ya, za);
+    X = xa[0]; Y = ya[0]; B = za[0];
 }
 
 // One step of the three second-order sections of the truncated-cosine recursive Gaussian,

@@ -494,10 +494,46 @@ struct IngestSideLds {
     float lin1[3][16][17]; // level-1 linear RGB
 };
 
+// XYB tiles out of LDS: a 32x32 tile of level A (tile origin tx0, ty0) and the 16x16 tile of level A+1 below it, each
+// in both orientations; float4 per lane, so 8 (4) neighbouring lanes complete a 128-B (64-B) run of one row.
+__device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const TmScaleGeom &sa, const TmScaleGeom &sb,
+                                                 float *__restrict__ xyb, float *__restrict__ xybt, int tx0, int ty0, int tid)
+{
+    {
+        const int r = tid >> 3, q4 = (tid & 7) * 4;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#ifndef TM_EXP_NOSTORE_N
+            if (ty0 + r < sa.h && tx0 + q4 < sa.w)
+                *(float4 *)(xyb + sa.off + c * sa.plane + (size_t)(ty0 + r) * sa.pitch + tx0 + q4) =
+                    make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
+#endif
+#ifndef TM_EXP_NOSTORE_T
+            if (tx0 + r < sa.w && ty0 + q4 < sa.h)
+                *(float4 *)(xybt + sa.off_t + c * sa.plane_t + (size_t)(tx0 + r) * sa.pitch_t + ty0 + q4) =
+                    make_float4(L.t0[c][q4][r], L.t0[c][q4 + 1][r], L.t0[c][q4 + 2][r], L.t0[c][q4 + 3][r]);
+#endif
+        }
+    }
+    if (tid < 192) {
+        const int c = tid >> 6, r = (tid & 63) >> 2, q4 = (tid & 3) * 4;
+        const int x1 = tx0 / 2, y1 = ty0 / 2;
+        if (y1 + r < sb.h && x1 + q4 < sb.w)
+            *(float4 *)(xyb + sb.off + c * sb.plane + (size_t)(y1 + r) * sb.pitch + x1 + q4) =
+                make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
+        if (x1 + r < sb.w && y1 + q4 < sb.h)
+            *(float4 *)(xybt + sb.off_t + c * sb.plane_t + (size_t)(x1 + r) * sb.pitch_t + y1 + q4) =
+                make_float4(L.t1[c][q4][r], L.t1[c][q4 + 1][r], L.t1[c][q4 + 2][r], L.t1[c][q4 + 3][r]);
+    }
+}
+
+#ifndef TM_TILE32_WAVES
+#define TM_TILE32_WAVES 5 // waves per SIMD the register allocation is held to
+#endif
 // KIND >= 0: every frame of the launch has this TM_KIND_* (the normal case; the host checks), so all format
 // branches fold away and the sample loads of a quad are issued back to back; KIND = -1: per-frame dispatch.
 template <int KIND>
-__global__ void __launch_bounds__(256) k_ingest_tile32(TmGeom g, const TmFrameDesc *__restrict__ desc,
+__global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g, const TmFrameDesc *__restrict__ desc,
                                                        const float *__restrict__ lut, const float *__restrict__ coef,
                                                        const double *__restrict__ gtab, const float *__restrict__ yuvlut,
                                                        float *__restrict__ XYB, float *__restrict__ XYBT,
@@ -555,55 +591,29 @@ __global__ void __launch_bounds__(256) k_ingest_tile32(TmGeom g, const TmFrameDe
                 }
             }
         }
-        // ---- level-0 XYB into the LDS tile, level-1 linear pixel of this quad and its XYB
-#pragma unroll
-        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < 2; ++ix) {
-                float a, b, c;
-                tmdev::linear_to_xyb(px[iy][ix][0], px[iy][ix][1], px[iy][ix][2], a, b, c);
-                L.t0[0][2 * qy + iy][2 * qx + ix] = a;
-                L.t0[1][2 * qy + iy][2 * qx + ix] = b;
-                L.t0[2][2 * qy + iy][2 * qx + ix] = c;
-            }
+        // ---- level-0 XYB into the LDS tile, level-1 linear pixel of this quad and its XYB (five pixels = 15 cube
+        // roots, evaluated pairwise)
         {
             const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
-            float l1[3], a, b, c;
+            float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                l1[ch] = ds4(px[0][0][ch], px[0][1][ch], px[1][0][ch], px[1][1][ch], okx, oky);
-                L.lin1[ch][qy][qx] = l1[ch];
+            for (int k = 0; k < 4; ++k) { lr[k] = px[k >> 1][k & 1][0]; lg[k] = px[k >> 1][k & 1][1]; lb[k] = px[k >> 1][k & 1][2]; }
+            lr[4] = ds4(px[0][0][0], px[0][1][0], px[1][0][0], px[1][1][0], okx, oky);
+            lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
+            lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
+            L.lin1[0][qy][qx] = lr[4]; L.lin1[1][qy][qx] = lg[4]; L.lin1[2][qy][qx] = lb[4];
+            tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                L.t0[0][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xa[k];
+                L.t0[1][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xb[k];
+                L.t0[2][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xc[k];
             }
-            tmdev::linear_to_xyb(l1[0], l1[1], l1[2], a, b, c);
-            L.t1[0][qy][qx] = a; L.t1[1][qy][qx] = b; L.t1[2][qy][qx] = c;
+            L.t1[0][qy][qx] = xa[4]; L.t1[1][qy][qx] = xb[4]; L.t1[2][qy][qx] = xc[4];
         }
         TM_LDS_BARRIER();
-        // ---- level 0 out of the tile: float4 per lane, 8 lanes per 128-B line, both orientations
-        {
-            const TmScaleGeom sg = g.s[0];
-            const int r = tid >> 3, q4 = (tid & 7) * 4;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (ty0 + r < h && tx0 + q4 < w)
-                    *(float4 *)(xyb + sg.off + c * sg.plane + (size_t)(ty0 + r) * sg.pitch + tx0 + q4) =
-                        make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
-                if (tx0 + r < w && ty0 + q4 < h)
-                    *(float4 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(tx0 + r) * sg.pitch_t + ty0 + q4) =
-                        make_float4(L.t0[c][q4][r], L.t0[c][q4 + 1][r], L.t0[c][q4 + 2][r], L.t0[c][q4 + 3][r]);
-            }
-        }
-        // ---- level 1 out of its tile (16 px = 64 B per row of the tile)
-        if (tid < 192) {
-            const TmScaleGeom sg = g.s[1];
-            const int c = tid >> 6, r = (tid & 63) >> 2, q4 = (tid & 3) * 4;
-            const int x1 = tx0 / 2, y1 = ty0 / 2;
-            if (y1 + r < sg.h && x1 + q4 < sg.w)
-                *(float4 *)(xyb + sg.off + c * sg.plane + (size_t)(y1 + r) * sg.pitch + x1 + q4) =
-                    make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
-            if (x1 + r < sg.w && y1 + q4 < sg.h)
-                *(float4 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(x1 + r) * sg.pitch_t + y1 + q4) =
-                    make_float4(L.t1[c][q4][r], L.t1[c][q4 + 1][r], L.t1[c][q4 + 2][r], L.t1[c][q4 + 3][r]);
-        }
+        // ---- levels 0 and 1 out of their tiles
+        store_tiles_both(L, g.s[0], g.s[1], xyb, xybt, tx0, ty0, tid);
         // ---- level-2 LINEAR pixels of this tile (8x8) go to HBM: levels 2..5 are finished by k_ingest_upper.
         // (Doing them here cost four more barriers per side with 3/4 .. 255/256 of the workgroup idle.)
         if (tid < 64) {
@@ -639,7 +649,7 @@ __global__ void __launch_bounds__(256) k_ingest_tile32(TmGeom g, const TmFrameDe
 __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB,
                                                       float *__restrict__ XYBT)
 {
-    __shared__ float lin3[3][16][17];
+    __shared__ IngestSideLds L; // t0: level-2 XYB tile, t1: level-3 XYB tile, lin1: level-3 linear RGB
     __shared__ float lin4[3][8][9];
     const int tid = threadIdx.x, qx = tid & 15, qy = tid >> 4;
     const int img = blockIdx.z; // slot*2 + side
@@ -648,28 +658,33 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT + (size_t)img * g.pyr_t;
     const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
-    float px[2][2][3];
-#pragma unroll
-    for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-        for (int ix = 0; ix < 2; ++ix) {
-            const bool in = X0 + ix < s2.w && Y0 + iy < s2.h;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) px[iy][ix][c] = in ? l2[c * s2.plane + (size_t)(Y0 + iy) * s2.pitch + X0 + ix] : 0.0f;
-            store_xyb_px(xyb, xybt, s2, X0 + ix, Y0 + iy, px[iy][ix]);
-        }
     {
-        const bool okx = X0 + 1 < s2.w, oky = Y0 + 1 < s2.h;
-        float v[3];
+        float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v[c] = ds4(px[0][0][c], px[0][1][c], px[1][0][c], px[1][1][c], okx, oky);
-            lin3[c][qy][qx] = v[c];
+        for (int k = 0; k < 4; ++k) {
+            const int x = X0 + (k & 1), y = Y0 + (k >> 1);
+            const bool in = x < s2.w && y < s2.h;
+            const size_t o = (size_t)(in ? y : 0) * s2.pitch + (in ? x : 0);
+            const float a = l2[o], b = l2[s2.plane + o], c = l2[2 * s2.plane + o];
+            lr[k] = in ? a : 0.0f; lg[k] = in ? b : 0.0f; lb[k] = in ? c : 0.0f;
         }
-        store_xyb_px(xyb, xybt, g.s[3], X0 / 2, Y0 / 2, v);
+        const bool okx = X0 + 1 < s2.w, oky = Y0 + 1 < s2.h;
+        lr[4] = ds4(lr[0], lr[1], lr[2], lr[3], okx, oky);
+        lg[4] = ds4(lg[0], lg[1], lg[2], lg[3], okx, oky);
+        lb[4] = ds4(lb[0], lb[1], lb[2], lb[3], okx, oky);
+        L.lin1[0][qy][qx] = lr[4]; L.lin1[1][qy][qx] = lg[4]; L.lin1[2][qy][qx] = lb[4];
+        tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            L.t0[0][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xa[k];
+            L.t0[1][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xb[k];
+            L.t0[2][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xc[k];
+        }
+        L.t1[0][qy][qx] = xa[4]; L.t1[1][qy][qx] = xb[4]; L.t1[2][qy][qx] = xc[4];
     }
     TM_LDS_BARRIER();
-    if (tid < 64) {
+    store_tiles_both(L, s2, g.s[3], xyb, xybt, tx0, ty0, tid);
+    if (tid < 64) { // level 4: 8x8 per tile
         const TmScaleGeom s3 = g.s[3];
         const int ox = tid & 7, oy = tid >> 3;
         const int XL = (tx0 >> 2) + ox, YL = (ty0 >> 2) + oy;
@@ -677,13 +692,13 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
         float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            v[c] = ds4(lin3[c][2 * oy][2 * ox], lin3[c][2 * oy][2 * ox + 1], lin3[c][2 * oy + 1][2 * ox], lin3[c][2 * oy + 1][2 * ox + 1], okx, oky);
+            v[c] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox], L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
             lin4[c][oy][ox] = v[c];
         }
         store_xyb_px(xyb, xybt, g.s[4], XL, YL, v);
     }
     TM_LDS_BARRIER();
-    if (tid < 16) {
+    if (tid < 16) { // level 5: 4x4 per tile
         const TmScaleGeom s4 = g.s[4];
         const int ox = tid & 3, oy = tid >> 2;
         const int XL = (tx0 >> 3) + ox, YL = (ty0 >> 3) + oy;
