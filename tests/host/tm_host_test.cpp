@@ -1,0 +1,106 @@
+// tests/host/tm_host_test.cpp -- TEST INFRASTRUCTURE: exposes the host-side pieces of turbo-metrics_amd/host that need no
+// GPU (number formatting, Stats, image / Y4M decoding, output layer) to the pytest tier through a tiny command line.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../../turbo-metrics_amd/host/frame_sources.hpp"
+#include "../../turbo-metrics_amd/host/output.hpp"
+#include "../../turbo-metrics_amd/host/rust_fmt.hpp"
+
+using namespace tm_host;
+
+static double parse_double(const std::string &s)
+{
+    if (s == "inf") return INFINITY;
+    if (s == "-inf") return -INFINITY;
+    if (s == "nan") return NAN;
+    return strtod(s.c_str(), nullptr); // accepts hex floats
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    const std::string cmd = argv[1];
+    try {
+        if (cmd == "fmt") { // fmt v...  -> one line per value: display|debug|json
+            for (int i = 2; i < argc; ++i) {
+                const double v = parse_double(argv[i]);
+                std::cout << display(v) << "|" << debug(v) << "|" << json_number(v) << "\n";
+            }
+        } else if (cmd == "stats") { // stats v... -> compact json of Stats
+            std::vector<double> v;
+            for (int i = 2; i < argc; ++i) v.push_back(parse_double(argv[i]));
+            std::cout << stats_json(Stats::compute(v), 0, false) << "\n";
+        } else if (cmd == "output") { // output MODE psnr,ssim,msssim,ssimulacra2(0/1 flags) < lines of scores
+            Output o;
+            if (argc < 4 || !parse_output(argv[2], o)) return 2;
+            Metrics m;
+            m.psnr = argv[3][0] == '1'; m.ssim = argv[3][1] == '1'; m.msssim = argv[3][2] == '1'; m.ssimulacra2 = argv[3][3] == '1';
+            std::vector<double> a, b, c, d;
+            output_prepare(o, m, std::cout);
+            std::string line;
+            size_t n = 0;
+            while (std::getline(std::cin, line)) {
+                std::istringstream ss(line);
+                FrameScores r;
+                std::string t;
+                if (m.psnr) { ss >> t; r.psnr = parse_double(t); a.push_back(*r.psnr); }
+                if (m.ssim) { ss >> t; r.ssim = parse_double(t); b.push_back(*r.ssim); }
+                if (m.msssim) { ss >> t; r.msssim = parse_double(t); c.push_back(*r.msssim); }
+                if (m.ssimulacra2) { ss >> t; r.ssimulacra2 = parse_double(t); d.push_back(*r.ssimulacra2); }
+                output_single_score(o, r, std::cout);
+                ++n;
+            }
+            MetricsResults res;
+            res.frame_count = n;
+            if (m.psnr) res.psnr = MetricAggregate::from(a);
+            if (m.ssim) res.ssim = MetricAggregate::from(b);
+            if (m.msssim) res.msssim = MetricAggregate::from(c);
+            if (m.ssimulacra2) res.ssimulacra2 = MetricAggregate::from(d);
+            output_results(o, res, std::cout);
+        } else if (cmd == "source") {
+            // source PATH OUT [--width W --height H --bits B --cp N --mc N --tc N --skip N]: every frame's bytes as handed
+            // to the engine are appended to OUT (biplanar kinds: `rows` luma rows + chroma rows at the surface pitch);
+            // stdout: one description line, then one line per frame
+            SourceHints h;
+            uint32_t skip = 0;
+            for (int i = 4; i + 1 < argc; i += 2) {
+                const std::string k = argv[i];
+                const int v = atoi(argv[i + 1]);
+                if (k == "--width") h.width = v; else if (k == "--height") h.height = v; else if (k == "--bits") h.bits = v;
+                else if (k == "--cp") h.cp = v; else if (k == "--mc") h.mc = v; else if (k == "--tc") h.tc = v; else if (k == "--skip") skip = v;
+            }
+            auto src = create_source(argv[2], h);
+            const auto cc = src->color_characteristics();
+            std::cout << src->format_id().str() << " " << src->width() << " " << src->height() << " " << to_string(cc.first.cp) << " "
+                      << to_string(cc.first.mc) << " " << to_string(cc.first.tc) << " " << to_string(cc.second) << " " << src->frame_count() << "\n";
+            std::ofstream out(argv[3], std::ios::binary);
+            src->skip_frames(skip);
+            HwFrame f;
+            while (src->next_frame(f)) {
+                const uint32_t w = src->width(), hh = src->height();
+                if (f.kind == HwFrame::NvDecNV12 || f.kind == HwFrame::NvDecP016) {
+                    const size_t luma_rows = ((const char *)f.uv - (const char *)f.data) / f.pitch, crows = (hh + 1) / 2;
+                    out.write((const char *)f.data, (std::streamsize)(f.pitch * luma_rows));
+                    out.write((const char *)f.uv, (std::streamsize)(f.pitch * crows));
+                    std::cout << (f.kind == HwFrame::NvDecNV12 ? "nv12 " : "p016 ") << f.pitch << " " << luma_rows << " " << crows << "\n";
+                } else {
+                    out.write((const char *)f.data, (std::streamsize)(f.pitch * hh));
+                    std::cout << (f.kind == HwFrame::Npp8 ? "rgb8 " : f.kind == HwFrame::Npp16 ? "rgb16 " : "rgbf32 ") << f.pitch << " " << w << "\n";
+                }
+            }
+        } else if (cmd == "colors") { // colors CP MC TC HEIGHT -> resolved characteristics + engine codes (or the error)
+            const ColorCharacteristics c = ColorCharacteristics::from_codes(atoi(argv[2]), atoi(argv[3]), atoi(argv[4])).or_(color_characteristics_fallback(atoi(argv[5])));
+            std::cout << to_string(c.cp) << " " << to_string(c.mc) << " " << to_string(c.tc) << " ";
+            std::cout << get_color_matrix(c) << " " << get_transfer(c) << "\n";
+        } else return 2;
+    } catch (const std::exception &e) {
+        std::cout << "ERROR: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

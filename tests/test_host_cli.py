@@ -1,0 +1,377 @@
+"""C++ host side (turbo-metrics_amd/host): number formatting, Stats, frame sources and the output layer on the CPU tier
+(through tests/host/tm_host_test); the `turbo-metrics` command line itself on the GPU tier.
+
+Expected texts follow the reference's output layer (crates/turbo-metrics-cli/src/output.rs, quick-stats/src/lib.rs):
+Rust `{}` for CSV, serde_json (ryu) for JSON, `{:#?}` for the default report."""
+import json
+import os
+import struct
+import subprocess
+import zlib
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+from tm_pkg import tm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "turbo-metrics_amd", "host")
+HELPER = os.path.join(ROOT, "tests", "host", "tm_host_test")
+CLI = os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")
+
+
+@pytest.fixture(scope="module")
+def helper():
+    srcs = [os.path.join(ROOT, "tests", "host", "tm_host_test.cpp")] + [os.path.join(HOST, f) for f in ("frame_sources.cpp", "output.cpp", "turbo_metrics.cpp")]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
+    if not os.path.exists(HELPER) or any(os.path.getmtime(d) > os.path.getmtime(HELPER) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", HELPER] + srcs + ["-L" + os.path.join(ROOT, "turbo-metrics_amd"),
+                              "-lturbometrics_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "turbo-metrics_amd")])
+    return HELPER
+
+
+def run(helper, *args, stdin=None):
+    return subprocess.run([helper] + [str(a) for a in args], input=stdin, capture_output=True, text=True, check=False).stdout
+
+
+# ---- number formatting ---------------------------------------------------------------------------------------------
+def rust_display(x):
+    x = float(x)
+    if x != x:
+        return "NaN"
+    if x in (float("inf"), float("-inf")):
+        return "inf" if x > 0 else "-inf"
+    s = format(Decimal(repr(x)), "f")
+    if "." in s:
+        s = s.rstrip("0").rstrip(".")
+    return s if x != 0 else ("-0" if str(x).startswith("-") else "0")
+
+
+def test_f64_text_forms_follow_rust_display_debug_and_serde_json(helper):
+    rng = np.random.default_rng(3)
+    vals = [100.0, 0.1, 74.54997609000992, 17.398505, 1e-7, 1e16, 9999999999999998.0, 1e15, 123456.789, 0.0001, 0.00009999, 5e-324,
+            35.73, 99.99, 1.0, 2.5, 1e21, 0.00001, 0.000001, 1e-5 * 0.99, 12345678.9] + list(rng.random(40) * 100) + list(10.0 ** rng.uniform(-9, 19, 40))
+    out = run(helper, "fmt", *[repr(float(v)) for v in vals]).strip().split("\n")
+    assert len(out) == len(vals)
+    for v, line in zip(vals, out):
+        v = float(v)
+        disp, dbg, js = line.split("|")
+        assert disp == rust_display(v), (v, disp)
+        assert float(disp) == v and "e" not in disp  # Display never uses an exponent and round-trips
+        assert float(dbg) == v and float(js) == v    # shortest round-trip digits everywhere
+        assert json.loads(js) == v
+        a = abs(v)
+        assert ("e" in dbg) == (a < 1e-4 or a >= 1e16), (v, dbg)        # core::fmt float_to_general_debug
+        if "e" not in dbg:
+            assert "." in dbg                                            # Debug keeps ".0"
+        assert ("e" in js) == (not (1e-5 <= a < 1e16)), (v, js)  # ryu: decimal iff -5 < kk <= 16
+        if "e" not in js:
+            assert "." in js
+    assert run(helper, "fmt", "inf", "nan", "0", "-0.0").strip().split("\n") == ["inf|inf|null", "NaN|NaN|null", "0|0.0|0.0", "-0|-0.0|-0.0"]
+    # exact forms of a few known values
+    assert run(helper, "fmt", "100", "1e-7", "1e16", "1.5e-5").strip().split("\n") == [
+        "100|100.0|100.0", "0.0000001|1e-7|1e-7", "10000000000000000|1e16|1e16", "0.000015|1.5e-5|0.000015"]
+
+
+def test_stats_match_quick_stats_definitions(helper):
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 5, 100, 1001):
+        v = rng.random(n) * 100
+        got = json.loads(run(helper, "stats", *[repr(float(x)) for x in v]))
+        s = np.sort(v)
+        assert got["min"] == s[0] and got["max"] == s[-1]
+        np.testing.assert_allclose(got["mean"], v.mean(), rtol=1e-14)
+        np.testing.assert_allclose(got["var"], v.var() if n > 1 else 0.0, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got["sample_var"], v.var(ddof=1) if n > 1 else 0.0, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got["stddev"], np.sqrt(got["var"]), rtol=1e-15)
+        for k, p in (("p1", 1), ("p5", 5), ("p50", 50), ("p95", 95), ("p99", 99)):
+            np.testing.assert_allclose(got[k], np.percentile(v, p), rtol=1e-13)  # linear interpolation on (n-1)*p/100
+    # the reference's own example values (quick-stats/src/lib.rs:101-107)
+    assert json.loads(run(helper, "stats", 0, 1, 3, 4))["mean"] == 2.0
+    assert run(helper, "stats").startswith("ERROR")  # empty input: the reference panics (index out of bounds)
+
+
+# ---- output layer --------------------------------------------------------------------------------------------------
+SCORES = "35.5 80.25\n100 99.99\n"
+
+
+def test_output_csv_repeats_header_and_rows_like_the_reference(helper):
+    out = run(helper, "output", "csv", "1001", stdin=SCORES)
+    # prepare(): header; per frame: row; output_results(): header + every row again (output.rs:25-37,104-139)
+    assert out == "psnr,ssimulacra2\n35.5,80.25\n100,99.99\npsnr,ssimulacra2\n35.5,80.25\n100,99.99\n"
+
+
+def test_output_json_lines(helper):
+    out = run(helper, "output", "json-lines", "1001", stdin=SCORES).strip().split("\n")
+    assert out[0] == '{"psnr":35.5,"ssimulacra2":80.25}' and out[1] == '{"psnr":100.0,"ssimulacra2":99.99}'
+    last = json.loads(out[2])
+    assert list(last) == ["frame_count", "psnr", "ssimulacra2"] and last["frame_count"] == 2
+    assert list(last["psnr"]) == ["min", "max", "mean", "var", "sample_var", "stddev", "sample_stddev", "p1", "p5", "p50", "p95", "p99"]
+    assert out[2].startswith('{"frame_count":2,"psnr":{"min":35.5,"max":100.0,"mean":67.75,')
+
+
+def test_output_json_pretty(helper):
+    out = run(helper, "output", "json", "0001", stdin="80.25\n99.99\n")
+    assert out.startswith('{\n  "frame_count": 2,\n  "ssimulacra2": {\n    "scores": [\n      80.25,\n      99.99\n    ],\n    "stats": {\n      "min": 80.25,\n')
+    assert out.endswith('      "p99": ' + json.dumps(json.loads(out)["ssimulacra2"]["stats"]["p99"]) + "\n    }\n  }\n}\n")
+    d = json.loads(out)
+    assert d["frame_count"] == 2 and d["ssimulacra2"]["scores"] == [80.25, 99.99]
+
+
+def test_output_default_is_rust_pretty_debug(helper):
+    out = run(helper, "output", "default", "0001", stdin="80.25\n99.75\n")
+    assert out == ("SSIMULACRA2: Stats {\n    min: 80.25,\n    max: 99.75,\n    mean: 90.0,\n    var: 95.0625,\n    sample_var: 190.125,\n"
+                   "    stddev: 9.75,\n    sample_stddev: 13.788582233137676,\n    p1: 80.445,\n    p5: 81.225,\n    p50: 90.0,\n    p95: 98.775,\n    p99: 99.555,\n}\n")
+
+
+def test_psnr_of_identical_frames_prints_inf_and_null(helper):
+    assert run(helper, "output", "csv", "1000", stdin="inf\n").split("\n")[1] == "inf"
+    assert run(helper, "output", "json-lines", "1000", stdin="inf\n").split("\n")[0] == '{"psnr":null}'
+
+
+# ---- colour metadata -------------------------------------------------------------------------------------------------
+def test_colour_fallback_and_todo_combinations(helper):
+    assert run(helper, "colors", 2, 2, 2, 480).split() == ["BT601_525", "BT601_525", "BT709", "1", "0"]   # color.rs:51-78
+    assert run(helper, "colors", 2, 2, 2, 576).split() == ["BT601_625", "BT601_625", "BT709", "2", "0"]
+    assert run(helper, "colors", 2, 2, 2, 1080).split() == ["BT709", "BT709", "BT709", "0", "0"]
+    assert run(helper, "colors", 2, 2, 2, 2160).split() == ["BT709", "BT709", "BT709", "0", "0"]
+    assert run(helper, "colors", 1, 1, 1, 480).split() == ["BT709", "BT709", "BT709", "0", "0"]
+    assert run(helper, "colors", 5, 5, 6, 1080).split()[:3] == ["BT601_625", "BT601_625", "BT709"]
+    assert "not implemented" in run(helper, "colors", 1, 6, 1, 1080)   # mixed primaries / matrix: todo!() at color.rs:85
+    assert "not implemented" in run(helper, "colors", 1, 1, 4, 1080)   # gamma 2.2 transfer: todo!() at color.rs:92
+
+
+# ---- frame sources ---------------------------------------------------------------------------------------------------
+def png_bytes(arr, interlace=False):
+    """Minimal PNG writer (RGB 8/16 bit, filter 0, optional Adam7) -- Pillow cannot write 16-bit RGB or interlaced files."""
+    h, w, _ = arr.shape
+    depth = 8 if arr.dtype == np.uint8 else 16
+    be = arr if depth == 8 else arr.astype(">u2")
+
+    def rows(sub):
+        return b"".join(b"\x00" + sub[y].tobytes() for y in range(sub.shape[0]))
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = be[y0::dy, x0::dx]
+            if sub.size:
+                raw += rows(sub)
+    else:
+        raw = rows(be)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    ihdr = struct.pack(">IIBBBBB", w, h, depth, 2, 0, 0, 1 if interlace else 0)
+    comp = zlib.compress(raw, 6)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b"")
+
+
+def read_dump(helper, path, out, *extra):
+    txt = run(helper, "source", path, out, *extra).strip().split("\n")
+    return txt[0].split(), [t.split() for t in txt[1:]], (np.fromfile(out, np.uint8) if os.path.exists(out) else None)
+
+
+def test_png_sources_decode_to_packed_rgb(helper, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    a8 = (rng.random((37, 53, 3)) * 255).astype(np.uint8)
+    a8[5:20, 3:30] = (np.arange(27)[None, :, None] * 9 + np.arange(15)[:, None, None] * 3).astype(np.uint8)  # smooth area: PNG filters 1-4
+    p = str(tmp_path / "a.png")
+    Image.fromarray(a8).save(p, optimize=True)
+    head, frames, data = read_dump(helper, p, str(tmp_path / "a.bin"))
+    assert head[:3] == ["PNG/turbo-metrics-hip", "53", "37"] and head[3:7] == ["BT709", "BT709", "BT709", "Full"] and head[7] == "1"
+    assert frames == [["rgb8", str(53 * 3), "53"]] and np.array_equal(data.reshape(37, 53, 3), a8)
+    a16 = (rng.random((19, 23, 3)) * 65535).astype(np.uint16)
+    for inter in (False, True):
+        p = str(tmp_path / f"b{int(inter)}.png")
+        open(p, "wb").write(png_bytes(a16, inter))
+        head, frames, data = read_dump(helper, p, str(tmp_path / "b.bin"))
+        assert frames == [["rgb16", str(23 * 6), "23"]] and np.array_equal(data.view(np.uint16).reshape(19, 23, 3), a16), inter
+    p = str(tmp_path / "c.png")
+    open(p, "wb").write(png_bytes(a8, True))
+    assert np.array_equal(read_dump(helper, p, str(tmp_path / "c.bin"))[2].reshape(37, 53, 3), a8)
+    # like the reference, only RGB layouts are accepted (img.rs:17-37 is todo!() for the rest)
+    p = str(tmp_path / "g.png")
+    Image.fromarray(a8[..., 0]).save(p)
+    assert "not implemented" in run(helper, "source", p, str(tmp_path / "g.bin"))
+    p = str(tmp_path / "rgba.png")
+    Image.fromarray(np.dstack([a8, a8[..., :1]])).save(p)
+    assert "not implemented" in run(helper, "source", p, str(tmp_path / "rgba.bin"))
+    # fewer than PROBE_LEN bytes: io::ErrorKind::UnexpectedEof (input_image.rs:51-53)
+    p = str(tmp_path / "short.png")
+    open(p, "wb").write(b"\x89PNG\r\n\x1a\n")
+    assert "unexpected end of file" in run(helper, "source", p, str(tmp_path / "s.bin"))
+    p = str(tmp_path / "x.jpg")
+    open(p, "wb").write(b"\xff\xd8\xff\xe0" + bytes(200))
+    assert "detected as JPEG but no decoder is available" in run(helper, "source", p, str(tmp_path / "j.bin"))
+
+
+def test_ppm_and_pfm_sources(helper, tmp_path):
+    rng = np.random.default_rng(2)
+    a8 = (rng.random((9, 31, 3)) * 255).astype(np.uint8)
+    p = str(tmp_path / "a.ppm")
+    open(p, "wb").write(b"P6\n# comment\n31 9\n255\n" + a8.tobytes() + bytes(64))
+    _, frames, data = read_dump(helper, p, str(tmp_path / "a.bin"))
+    assert frames[0][0] == "rgb8" and np.array_equal(data.reshape(9, 31, 3), a8)
+    a16 = (rng.random((9, 31, 3)) * 65535).astype(np.uint16)
+    open(p, "wb").write(b"P6 31 9 65535\n" + a16.astype(">u2").tobytes())
+    _, frames, data = read_dump(helper, p, str(tmp_path / "a.bin"))
+    assert frames[0][0] == "rgb16" and np.array_equal(data.view(np.uint16).reshape(9, 31, 3), a16)
+    af = rng.random((9, 31, 3)).astype(np.float32)
+    p = str(tmp_path / "a.pfm")
+    open(p, "wb").write(b"PF\n31 9\n-1.0\n" + af[::-1].tobytes())  # PFM rows run bottom to top
+    _, frames, data = read_dump(helper, p, str(tmp_path / "f.bin"))
+    assert frames[0][0] == "rgbf32" and np.array_equal(data.view(np.float32).reshape(9, 31, 3), af)
+
+
+def write_y4m(path, frames, w, h, bits, extra=""):
+    cs = "C420jpeg" if bits == 8 else f"C420p{bits}"
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip A1:1 {cs}{extra}\n".encode())
+        for planes in frames:
+            f.write(b"FRAME\n")
+            for pl in planes:
+                f.write(pl.astype(np.uint8 if bits == 8 else "<u2").tobytes())
+
+
+@pytest.mark.parametrize("w,h,bits", [(70, 38, 8), (33, 67, 8), (46, 30, 10)])
+def test_y4m_is_repacked_to_the_nvdec_surface_contract(helper, tmp_path, w, h, bits):
+    pairs = [tm.synth.yuv420_pair(w, h, n, bits) for n in range(3)]
+    p = str(tmp_path / "v.y4m")
+    write_y4m(p, [pr[0] for pr in pairs], w, h, bits)
+    head, frames, data = read_dump(helper, p, str(tmp_path / "v.bin"))
+    assert head[0] == "Y4M/I420" + ("" if bits == 8 else "p10") + "/turbo-metrics-hip" and head[1:3] == [str(w), str(h)]
+    want_mc = "BT601_525" if h <= 525 else "BT709"
+    assert head[3:7] == [want_mc, want_mc, "BT709", "Limited"] and head[7] == "3"
+    assert len(frames) == 3
+    kind, pitch, lrows, crows = frames[0][0], int(frames[0][1]), int(frames[0][2]), int(frames[0][3])
+    assert kind == ("nv12" if bits == 8 else "p016") and pitch % 256 == 0 and lrows >= h and crows == (h + 1) // 2
+    per = pitch * (lrows + crows)
+    for n, pr in enumerate(pairs):
+        surf, sp, sch = tm.synth.pack_biplanar(pr[0], w, h, bits, pitch=pitch, coded_height=lrows)
+        want = surf.reshape(-1, pitch)
+        got = data[n * per:(n + 1) * per].reshape(-1, pitch)
+        assert np.array_equal(got[:h], want[:h]) and np.array_equal(got[lrows:lrows + crows], want[sch:sch + crows])
+    # --skip drops leading pictures; XCOLORRANGE=FULL is carried through (and refused by the engine later, like todo!())
+    head, frames, _ = read_dump(helper, p, str(tmp_path / "v2.bin"), "--skip", 2)
+    assert len(frames) == 1
+    write_y4m(p, [pairs[0][0]], w, h, bits, " XCOLORRANGE=FULL")
+    assert read_dump(helper, p, str(tmp_path / "v3.bin"))[0][6] == "Full"
+    # headerless planar stream with the geometry from the command line
+    raw = str(tmp_path / "v.yuv")
+    with open(raw, "wb") as f:
+        for pr in pairs:
+            for pl in pr[0]:
+                f.write(pl.astype(np.uint8 if bits == 8 else "<u2").tobytes())
+    head, frames, data2 = read_dump(helper, raw, str(tmp_path / "r.bin"), "--width", w, "--height", h, "--bits", bits, "--cp", 1, "--mc", 1, "--tc", 1)
+    assert head[3:6] == ["BT709", "BT709", "BT709"] and len(frames) == 3 and np.array_equal(data2, data)
+    assert "not a PNG" in run(helper, "source", raw, str(tmp_path / "n.bin"))
+
+
+def test_y4m_rejects_what_the_reference_cannot_represent(helper, tmp_path):
+    p = str(tmp_path / "v.y4m")
+    open(p, "wb").write(b"YUV4MPEG2 W64 H64 F30:1 Ip A1:1 C444\nFRAME\n" + bytes(64 * 64 * 3))
+    assert "not implemented" in run(helper, "source", p, str(tmp_path / "o.bin"))
+
+
+# ---- the command line on the device ------------------------------------------------------------------------------------
+def cli(*args, stdin=None):
+    r = subprocess.run([CLI] + [str(a) for a in args], input=stdin, capture_output=True, check=False)
+    return r.returncode, r.stdout.decode(), r.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_cli_png_pair_all_outputs(tmp_path):
+    from PIL import Image
+    from oracle import oracle as O
+    w, h = 160, 96
+    r8, d8 = tm.synth.rgb8_pair(w, h)
+    pr, pd = str(tmp_path / "r.png"), str(tmp_path / "d.png")
+    Image.fromarray(r8).save(pr)
+    Image.fromarray(d8).save(pd)
+    want, _ = O.ssimulacra2_from_linear(O.rgb8_to_linear(r8), O.rgb8_to_linear(d8))
+    _, want_psnr = O.psnr(O.rgb8_to_linear(r8), O.rgb8_to_linear(d8))
+    rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json")
+    assert rc == 0, err
+    d = json.loads(out)
+    assert d["frame_count"] == 1 and abs(d["ssimulacra2"]["scores"][0] - want) <= 1e-9 and d["psnr"]["scores"][0] == want_psnr
+    assert list(d) == ["frame_count", "psnr", "ssimulacra2"]
+    assert "Processed: 1 (decoded: ~1) frame pairs" in err and "codec=PNG/" in err
+    score = d["ssimulacra2"]["scores"][0]
+    rc, out, _ = cli(pr, pd, "--metrics", "ssimulacra2", "--output", "csv")
+    assert rc == 0 and out == f"ssimulacra2\n{rust_display(score)}\nssimulacra2\n{rust_display(score)}\n"
+    rc, out, _ = cli(pr, pd, "--metrics=ssimulacra2", "--output=json-lines")
+    lines = out.strip().split("\n")
+    assert json.loads(lines[0]) == {"ssimulacra2": score} and json.loads(lines[1])["ssimulacra2"]["p50"] == score
+    rc, out, _ = cli(pr, pd, "-m", "ssimulacra2")
+    assert rc == 0 and out.startswith("SSIMULACRA2: Stats {\n    min: ") and out.count("\n") == 14
+    # identical images: PSNR = inf (CSV "inf", JSON null)
+    rc, out, _ = cli(pr, pr, "-m", "psnr", "--output", "csv")
+    assert out.split("\n")[1] == "inf"
+    rc, out, _ = cli(pr, pr, "-m", "psnr", "--output", "json-lines")
+    assert out.split("\n")[0] == '{"psnr":null}'
+    # stdin as one of the inputs
+    rc, out, _ = cli("-", pd, "-m", "ssimulacra2", "--output", "csv", stdin=open(pr, "rb").read())
+    assert rc == 0 and out.split("\n")[1] == rust_display(score)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 10])
+def test_cli_y4m_stream_frame_selection_batching_and_pipeline(tmp_path, bits):
+    from oracle import oracle as O
+    w, h, n = 96, 64, 11
+    pairs = [tm.synth.yuv420_pair(w, h, i, bits) for i in range(n)]
+    pr, pd = str(tmp_path / "r.y4m"), str(tmp_path / "d.y4m")
+    write_y4m(pr, [p[0] for p in pairs], w, h, bits)
+    write_y4m(pd, [p[1] for p in pairs], w, h, bits)
+    want = []
+    for p in pairs:
+        sr, pit, ch = tm.synth.pack_biplanar(p[0], w, h, bits)
+        sd, _, _ = tm.synth.pack_biplanar(p[1], w, h, bits)
+        m = 1  # height 64 <= 525 -> BT601_525 by the reference's fallback (color.rs:51-78)
+        lr = O.yuv420_biplanar_to_linear(sr, pit, ch, w, h, 8 if bits == 8 else 16, m)
+        ld = O.yuv420_biplanar_to_linear(sd, pit, ch, w, h, 8 if bits == 8 else 16, m)
+        want.append(O.ssimulacra2_from_linear(lr, ld)[0])
+
+    def scores(*extra):
+        rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--output", "json", *extra)
+        assert rc == 0, err
+        return json.loads(out)["ssimulacra2"]["scores"], err
+    base, err = scores("--batch", 4)
+    assert len(base) == n and max(abs(a - b) for a, b in zip(base, want)) <= 1e-9
+    assert "mc=BT601_525" in err and f"frame_count={n}" in err
+    assert scores("--batch", 1, "--no-pipeline")[0] == base      # batching and pipelining never change a bit
+    assert scores("--batch", 3)[0] == base and scores("--batch", 16, "--full-sums")[0] == base
+    assert scores("--every", 3)[0] == [base[i] for i in (0, 3, 6, 9)]
+    assert scores("--skip", 2, "--frames", 3)[0] == base[2:5]
+    got, _ = scores("--skip-ref", 1)
+    assert len(got) == n - 1 and got != base[1:]                 # reference frame i+1 against distorted frame i
+    # explicit BT.709 metadata overrides the fallback
+    rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--output", "json", "--color-primaries", 1, "--matrix-coefficients", 1, "--transfer-characteristics", 1)
+    assert rc == 0 and "mc=BT709" in err and json.loads(out)["ssimulacra2"]["scores"] != base
+
+
+@pytest.mark.gpu
+def test_cli_error_paths(tmp_path):
+    from PIL import Image
+    a = (np.random.default_rng(0).random((32, 48, 3)) * 255).astype(np.uint8)
+    p1, p2 = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    Image.fromarray(a).save(p1)
+    Image.fromarray(a[:, :40]).save(p2)
+    rc, _, err = cli(p1, p2, "-m", "ssimulacra2")
+    assert rc == 1 and "Reference and distorted are not the same size" in err
+    rc, _, err = cli("-", "-", "-m", "ssimulacra2")
+    assert rc == 1 and "Can't read both reference and distorted from stdin" in err
+    rc, _, err = cli(p1, str(tmp_path / "missing.png"), "-m", "ssimulacra2")
+    assert rc == 1 and "Could not read distorted" in err
+    rc, _, err = cli(p1, p1, "-m", "ssim")
+    assert rc == 1 and "Could not initialize engine" in err     # SSIM inside NPP is pinned by nothing: refused, not guessed
+    rc, _, err = cli(p1, p1, "-m", "vmaf")
+    assert rc == 2 and "possible values: psnr, ssim, msssim, ssimulacra2" in err
+    rc, _, err = cli(p1)
+    assert rc == 2
+    y = str(tmp_path / "f.y4m")
+    write_y4m(y, [tm.synth.yuv420_pair(48, 32, 0, 8)[0]], 48, 32, 8, " XCOLORRANGE=FULL")
+    rc, _, err = cli(y, y, "-m", "ssimulacra2")
+    assert rc == 1 and "unsupported" in err                      # full-range YUV: todo!() in the reference

@@ -1,0 +1,453 @@
+// frame_sources.cpp -- see frame_sources.hpp
+#include "frame_sources.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+#include <sstream>
+
+namespace tm_host {
+
+namespace {
+
+[[noreturn]] void fail(const std::string &m) { throw std::runtime_error(m); }
+
+uint32_t be32(const unsigned char *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+} // namespace
+
+// ---- probing -------------------------------------------------------------------------------------------------------
+ImageFormat probe_image(const unsigned char *s, size_t len)
+{
+    if (len < PROBE_LEN) fail("unexpected end of file"); // io::ErrorKind::UnexpectedEof, input_image.rs:51-53
+    static const unsigned char png[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (!memcmp(s, png, 8)) return ImageFormat::PNG;
+    if (s[0] == 'P' && s[1] == '6' && (s[2] == '\n' || s[2] == ' ' || s[2] == '\r' || s[2] == '\t')) return ImageFormat::PPM;
+    if (s[0] == 'P' && s[1] == 'F' && (s[2] == '\n' || s[2] == ' ' || s[2] == '\r')) return ImageFormat::PFM;
+    if (s[0] == 0xFF && s[1] == 0xD8 && s[2] == 0xFF) return ImageFormat::JPEG;
+    if (!memcmp(s, "GIF8", 4) || !memcmp(s, "BM", 2) || (!memcmp(s, "RIFF", 4) && !memcmp(s + 8, "WEBP", 4)) ||
+        !memcmp(s, "II*\0", 4) || !memcmp(s, "MM\0*", 4) || !memcmp(s, "qoif", 4))
+        return ImageFormat::Other;
+    return ImageFormat::Unknown;
+}
+
+bool can_decode(ImageFormat f) { return f == ImageFormat::PNG || f == ImageFormat::PPM || f == ImageFormat::PFM; }
+
+const char *to_string(ImageFormat f)
+{
+    switch (f) {
+    case ImageFormat::PNG: return "PNG";
+    case ImageFormat::PPM: return "PPM";
+    case ImageFormat::PFM: return "PFM";
+    case ImageFormat::JPEG: return "JPEG";
+    case ImageFormat::Other: return "Other";
+    default: return "Unknown";
+    }
+}
+
+// ---- PNG -----------------------------------------------------------------------------------------------------------
+namespace {
+
+int paeth(int a, int b, int c)
+{
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// undo the per-scanline filters of one (sub)image in place; `raw` holds rows of 1 + stride bytes; returns packed rows
+void unfilter(const unsigned char *raw, size_t rows, size_t stride, size_t bpp, std::vector<unsigned char> &out)
+{
+    out.assign(rows * stride, 0);
+    std::vector<unsigned char> zero(stride, 0);
+    for (size_t y = 0; y < rows; ++y) {
+        const unsigned char ft = raw[y * (stride + 1)];
+        const unsigned char *in = raw + y * (stride + 1) + 1;
+        unsigned char *cur = out.data() + y * stride;
+        const unsigned char *up = y ? cur - stride : zero.data();
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
+            int v;
+            switch (ft) {
+            case 0: v = in[i]; break;
+            case 1: v = in[i] + a; break;
+            case 2: v = in[i] + b; break;
+            case 3: v = in[i] + ((a + b) >> 1); break;
+            case 4: v = in[i] + paeth(a, b, c); break;
+            default: fail("PNG: invalid filter type");
+            }
+            cur[i] = (unsigned char)v;
+        }
+    }
+}
+
+} // namespace
+
+CpuImg decode_png(const unsigned char *d, size_t len)
+{
+    if (len < 8 + 25) fail("PNG: truncated");
+    size_t pos = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<unsigned char> idat;
+    bool end = false;
+    while (!end && pos + 12 <= len) {
+        const uint32_t clen = be32(d + pos);
+        const unsigned char *type = d + pos + 4, *body = d + pos + 8;
+        if (pos + 12 + (size_t)clen > len) fail("PNG: truncated chunk");
+        if (!memcmp(type, "IHDR", 4)) {
+            if (clen != 13) fail("PNG: bad IHDR");
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+            if (body[10] != 0 || body[11] != 0) fail("PNG: unknown compression/filter method");
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + clen);
+        } else if (!memcmp(type, "IEND", 4)) {
+            end = true;
+        }
+        pos += 12 + (size_t)clen;
+    }
+    if (ctype < 0 || w == 0 || h == 0) fail("PNG: no IHDR");
+    // the reference accepts RGB sample layouts only (turbo-metrics/src/img.rs:17-37: anything else is todo!())
+    if (ctype != 2) fail("not implemented: PNG colour type " + std::to_string(ctype) + " (only RGB is supported, as in the reference)");
+    if (depth != 8 && depth != 16) fail("PNG: RGB must be 8 or 16 bits per sample");
+    if (interlace > 1) fail("PNG: unknown interlace method");
+    const size_t bpp = 3 * (size_t)depth / 8;
+
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole[1] = {{0, 0, 1, 1}};
+    const Pass *passes = interlace ? adam7 : whole;
+    const int npass = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int p = 0; p < npass; ++p) {
+        const size_t pw = (w > passes[p].x0) ? (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+        const size_t ph = (h > passes[p].y0) ? (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+        if (pw && ph) raw_size += ph * (1 + pw * bpp);
+    }
+    std::vector<unsigned char> raw(raw_size);
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) fail("PNG: inflateInit failed");
+        zs.next_in = idat.data(); zs.avail_in = (uInt)idat.size();
+        zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
+        if (idat.size() > 0xFFFFFFFFu || raw.size() > 0xFFFFFFFFu) { inflateEnd(&zs); fail("PNG: image too large"); }
+        const int rc = inflate(&zs, Z_FINISH);
+        const size_t got = raw.size() - zs.avail_out;
+        inflateEnd(&zs);
+        if ((rc != Z_STREAM_END && rc != Z_BUF_ERROR && rc != Z_OK) || got != raw.size()) fail("PNG: corrupt image data");
+    }
+    CpuImg img;
+    img.width = w; img.height = h;
+    img.sample_type = depth == 8 ? CpuImg::U8 : CpuImg::U16;
+    img.data.assign((size_t)w * h * bpp, 0);
+    size_t off = 0;
+    std::vector<unsigned char> rows;
+    for (int p = 0; p < npass; ++p) {
+        const size_t pw = (w > passes[p].x0) ? (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+        const size_t ph = (h > passes[p].y0) ? (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+        if (!pw || !ph) continue;
+        unfilter(raw.data() + off, ph, pw * bpp, bpp, rows);
+        off += ph * (1 + pw * bpp);
+        for (size_t y = 0; y < ph; ++y)
+            for (size_t x = 0; x < pw; ++x)
+                memcpy(img.data.data() + (((size_t)passes[p].y0 + y * passes[p].dy) * w + passes[p].x0 + x * passes[p].dx) * bpp,
+                       rows.data() + (y * pw + x) * bpp, bpp);
+    }
+    if (depth == 16) // network order -> host order
+        for (size_t i = 0; i + 1 < img.data.size(); i += 2) std::swap(img.data[i], img.data[i + 1]);
+    return img;
+}
+
+// ---- PPM (P6) / PFM (PF) --------------------------------------------------------------------------------------------
+CpuImg decode_pnm(const unsigned char *d, size_t len)
+{
+    size_t pos = 2;
+    auto token = [&]() {
+        for (;;) {
+            while (pos < len && (d[pos] == ' ' || d[pos] == '\n' || d[pos] == '\r' || d[pos] == '\t')) ++pos;
+            if (pos < len && d[pos] == '#') { while (pos < len && d[pos] != '\n') ++pos; continue; }
+            break;
+        }
+        std::string t;
+        while (pos < len && !(d[pos] == ' ' || d[pos] == '\n' || d[pos] == '\r' || d[pos] == '\t')) t.push_back((char)d[pos++]);
+        if (t.empty()) fail("PNM: truncated header");
+        return t;
+    };
+    const bool pfm = d[1] == 'F';
+    CpuImg img;
+    img.width = (uint32_t)std::stoul(token());
+    img.height = (uint32_t)std::stoul(token());
+    const std::string third = token();
+    ++pos; // the single whitespace byte after the header
+    if (img.width == 0 || img.height == 0) fail("PNM: empty image");
+    const size_t n = (size_t)img.width * img.height * 3;
+    if (pfm) {
+        const double scale = std::stod(third);
+        if (pos + n * 4 > len) fail("PFM: truncated");
+        img.sample_type = CpuImg::F32;
+        img.data.resize(n * 4);
+        const size_t row = (size_t)img.width * 12;
+        for (uint32_t y = 0; y < img.height; ++y) { // PFM rows run bottom to top
+            const unsigned char *src = d + pos + (size_t)(img.height - 1 - y) * row;
+            unsigned char *dst = img.data.data() + (size_t)y * row;
+            if (scale < 0) memcpy(dst, src, row);
+            else for (size_t i = 0; i < row; i += 4) { dst[i] = src[i + 3]; dst[i + 1] = src[i + 2]; dst[i + 2] = src[i + 1]; dst[i + 3] = src[i]; }
+        }
+    } else {
+        const unsigned long maxval = std::stoul(third);
+        if (maxval != 255 && maxval != 65535) fail("PPM: maxval must be 255 or 65535");
+        const size_t bps = maxval == 255 ? 1 : 2;
+        if (pos + n * bps > len) fail("PPM: truncated");
+        img.sample_type = bps == 1 ? CpuImg::U8 : CpuImg::U16;
+        img.data.assign(d + pos, d + pos + n * bps);
+        if (bps == 2)
+            for (size_t i = 0; i + 1 < img.data.size(); i += 2) std::swap(img.data[i], img.data[i + 1]);
+    }
+    return img;
+}
+
+// ---- ImageFrameSource ------------------------------------------------------------------------------------------------
+ImageFrameSource::ImageFrameSource(std::vector<unsigned char> file, ImageFormat f) : format_(f)
+{
+    CpuImg img = f == ImageFormat::PNG ? decode_png(file.data(), file.size()) : decode_pnm(file.data(), file.size());
+    width_ = img.width; height_ = img.height;
+    frames_.push_back(std::move(img));
+}
+
+FormatIdentifier ImageFrameSource::format_id() const { return FormatIdentifier{std::nullopt, to_string(format_), "turbo-metrics-hip"}; }
+
+std::pair<ColorCharacteristics, ColorRange> ImageFrameSource::color_characteristics() const
+{
+    // input_image.rs:183-194: image colour metadata is not read; unused on the image path
+    ColorCharacteristics c;
+    c.cp = ColourPrimaries::BT709; c.mc = MatrixCoefficients::BT709; c.tc = TransferCharacteristic::BT709;
+    return {c, ColorRange::Full};
+}
+
+void ImageFrameSource::skip_frames(uint32_t n)
+{
+    for (uint32_t i = 0; i < n && !frames_.empty(); ++i) frames_.pop_front();
+}
+
+bool ImageFrameSource::next_frame(HwFrame &out)
+{
+    if (frames_.empty()) return false;
+    current_ = std::move(frames_.front());
+    frames_.pop_front();
+    out = HwFrame{};
+    const size_t bps = current_.sample_type == CpuImg::U8 ? 1 : (current_.sample_type == CpuImg::U16 ? 2 : 4);
+    out.kind = current_.sample_type == CpuImg::U8 ? HwFrame::Npp8 : (current_.sample_type == CpuImg::U16 ? HwFrame::Npp16 : HwFrame::Npp32);
+    out.data = current_.data.data();
+    out.pitch = (size_t)current_.width * 3 * bps;
+    return true;
+}
+
+// ---- planar 4:2:0 streams ---------------------------------------------------------------------------------------------
+YuvStreamSource::YuvStreamSource(FILE *in, bool y4m, uint32_t w, uint32_t h, int bits, ColorCharacteristics cc, ColorRange cr,
+                                 size_t frame_count, std::string codec)
+    : in_(in), y4m_(y4m), w_(w), h_(h), bits_(bits), cc_(cc), cr_(cr), frame_count_(frame_count), codec_(std::move(codec))
+{
+    const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
+    planar_.resize(((size_t)w_ * h_ + 2 * cw * ch) * bps);
+    pitch_ = round_up(std::max((size_t)w_, cw * 2) * bps, 256);
+    surface_.assign(pitch_ * (round_up(h_, 2) + ch), 0);
+}
+
+YuvStreamSource::~YuvStreamSource()
+{
+    if (in_ && in_ != stdin) fclose(in_);
+}
+
+FormatIdentifier YuvStreamSource::format_id() const
+{
+    return FormatIdentifier{y4m_ ? std::optional<std::string>("Y4M") : std::nullopt, codec_, "turbo-metrics-hip"};
+}
+
+bool YuvStreamSource::read_picture(bool keep)
+{
+    if (y4m_) {
+        char tag[6];
+        const size_t got = fread(tag, 1, 5, in_);
+        if (got == 0) return false;
+        if (got != 5 || memcmp(tag, "FRAME", 5)) fail("Y4M: expected a FRAME header");
+        int c;
+        while ((c = fgetc(in_)) != '\n')
+            if (c == EOF) fail("Y4M: truncated FRAME header");
+    }
+    const size_t got = fread(planar_.data(), 1, planar_.size(), in_);
+    if (got == 0 && !y4m_) return false;
+    if (got != planar_.size()) {
+        if (!y4m_ && feof(in_)) return false; // a trailing partial picture of a raw stream is ignored
+        fail("truncated picture in the YUV stream");
+    }
+    if (!keep) return true;
+    // planar I420 -> the NVDEC surface contract: luma rows at `pitch`, then interleaved CbCr rows at the same pitch
+    const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
+    unsigned char *luma = surface_.data(), *uv = surface_.data() + pitch_ * round_up(h_, 2);
+    if (bits_ == 8) {
+        const unsigned char *y = planar_.data(), *u = y + (size_t)w_ * h_, *v = u + cw * ch;
+        for (uint32_t r = 0; r < h_; ++r) memcpy(luma + r * pitch_, y + (size_t)r * w_, w_);
+        for (size_t r = 0; r < ch; ++r) {
+            unsigned char *o = uv + r * pitch_;
+            for (size_t x = 0; x < cw; ++x) { o[2 * x] = u[r * cw + x]; o[2 * x + 1] = v[r * cw + x]; }
+        }
+    } else {
+        const int sh = 16 - bits_; // P016: the value sits in the high bits (cudarse-video/src/dec.rs:398-400)
+        const uint16_t *y = (const uint16_t *)planar_.data(), *u = y + (size_t)w_ * h_, *v = u + cw * ch;
+        for (uint32_t r = 0; r < h_; ++r) {
+            uint16_t *o = (uint16_t *)(luma + r * pitch_);
+            for (uint32_t x = 0; x < w_; ++x) o[x] = (uint16_t)(y[(size_t)r * w_ + x] << sh);
+        }
+        for (size_t r = 0; r < ch; ++r) {
+            uint16_t *o = (uint16_t *)(uv + r * pitch_);
+            for (size_t x = 0; x < cw; ++x) { o[2 * x] = (uint16_t)(u[r * cw + x] << sh); o[2 * x + 1] = (uint16_t)(v[r * cw + x] << sh); }
+        }
+    }
+    return true;
+}
+
+void YuvStreamSource::skip_frames(uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        if (!read_picture(false)) break;
+}
+
+bool YuvStreamSource::next_frame(HwFrame &out)
+{
+    if (!read_picture(true)) return false;
+    out = HwFrame{};
+    out.kind = bits_ == 8 ? HwFrame::NvDecNV12 : HwFrame::NvDecP016;
+    out.data = surface_.data();
+    out.uv = surface_.data() + pitch_ * round_up(h_, 2);
+    out.pitch = pitch_;
+    return true;
+}
+
+// ---- create_source ---------------------------------------------------------------------------------------------------
+namespace {
+
+long file_size_or_zero(FILE *f)
+{
+    const long at = ftell(f);
+    if (at < 0 || fseek(f, 0, SEEK_END) != 0) return 0;
+    const long end = ftell(f);
+    fseek(f, at, SEEK_SET);
+    return end;
+}
+
+} // namespace
+
+std::unique_ptr<FrameSource> create_source(const std::string &path, const SourceHints &hints)
+{
+    const bool is_stdin = path == "-";
+    FILE *f = is_stdin ? stdin : fopen(path.c_str(), "rb");
+    if (!f) fail("could not open '" + path + "'");
+    unsigned char probe[PROBE_LEN];
+    const size_t got = fread(probe, 1, PROBE_LEN, f);
+    auto close = [&] { if (!is_stdin) fclose(f); };
+    ImageFormat fmt = ImageFormat::Unknown;
+    try {
+        if (!hints.force_raw) fmt = probe_image(probe, got);
+    } catch (...) { close(); throw; }
+
+    if (fmt != ImageFormat::Unknown) {
+        if (!can_decode(fmt)) {
+            close();
+            fail("'" + path + "' detected as " + to_string(fmt) + " but no decoder is available (missing crate feature or unimplemented).");
+        }
+        std::vector<unsigned char> data(probe, probe + got);
+        unsigned char buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
+        close();
+        return std::make_unique<ImageFrameSource>(std::move(data), fmt);
+    }
+
+    if (!hints.force_raw && got >= 10 && !memcmp(probe, "YUV4MPEG2 ", 10)) {
+        // the stream header ends at the first '\n'; it may be longer than the probe
+        std::string header((const char *)probe, got);
+        size_t nl = header.find('\n');
+        while (nl == std::string::npos) {
+            const int c = fgetc(f);
+            if (c == EOF) { close(); fail("Y4M: truncated stream header"); }
+            header.push_back((char)c);
+            if (c == '\n') nl = header.size() - 1;
+            if (header.size() > 4096) { close(); fail("Y4M: stream header too long"); }
+        }
+        const std::string rest = header.substr(nl + 1); // bytes of the first FRAME that the probe already consumed
+        std::istringstream ss(header.substr(10, nl - 10));
+        uint32_t w = 0, h = 0;
+        int bits = 8;
+        std::string cs = "420";
+        bool full = hints.full_range;
+        std::string tok;
+        while (ss >> tok) {
+            if (tok[0] == 'W') w = (uint32_t)std::stoul(tok.substr(1));
+            else if (tok[0] == 'H') h = (uint32_t)std::stoul(tok.substr(1));
+            else if (tok[0] == 'C') cs = tok.substr(1);
+            else if (tok == "XCOLORRANGE=FULL") full = true;
+            else if (tok == "XCOLORRANGE=LIMITED") full = false;
+        }
+        if (w == 0 || h == 0) { close(); fail("Y4M: missing W/H"); }
+        if (cs.rfind("420", 0) != 0) { close(); fail("not implemented: Y4M colourspace C" + cs + " (only 4:2:0 reaches the NV12 / P016 surfaces of the reference)"); }
+        const size_t pp = cs.find('p', 3);
+        if (pp != std::string::npos && pp + 1 < cs.size() && isdigit((unsigned char)cs[pp + 1])) bits = std::stoi(cs.substr(pp + 1));
+        if (bits != 8 && bits != 10 && bits != 12 && bits != 14 && bits != 16) { close(); fail("Y4M: unsupported bit depth in C" + cs); }
+        // put the over-read bytes back: only possible on a seekable file; on a pipe we re-feed them through a memory stream
+        FILE *in = f;
+        if (!rest.empty()) {
+            if (!is_stdin && fseek(f, (long)(nl + 1), SEEK_SET) == 0) {
+                // rewound
+            } else {
+                // non-seekable: splice `rest` in front of the remaining stream with a cookie-less trick: a pipe-free
+                // approach is to read everything left into memory
+                std::vector<unsigned char> all(rest.begin(), rest.end());
+                unsigned char buf[1 << 16];
+                size_t n;
+                while ((n = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + n);
+                in = fmemopen(nullptr, all.size() ? all.size() : 1, "w+b");
+                if (!in) { close(); fail("Y4M: could not buffer the stream"); }
+                fwrite(all.data(), 1, all.size(), in);
+                rewind(in);
+                close();
+            }
+        }
+        const size_t bps = bits > 8 ? 2 : 1, cw = (w + 1) / 2, ch = (h + 1) / 2;
+        const size_t pic = ((size_t)w * h + 2 * cw * ch) * bps + 6;
+        const long total = in == f && !is_stdin ? file_size_or_zero(f) : 0;
+        const size_t count = total > (long)(nl + 1) ? ((size_t)total - (nl + 1)) / pic : 0;
+        const ColorCharacteristics cc = ColorCharacteristics::from_codes(hints.cp, hints.mc, hints.tc).or_(color_characteristics_fallback(h));
+        return std::make_unique<YuvStreamSource>(in, true, w, h, bits, cc, full ? ColorRange::Full : ColorRange::Limited, count,
+                                                 "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
+    }
+
+    if (hints.width && hints.height) { // headerless planar 4:2:0
+        FILE *in = f;
+        if (is_stdin || fseek(f, 0, SEEK_SET) != 0) {
+            std::vector<unsigned char> all(probe, probe + got);
+            unsigned char buf[1 << 16];
+            size_t n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + n);
+            in = fmemopen(nullptr, all.size() ? all.size() : 1, "w+b");
+            if (!in) { close(); fail("could not buffer the raw stream"); }
+            fwrite(all.data(), 1, all.size(), in);
+            rewind(in);
+            close();
+        }
+        const int bits = hints.bits;
+        const size_t bps = bits > 8 ? 2 : 1, cw = (hints.width + 1) / 2, ch = (hints.height + 1) / 2;
+        const size_t pic = ((size_t)hints.width * hints.height + 2 * cw * ch) * bps;
+        const long total = in == f ? file_size_or_zero(f) : 0;
+        const ColorCharacteristics cc = ColorCharacteristics::from_codes(hints.cp, hints.mc, hints.tc).or_(color_characteristics_fallback(hints.height));
+        return std::make_unique<YuvStreamSource>(in, false, hints.width, hints.height, bits, cc, hints.full_range ? ColorRange::Full : ColorRange::Limited,
+                                                 total > 0 ? (size_t)total / pic : 0, "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
+    }
+    close();
+    fail("'" + path + "': not a PNG / PPM / PFM image nor a Y4M stream (for headerless planar YUV give --width/--height); "
+         "MKV / IVF demuxing and hardware decode of the reference are NVDEC-specific and have no counterpart here");
+}
+
+} // namespace tm_host

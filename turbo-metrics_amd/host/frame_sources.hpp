@@ -1,0 +1,101 @@
+// frame_sources.hpp -- CPU frame sources for the CLI: counterparts of the reference's FrameSource implementations
+// (turbo-metrics/src/input_image.rs:91-229 for still images; its video sources are NVDEC demux/decode, which has no
+// place on this hardware, so decoded video enters as Y4M / raw planar YUV and is repacked to the NV12 / P016 surface
+// contract of cudarse-video/src/dec.rs:299-403 that the ingest kernel consumes).
+//
+//   ImageFrameSource   PNG (8/16-bit RGB, also Adam7), PPM P6 (8/16-bit), PFM "PF" (f32 RGB): like the reference,
+//                      only RGB sample layouts are accepted (img.rs:17-37 is todo!() for anything else)
+//   Y4mFrameSource     YUV4MPEG2, C420* 8-bit -> NV12, C420p10 / p12 / p16 -> P016 (value MSB aligned in 16 bits)
+//   RawYuvFrameSource  headerless planar I420 / I420p10 with the size given on the command line
+#pragma once
+#include <cstdio>
+#include <deque>
+#include <istream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "turbo_metrics.hpp"
+
+namespace tm_host {
+
+constexpr size_t PROBE_LEN = 64; // input_image.rs:19
+
+// what the first bytes look like; Unknown -> not an image (the CLI then tries the video path)
+enum class ImageFormat { Unknown, PNG, PPM, PFM, JPEG, Other };
+// needs at least PROBE_LEN bytes like ImageProbe::probe_image (input_image.rs:49-53), else throws "unexpected end of file"
+ImageFormat probe_image(const unsigned char *start, size_t len);
+bool can_decode(ImageFormat f);
+const char *to_string(ImageFormat f);
+
+struct CpuImg { // img.rs:40-48
+    enum Sample { U8, U16, F32 } sample_type = U8;
+    uint32_t width = 0, height = 0;
+    std::vector<unsigned char> data; // packed RGB
+};
+
+// decoders (throw std::runtime_error with the reason)
+CpuImg decode_png(const unsigned char *data, size_t len);
+CpuImg decode_pnm(const unsigned char *data, size_t len);
+
+class ImageFrameSource : public FrameSource {
+public:
+    ImageFrameSource(std::vector<unsigned char> file, ImageFormat f);
+    FormatIdentifier format_id() const override;
+    uint32_t width() const override { return width_; }
+    uint32_t height() const override { return height_; }
+    std::pair<ColorCharacteristics, ColorRange> color_characteristics() const override;
+    size_t frame_count() const override { return frames_.size(); }
+    void skip_frames(uint32_t n) override;
+    bool next_frame(HwFrame &out) override;
+
+private:
+    std::deque<CpuImg> frames_;
+    CpuImg current_;
+    ImageFormat format_;
+    uint32_t width_ = 0, height_ = 0;
+};
+
+// planar 4:2:0 stream -> biplanar surfaces
+class YuvStreamSource : public FrameSource {
+public:
+    // takes ownership of `in` (closed with fclose unless it is stdin).  bits: 8, 10, 12 or 16.  header_frames: true = Y4M
+    // ("FRAME...\n" before every picture)
+    YuvStreamSource(FILE *in, bool y4m, uint32_t w, uint32_t h, int bits, ColorCharacteristics cc, ColorRange cr, size_t frame_count,
+                    std::string codec);
+    ~YuvStreamSource() override;
+    FormatIdentifier format_id() const override;
+    uint32_t width() const override { return w_; }
+    uint32_t height() const override { return h_; }
+    std::pair<ColorCharacteristics, ColorRange> color_characteristics() const override { return {cc_, cr_}; }
+    size_t frame_count() const override { return frame_count_; }
+    void skip_frames(uint32_t n) override;
+    bool next_frame(HwFrame &out) override;
+
+private:
+    bool read_picture(bool keep);
+    FILE *in_;
+    bool y4m_;
+    uint32_t w_, h_;
+    int bits_;
+    ColorCharacteristics cc_;
+    ColorRange cr_;
+    size_t frame_count_;
+    std::string codec_;
+    size_t pitch_ = 0;
+    std::vector<unsigned char> planar_, surface_;
+};
+
+struct SourceHints { // what a headerless stream cannot say about itself (CLI flags)
+    uint32_t width = 0, height = 0;
+    int bits = 8;
+    int cp = 2, mc = 2, tc = 2; // H.273 codes, 2 = unspecified -> fallback by height (color.rs:51-78)
+    bool full_range = false;
+    bool force_raw = false;
+};
+
+// == create_source (turbo-metrics-cli/src/main.rs:172-209): probe the first PROBE_LEN bytes, pick a decoder.
+// path "-" reads stdin.
+std::unique_ptr<FrameSource> create_source(const std::string &path, const SourceHints &hints);
+
+} // namespace tm_host

@@ -1,0 +1,236 @@
+// main.cpp -- `turbo-metrics`: the command line of the reference (crates/turbo-metrics-cli/src/main.rs:31-356) over the
+// MI355X engine.  Same positional arguments, same flags (-m/--metrics, --every, --skip, --skip-ref, --skip-dis, --frames,
+// --output), same stdout formats (output.cpp), status on stderr, ExitCode::FAILURE on the same conditions.
+// Additions (no counterpart in the reference, all optional): --batch, --device, --no-pipeline, --full-sums, and the
+// description of headerless YUV input (--width, --height, --bits, --color-primaries, --matrix-coefficients,
+// --transfer-characteristics, --full-range).
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "frame_sources.hpp"
+#include "output.hpp"
+#include "turbo_metrics.hpp"
+
+using namespace tm_host;
+
+namespace {
+
+enum Level { L_ERROR = 0, L_WARN, L_INFO, L_DEBUG, L_TRACE };
+Level g_level = L_INFO;
+
+void log_line(Level lv, const char *target, const std::string &msg)
+{
+    if (lv > g_level) return;
+    static const char *names[] = {"ERROR", " WARN", " INFO", "DEBUG", "TRACE"};
+    std::cerr << names[lv] << " " << target << ": " << msg << "\n"; // tracing fmt::layer().compact().without_time()
+}
+
+const char *kTarget = "turbo_metrics_cli";
+
+void usage(std::ostream &os)
+{
+    os << "Turbo metrics compares two images or videos using quality metrics\n\n"
+          "Usage: turbo-metrics [OPTIONS] <REFERENCE> <DISTORTED>\n\n"
+          "Arguments:\n"
+          "  <REFERENCE>  Reference media. Use `-` to read from stdin\n"
+          "  <DISTORTED>  Distorted media. Use `-` to read from stdin\n\n"
+          "Options:\n"
+          "  -m, --metrics <METRICS>    Select the metrics to compute [possible values: psnr, ssim, msssim, ssimulacra2]\n"
+          "      --every <EVERY>        Only compute metrics every few frames [default: 0]\n"
+          "      --skip <SKIP>          Index of the first frame to start computing at [default: 0]\n"
+          "      --skip-ref <SKIP_REF>  Index of the first reference frame, additive with `skip` [default: 0]\n"
+          "      --skip-dis <SKIP_DIS>  Index of the first distorted frame, additive with `skip` [default: 0]\n"
+          "      --frames <FRAMES>      Amount of frames to compute [default: 0]\n"
+          "      --output <OUTPUT>      stdout format [possible values: default, json, json-lines, csv]\n"
+          "      --batch <N>            frame pairs per GPU launch [default: 8]\n"
+          "      --device <N>           GPU ordinal [default: 0]\n"
+          "      --no-pipeline          do not overlap reading/upload of the next batch with the current one\n"
+          "      --full-sums            compute all 108 SSIMULACRA2 sums, also the zero-weighted ones\n"
+          "      --width <W> --height <H> [--bits 8|10|12|16]   headerless planar 4:2:0 input\n"
+          "      --color-primaries <N> --matrix-coefficients <N> --transfer-characteristics <N>   H.273 codes (1, 5, 6; 2 = by height)\n"
+          "      --full-range           the YUV input is full range (unsupported by the reference and here)\n"
+          "  -h, --help                 Print help\n"
+          "  -V, --version              Print version\n";
+}
+
+bool parse_u32(const std::string &s, uint32_t &out)
+{
+    if (s.empty()) return false;
+    char *end = nullptr;
+    const unsigned long v = strtoul(s.c_str(), &end, 10);
+    if (*end || v > 0xFFFFFFFFul || s[0] == '-') return false;
+    out = (uint32_t)v;
+    return true;
+}
+
+std::string format_duration(std::chrono::milliseconds d) // main.rs:357-385
+{
+    long long secs = d.count() / 1000;
+    const long long millis = d.count() % 1000, minutes = secs / 60;
+    secs %= 60;
+    std::string s;
+    if (minutes > 0) { s += std::to_string(minutes) + " m"; if (secs > 0) s += " "; }
+    if (secs > 0) { s += std::to_string(secs) + " s"; if (millis > 0) s += " "; }
+    if (millis > 0) s += std::to_string(millis) + " ms";
+    return s;
+}
+
+void log_source(const char *target, const FrameSource &src)
+{
+    const auto cc = src.color_characteristics();
+    log_line(L_INFO, target, "codec=" + src.format_id().str() + " width=" + std::to_string(src.width()) + " height=" + std::to_string(src.height()) +
+                                 " cp=" + to_string(cc.first.cp) + " mc=" + to_string(cc.first.mc) + " tc=" + to_string(cc.first.tc) +
+                                 " cr=" + to_string(cc.second) + " frame_count=" + std::to_string(src.frame_count()));
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (const char *env = getenv("RUST_LOG")) {
+        const std::string v = env;
+        if (v == "error") g_level = L_ERROR; else if (v == "warn") g_level = L_WARN; else if (v == "info") g_level = L_INFO;
+        else if (v == "debug") g_level = L_DEBUG; else if (v == "trace") g_level = L_TRACE;
+    }
+    std::vector<std::string> pos;
+    Metrics metrics;
+    Options opts;
+    Output output = Output::Default;
+    SourceHints hints;
+    uint32_t batch = 8, device = 0;
+    bool pipeline = true, full_sums = false;
+
+    auto bad = [&](const std::string &m) {
+        std::cerr << "error: " << m << "\n\nFor more information, try '--help'.\n";
+        return 2; // clap's usage-error exit code
+    };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i], val;
+        bool has_val = false;
+        if (a.rfind("--", 0) == 0) {
+            const size_t eq = a.find('=');
+            if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); has_val = true; }
+        }
+        auto value = [&](std::string &dst) {
+            if (has_val) { dst = val; return true; }
+            if (i + 1 >= argc) return false;
+            dst = argv[++i];
+            return true;
+        };
+        auto u32 = [&](uint32_t &dst) {
+            std::string s;
+            return value(s) && parse_u32(s, dst);
+        };
+        if (a == "-h" || a == "--help") { usage(std::cout); return 0; }
+        if (a == "-V" || a == "--version") { std::cout << "turbo-metrics " << tm_version() << "\n"; return 0; }
+        if (a == "-m" || a == "--metrics") {
+            std::string s;
+            if (!value(s)) return bad("a value is required for '--metrics <METRICS>' but none was supplied");
+            if (s == "psnr") metrics.psnr = true; else if (s == "ssim") metrics.ssim = true; else if (s == "msssim") metrics.msssim = true;
+            else if (s == "ssimulacra2") metrics.ssimulacra2 = true;
+            else return bad("invalid value '" + s + "' for '--metrics <METRICS>'\n  [possible values: psnr, ssim, msssim, ssimulacra2]");
+        } else if (a.rfind("-m", 0) == 0 && a.size() > 2 && a[1] == 'm') { // -mpsnr
+            const std::string s = a.substr(2);
+            if (s == "psnr") metrics.psnr = true; else if (s == "ssim") metrics.ssim = true; else if (s == "msssim") metrics.msssim = true;
+            else if (s == "ssimulacra2") metrics.ssimulacra2 = true;
+            else return bad("invalid value '" + s + "' for '--metrics <METRICS>'");
+        } else if (a == "--every") { if (!u32(opts.every)) return bad("invalid value for '--every <EVERY>'"); }
+        else if (a == "--skip") { if (!u32(opts.skip)) return bad("invalid value for '--skip <SKIP>'"); }
+        else if (a == "--skip-ref") { if (!u32(opts.skip_ref)) return bad("invalid value for '--skip-ref <SKIP_REF>'"); }
+        else if (a == "--skip-dis") { if (!u32(opts.skip_dis)) return bad("invalid value for '--skip-dis <SKIP_DIS>'"); }
+        else if (a == "--frames") { if (!u32(opts.frames)) return bad("invalid value for '--frames <FRAMES>'"); }
+        else if (a == "--output") {
+            std::string s;
+            if (!value(s) || !parse_output(s, output)) return bad("invalid value '" + s + "' for '--output <OUTPUT>'\n  [possible values: default, json, json-lines, csv]");
+        } else if (a == "--batch") { if (!u32(batch) || batch == 0) return bad("invalid value for '--batch <N>'"); }
+        else if (a == "--device") { if (!u32(device)) return bad("invalid value for '--device <N>'"); }
+        else if (a == "--no-pipeline") pipeline = false;
+        else if (a == "--full-sums") full_sums = true;
+        else if (a == "--width") { if (!u32(hints.width)) return bad("invalid value for '--width <W>'"); }
+        else if (a == "--height") { if (!u32(hints.height)) return bad("invalid value for '--height <H>'"); }
+        else if (a == "--bits") { uint32_t b; if (!u32(b) || (b != 8 && b != 10 && b != 12 && b != 16)) return bad("invalid value for '--bits'"); hints.bits = (int)b; }
+        else if (a == "--color-primaries") { uint32_t v; if (!u32(v)) return bad("invalid value for '--color-primaries'"); hints.cp = (int)v; }
+        else if (a == "--matrix-coefficients") { uint32_t v; if (!u32(v)) return bad("invalid value for '--matrix-coefficients'"); hints.mc = (int)v; }
+        else if (a == "--transfer-characteristics") { uint32_t v; if (!u32(v)) return bad("invalid value for '--transfer-characteristics'"); hints.tc = (int)v; }
+        else if (a == "--full-range") hints.full_range = true;
+        else if (a == "--raw") hints.force_raw = true;
+        else if (a.size() > 1 && a[0] == '-' && a != "-") return bad("unexpected argument '" + a + "' found");
+        else pos.push_back(a);
+    }
+    if (pos.size() != 2) return bad("the following required arguments were not provided:\n  <REFERENCE>\n  <DISTORTED>");
+
+    const bool ref_is_stdin = pos[0] == "-", dis_is_stdin = pos[1] == "-";
+    if (ref_is_stdin && dis_is_stdin) {
+        log_line(L_ERROR, kTarget, "Can't read both reference and distorted from stdin");
+        return EXIT_FAILURE;
+    }
+
+    // Frame sources might need the device (main.rs:138-139)
+    try {
+        init_hip((int)device);
+    } catch (const std::exception &e) {
+        log_line(L_ERROR, kTarget, std::string("Could not initialize the GPU : ") + e.what());
+        return EXIT_FAILURE;
+    }
+
+    std::unique_ptr<FrameSource> source_ref, source_dis;
+    try {
+        source_ref = create_source(pos[0], hints);
+    } catch (const std::exception &e) {
+        log_line(L_ERROR, kTarget, std::string("Could not read reference : ") + e.what());
+        return EXIT_FAILURE;
+    }
+    try {
+        source_dis = create_source(pos[1], hints);
+    } catch (const std::exception &e) {
+        log_line(L_ERROR, kTarget, std::string("Could not read distorted : ") + e.what());
+        return EXIT_FAILURE;
+    }
+    if (source_ref->width() != source_dis->width() || source_ref->height() != source_dis->height()) {
+        // the reference logs this and carries on into undefined territory (main.rs:156-158); here it is fatal
+        log_line(L_ERROR, kTarget, "Reference and distorted are not the same size");
+        return EXIT_FAILURE;
+    }
+
+    std::unique_ptr<TurboMetrics> turbo;
+    try {
+        if (metrics.mask() == 0) throw std::runtime_error("no metric selected (-m psnr|ssim|msssim|ssimulacra2)");
+        turbo = std::make_unique<TurboMetrics>(source_ref->width(), source_ref->height(), metrics, batch, pipeline);
+        if (full_sums) turbo->set_full_sums(true);
+    } catch (const std::exception &e) {
+        log_line(L_ERROR, kTarget, std::string("Could not initialize engine : ") + e.what());
+        return EXIT_FAILURE;
+    }
+
+    log_source("reference", *source_ref);
+    log_source("distorted", *source_dis);
+    log_line(L_DEBUG, kTarget, "Initialized, now processing ...");
+
+    const auto start = std::chrono::steady_clock::now();
+    output_prepare(output, metrics, std::cout);
+    MetricsResults results;
+    uint32_t decode_count = 0;
+    try {
+        results = turbo->compute_all(*source_ref, *source_dis, opts,
+                                     [&](const FrameScores &r) { output_single_score(output, r, std::cout); }, &decode_count);
+    } catch (const std::exception &e) {
+        std::cout.flush();
+        log_line(L_ERROR, kTarget, std::string("Computation failed : ") + e.what());
+        return EXIT_FAILURE;
+    }
+    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start);
+    const long long dms = ms.count() > 0 ? ms.count() : 1; // the reference divides by as_millis() (main.rs:332)
+    const unsigned long long fps = (unsigned long long)results.frame_count * 1000ull / (unsigned long long)dms;
+    const double perf = (double)source_ref->width() * (double)source_ref->height() * (double)results.frame_count / (double)dms / 1000.0;
+    char perf_s[64];
+    snprintf(perf_s, sizeof perf_s, "%.3f", perf);
+    log_line(L_INFO, kTarget, "Processed: " + std::to_string(results.frame_count) + " (decoded: ~" + std::to_string(decode_count + opts.skip) +
+                                  ") frame pairs in " + format_duration(ms) + " (" + std::to_string(fps) + " fps) (Mpx/s: " + perf_s + ")");
+    output_results(output, results, std::cout);
+    std::cout.flush();
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,272 @@
+// turbo_metrics.cpp -- see turbo_metrics.hpp.  Host orchestration only: frame selection, batching over the engine's
+// slots, ping-pong pipelining of two engines; every number comes out of libturbometrics_hip.so.
+#include "turbo_metrics.hpp"
+
+#include <cstring>
+
+namespace tm_host {
+
+TmError::TmError(int c, const std::string &where)
+    : std::runtime_error(where + ": " + tm_strerror(c) + (c == TM_ERR_HIP ? std::string(" [") + tm_last_hip_error() + "]" : std::string())),
+      code(c)
+{
+}
+
+static void chk(int code, const char *where)
+{
+    if (code != TM_OK) throw TmError(code, where);
+}
+
+void init_hip(int device) { chk(tm_init(device), "tm_init"); }
+
+// ---- colour metadata ---------------------------------------------------------------------------------------------
+ColorCharacteristics ColorCharacteristics::from_codes(int cp, int mc, int tc)
+{
+    ColorCharacteristics c;
+    switch (cp) {
+    case 1: c.cp = ColourPrimaries::BT709; break;
+    case 2: c.cp = ColourPrimaries::Unspecified; break;
+    case 5: c.cp = ColourPrimaries::BT601_625; break;
+    case 6: c.cp = ColourPrimaries::BT601_525; break;
+    case 0: case 3: c.cp = ColourPrimaries::Invalid; break;
+    default: c.cp = ColourPrimaries::Unsupported; break;
+    }
+    switch (mc) {
+    case 1: c.mc = MatrixCoefficients::BT709; break;
+    case 2: c.mc = MatrixCoefficients::Unspecified; break;
+    case 5: c.mc = MatrixCoefficients::BT601_625; break;
+    case 6: c.mc = MatrixCoefficients::BT601_525; break;
+    case 3: c.mc = MatrixCoefficients::Invalid; break;
+    default: c.mc = MatrixCoefficients::Unsupported; break; // 0 = identity, 4 = FCC, ...
+    }
+    switch (tc) {
+    case 1: case 6: c.tc = TransferCharacteristic::BT709; break;
+    case 2: c.tc = TransferCharacteristic::Unspecified; break;
+    case 0: case 3: c.tc = TransferCharacteristic::Invalid; break;
+    default: c.tc = TransferCharacteristic::Unsupported; break;
+    }
+    return c;
+}
+
+ColorCharacteristics ColorCharacteristics::or_(const ColorCharacteristics &o) const
+{
+    ColorCharacteristics r = *this;
+    if (cp == ColourPrimaries::Unspecified || cp == ColourPrimaries::Invalid) r.cp = o.cp;
+    if (mc == MatrixCoefficients::Unspecified || mc == MatrixCoefficients::Invalid) r.mc = o.mc;
+    if (tc == TransferCharacteristic::Unspecified || tc == TransferCharacteristic::Invalid) r.tc = o.tc;
+    return r;
+}
+
+ColorCharacteristics color_characteristics_fallback(uint32_t height)
+{
+    ColorCharacteristics c;
+    c.tc = TransferCharacteristic::BT709;
+    if (height <= 525) { c.cp = ColourPrimaries::BT601_525; c.mc = MatrixCoefficients::BT601_525; }
+    else if (height <= 625) { c.cp = ColourPrimaries::BT601_625; c.mc = MatrixCoefficients::BT601_625; }
+    else { c.cp = ColourPrimaries::BT709; c.mc = MatrixCoefficients::BT709; }
+    return c;
+}
+
+int get_color_matrix(const ColorCharacteristics &c)
+{
+    if (c.cp == ColourPrimaries::BT709 && c.mc == MatrixCoefficients::BT709) return TM_MATRIX_BT709;
+    if (c.cp == ColourPrimaries::BT601_525 && c.mc == MatrixCoefficients::BT601_525) return TM_MATRIX_BT601_525;
+    if (c.cp == ColourPrimaries::BT601_625 && c.mc == MatrixCoefficients::BT601_625) return TM_MATRIX_BT601_625;
+    throw std::runtime_error(std::string("not implemented: colour primaries ") + to_string(c.cp) + " with matrix coefficients " +
+                             to_string(c.mc) + " (todo!() in the reference, turbo-metrics/src/color.rs:85)");
+}
+
+int get_transfer(const ColorCharacteristics &c)
+{
+    if (c.tc == TransferCharacteristic::BT709) return TM_TRANSFER_BT709;
+    throw std::runtime_error(std::string("not implemented: transfer characteristic ") + to_string(c.tc) +
+                             " (todo!() in the reference, turbo-metrics/src/color.rs:92)");
+}
+
+const char *to_string(ColourPrimaries v)
+{
+    switch (v) {
+    case ColourPrimaries::Invalid: return "Invalid";
+    case ColourPrimaries::Unspecified: return "Unspecified";
+    case ColourPrimaries::Unsupported: return "Unsupported";
+    case ColourPrimaries::BT709: return "BT709";
+    case ColourPrimaries::BT601_525: return "BT601_525";
+    default: return "BT601_625";
+    }
+}
+const char *to_string(MatrixCoefficients v)
+{
+    switch (v) {
+    case MatrixCoefficients::Invalid: return "Invalid";
+    case MatrixCoefficients::Unspecified: return "Unspecified";
+    case MatrixCoefficients::Unsupported: return "Unsupported";
+    case MatrixCoefficients::BT709: return "BT709";
+    case MatrixCoefficients::BT601_525: return "BT601_525";
+    default: return "BT601_625";
+    }
+}
+const char *to_string(TransferCharacteristic v)
+{
+    switch (v) {
+    case TransferCharacteristic::Invalid: return "Invalid";
+    case TransferCharacteristic::Unspecified: return "Unspecified";
+    case TransferCharacteristic::Unsupported: return "Unsupported";
+    default: return "BT709";
+    }
+}
+const char *to_string(ColorRange v) { return v == ColorRange::Full ? "Full" : "Limited"; }
+
+// ---- engine --------------------------------------------------------------------------------------------------------
+TurboMetrics::TurboMetrics(uint32_t width, uint32_t height, const Metrics &metrics, uint32_t batch, bool pipeline)
+    : w_(width), h_(height), batch_(batch ? batch : 1), metrics_(metrics)
+{
+    chk(tm_engine_create(&eng_[0], w_, h_, metrics_.mask(), batch_), "tm_engine_create");
+    if (pipeline) {
+        const int rc = tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), batch_);
+        if (rc != TM_OK) {
+            tm_engine_destroy(eng_[0]);
+            eng_[0] = nullptr;
+            throw TmError(rc, "tm_engine_create (second engine of the pipeline)");
+        }
+    }
+}
+
+TurboMetrics::~TurboMetrics()
+{
+    for (tm_engine *e : eng_)
+        if (e) tm_engine_destroy(e);
+}
+
+size_t TurboMetrics::mem_usage() const
+{
+    return tm_engine_mem_usage(eng_[0]) + (eng_[1] ? tm_engine_mem_usage(eng_[1]) : 0);
+}
+
+void TurboMetrics::set_full_sums(bool on)
+{
+    for (tm_engine *e : eng_)
+        if (e) chk(tm_engine_set_full_sums(e, on ? 1 : 0), "tm_engine_set_full_sums");
+}
+
+// == convert_frame_to_linearrgb (color.rs:96-116): kernel selection by frame kind and colour metadata
+void TurboMetrics::set_frame(tm_engine *e, uint32_t slot, int side, const HwFrame &f, const ColorInfo &c)
+{
+    const int mem = f.device ? TM_MEM_DEVICE : TM_MEM_HOST;
+    switch (f.kind) {
+    case HwFrame::NvDecNV12:
+    case HwFrame::NvDecP016: {
+        const int matrix = get_color_matrix(c.first), transfer = get_transfer(c.first);
+        const int full = c.second == ColorRange::Full ? 1 : 0;
+        if (f.kind == HwFrame::NvDecNV12)
+            chk(tm_engine_set_frame_nv12(e, slot, side, f.data, f.uv, f.pitch, matrix, transfer, full, mem), "tm_engine_set_frame_nv12");
+        else
+            chk(tm_engine_set_frame_p016(e, slot, side, f.data, f.uv, f.pitch, matrix, transfer, full, mem), "tm_engine_set_frame_p016");
+        break;
+    }
+    case HwFrame::Npp8: chk(tm_engine_set_frame_rgb8(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgb8"); break;
+    case HwFrame::Npp16: chk(tm_engine_set_frame_rgb16(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgb16"); break;
+    case HwFrame::Npp32: chk(tm_engine_set_frame_rgbf32(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgbf32"); break;
+    }
+}
+
+FrameScores TurboMetrics::scores_of(tm_engine *e, uint32_t slot)
+{
+    tm_frame_scores s;
+    chk(tm_engine_get_scores(e, slot, &s), "tm_engine_get_scores");
+    FrameScores r;
+    if (s.valid & TM_METRIC_PSNR) r.psnr = s.psnr;
+    if (s.valid & TM_METRIC_SSIM) r.ssim = s.ssim;
+    if (s.valid & TM_METRIC_MSSSIM) r.msssim = s.msssim;
+    if (s.valid & TM_METRIC_SSIMULACRA2) r.ssimulacra2 = s.ssimulacra2;
+    return r;
+}
+
+FrameScores TurboMetrics::compute_one(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis)
+{
+    set_frame(eng_[0], 0, TM_SIDE_REF, fref, cref);
+    set_frame(eng_[0], 0, TM_SIDE_DIS, fdis, cdis);
+    chk(tm_engine_compute_async(eng_[0], 1), "tm_engine_compute_async");
+    chk(tm_engine_sync(eng_[0]), "tm_engine_sync");
+    return scores_of(eng_[0], 0);
+}
+
+MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts,
+                                         const std::function<void(const FrameScores &)> &on_frame, uint32_t *decode_count_out)
+{
+    if (frames_ref.width() != frames_dis.width() || frames_ref.height() != frames_dis.height())
+        throw std::runtime_error("Reference and distorted are not the same size"); // assert_eq! at lib.rs:368-372
+    const ColorInfo cref = frames_ref.color_characteristics(), cdis = frames_dis.color_characteristics();
+
+    std::optional<std::vector<double>> s_psnr, s_ssim, s_msssim, s_ssimu;
+    if (metrics_.psnr) s_psnr.emplace();
+    if (metrics_.ssim) s_ssim.emplace();
+    if (metrics_.msssim) s_msssim.emplace();
+    if (metrics_.ssimulacra2) s_ssimu.emplace();
+
+    uint32_t decode_count = 0;
+    size_t compute_count = 0;
+    frames_ref.skip_frames(opts.skip_ref + opts.skip);
+    frames_dis.skip_frames(opts.skip_dis + opts.skip);
+
+    // A batch in flight on engine `cur` while the next one is being read and uploaded into the other engine.
+    uint32_t filled[2] = {0, 0};
+    bool in_flight[2] = {false, false};
+    int cur = 0;
+    auto drain = [&](int i) {
+        if (!in_flight[i]) return;
+        chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
+        for (uint32_t slot = 0; slot < filled[i]; ++slot) {
+            const FrameScores r = scores_of(eng_[i], slot);
+            if (on_frame) on_frame(r);
+            if (s_psnr && r.psnr) s_psnr->push_back(*r.psnr);
+            if (s_ssim && r.ssim) s_ssim->push_back(*r.ssim);
+            if (s_msssim && r.msssim) s_msssim->push_back(*r.msssim);
+            if (s_ssimu && r.ssimulacra2) s_ssimu->push_back(*r.ssimulacra2);
+            ++compute_count;
+        }
+        in_flight[i] = false;
+        filled[i] = 0;
+    };
+    auto submit = [&](int i) {
+        if (filled[i] == 0) return;
+        chk(tm_engine_compute_async(eng_[i], filled[i]), "tm_engine_compute_async");
+        in_flight[i] = true;
+    };
+
+    HwFrame fref, fdis;
+    while (frames_ref.next_frame(fref) && frames_dis.next_frame(fdis)) {
+        if (opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0) { // lib.rs:391-394
+            ++decode_count;
+            continue;
+        }
+        if (opts.frames > 0 && decode_count >= opts.frames) break; // lib.rs:396-398
+        ++decode_count;
+        set_frame(eng_[cur], filled[cur], TM_SIDE_REF, fref, cref);
+        set_frame(eng_[cur], filled[cur], TM_SIDE_DIS, fdis, cdis);
+        if (++filled[cur] == batch_) {
+            submit(cur);
+            if (eng_[1]) {
+                cur ^= 1;
+                drain(cur); // the batch submitted before this one: done (or nearly) while we were reading
+            } else {
+                drain(cur);
+            }
+        }
+    }
+    submit(cur);
+    if (eng_[1]) drain(cur ^ 1);
+    drain(cur);
+    if (decode_count_out) *decode_count_out = decode_count;
+
+    MetricsResults res;
+    res.frame_count = compute_count;
+    if (compute_count == 0 && (s_psnr || s_ssim || s_msssim || s_ssimu))
+        throw std::out_of_range("no frame pair was processed (the reference panics in Stats::compute: index out of bounds)");
+    if (s_psnr) res.psnr = MetricAggregate::from(std::move(*s_psnr));
+    if (s_ssim) res.ssim = MetricAggregate::from(std::move(*s_ssim));
+    if (s_msssim) res.msssim = MetricAggregate::from(std::move(*s_msssim));
+    if (s_ssimu) res.ssimulacra2 = MetricAggregate::from(std::move(*s_ssimu));
+    return res;
+}
+
+} // namespace tm_host

@@ -1,0 +1,179 @@
+// turbo_metrics.hpp -- C++ host side of the frame-pair path, above the C ABI (include/turbo_metrics_hip.h).
+//
+// The reference's host code is Rust; this image has no Rust toolchain, so the host side is C++17 with the
+// reference's own names, argument meaning and error behaviour (paths relative to /root/reference/crates):
+//   Metrics, Options                       turbo-metrics/src/lib.rs:27-54
+//   MetricAggregate, MetricsResults,
+//   MetricsStats, FrameScores              turbo-metrics/src/lib.rs:56-123
+//   HwFrame, FormatIdentifier, FrameSource turbo-metrics/src/lib.rs:125-186
+//   TurboMetrics::{new, metrics,
+//     compute_one, compute_all}            turbo-metrics/src/lib.rs:188-433
+//   init_cuda                              turbo-metrics/src/lib.rs:438-456   (here init_hip)
+//   ColorCharacteristics & fallback, ColorRange, get_color_matrix, get_transfer
+//                                          turbo-metrics/src/color.rs:10-94, codec-bitstream/src/lib.rs:98-248
+//   Stats                                  quick-stats/src/lib.rs:4-97
+// Everything numeric happens in libturbometrics_hip.so; nothing here computes a metric.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/turbo_metrics_hip.h"
+#include "quick_stats.hpp"
+
+namespace tm_host {
+
+struct Metrics {
+    bool psnr = false, ssim = false, msssim = false, ssimulacra2 = false;
+    uint32_t mask() const
+    {
+        return (psnr ? (uint32_t)TM_METRIC_PSNR : 0u) | (ssim ? (uint32_t)TM_METRIC_SSIM : 0u) |
+               (msssim ? (uint32_t)TM_METRIC_MSSSIM : 0u) | (ssimulacra2 ? (uint32_t)TM_METRIC_SSIMULACRA2 : 0u);
+    }
+};
+
+struct Options {
+    uint32_t every = 0, skip = 0, skip_ref = 0, skip_dis = 0, frames = 0;
+};
+
+struct MetricAggregate {
+    std::vector<double> scores;
+    Stats stats;
+    static MetricAggregate from(std::vector<double> v)
+    {
+        MetricAggregate a;
+        a.stats = Stats::compute(v);
+        a.scores = std::move(v);
+        return a;
+    }
+};
+
+struct MetricsResults {
+    size_t frame_count = 0;
+    std::optional<MetricAggregate> psnr, ssim, msssim, ssimulacra2;
+};
+
+struct MetricsStats {
+    size_t frame_count = 0;
+    std::optional<Stats> psnr, ssim, msssim, ssimulacra2;
+    static MetricsStats from(const MetricsResults &r)
+    {
+        MetricsStats s;
+        s.frame_count = r.frame_count;
+        if (r.psnr) s.psnr = r.psnr->stats;
+        if (r.ssim) s.ssim = r.ssim->stats;
+        if (r.msssim) s.msssim = r.msssim->stats;
+        if (r.ssimulacra2) s.ssimulacra2 = r.ssimulacra2->stats;
+        return s;
+    }
+};
+
+struct FrameScores {
+    std::optional<double> psnr, ssim, msssim, ssimulacra2;
+};
+
+// ---- colour metadata (H.273 code points the reference understands, codec-bitstream/src/lib.rs:98-248) ----------
+enum class ColourPrimaries { Invalid, Unspecified, Unsupported, BT709, BT601_525, BT601_625 };
+enum class MatrixCoefficients { Invalid, Unspecified, Unsupported, BT709, BT601_525, BT601_625 };
+enum class TransferCharacteristic { Invalid, Unspecified, Unsupported, BT709 };
+enum class ColorRange { Limited, Full };
+
+struct ColorCharacteristics {
+    ColourPrimaries cp = ColourPrimaries::Unspecified;
+    MatrixCoefficients mc = MatrixCoefficients::Unspecified;
+    TransferCharacteristic tc = TransferCharacteristic::Unspecified;
+    // H.264 table E-3/E-4/E-5 code points as the reference maps them (codec-bitstream/src/h264.rs:104-166, lib.rs:98-248):
+    // 1 = BT.709, 2 = unspecified, 5 = BT601_625, 6 = BT601_525 (transfer: 1 and 6 -> BT709), 0 / 3 invalid, rest unsupported
+    static ColorCharacteristics from_codes(int cp, int mc, int tc);
+    // `.or(fallback)` (codec-bitstream/src/lib.rs:68-95): an Unspecified or Invalid field is taken from `other`
+    ColorCharacteristics or_(const ColorCharacteristics &other) const;
+};
+// turbo-metrics/src/color.rs:51-78: unspecified metadata falls back by frame height
+ColorCharacteristics color_characteristics_fallback(uint32_t height);
+// color.rs:80-94; combinations the reference leaves as todo!() throw std::runtime_error("not implemented: ...")
+int get_color_matrix(const ColorCharacteristics &c);
+int get_transfer(const ColorCharacteristics &c);
+const char *to_string(ColourPrimaries v);
+const char *to_string(MatrixCoefficients v);
+const char *to_string(TransferCharacteristic v);
+const char *to_string(ColorRange v);
+
+// ---- frames ----------------------------------------------------------------------------------------------------
+// One decoded frame handed to the engine (== HwFrame, lib.rs:125-130).  NvDecNV12 / NvDecP016 carry the surface
+// contract of an NVDEC mapping (cudarse-video/src/dec.rs:299-403): luma rows at `pitch`, interleaved CbCr at `uv`.
+struct HwFrame {
+    enum Kind { NvDecNV12, NvDecP016, Npp8, Npp16, Npp32 } kind = Npp8;
+    const void *data = nullptr; // luma plane or packed RGB
+    const void *uv = nullptr;   // CbCr plane (NvDec kinds)
+    size_t pitch = 0;           // bytes
+    bool device = false;        // the pointers are device memory (zero copy) rather than host memory
+};
+
+struct FormatIdentifier {
+    std::optional<std::string> container;
+    std::string codec, decoder;
+    std::string str() const { return (container ? *container + "/" : std::string()) + codec + "/" + decoder; }
+};
+
+// == trait FrameSource (lib.rs:148-156).  next_frame returns false at end of stream; the frame's memory stays valid
+// until the next call on the same source.  Errors are exceptions (the reference returns Box<dyn Error>).
+class FrameSource {
+public:
+    virtual ~FrameSource() = default;
+    virtual FormatIdentifier format_id() const = 0;
+    virtual uint32_t width() const = 0;
+    virtual uint32_t height() const = 0;
+    virtual std::pair<ColorCharacteristics, ColorRange> color_characteristics() const = 0;
+    virtual size_t frame_count() const = 0; // 0 when unknown
+    virtual void skip_frames(uint32_t n) = 0;
+    virtual bool next_frame(HwFrame &out) = 0;
+};
+
+class TmError : public std::runtime_error {
+public:
+    int code;
+    TmError(int code, const std::string &where);
+};
+
+// Bind the process to `device`; throws when there is no usable gfx950 GPU (there is no CPU path).
+void init_hip(int device = 0);
+
+class TurboMetrics {
+public:
+    // `batch` frame-pair slots per launch (1 == the reference's one pair at a time); `pipeline`: keep a second engine so
+    // that reading / uploading the next batch overlaps the current one's kernels (compute_all only)
+    TurboMetrics(uint32_t width, uint32_t height, const Metrics &metrics, uint32_t batch = 1, bool pipeline = false);
+    ~TurboMetrics();
+    TurboMetrics(const TurboMetrics &) = delete;
+    TurboMetrics &operator=(const TurboMetrics &) = delete;
+
+    Metrics metrics() const { return metrics_; }
+    uint32_t width() const { return w_; }
+    uint32_t height() const { return h_; }
+    uint32_t batch() const { return batch_; }
+    size_t mem_usage() const;
+    // also compute the 56 SSIMULACRA2 sums whose weight is 0.0 (see tm_engine_set_full_sums); the scores do not change
+    void set_full_sums(bool on);
+
+    using ColorInfo = std::pair<ColorCharacteristics, ColorRange>;
+    // == compute_one (lib.rs:268-360): convert both frames, compute every selected metric, block, return the scores
+    FrameScores compute_one(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis);
+
+    // == compute_all (lib.rs:362-433) with the frame selection of Options; `on_frame` (optional) sees every FrameScores
+    // in stream order (the CLI's output_single_score).  Returns the number of frames decoded (for the CLI's log line).
+    MetricsResults compute_all(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts,
+                               const std::function<void(const FrameScores &)> &on_frame = nullptr, uint32_t *decode_count = nullptr);
+
+private:
+    void set_frame(tm_engine *e, uint32_t slot, int side, const HwFrame &f, const ColorInfo &c);
+    FrameScores scores_of(tm_engine *e, uint32_t slot);
+    uint32_t w_, h_, batch_;
+    Metrics metrics_;
+    tm_engine *eng_[2] = {nullptr, nullptr};
+};
+
+} // namespace tm_host
