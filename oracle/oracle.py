@@ -15,7 +15,7 @@ SCALES = 6
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("tm_oracle.c", "tm_cpu_path.c", "tm_math.h", "tm_oracle_tables.inc", "tm_math_tables.inc", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("tm_oracle.c", "tm_cpu_path.c", "tm_ssim.c", "tm_math.h", "tm_oracle_tables.inc", "tm_math_tables.inc", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if force or stale:
@@ -46,6 +46,8 @@ def lib():
         L.tmo_cpu_path_score_linear.argtypes = [fp, fp, C.c_int, C.c_int]
         L.tmo_cpu_path_score_srgb8.restype = C.c_double
         L.tmo_cpu_path_score_srgb8.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.tmo_ssim_from_sums.restype = C.c_double; L.tmo_ssim_from_sums.argtypes = [dp, C.c_int, C.c_int]
+        L.tmo_msssim_from_sums.restype = C.c_double; L.tmo_msssim_from_sums.argtypes = [dp, C.c_int, C.c_int]
         L.tmo_yuv420_biplanar_to_linear.restype = C.c_int
         L.tmo_yuv420_biplanar_to_linear.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, fp]
     return _lib
@@ -263,3 +265,35 @@ def cpu_path_score_srgb8(ref_rgb, dis_rgb):
     dis_rgb = np.ascontiguousarray(dis_rgb, np.uint8)
     h, w, _ = ref_rgb.shape
     return float(lib().tmo_cpu_path_score_srgb8(ref_rgb.ctypes.data_as(C.c_void_p), dis_rgb.ctypes.data_as(C.c_void_p), w, h))
+
+
+# ---- SSIM / MS-SSIM of the u8-quantised linear RGB pair (oracle/tm_ssim.c: BUILD-DEFINED, parity unpinned) ----------
+def ssim_window():
+    out = np.zeros(11, np.float32)
+    lib().tmo_ssim_window(_fp(out))
+    return out
+
+
+def msssim_sums(ref_lin, dis_lin):
+    """(3 channels, 5 scales, [sum ssim, sum cs]) of the quantised pair; ref_lin/dis_lin: (3, h, w) linear RGB"""
+    a, b = quantize_u8(ref_lin), quantize_u8(dis_lin)
+    _, h, w = a.shape
+    sums = np.zeros(30, np.float64)
+    lib().tmo_msssim_sums(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), w, h, _dp(sums))
+    return sums.reshape(3, 5, 2)
+
+
+def ssim_from_sums(sums, w, h):
+    s = np.ascontiguousarray(np.asarray(sums, np.float64).ravel())
+    return float(lib().tmo_ssim_from_sums(_dp(s), w, h))
+
+
+def msssim_from_sums(sums, w, h):
+    s = np.ascontiguousarray(np.asarray(sums, np.float64).ravel())
+    return float(lib().tmo_msssim_from_sums(_dp(s), w, h))
+
+
+def ssim_msssim(ref_lin, dis_lin):
+    _, h, w = np.asarray(ref_lin).shape
+    s = msssim_sums(ref_lin, dis_lin)
+    return ssim_from_sums(s, w, h), msssim_from_sums(s, w, h), s

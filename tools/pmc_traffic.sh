@@ -4,13 +4,15 @@
 set -u
 TAG=${1:-r01}
 WL=${2:-1080p_nv12}
+EXTRA=${3:-}          # e.g. --full-sums
+SUF=${EXTRA:+_full}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_${WL}_$C -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_${WL}${SUF}_$C -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-compare $EXTRA > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
 done
 cd $R
-python3 tools/parse_pmc.py gpurun_out/${TAG}_pmc_${WL}_FETCH_SIZE gpurun_out/${TAG}_pmc_${WL}_WRITE_SIZE $WL > gpurun_out/${TAG}_pmc_traffic_$WL.json
-cat gpurun_out/${TAG}_pmc_traffic_$WL.json
+python3 tools/parse_pmc.py gpurun_out/${TAG}_pmc_${WL}${SUF}_FETCH_SIZE gpurun_out/${TAG}_pmc_${WL}${SUF}_WRITE_SIZE $WL > gpurun_out/${TAG}_pmc_traffic_$WL$SUF.json
+cat gpurun_out/${TAG}_pmc_traffic_$WL$SUF.json
