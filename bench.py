@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--workload", default="1080p_nv12", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled over the batch)")
-    ap.add_argument("--metrics", default="ssimulacra2", help="comma list: ssimulacra2,psnr")
+    ap.add_argument("--metrics", default="ssimulacra2", help="comma list: ssimulacra2,psnr,ssim,msssim")
     ap.add_argument("--full-sums", action="store_true", help="compute all 108 per-scale sums like the reference (default: only the 52 with a non-zero weight; same score)")
     ap.add_argument("--no-compare", action="store_true", help="skip the short extra run with the other full_sums setting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,7 +79,7 @@ def main():
     w, h, kind, default_b, cfg_name = WORKLOADS[args.workload]
     B = args.batch or default_b
     mets = set(args.metrics.split(","))
-    metrics = tm.Metrics(ssimulacra2="ssimulacra2" in mets, psnr="psnr" in mets)
+    metrics = tm.Metrics(ssimulacra2="ssimulacra2" in mets, psnr="psnr" in mets, ssim="ssim" in mets, msssim="msssim" in mets)
     eng = tm.TurboMetrics(w, h, metrics, batch=B)
 
     # ---- synthetic decoded surfaces, resident in HBM before the timed region (weak scaling: every rank

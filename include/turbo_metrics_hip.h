@@ -125,6 +125,17 @@ int tm_engine_get_job_modes(const tm_engine *e, int out[18]);
 /* PSNR input: exact integer sum of squared differences of the u8-quantised linear RGB pair */
 int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out);
 
+/* SSIM / MS-SSIM of the u8-quantised linear RGB pair (the inputs of nppiSSIM_8u_C3R_Ctx / nppiWMSSSIM_8u_C3R_Ctx,
+ * turbo-metrics/src/lib.rs:319-337).  NPP is closed source and no reference test pins its output: the definition here
+ * is BUILD-DEFINED (Wang et al. 2004 / 2003) -- 11x11 Gaussian window (sigma 1.5) over the windows
+ * inside the image, K1 = 0.01, K2 = 0.03, L = 255, per channel then averaged; MS-SSIM: five dyadic scales.
+ * Raw sums [channel 3][scale 5][sum of ssim, sum of cs] over the (w-10) x (h-10) windows of each scale (SSIM alone fills
+ * scale 0 only); the two host functions turn them into the scores that tm_engine_get_scores reports. */
+int tm_engine_get_ssim_sums(tm_engine *e, uint32_t slot, double out[30]);
+double tm_ssim_from_sums(const double sums[30], uint32_t width, uint32_t height);
+double tm_msssim_from_sums(const double sums[30], uint32_t width, uint32_t height);
+void tm_ssim_window(float g[11]);
+
 /* SSIMULACRA2 post-processing (ssimulacra2-cuda/src/lib.rs:449-623) as a pure host function */
 double tm_ssimulacra2_score_from_sums(const double sums[108], uint32_t width, uint32_t height);
 

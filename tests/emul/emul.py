@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _LIB = os.path.join(_HERE, "libtm_emul.so")
 _SRCS = [os.path.join(_HERE, "tm_emul.cpp"), os.path.join(_HERE, "hip_emul.h")] + [
-    os.path.join(_ROOT, "turbo-metrics_amd", "csrc", f) for f in ("tm_kernels.h", "tm_device_math.h", "tm_geom.h", "tm_math_tables.inc")]
+    os.path.join(_ROOT, "turbo-metrics_amd", "csrc", f) for f in ("tm_kernels.h", "tm_ssim_kernels.h", "tm_device_math.h", "tm_geom.h", "tm_math_tables.inc")]
 
 
 def build():
@@ -40,6 +40,11 @@ class Geom(C.Structure):
     _fields_ = [("s", ScaleGeom * 6), ("pyr", C.c_ulonglong), ("pyr_t", C.c_ulonglong), ("vblk", C.c_int * 7), ("hblk", C.c_int * 7)]
 
 
+class SsimGeom(C.Structure):
+    _fields_ = [("w", C.c_int * 5), ("h", C.c_int * 5), ("pitch", C.c_int * 5), ("off", C.c_ulonglong * 5), ("qplane", C.c_ulonglong),
+                ("pyr", C.c_ulonglong), ("tiles_x", C.c_int * 5), ("tiles_y", C.c_int * 5), ("tile_off", C.c_int * 6), ("g", C.c_float * 11)]
+
+
 class FrameDesc(C.Structure):
     _fields_ = [("p0", C.c_void_p), ("p1", C.c_void_p), ("pitch", C.c_ulonglong), ("kind", C.c_int), ("matrix", C.c_int)]
 
@@ -50,7 +55,7 @@ KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 
 class Emulated:
     """Runs the whole generation-0 pipeline for n slots; keeps the arenas for plane inspection."""
 
-    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True):
+    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True, ssim_window=None):
         """frames: list of (ref, dis) where each is dict(kind=, data=np.ndarray, pitch=, coded_height=, matrix=)."""
         L = C.CDLL(build())
         L.emul_geom_size.restype = C.c_size_t
@@ -82,8 +87,26 @@ class Emulated:
             weights = np.ones(108)
         weights = np.ascontiguousarray(weights, np.float64).ravel()
         assert weights.size == 108
+        # SSIM / MS-SSIM (only with the tile32 ingest, which writes the quantised u8 planes): ssim_window = the 11 taps
+        self.sg = None
+        qu8, qplane, qpitch = None, 0, 0
+        if ssim_window is not None:
+            L.emul_ssim_geom_size.restype = C.c_size_t
+            assert L.emul_ssim_geom_size() == C.sizeof(SsimGeom), (L.emul_ssim_geom_size(), C.sizeof(SsimGeom))
+            gw = np.ascontiguousarray(ssim_window, np.float32)
+            self.sg = SsimGeom()
+            L.emul_ssim_geom(w, h, vp(gw), C.byref(self.sg))
+            qplane, qpitch = self.sg.qplane, self.sg.pitch[0]
+            self.QU8 = np.zeros(n * 2 * 3 * qplane, np.uint8)
+            qu8 = vp(self.QU8)
+        L.emul_pipeline.argtypes = None
         L.emul_pipeline(w, h, n, desc, vp(lut), vp(coef), vp(powtab), int(want_sse), vp(self.LIN), vp(self.XYB), vp(self.XYBT), vp(self.V),
-                        vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant), vp(weights), int(full_sums))
+                        vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant), vp(weights), int(full_sums), qu8, C.c_ulonglong(qplane), int(qpitch))
+        if ssim_window is not None:
+            self.SPYR = np.zeros(max(1, n * 2 * 3 * self.sg.pyr), np.float32)
+            self.SPART = np.zeros(max(1, n * 3 * self.sg.tile_off[5] * 2), np.float64)
+            self.SSUMS = np.zeros(n * 30, np.float64)
+            L.emul_ssim(w, h, n, vp(gw), qu8, vp(self.SPYR), vp(self.SPART), vp(self.SSUMS))
         self.w, self.h, self.n = w, h, n
 
     def plane(self, arena, slot, scale, index, channel, transposed=False, per_slot=2):
@@ -93,6 +116,14 @@ class Emulated:
             return arena[base:base + sg.plane_t].reshape(-1, sg.pitch_t)[:sg.w, :sg.h]
         base = (slot * per_slot + index) * self.g.pyr + sg.off + channel * sg.plane
         return arena[base:base + sg.plane].reshape(sg.h, sg.pitch)[:, :sg.w]
+
+    def qplane(self, slot, side, c):
+        sg = self.sg
+        base = ((slot * 2 + side) * 3 + c) * sg.qplane
+        return self.QU8[base:base + sg.qplane].reshape(sg.h[0], sg.pitch[0])[:, :sg.w[0]]
+
+    def ssim_sums(self, slot):
+        return self.SSUMS[slot * 30:(slot + 1) * 30].reshape(3, 5, 2)
 
     def sums(self, slot):
         return self.SUMS[slot * 108:(slot + 1) * 108].reshape(6, 6, 3)

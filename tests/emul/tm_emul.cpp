@@ -38,6 +38,7 @@ void tm_emul_wave_barrier()
 void tm_emul_syncthreads() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
 
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
+#include "../../turbo-metrics_amd/csrc/tm_ssim_kernels.h"
 
 // a whole workgroup of `nthreads` host threads; __syncthreads() is a real barrier
 template <typename F> static void launch_wg_lockstep(dim3 grid, unsigned nthreads, F f)
@@ -117,7 +118,7 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
 
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
-                   int variant, const double *weights, int full_sums)
+                   int variant, const double *weights, int full_sums, unsigned char *QU8, unsigned long long qplane, int qpitch)
 {
     const int ingest_gen = variant >> 8;
     variant &= 255;
@@ -138,9 +139,9 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
         launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n), 256, [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
           switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse); break;
-          case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse); break;
-          default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse); break; } } });
+          case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, XYBT); });
     }
     const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
@@ -160,5 +161,26 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
     else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });
+}
+
+size_t emul_ssim_geom_size(void) { return sizeof(TmSsimGeom); }
+void emul_ssim_geom(int w, int h, const float *g, TmSsimGeom *out) { tm_make_ssim_geom(out, w, h, g); }
+
+// SSIM / MS-SSIM stage on the planar u8 planes the ingest kernel left in QU8: pyramid, statistics, finisher.
+// PYR: n*2*3*sg.pyr floats, PART: n*3*tile_off[5]*2 doubles, SUMS: n*30 doubles
+void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, float *PYR, double *PART, double *SUMS)
+{
+    TmSsimGeom sg; tm_make_ssim_geom(&sg, w, h, g);
+    for (int s = 1; s < TM_SSIM_SCALES; ++s) {
+        if (sg.w[s] <= 0 || sg.h[s] <= 0) break;
+        if (s == 1) launch(dim3((sg.w[s] + 63) / 64, sg.h[s], n * 6), dim3(64), [&] { tmk::k_ssim_down<true>(sg, s, QU8, PYR); });
+        else launch(dim3((sg.w[s] + 63) / 64, sg.h[s], n * 6), dim3(64), [&] { tmk::k_ssim_down<false>(sg, s, QU8, PYR); });
+    }
+    for (int s = 0; s < TM_SSIM_SCALES; ++s) {
+        if (sg.tiles_x[s] == 0 || sg.tiles_y[s] == 0) continue;
+        if (s == 0) launch_wg_lockstep(dim3(sg.tiles_x[s], sg.tiles_y[s], n * 3), 256, [&] { tmk::k_ssim_stats<true>(sg, s, QU8, PYR, PART); });
+        else launch_wg_lockstep(dim3(sg.tiles_x[s], sg.tiles_y[s], n * 3), 256, [&] { tmk::k_ssim_stats<false>(sg, s, QU8, PYR, PART); });
+    }
+    launch(dim3(n), dim3(32), [&] { tmk::k_ssim_finish(sg, PART, SUMS); });
 }
 }

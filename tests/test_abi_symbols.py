@@ -51,7 +51,8 @@ def test_create_rejects_bad_arguments_before_touching_the_device():
     assert L.tm_engine_create(C.byref(h), 0, 10, 8, 1) == tm.ffi.TM_ERR_INVALID_ARG
     assert L.tm_engine_create(C.byref(h), 10, 10, 0, 1) == tm.ffi.TM_ERR_INVALID_ARG
     assert L.tm_engine_create(C.byref(h), 10, 10, 8, 0) == tm.ffi.TM_ERR_INVALID_ARG
-    assert L.tm_engine_create(C.byref(h), 10, 10, 2, 1) == tm.ffi.TM_ERR_UNSUPPORTED  # SSIM: NPP semantics unpinned
+    assert L.tm_engine_create(C.byref(h), 10, 10, 2, 1) == tm.ffi.TM_ERR_UNSUPPORTED  # SSIM needs one 11x11 window
+    assert L.tm_engine_create(C.byref(h), 175, 400, 4, 1) == tm.ffi.TM_ERR_UNSUPPORTED  # MS-SSIM: five dyadic scales
     assert h.value is None
 
 
@@ -82,3 +83,15 @@ def test_frame_selection_matches_reference_options():
     assert select(10, 0, 0, 0) == list(range(10))
     assert select(10, 3, 0, 0) == [0, 3, 6, 9]
     assert select(10, 0, 2, 3) == [2, 3, 4]
+
+
+def test_ssim_host_functions_match_oracle():
+    rng = np.random.default_rng(9)
+    for w, h in [(176, 176), (1920, 1080), (200, 300)]:
+        n = [(max(w >> s, 11) - 10) * (max(h >> s, 11) - 10) for s in range(5)]
+        sums = rng.random((3, 5, 2)) * np.array(n)[None, :, None]
+        assert tm.engine.ssim_from_sums(sums, w, h) == O.ssim_from_sums(sums, w, h)
+        assert tm.engine.msssim_from_sums(sums, w, h) == O.msssim_from_sums(sums, w, h)
+    g = (C.c_float * 11)()
+    tm.ffi.lib().tm_ssim_window(g)
+    assert np.array_equal(np.array(g, np.float32), O.ssim_window()) and abs(sum(g) - 1.0) < 1e-6

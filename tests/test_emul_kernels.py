@@ -113,3 +113,29 @@ def test_job_driven_blur_passes_full_and_pruned(w, h):
         assert np.array_equal(a[m], b[m])
         assert np.all(b[~m] == 0.0) or np.array_equal(a[~m & (b != 0)], b[~m & (b != 0)])  # EDGE jobs still report all four edge sums
         assert O.score_from_sums(a, w, h) == O.score_from_sums(b, w, h)
+
+
+@pytest.mark.parametrize("w,h", [(200, 180), (64, 40), (11, 11), (33, 12)])
+def test_ssim_kernels_match_oracle(w, h):
+    """SSIM / MS-SSIM stage (tm_ssim_kernels.h) on the CPU lane emulator: the u8 planes written by the ingest kernel are
+    the oracle's quantised frames bit for bit; the per-scale sums agree to 1e-12; the finishing functions agree exactly."""
+    frames = []
+    for n in range(2):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
+        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=0), dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0)))
+    r8, d8 = tm.synth.rgb8_pair(w, h)
+    frames.append((dict(kind="rgb8", data=r8), dict(kind="rgb8", data=d8)))
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 9, weights=O.weights(), ssim_window=O.ssim_window())
+    for slot, (fr, fd) in enumerate(frames):
+        lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+        for side in range(2):
+            q = O.quantize_u8(lin[side])
+            for c in range(3):
+                assert np.array_equal(em.qplane(slot, side, c), q[c]), ("q", slot, side, c)
+        want = O.msssim_sums(lin[0], lin[1])
+        np.testing.assert_allclose(em.ssim_sums(slot), want, rtol=1e-12, atol=1e-300)
+        got_ssim = tm.engine.ssim_from_sums(em.ssim_sums(slot), w, h)
+        assert got_ssim == O.ssim_from_sums(em.ssim_sums(slot), w, h)
+        assert abs(got_ssim - O.ssim_from_sums(want, w, h)) <= 1e-7
+        a, b = tm.engine.msssim_from_sums(em.ssim_sums(slot), w, h), O.msssim_from_sums(em.ssim_sums(slot), w, h)
+        assert (a == b) or (np.isnan(a) and np.isnan(b))   # NaN below 176x176

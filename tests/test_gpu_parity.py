@@ -245,3 +245,52 @@ def test_reference_mirror_types_and_errors():
     solo = [eng.compute_one(*frames[i]).ssimulacra2 for i in (0, 2, 4)]
     assert [r.ssimulacra2 for r in res] == solo
     eng.close()
+
+
+@pytest.mark.parametrize("w,h,metrics", [(200, 180, "both"), (64, 40, "ssim"), (333, 203, "both"), (1920, 1080, "both")])
+def test_ssim_and_msssim_match_oracle(w, h, metrics):
+    """SSIM / MS-SSIM are BUILD-DEFINED (NPP's are closed and unpinned): HIP vs the oracle's statement of the same
+    definition.  Per-scale sums to 1e-12, scores to 1e-6 (they are single floats by contract), fused with the other metrics."""
+    m = tm.Metrics(ssimulacra2=True, psnr=True, ssim=True, msssim=(metrics == "both"))
+    n = 2 if w * h > 10 ** 6 else 3
+    eng = tm.TurboMetrics(w, h, m, batch=n)
+    only = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=n)
+    frames = [nv12_frames(w, h, i) for i in range(n)]
+    if n == 3:
+        r8, d8 = tm.synth.rgb8_pair(w, h)
+        frames[2] = (tm.HwFrame.rgb(r8), tm.HwFrame.rgb(d8))
+    for slot, (fr, fd) in enumerate(frames):
+        eng.set_pair(slot, fr, fd)
+        only.set_pair(slot, fr, fd)
+    eng.compute_async(); eng.sync()
+    only.compute_async(); only.sync()
+    for slot, (fr, fd) in enumerate(frames):
+        lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+        want_ssim, want_ms, sums = O.ssim_msssim(lin[0], lin[1])
+        got = eng.scores(slot)
+        gs = eng.ssim_sums(slot)
+        nsc = 5 if metrics == "both" else 1
+        np.testing.assert_allclose(gs[:, :nsc], sums[:, :nsc], rtol=1e-12, atol=1e-300)
+        assert abs(got.ssim - want_ssim) <= 1e-6 and 0.0 < got.ssim <= 1.0
+        if metrics == "both":
+            assert abs(got.msssim - want_ms) <= 1e-6 and 0.0 < got.msssim <= 1.0
+        else:
+            assert got.msssim is None
+        # the fused pass leaves the other metrics untouched
+        assert got.ssimulacra2 == only.scores(slot).ssimulacra2
+        assert got.psnr == O.psnr(lin[0], lin[1])[1]
+    eng.close(); only.close()
+
+
+def test_ssim_of_identical_frames_is_one_and_size_limits():
+    w, h = 192, 176
+    fr, _ = nv12_frames(w, h, 1)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssim=True, msssim=True), batch=1)
+    s = eng.compute_one(fr, fr)
+    assert s.ssim == 1.0 and s.msssim == 1.0 and s.ssimulacra2 is None and s.psnr is None
+    eng.close()
+    with pytest.raises(tm.TmError) as ei:      # fifth dyadic scale smaller than the 11x11 window
+        tm.TurboMetrics(175, 300, tm.Metrics(msssim=True), batch=1)
+    assert ei.value.code == F.TM_ERR_UNSUPPORTED
+    with pytest.raises(tm.TmError):
+        tm.TurboMetrics(10, 300, tm.Metrics(ssim=True), batch=1)

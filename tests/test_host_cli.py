@@ -365,8 +365,10 @@ def test_cli_error_paths(tmp_path):
     assert rc == 1 and "Can't read both reference and distorted from stdin" in err
     rc, _, err = cli(p1, str(tmp_path / "missing.png"), "-m", "ssimulacra2")
     assert rc == 1 and "Could not read distorted" in err
-    rc, _, err = cli(p1, p1, "-m", "ssim")
-    assert rc == 1 and "Could not initialize engine" in err     # SSIM inside NPP is pinned by nothing: refused, not guessed
+    rc, _, err = cli(p1, p1, "-m", "msssim")
+    assert rc == 1 and "Could not initialize engine" in err     # 48x32: no fifth dyadic scale for MS-SSIM
+    rc, out, err = cli(p1, p1, "-m", "ssim", "-m", "psnr", "--output", "csv")
+    assert rc == 0 and out.split("\n")[:2] == ["psnr,ssim", "inf,1"]
     rc, _, err = cli(p1, p1, "-m", "vmaf")
     assert rc == 2 and "possible values: psnr, ssim, msssim, ssimulacra2" in err
     rc, _, err = cli(p1)

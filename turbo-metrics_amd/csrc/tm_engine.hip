@@ -20,6 +20,7 @@
 #include "../../include/turbo_metrics_hip.h"
 #include "tm_geom.h"
 #include "tm_kernels.h"
+#include "tm_ssim_kernels.h"
 #include "tm_tables.inc"
 #include "tm_math_tables.inc"
 
@@ -86,6 +87,10 @@ struct tm_engine {
     TmGeom g{};
     TmJobs jobs{};
     bool full_sums = false;
+    TmSsimGeom sg{};               // SSIM / MS-SSIM (only when the mask asks for them)
+    unsigned char *QU8 = nullptr;  // [slot][side][3] planar u8-quantised linear RGB
+    float *SPYR = nullptr;         // [slot][side][3] box pyramid, scales 1..4
+    double *SPART = nullptr, *SSUMS = nullptr, *h_ssums = nullptr;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_pipe[4] = {};
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr;
@@ -248,9 +253,13 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (width == 0 || height == 0 || width > 16384 || height > 16384 || batch_capacity == 0 || batch_capacity > 4096)
         return TM_ERR_INVALID_ARG;
     if ((metrics_mask & ~15u) || metrics_mask == 0) return TM_ERR_INVALID_ARG;
-    if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
-        // NPP's SSIM / MS-SSIM arithmetic is closed source and pinned by no reference test:
-        // not built yet rather than built to a guess.
+    // SSIM needs one 11x11 window, MS-SSIM one at the fifth dyadic scale
+    if ((metrics_mask & TM_METRIC_SSIM) && (width < TM_SSIM_TAPS || height < TM_SSIM_TAPS)) {
+        snprintf(g_hip_err, sizeof g_hip_err, "SSIM needs an image of at least 11x11");
+        return TM_ERR_UNSUPPORTED;
+    }
+    if ((metrics_mask & TM_METRIC_MSSSIM) && ((width >> 4) < TM_SSIM_TAPS || (height >> 4) < TM_SSIM_TAPS)) {
+        snprintf(g_hip_err, sizeof g_hip_err, "MS-SSIM (5 scales, 11x11 window) needs an image of at least 176x176");
         return TM_ERR_UNSUPPORTED;
     }
     tm_engine *e = new (std::nothrow) tm_engine();
@@ -273,6 +282,16 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->SSE, B, true))) return fail(rc);
+    if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
+        float gw[TM_SSIM_TAPS];
+        tm_ssim_window(gw);
+        tm_make_ssim_geom(&e->sg, (int)width, (int)height, gw);
+        if ((rc = dev_alloc(e, &e->QU8, B * 2 * 3 * e->sg.qplane, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->SPYR, B * 2 * 3 * e->sg.pyr, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->SPART, B * 3 * (size_t)e->sg.tile_off[TM_SSIM_SCALES] * 2, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->SSUMS, B * 30, true))) return fail(rc);
+        if ((he = hipHostMalloc((void **)&e->h_ssums, B * 30 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
+    }
     if ((rc = dev_alloc(e, &e->d_desc, B * 2, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->d_lut, 256, false))) return fail(rc);
     if ((rc = dev_alloc(e, &e->d_coef, 3 * 2 * 5, false))) return fail(rc);
@@ -308,6 +327,8 @@ void tm_engine_destroy(tm_engine *e)
     for (int i = 0; i < 4; ++i) if (e->ev_pipe[i]) (void)hipEventDestroy(e->ev_pipe[i]);
     for (void *p : e->staging) if (p) (void)hipFree(p);
     (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
+    (void)hipFree(e->QU8); (void)hipFree(e->SPYR); (void)hipFree(e->SPART); (void)hipFree(e->SSUMS);
+    if (e->h_ssums) (void)hipHostFree(e->h_ssums);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
     (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab); (void)hipFree(e->d_yuvlut);
     if (e->h_desc) (void)hipHostFree(e->h_desc);
@@ -366,6 +387,7 @@ int tm_engine_set_variant(tm_engine *e, int variant)
     // dispatch order of the two blur passes (default: slot-major)
     if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 2 || (variant >> 21) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
+    if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) != 2) return TM_ERR_INVALID_ARG; // only tile32 writes the u8 planes
     if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
         int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
@@ -406,6 +428,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     float *LIN2 = e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane;
     double *PART = e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
     unsigned long long *SSE = e->SSE + slot0;
+    unsigned char *QU8 = e->QU8 ? e->QU8 + (size_t)slot0 * 2 * 3 * e->sg.qplane : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
     if ((e->variant >> 8 & 255) == 0) { // generation 0: separate kernels, linear pyramid in HBM (kept as the on-device reference)
@@ -425,7 +448,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_T32(K) hipLaunchKernelGGL((tmk::k_ingest_tile32<K>), grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, XYBT, LIN2, SSE, want_sse)
+#define TM_LAUNCH_T32(K) hipLaunchKernelGGL((tmk::k_ingest_tile32<K>), grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, XYBT, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_T32(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_T32(TM_KIND_P016); break;
@@ -466,6 +489,24 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     } else if (ev) {
         HIPCHK(hipEventRecord(ev[2], st));
         HIPCHK(hipEventRecord(ev[3], st));
+    }
+    if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
+        // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
+        const TmSsimGeom &sg = e->sg;
+        float *SPYR = e->SPYR + (size_t)slot0 * 2 * 3 * sg.pyr;
+        double *SPART = e->SPART + (size_t)slot0 * 3 * sg.tile_off[TM_SSIM_SCALES] * 2, *SSUMS = e->SSUMS + (size_t)slot0 * 30;
+        const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
+        for (int s = 1; s < nscales; ++s) {
+            const dim3 grid((unsigned)((sg.w[s] + 63) / 64), (unsigned)sg.h[s], (unsigned)(n * 6));
+            if (s == 1) hipLaunchKernelGGL((tmk::k_ssim_down<true>), grid, dim3(64), 0, st, sg, s, QU8, SPYR);
+            else hipLaunchKernelGGL((tmk::k_ssim_down<false>), grid, dim3(64), 0, st, sg, s, QU8, SPYR);
+        }
+        for (int s = 0; s < nscales; ++s) {
+            const dim3 grid((unsigned)sg.tiles_x[s], (unsigned)sg.tiles_y[s], (unsigned)(n * 3));
+            if (s == 0) hipLaunchKernelGGL((tmk::k_ssim_stats<true>), grid, dim3(256), 0, st, sg, s, QU8, SPYR, SPART);
+            else hipLaunchKernelGGL((tmk::k_ssim_stats<false>), grid, dim3(256), 0, st, sg, s, QU8, SPYR, SPART);
+        }
+        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n), dim3(32), 0, st, sg, SPART, SSUMS);
     }
     return TM_OK;
 }
@@ -510,6 +551,8 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     if (e->mask & TM_METRIC_SSIMULACRA2)
         HIPCHK(hipMemcpyAsync(e->h_sums, e->SUMS, (size_t)n * 108 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (want_sse) HIPCHK(hipMemcpyAsync(e->h_sse, e->SSE, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM))
+        HIPCHK(hipMemcpyAsync(e->h_ssums, e->SSUMS, (size_t)n * 30 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
     e->ev_pending = e->profiling && chunks == 1;
     e->last_n = n_slots;
@@ -573,6 +616,50 @@ double tm_ssimulacra2_score_from_sums(const double sums[108], uint32_t width, ui
     return score;
 }
 
+void tm_ssim_window(float g[11])
+{
+    // g[k] = exp(-(k-5)^2 / (2 * 1.5^2)) / sum, evaluated in f64 and rounded to f32
+    double v[TM_SSIM_TAPS], sum = 0.0;
+    for (int k = 0; k < TM_SSIM_TAPS; ++k) { const double d = (double)(k - 5); v[k] = std::exp(-(d * d) / (2.0 * 1.5 * 1.5)); sum += v[k]; }
+    for (int k = 0; k < TM_SSIM_TAPS; ++k) g[k] = (float)(v[k] / sum);
+}
+
+double tm_ssim_from_sums(const double sums[30], uint32_t width, uint32_t height)
+{
+    if (width < TM_SSIM_TAPS || height < TM_SSIM_TAPS) return NAN;
+    const double n = (double)(width - 10) * (double)(height - 10);
+    double acc = 0.0;
+    for (int c = 0; c < 3; ++c) acc += sums[(c * TM_SSIM_SCALES + 0) * 2] / n;
+    return (double)(float)(acc / 3.0); // one Npp32f read back (ist.rs:118,133), widened (lib.rs:355-357)
+}
+
+double tm_msssim_from_sums(const double sums[30], uint32_t width, uint32_t height)
+{
+    static const double wt[TM_SSIM_SCALES] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+    if ((width >> 4) < TM_SSIM_TAPS || (height >> 4) < TM_SSIM_TAPS) return NAN;
+    double acc = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        double prod = 1.0;
+        uint32_t sw = width, sh = height;
+        for (int s = 0; s < TM_SSIM_SCALES; ++s) {
+            const double n = (double)(sw - 10) * (double)(sh - 10);
+            const double v = sums[(c * TM_SSIM_SCALES + s) * 2 + (s == TM_SSIM_SCALES - 1 ? 0 : 1)] / n;
+            prod *= std::pow(v > 0.0 ? v : 0.0, wt[s]);
+            sw /= 2; sh /= 2;
+        }
+        acc += prod;
+    }
+    return (double)(float)(acc / 3.0);
+}
+
+int tm_engine_get_ssim_sums(tm_engine *e, uint32_t slot, double out[30])
+{
+    if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
+    if (!e->have_results || slot >= e->last_n || !(e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM))) return TM_ERR_STATE;
+    memcpy(out, e->h_ssums + (size_t)slot * 30, 30 * sizeof(double));
+    return TM_OK;
+}
+
 int tm_engine_get_raw_sums(tm_engine *e, uint32_t slot, double out[108])
 {
     if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
@@ -605,6 +692,14 @@ int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out)
         const double mse = (double)e->h_sse[slot] / count;
         out->psnr = (double)(float)(10.0 * std::log10(255.0 * 255.0 / mse));
         out->valid |= TM_METRIC_PSNR;
+    }
+    if (e->mask & TM_METRIC_SSIM) {
+        out->ssim = tm_ssim_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h);
+        out->valid |= TM_METRIC_SSIM;
+    }
+    if (e->mask & TM_METRIC_MSSSIM) {
+        out->msssim = tm_msssim_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h);
+        out->valid |= TM_METRIC_MSSSIM;
     }
     return TM_OK;
 }

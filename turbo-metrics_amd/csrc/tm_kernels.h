@@ -538,7 +538,8 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
                                                        const double *__restrict__ gtab, const float *__restrict__ yuvlut,
                                                        float *__restrict__ XYB, float *__restrict__ XYBT,
                                                        float *__restrict__ LIN2, unsigned long long *__restrict__ SSE,
-                                                       int want_sse)
+                                                       int want_sse, unsigned char *__restrict__ QU8, unsigned long long qplane,
+                                                       int qpitch)
 {
     __shared__ double tab[96];
     __shared__ IngestSideLds L;
@@ -590,6 +591,20 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
                     sse += (unsigned)(dlt * dlt);
                 }
             }
+        }
+        if (QU8 != nullptr && X0 < w) { // planar u8 copy of the quantised frame (f32_to_8bit, sample_conv.rs:6-35) for SSIM / MS-SSIM
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+                    if (Y0 + iy < h) {
+                        const unsigned q0 = (unsigned)(int)rintf(px[iy][0][c] * 255.0f) & 255u;
+                        const unsigned q1 = (unsigned)(int)rintf(px[iy][1][c] * 255.0f) & 255u;
+                        // X0 is even and the pitch a multiple of 64: the pair is one aligned 16-bit store (the second
+                        // byte of an odd-width image lands in the row padding)
+                        *(unsigned short *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(Y0 + iy) * qpitch + X0) =
+                            (unsigned short)(q0 | (q1 << 8));
+                    }
         }
         // ---- level-0 XYB into the LDS tile, level-1 linear pixel of this quad and its XYB (five pixels = 15 cube
         // roots, evaluated pairwise)

@@ -203,6 +203,12 @@ class TurboMetrics:
         _chk(self._L.tm_engine_get_raw_sums(self._h, slot, out.ctypes.data_as(C.POINTER(C.c_double))), "tm_engine_get_raw_sums")
         return out.reshape(6, 6, 3)
 
+    def ssim_sums(self, slot: int) -> np.ndarray:
+        """(3 channels, 5 scales, [sum ssim, sum cs]) of the quantised pair (build-defined SSIM / MS-SSIM, see the header)"""
+        out = np.zeros(30, np.float64)
+        _chk(self._L.tm_engine_get_ssim_sums(self._h, slot, out.ctypes.data_as(C.POINTER(C.c_double))), "tm_engine_get_ssim_sums")
+        return out.reshape(3, 5, 2)
+
     def sse(self, slot: int) -> int:
         v = C.c_uint64()
         _chk(self._L.tm_engine_get_sse(self._h, slot, C.byref(v)), "tm_engine_get_sse")
@@ -303,3 +309,13 @@ class Ssimulacra2:
 def score_from_sums(sums, width, height) -> float:
     s = np.ascontiguousarray(np.asarray(sums, np.float64).ravel())
     return float(ffi.lib().tm_ssimulacra2_score_from_sums(s.ctypes.data_as(C.POINTER(C.c_double)), int(width), int(height)))
+
+
+def ssim_from_sums(sums, width, height) -> float:
+    s = np.ascontiguousarray(np.asarray(sums, np.float64).ravel())
+    return float(ffi.lib().tm_ssim_from_sums(s.ctypes.data_as(C.POINTER(C.c_double)), int(width), int(height)))
+
+
+def msssim_from_sums(sums, width, height) -> float:
+    s = np.ascontiguousarray(np.asarray(sums, np.float64).ravel())
+    return float(ffi.lib().tm_msssim_from_sums(s.ctypes.data_as(C.POINTER(C.c_double)), int(width), int(height)))

@@ -41,6 +41,10 @@ SYMBOLS = {
     "tm_engine_set_full_sums": (_i, [_vp, _i]),
     "tm_engine_get_job_modes": (_i, [_vp, C.POINTER(C.c_int)]),
     "tm_engine_get_sse": (_i, [_vp, _u32, C.POINTER(C.c_uint64)]),
+    "tm_engine_get_ssim_sums": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
+    "tm_ssim_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
+    "tm_msssim_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
+    "tm_ssim_window": (None, [C.POINTER(C.c_float)]),
     "tm_ssimulacra2_score_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
     "tm_engine_set_profiling": (_i, [_vp, _i]),
     "tm_engine_get_stage_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), _i]),
