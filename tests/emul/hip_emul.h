@@ -34,6 +34,7 @@ extern thread_local dim3 blockDim, gridDim;
 
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float a, float b) { return {a, b}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 static inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }

@@ -113,7 +113,7 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
     TmGeom g; tm_make_geom(&g, w, h);
     out[0] = (unsigned long long)n * 2 * g.pyr; out[1] = out[0];
     out[2] = (unsigned long long)n * 2 * g.pyr_t; out[3] = (unsigned long long)n * 5 * g.pyr_t;
-    out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = n;
+    out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = (unsigned long long)n * TM_SSE_BINS;
 }
 
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,
@@ -168,19 +168,15 @@ void emul_ssim_geom(int w, int h, const float *g, TmSsimGeom *out) { tm_make_ssi
 
 // SSIM / MS-SSIM stage on the planar u8 planes the ingest kernel left in QU8: pyramid, statistics, finisher.
 // PYR: n*2*3*sg.pyr floats, PART: n*3*tile_off[5]*2 doubles, SUMS: n*30 doubles
-void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, float *PYR, double *PART, double *SUMS)
+void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, float *PYR, double *PART, double *SUMS, int streamed)
 {
     TmSsimGeom sg; tm_make_ssim_geom(&sg, w, h, g);
-    for (int s = 1; s < TM_SSIM_SCALES; ++s) {
-        if (sg.w[s] <= 0 || sg.h[s] <= 0) break;
-        if (s == 1) launch(dim3((sg.w[s] + 63) / 64, sg.h[s], n * 6), dim3(64), [&] { tmk::k_ssim_down<true>(sg, s, QU8, PYR); });
-        else launch(dim3((sg.w[s] + 63) / 64, sg.h[s], n * 6), dim3(64), [&] { tmk::k_ssim_down<false>(sg, s, QU8, PYR); });
-    }
-    for (int s = 0; s < TM_SSIM_SCALES; ++s) {
-        if (sg.tiles_x[s] == 0 || sg.tiles_y[s] == 0) continue;
-        if (s == 0) launch_wg_lockstep(dim3(sg.tiles_x[s], sg.tiles_y[s], n * 3), 256, [&] { tmk::k_ssim_stats<true>(sg, s, QU8, PYR, PART); });
-        else launch_wg_lockstep(dim3(sg.tiles_x[s], sg.tiles_y[s], n * 3), 256, [&] { tmk::k_ssim_stats<false>(sg, s, QU8, PYR, PART); });
-    }
-    launch(dim3(n), dim3(32), [&] { tmk::k_ssim_finish(sg, PART, SUMS); });
+    if (sg.w[1] > 0 && sg.h[1] > 0)
+        launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n * 6), 256, [&] { tmk::k_ssim_pyramid(sg, QU8, PYR); });
+    int nscales = 0;
+    for (int s = 0; s < TM_SSIM_SCALES; ++s) if (sg.tiles_x[s] > 0 && sg.tiles_y[s] > 0) nscales = s + 1;
+    if (nscales > 0 && streamed) launch_wave_lockstep(dim3(n * 3, sg.item_off[nscales], 1), [&] { tmk::k_ssim_stream(sg, nscales, QU8, PYR, PART); });
+    else if (nscales > 0) launch_wg_lockstep(dim3(n * 3, sg.tile_off[nscales], 1), 256, [&] { tmk::k_ssim_stats(sg, nscales, QU8, PYR, PART); });
+    launch(dim3(n, 30, 1), dim3(64), [&] { tmk::k_ssim_finish(sg, streamed, PART, SUMS); });
 }
 }

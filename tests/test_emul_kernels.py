@@ -115,8 +115,9 @@ def test_job_driven_blur_passes_full_and_pruned(w, h):
         assert O.score_from_sums(a, w, h) == O.score_from_sums(b, w, h)
 
 
-@pytest.mark.parametrize("w,h", [(200, 180), (64, 40), (11, 11), (33, 12)])
-def test_ssim_kernels_match_oracle(w, h):
+@pytest.mark.parametrize("streamed", [True, False])
+@pytest.mark.parametrize("w,h", [(200, 180), (64, 40), (11, 11), (33, 12), (70, 300)])
+def test_ssim_kernels_match_oracle(w, h, streamed):
     """SSIM / MS-SSIM stage (tm_ssim_kernels.h) on the CPU lane emulator: the u8 planes written by the ingest kernel are
     the oracle's quantised frames bit for bit; the per-scale sums agree to 1e-12; the finishing functions agree exactly."""
     frames = []
@@ -125,7 +126,7 @@ def test_ssim_kernels_match_oracle(w, h):
         frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=0), dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0)))
     r8, d8 = tm.synth.rgb8_pair(w, h)
     frames.append((dict(kind="rgb8", data=r8), dict(kind="rgb8", data=d8)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 9, weights=O.weights(), ssim_window=O.ssim_window())
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 9, weights=O.weights(), ssim_window=O.ssim_window(), ssim_streamed=streamed)
     for slot, (fr, fd) in enumerate(frames):
         lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
         for side in range(2):

@@ -208,6 +208,13 @@ int check_yuv_args(int matrix, int transfer, int full_range)
     return TM_OK;
 }
 
+unsigned long long slot_sse(const tm_engine *e, uint32_t slot)
+{
+    unsigned long long tot = 0;
+    for (int i = 0; i < TM_SSE_BINS; ++i) tot += e->h_sse[(size_t)slot * TM_SSE_BINS + i];
+    return tot;
+}
+
 dim3 grid2(int w, int h, int z) { return dim3((unsigned)((w + 63) / 64), (unsigned)h, (unsigned)z); }
 
 } // namespace
@@ -281,14 +288,14 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->SSE, B, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->SSE, B * TM_SSE_BINS, true))) return fail(rc);
     if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         float gw[TM_SSIM_TAPS];
         tm_ssim_window(gw);
         tm_make_ssim_geom(&e->sg, (int)width, (int)height, gw);
         if ((rc = dev_alloc(e, &e->QU8, B * 2 * 3 * e->sg.qplane, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SPYR, B * 2 * 3 * e->sg.pyr, true))) return fail(rc);
-        if ((rc = dev_alloc(e, &e->SPART, B * 3 * (size_t)e->sg.tile_off[TM_SSIM_SCALES] * 2, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->SPART, B * 3 * (size_t)(e->sg.tile_off[TM_SSIM_SCALES] > e->sg.item_off[TM_SSIM_SCALES] ? e->sg.tile_off[TM_SSIM_SCALES] : e->sg.item_off[TM_SSIM_SCALES]) * 2, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SSUMS, B * 30, true))) return fail(rc);
         if ((he = hipHostMalloc((void **)&e->h_ssums, B * 30 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     }
@@ -306,7 +313,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(hip_fail(he, "k_build_yuv_lut"));
     if ((he = hipHostMalloc((void **)&e->h_desc, B * 2 * sizeof(TmFrameDesc), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     if ((he = hipHostMalloc((void **)&e->h_sums, B * 108 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
-    if ((he = hipHostMalloc((void **)&e->h_sse, B * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
+    if ((he = hipHostMalloc((void **)&e->h_sse, B * TM_SSE_BINS * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     for (size_t i = 0; i < B * 2; ++i) { e->h_desc[i] = TmFrameDesc{nullptr, nullptr, 0, TM_KIND_NONE, 0}; }
     e->staging.assign(B * 2, nullptr);
     e->staging_size.assign(B * 2, 0);
@@ -384,8 +391,8 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
     // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
-    // dispatch order of the two blur passes (default: slot-major)
-    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 2 || (variant >> 21) != 0) return TM_ERR_INVALID_ARG;
+    // dispatch order of the two blur passes (default: slot-major), bit 21: LDS-tiled SSIM statistics kernel (default: streaming)
+    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 2 || (variant >> 22) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) != 2) return TM_ERR_INVALID_ARG; // only tile32 writes the u8 planes
     if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
@@ -427,7 +434,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
     float *LIN2 = e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane;
     double *PART = e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
-    unsigned long long *SSE = e->SSE + slot0;
+    unsigned long long *SSE = e->SSE + (size_t)slot0 * TM_SSE_BINS;
     unsigned char *QU8 = e->QU8 ? e->QU8 + (size_t)slot0 * 2 * 3 * e->sg.qplane : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
@@ -494,19 +501,14 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
         const TmSsimGeom &sg = e->sg;
         float *SPYR = e->SPYR + (size_t)slot0 * 2 * 3 * sg.pyr;
-        double *SPART = e->SPART + (size_t)slot0 * 3 * sg.tile_off[TM_SSIM_SCALES] * 2, *SSUMS = e->SSUMS + (size_t)slot0 * 30;
+        double *SPART = e->SPART + (size_t)slot0 * 3 * (sg.tile_off[TM_SSIM_SCALES] > sg.item_off[TM_SSIM_SCALES] ? sg.tile_off[TM_SSIM_SCALES] : sg.item_off[TM_SSIM_SCALES]) * 2, *SSUMS = e->SSUMS + (size_t)slot0 * 30;
         const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
-        for (int s = 1; s < nscales; ++s) {
-            const dim3 grid((unsigned)((sg.w[s] + 63) / 64), (unsigned)sg.h[s], (unsigned)(n * 6));
-            if (s == 1) hipLaunchKernelGGL((tmk::k_ssim_down<true>), grid, dim3(64), 0, st, sg, s, QU8, SPYR);
-            else hipLaunchKernelGGL((tmk::k_ssim_down<false>), grid, dim3(64), 0, st, sg, s, QU8, SPYR);
-        }
-        for (int s = 0; s < nscales; ++s) {
-            const dim3 grid((unsigned)sg.tiles_x[s], (unsigned)sg.tiles_y[s], (unsigned)(n * 3));
-            if (s == 0) hipLaunchKernelGGL((tmk::k_ssim_stats<true>), grid, dim3(256), 0, st, sg, s, QU8, SPYR, SPART);
-            else hipLaunchKernelGGL((tmk::k_ssim_stats<false>), grid, dim3(256), 0, st, sg, s, QU8, SPYR, SPART);
-        }
-        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n), dim3(32), 0, st, sg, SPART, SSUMS);
+        if (nscales > 1)
+            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 31) / 32), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(256), 0, st, sg, QU8, SPYR);
+        const int streamed = (e->variant >> 21) & 1 ? 0 : 1; // bit 21 set: the LDS-tiled statistics kernel (A/B)
+        if (streamed) hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, QU8, SPYR, SPART);
+        else hipLaunchKernelGGL(tmk::k_ssim_stats, dim3((unsigned)(n * 3), (unsigned)sg.tile_off[nscales], 1), dim3(256), 0, st, sg, nscales, QU8, SPYR, SPART);
+        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, streamed, SPART, SSUMS);
     }
     return TM_OK;
 }
@@ -524,7 +526,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     const int n = (int)n_slots;
     HIPCHK(hipMemcpyAsync(e->d_desc, e->h_desc, (size_t)n * 2 * sizeof(TmFrameDesc), hipMemcpyHostToDevice, st));
     const int want_sse = (e->mask & TM_METRIC_PSNR) ? 1 : 0;
-    if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * sizeof(unsigned long long), st));
+    if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * TM_SSE_BINS * sizeof(unsigned long long), st));
     int chunks = (e->variant >> 16) & 15;
     if (chunks < 1) chunks = 1;
     if (chunks > n) chunks = n;
@@ -550,7 +552,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     }
     if (e->mask & TM_METRIC_SSIMULACRA2)
         HIPCHK(hipMemcpyAsync(e->h_sums, e->SUMS, (size_t)n * 108 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (want_sse) HIPCHK(hipMemcpyAsync(e->h_sse, e->SSE, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (want_sse) HIPCHK(hipMemcpyAsync(e->h_sse, e->SSE, (size_t)n * TM_SSE_BINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM))
         HIPCHK(hipMemcpyAsync(e->h_ssums, e->SSUMS, (size_t)n * 30 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
@@ -672,7 +674,7 @@ int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out)
 {
     if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
     if (!e->have_results || slot >= e->last_n || !(e->mask & TM_METRIC_PSNR)) return TM_ERR_STATE;
-    *out = e->h_sse[slot];
+    *out = slot_sse(e, slot);
     return TM_OK;
 }
 
@@ -689,7 +691,7 @@ int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out)
         // PSNR of the u8-quantised linear RGB pair (turbo-metrics/src/lib.rs:296-318); NPP returns one
         // Npp32f (cudarse-npp/src/image/ist.rs:118) which the engine widens (lib.rs:355).
         const double count = 3.0 * (double)e->w * (double)e->h;
-        const double mse = (double)e->h_sse[slot] / count;
+        const double mse = (double)slot_sse(e, slot) / count;
         out->psnr = (double)(float)(10.0 * std::log10(255.0 * 255.0 / mse));
         out->valid |= TM_METRIC_PSNR;
     }

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #define TM_SCALES 6
+#define TM_SSE_BINS 64 /* integer SSE accumulators per slot (spreads the atomics of the ingest kernel) */
 
 struct TmScaleGeom {
     int w, h;

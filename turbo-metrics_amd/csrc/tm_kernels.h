@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
                     const int dlt = q[0][iy][ix][c] - q[1][iy][ix][c];
                     sse += (unsigned)(dlt * dlt);
                 }
-        if (tm_wave_sum_u32(sse)) atomicAdd(&SSE[slot], (unsigned long long)sse);
+        if (tm_wave_sum_u32(sse)) atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS], (unsigned long long)sse);
     }
 }
 
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
         if (tid == 0) {
             unsigned long long tot = 0;
             for (int i = 0; i < 256; ++i) tot += sse_s[i];
-            atomicAdd(&SSE[slot], tot);
+            atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS], tot);
         }
     }
 }
@@ -544,6 +544,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
     __shared__ double tab[96];
     __shared__ IngestSideLds L;
     __shared__ unsigned sse_s[256];
+    __shared__ __attribute__((aligned(16))) unsigned short qt[3][32][16]; // u8 tile, two pixels per entry (SSIM / MS-SSIM only)
     const int tid = threadIdx.x;
     const int qx = tid & 15, qy = tid >> 4; // quad inside the tile
     const int slot = blockIdx.z;
@@ -592,19 +593,15 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
                 }
             }
         }
-        if (QU8 != nullptr && X0 < w) { // planar u8 copy of the quantised frame (f32_to_8bit, sample_conv.rs:6-35) for SSIM / MS-SSIM
+        if (QU8 != nullptr) { // u8-quantised pixels (f32_to_8bit, sample_conv.rs:6-35) into the LDS byte tile; stored below
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int iy = 0; iy < 2; ++iy)
-                    if (Y0 + iy < h) {
-                        const unsigned q0 = (unsigned)(int)rintf(px[iy][0][c] * 255.0f) & 255u;
-                        const unsigned q1 = (unsigned)(int)rintf(px[iy][1][c] * 255.0f) & 255u;
-                        // X0 is even and the pitch a multiple of 64: the pair is one aligned 16-bit store (the second
-                        // byte of an odd-width image lands in the row padding)
-                        *(unsigned short *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(Y0 + iy) * qpitch + X0) =
-                            (unsigned short)(q0 | (q1 << 8));
-                    }
+                for (int iy = 0; iy < 2; ++iy) {
+                    const unsigned q0 = (unsigned)(int)rintf(px[iy][0][c] * 255.0f) & 255u;
+                    const unsigned q1 = (unsigned)(int)rintf(px[iy][1][c] * 255.0f) & 255u;
+                    qt[c][2 * qy + iy][qx] = (unsigned short)(q0 | (q1 << 8));
+                }
         }
         // ---- level-0 XYB into the LDS tile, level-1 linear pixel of this quad and its XYB (five pixels = 15 cube
         // roots, evaluated pairwise)
@@ -629,6 +626,12 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
         TM_LDS_BARRIER();
         // ---- levels 0 and 1 out of their tiles
         store_tiles_both(L, g.s[0], g.s[1], xyb, xybt, tx0, ty0, tid);
+        if (QU8 != nullptr && tid < 192) { // the u8 tile: 16 pixels = one 16-B store per lane, two lanes per row
+            const int c = tid >> 6, r = (tid & 63) >> 1, half = tid & 1;
+            if (ty0 + r < h && tx0 + 16 * half < w)
+                *(uint4 *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(ty0 + r) * qpitch + tx0 + 16 * half) =
+                    *(const uint4 *)&qt[c][r][8 * half];
+        }
         // ---- level-2 LINEAR pixels of this tile (8x8) go to HBM: levels 2..5 are finished by k_ingest_upper.
         // (Doing them here cost four more barriers per side with 3/4 .. 255/256 of the workgroup idle.)
         if (tid < 64) {
@@ -646,13 +649,17 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
         }
         TM_LDS_BARRIER(); // the tile is reused by the next side
     }
-    if (want_sse) { // per-wave sum through LDS (wave-synchronous), one 64-bit integer atomic per wave: exact, order-free
+    if (want_sse) {
+        // per-wave sum through LDS (wave-synchronous), one 64-bit integer atomic per wave into one of TM_SSE_BINS
+        // accumulators of the slot (exact and order-free; a single address per slot serialised 8 000 atomics at 1080p and
+        // doubled the kernel's time); the host adds the bins
         sse_s[tid] = sse;
         __builtin_amdgcn_wave_barrier();
         if ((tid & 63) == 0) {
             unsigned long long tot = 0;
             for (int i = 0; i < 64; ++i) tot += sse_s[tid + i];
-            atomicAdd(&SSE[slot], tot);
+            const unsigned bin = (blockIdx.x * 4 + (tid >> 6) + blockIdx.y * 29) % TM_SSE_BINS;
+            atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS + bin], tot);
         }
     }
 }
