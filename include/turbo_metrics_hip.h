@@ -69,7 +69,9 @@ enum { TM_SIDE_REF = 0, TM_SIDE_DIS = 1 };
  * ingest kernel at compute time and must stay valid until tm_engine_sync returns (the
  * reference has the same rule for mapped NVDEC surfaces). TM_MEM_HOST is copied into an
  * engine-owned device surface on the engine's stream before the call returns control. */
-enum { TM_MEM_HOST = 0, TM_MEM_DEVICE = 1 };
+enum { TM_MEM_HOST = 0, TM_MEM_DEVICE = 1, TM_MEM_HOST_PINNED = 2 };
+/* TM_MEM_HOST_PINNED: page-locked host memory (tm_host_alloc): copied into the engine-owned surface by an asynchronous
+ * DMA on the engine's stream; like TM_MEM_DEVICE the bytes must stay untouched until tm_engine_sync returns. */
 
 /* == turbo_metrics::FrameScores (lib.rs:112-123); `valid` has the TM_METRIC_* bits of the
  * Option<> fields that are Some(). */
@@ -84,6 +86,10 @@ typedef struct tm_frame_scores {
 /* Bind the calling process to `device` (hipSetDevice) and make sure a gfx950 device is there.
  * Fails loudly (TM_ERR_HIP / TM_ERR_UNSUPPORTED) when no usable GPU exists: there is no CPU path. */
 int tm_init(int device);
+
+/* page-locked host memory for frame staging (hipHostMalloc / hipHostFree); NULL when out of memory */
+void *tm_host_alloc(size_t bytes);
+void tm_host_free(void *p);
 
 int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t metrics_mask,
                      uint32_t batch_capacity);

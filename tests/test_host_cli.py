@@ -27,7 +27,7 @@ def helper():
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
     if not os.path.exists(HELPER) or any(os.path.getmtime(d) > os.path.getmtime(HELPER) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", HELPER] + srcs + ["-L" + os.path.join(ROOT, "turbo-metrics_amd"),
-                              "-lturbometrics_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "turbo-metrics_amd")])
+                              "-lturbometrics_hip", "-lz", "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "turbo-metrics_amd")])
     return HELPER
 
 

@@ -163,7 +163,7 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
 {
     int rc = check_slot_side(e, slot, side);
     if (rc) return rc;
-    if (!p0 || (mem != TM_MEM_HOST && mem != TM_MEM_DEVICE)) return TM_ERR_INVALID_ARG;
+    if (!p0 || (mem != TM_MEM_HOST && mem != TM_MEM_DEVICE && mem != TM_MEM_HOST_PINNED)) return TM_ERR_INVALID_ARG;
     const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016;
     if (yuv && !p1) return TM_ERR_INVALID_ARG;
     const size_t bps = kind == TM_KIND_NV12 || kind == TM_KIND_RGB8 ? 1 : (kind == TM_KIND_P016 || kind == TM_KIND_RGB16 ? 2 : 4);
@@ -192,8 +192,9 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
             if (rc) return rc;
             d.p1 = s + spitch * e->h;
         } else d.p1 = nullptr;
-        // pageable source: make sure the bytes have left the caller's buffer before returning
-        HIPCHK(hipStreamSynchronize(e->stream));
+        // pageable source: make sure the bytes have left the caller's buffer before returning (a pinned source is
+        // the caller's to keep alive until tm_engine_sync, so its DMA stays asynchronous)
+        if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
         d.p0 = s; d.pitch = spitch;
     }
     d.kind = kind; d.matrix = matrix;
@@ -236,6 +237,18 @@ const char *tm_strerror(int code)
     case TM_ERR_STATE: return "invalid state (compute before all frames set, or results not ready)";
     default: return "unknown error";
     }
+}
+
+void *tm_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void tm_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int tm_init(int device)

@@ -11,7 +11,7 @@ TM_METRIC_PSNR, TM_METRIC_SSIM, TM_METRIC_MSSSIM, TM_METRIC_SSIMULACRA2 = 1, 2, 
 TM_MATRIX_BT709, TM_MATRIX_BT601_525, TM_MATRIX_BT601_625 = 0, 1, 2
 TM_TRANSFER_BT709 = 0
 TM_SIDE_REF, TM_SIDE_DIS = 0, 1
-TM_MEM_HOST, TM_MEM_DEVICE = 0, 1
+TM_MEM_HOST, TM_MEM_DEVICE, TM_MEM_HOST_PINNED = 0, 1, 2
 TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_COUNT = 0, 1, 2, 3
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
 
@@ -25,6 +25,8 @@ class FrameScoresC(C.Structure):
 _vp, _u32, _i, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
 SYMBOLS = {
     "tm_init": (_i, [_i]),
+    "tm_host_alloc": (_vp, [_sz]),
+    "tm_host_free": (None, [_vp]),
     "tm_engine_create": (_i, [C.POINTER(_vp), _u32, _u32, _u32, _u32]),
     "tm_engine_destroy": (None, [_vp]),
     "tm_engine_mem_usage": (_sz, [_vp]),

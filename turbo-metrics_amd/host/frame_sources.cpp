@@ -253,12 +253,45 @@ YuvStreamSource::YuvStreamSource(FILE *in, bool y4m, uint32_t w, uint32_t h, int
     const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
     planar_.resize(((size_t)w_ * h_ + 2 * cw * ch) * bps);
     pitch_ = round_up(std::max((size_t)w_, cw * 2) * bps, 256);
-    surface_.assign(pitch_ * (round_up(h_, 2) + ch), 0);
+    surface_bytes_ = pitch_ * (round_up(h_, 2) + ch);
 }
 
 YuvStreamSource::~YuvStreamSource()
 {
     if (in_ && in_ != stdin) fclose(in_);
+    for (unsigned char *p : ring_) {
+        if (ring_pinned_) tm_host_free(p);
+        else free(p);
+    }
+}
+
+void YuvStreamSource::set_lookahead(size_t frames)
+{
+    if (ring_.empty()) lookahead_ = frames ? frames : 1;
+}
+
+void YuvStreamSource::ensure_ring()
+{
+    if (!ring_.empty()) return;
+    const size_t n = lookahead_ + 1;
+    ring_pinned_ = true;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned char *p = (unsigned char *)tm_host_alloc(surface_bytes_);
+        if (!p) { // fall back to pageable memory for the whole ring (the engine then copies synchronously)
+            for (unsigned char *q : ring_) tm_host_free(q);
+            ring_.clear();
+            ring_pinned_ = false;
+            break;
+        }
+        memset(p, 0, surface_bytes_);
+        ring_.push_back(p);
+    }
+    if (!ring_pinned_)
+        for (size_t i = 0; i < n; ++i) {
+            unsigned char *p = (unsigned char *)calloc(1, surface_bytes_);
+            if (!p) fail("out of memory for the frame ring");
+            ring_.push_back(p);
+        }
 }
 
 FormatIdentifier YuvStreamSource::format_id() const
@@ -266,8 +299,9 @@ FormatIdentifier YuvStreamSource::format_id() const
     return FormatIdentifier{y4m_ ? std::optional<std::string>("Y4M") : std::nullopt, codec_, "turbo-metrics-hip"};
 }
 
-bool YuvStreamSource::read_picture(bool keep)
+bool YuvStreamSource::read_picture(unsigned char *surface)
 {
+    const bool keep = surface != nullptr;
     if (y4m_) {
         char tag[6];
         const size_t got = fread(tag, 1, 5, in_);
@@ -286,7 +320,7 @@ bool YuvStreamSource::read_picture(bool keep)
     if (!keep) return true;
     // planar I420 -> the NVDEC surface contract: luma rows at `pitch`, then interleaved CbCr rows at the same pitch
     const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
-    unsigned char *luma = surface_.data(), *uv = surface_.data() + pitch_ * round_up(h_, 2);
+    unsigned char *luma = surface, *uv = surface + pitch_ * round_up(h_, 2);
     if (bits_ == 8) {
         const unsigned char *y = planar_.data(), *u = y + (size_t)w_ * h_, *v = u + cw * ch;
         for (uint32_t r = 0; r < h_; ++r) memcpy(luma + r * pitch_, y + (size_t)r * w_, w_);
@@ -312,17 +346,21 @@ bool YuvStreamSource::read_picture(bool keep)
 void YuvStreamSource::skip_frames(uint32_t n)
 {
     for (uint32_t i = 0; i < n; ++i)
-        if (!read_picture(false)) break;
+        if (!read_picture(nullptr)) break;
 }
 
 bool YuvStreamSource::next_frame(HwFrame &out)
 {
-    if (!read_picture(true)) return false;
+    ensure_ring();
+    unsigned char *surface = ring_[ring_pos_];
+    if (!read_picture(surface)) return false;
+    ring_pos_ = (ring_pos_ + 1) % ring_.size();
     out = HwFrame{};
     out.kind = bits_ == 8 ? HwFrame::NvDecNV12 : HwFrame::NvDecP016;
-    out.data = surface_.data();
-    out.uv = surface_.data() + pitch_ * round_up(h_, 2);
+    out.data = surface;
+    out.uv = surface + pitch_ * round_up(h_, 2);
     out.pitch = pitch_;
+    out.pinned = ring_pinned_;
     return true;
 }
 

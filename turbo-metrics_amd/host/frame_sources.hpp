@@ -71,9 +71,10 @@ public:
     size_t frame_count() const override { return frame_count_; }
     void skip_frames(uint32_t n) override;
     bool next_frame(HwFrame &out) override;
+    void set_lookahead(size_t frames) override;
 
 private:
-    bool read_picture(bool keep);
+    bool read_picture(unsigned char *surface);
     FILE *in_;
     bool y4m_;
     uint32_t w_, h_;
@@ -82,8 +83,14 @@ private:
     ColorRange cr_;
     size_t frame_count_;
     std::string codec_;
-    size_t pitch_ = 0;
-    std::vector<unsigned char> planar_, surface_;
+    size_t pitch_ = 0, surface_bytes_ = 0;
+    std::vector<unsigned char> planar_;
+    // ring of page-locked surfaces (tm_host_alloc): a frame stays valid for `lookahead` further next_frame calls, which
+    // lets the engine pull it by asynchronous DMA; plain memory when page-locking fails
+    std::vector<unsigned char *> ring_;
+    bool ring_pinned_ = false;
+    size_t ring_pos_ = 0, lookahead_ = 1;
+    void ensure_ring();
 };
 
 struct SourceHints { // what a headerless stream cannot say about itself (CLI flags)

@@ -2,7 +2,11 @@
 // slots, ping-pong pipelining of two engines; every number comes out of libturbometrics_hip.so.
 #include "turbo_metrics.hpp"
 
+#include <condition_variable>
 #include <cstring>
+#include <exception>
+#include <mutex>
+#include <thread>
 
 namespace tm_host {
 
@@ -151,7 +155,7 @@ void TurboMetrics::set_full_sums(bool on)
 // == convert_frame_to_linearrgb (color.rs:96-116): kernel selection by frame kind and colour metadata
 void TurboMetrics::set_frame(tm_engine *e, uint32_t slot, int side, const HwFrame &f, const ColorInfo &c)
 {
-    const int mem = f.device ? TM_MEM_DEVICE : TM_MEM_HOST;
+    const int mem = f.device ? TM_MEM_DEVICE : (f.pinned ? TM_MEM_HOST_PINNED : TM_MEM_HOST);
     switch (f.kind) {
     case HwFrame::NvDecNV12:
     case HwFrame::NvDecP016: {
@@ -205,6 +209,9 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
 
     uint32_t decode_count = 0;
     size_t compute_count = 0;
+    // a pinned frame is read by DMA until its batch has synced: with two engines that is up to 2 * batch frames later
+    frames_ref.set_lookahead((size_t)batch_ * (eng_[1] ? 2 : 1) + 1);
+    frames_dis.set_lookahead((size_t)batch_ * (eng_[1] ? 2 : 1) + 1);
     frames_ref.skip_frames(opts.skip_ref + opts.skip);
     frames_dis.skip_frames(opts.skip_dis + opts.skip);
 
@@ -233,8 +240,46 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
         in_flight[i] = true;
     };
 
+    // the two sources are read concurrently: the reference stream on a helper thread, the distorted one here
     HwFrame fref, fdis;
-    while (frames_ref.next_frame(fref) && frames_dis.next_frame(fdis)) {
+    struct Fetch {
+        std::mutex m;
+        std::condition_variable cv;
+        bool want = false, done = false, quit = false, ok = false;
+        std::exception_ptr err;
+    } fx;
+    std::thread helper([&] {
+        std::unique_lock<std::mutex> lk(fx.m);
+        for (;;) {
+            fx.cv.wait(lk, [&] { return fx.want || fx.quit; });
+            if (fx.quit) return;
+            fx.want = false;
+            lk.unlock();
+            bool ok = false;
+            std::exception_ptr err;
+            try { ok = frames_ref.next_frame(fref); } catch (...) { err = std::current_exception(); }
+            lk.lock();
+            fx.ok = ok; fx.err = err; fx.done = true;
+            fx.cv.notify_all();
+        }
+    });
+    struct Joiner {
+        Fetch &f; std::thread &t;
+        ~Joiner() { { std::lock_guard<std::mutex> g(f.m); f.quit = true; } f.cv.notify_all(); if (t.joinable()) t.join(); }
+    } joiner{fx, helper};
+    auto next_pair = [&]() {
+        { std::lock_guard<std::mutex> g(fx.m); fx.want = true; fx.done = false; }
+        fx.cv.notify_all();
+        bool ok_dis = false;
+        std::exception_ptr err_dis;
+        try { ok_dis = frames_dis.next_frame(fdis); } catch (...) { err_dis = std::current_exception(); }
+        std::unique_lock<std::mutex> lk(fx.m);
+        fx.cv.wait(lk, [&] { return fx.done; });
+        if (fx.err) std::rethrow_exception(fx.err);
+        if (err_dis) std::rethrow_exception(err_dis);
+        return fx.ok && ok_dis;
+    };
+    while (next_pair()) {
         if (opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0) { // lib.rs:391-394
             ++decode_count;
             continue;

@@ -111,6 +111,7 @@ struct HwFrame {
     const void *uv = nullptr;   // CbCr plane (NvDec kinds)
     size_t pitch = 0;           // bytes
     bool device = false;        // the pointers are device memory (zero copy) rather than host memory
+    bool pinned = false;        // host memory from tm_host_alloc that stays untouched until the engine has synced: async DMA
 };
 
 struct FormatIdentifier {
@@ -131,6 +132,9 @@ public:
     virtual size_t frame_count() const = 0; // 0 when unknown
     virtual void skip_frames(uint32_t n) = 0;
     virtual bool next_frame(HwFrame &out) = 0;
+    // How many further next_frame calls a returned frame must survive (the engine reads a pinned frame asynchronously until
+    // its batch has synced).  Sources that hand out pinned memory size their ring from this; call before the first frame.
+    virtual void set_lookahead(size_t frames) {}
 };
 
 class TmError : public std::runtime_error {
