@@ -45,6 +45,12 @@ __device__ __forceinline__ bool tm_wave_sum_u32(unsigned &v)
 #define TM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+#ifdef TM_EXP_NOLUT
+#define TM_EXP_NOLUT_V 1
+#else
+#define TM_EXP_NOLUT_V 0
+#endif
+
 namespace tmk {
 
 __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, int nrows, int pitch)
@@ -94,7 +100,7 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
             const unsigned ys = yv[iy][ix];
             const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
             px[iy][ix][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
-            if (BITS == 8 && rb != nullptr) {
+            if (BITS == 8 && rb != nullptr && !TM_EXP_NOLUT_V) {
                 const float *t = rb + (size_t)d.matrix * 2 * 65536;
                 px[iy][ix][0] = t[(ys << 8) | ucr];
                 px[iy][ix][2] = t[65536 + ((ys << 8) | ucb)];
@@ -102,6 +108,47 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
                 px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
                 px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
             }
+        }
+    }
+}
+
+// ingest_yuv_quad in two phases, so that the tile32 kernel can have the next side's samples in flight while it
+// stores the current side (raw: [0..3] luma iy*2+ix, [4] cb, [5] cr)
+template <typename T>
+__device__ __forceinline__ void yuv_quad_load(const TmFrameDesc &d, int qx, int qy, unsigned (&raw)[6])
+{
+    const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
+    const T *yrow0 = (const T *)((const char *)d.p0 + (size_t)(2 * qy) * d.pitch) + 2 * qx;
+    const T *yrow1 = (const T *)((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch) + 2 * qx;
+    raw[4] = uv[0]; raw[5] = uv[1];
+    raw[0] = yrow0[0]; raw[1] = yrow0[1]; raw[2] = yrow1[0]; raw[3] = yrow1[1];
+}
+
+template <int BITS>
+__device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const unsigned (&raw)[6], const float *__restrict__ coef,
+                                                 const double *__restrict__ tab, float (&px)[2][2][3], const float *__restrict__ rb)
+{
+    const float *k = coef + (d.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
+    const int neutral = 1 << (BITS - 1);
+    const unsigned ymin = 16u << (BITS - 8);
+    const unsigned ucb = raw[4], ucr = raw[5];
+    const float cb = (float)((int)ucb - neutral);
+    const float cr = (float)((int)ucr - neutral);
+    const float r_ = k[1] * cr;
+    const float g_ = __builtin_fmaf(k[3], cb, k[4] * cr);
+    const float b_ = k[2] * cb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned ys = raw[q];
+        const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
+        px[q >> 1][q & 1][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
+        if (BITS == 8 && rb != nullptr && !TM_EXP_NOLUT_V) {
+            const float *t = rb + (size_t)d.matrix * 2 * 65536;
+            px[q >> 1][q & 1][0] = t[(ys << 8) | ucr];
+            px[q >> 1][q & 1][2] = t[65536 + ((ys << 8) | ucb)];
+        } else {
+            px[q >> 1][q & 1][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
+            px[q >> 1][q & 1][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
         }
     }
 }
@@ -553,12 +600,23 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
     const int w = g.s[0].w, h = g.s[0].h;
     unsigned qref[3] = {0, 0, 0};
     unsigned sse = 0;
+    // YUV kinds: the quad's six samples are fetched one side ahead -- side 0 before the table barrier, side 1 while
+    // side 0 is being stored -- so that their latency never sits in front of the arithmetic
+    constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016;
+    const bool quad_ok = X0 + 1 < w && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
+    unsigned raw[6] = {0, 0, 0, 0, 0, 0};
+    TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
+    if (YUV && quad_ok) {
+        if (KIND == TM_KIND_NV12) yuv_quad_load<unsigned char>(dd0, X0 / 2, Y0 / 2, raw);
+        else yuv_quad_load<unsigned short>(dd0, X0 / 2, Y0 / 2, raw);
+    }
     if (tid < 96) tab[tid] = gtab[tid];
     TM_LDS_BARRIER();
 
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
-        const TmFrameDesc d = desc[slot * 2 + side];
+        TmFrameDesc d = dd0;
+        if (side) d = dd1;
         const int kind = KIND >= 0 ? KIND : d.kind;
         float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
         float *xybt = XYBT + (size_t)(slot * 2 + side) * g.pyr_t;
@@ -570,8 +628,17 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
             for (int ix = 0; ix < 2; ++ix)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
-        if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
-            if (X0 + 1 < w && Y0 + 1 < h) { // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
+        if (YUV) {
+            if (quad_ok) {
+                if (KIND == TM_KIND_NV12) yuv_quad_convert<8>(d, raw, coef, tab, px, yuvlut);
+                else yuv_quad_convert<16>(d, raw, coef, tab, px, nullptr);
+                if (side == 0) { // next side's samples: in flight during this side's XYB arithmetic and stores
+                    if (KIND == TM_KIND_NV12) yuv_quad_load<unsigned char>(dd1, X0 / 2, Y0 / 2, raw);
+                    else yuv_quad_load<unsigned short>(dd1, X0 / 2, Y0 / 2, raw);
+                }
+            }
+        } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
+            if (quad_ok) {
                 if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px, yuvlut);
                 else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
             }
