@@ -128,8 +128,20 @@ int tm_engine_get_raw_sums(tm_engine *e, uint32_t slot, double out[108]);
 int tm_engine_set_full_sums(tm_engine *e, int on);
 /* what the blur passes compute per [scale*3 + channel]: 0 nothing, 1 edge terms only (mu1, mu2), 2 everything */
 int tm_engine_get_job_modes(const tm_engine *e, int out[18]);
-/* PSNR input: exact integer sum of squared differences of the u8-quantised linear RGB pair */
+/* PSNR input: exact integer sum of squared differences of the u8-quantised linear RGB pair (all three channels; and per
+ * channel R, G, B) */
 int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out);
+int tm_engine_get_sse_channels(tm_engine *e, uint32_t slot, uint64_t out[3]);
+/* 10 log10(255^2 n / sse) as the single Npp32f the reference reads back, widened (turbo-metrics/src/lib.rs:355) */
+double tm_psnr_from_sse(uint64_t sse, uint64_t n_samples);
+
+/* How PSNR / SSIM / MS-SSIM combine the three channels (NPP's nppi*_8u_C3R is closed source; the reference reads back one
+ * float, cudarse-npp/src/image/ist.rs:118-133):
+ *   TM_CHANNELS_POOLED (default)  PSNR from the MSE over all 3*w*h samples; SSIM / MS-SSIM = mean of the three channels
+ *   TM_CHANNELS_FIRST             the value of channel 0 (R) only -- what the reference would see if NPP writes one value
+ *                                 per channel into the buffer of which it reads the first */
+enum { TM_CHANNELS_POOLED = 0, TM_CHANNELS_FIRST = 1 };
+int tm_engine_set_channel_mode(tm_engine *e, int mode);
 
 /* SSIM / MS-SSIM of the u8-quantised linear RGB pair (the inputs of nppiSSIM_8u_C3R_Ctx / nppiWMSSSIM_8u_C3R_Ctx,
  * turbo-metrics/src/lib.rs:319-337).  NPP is closed source and no reference test pins its output: the definition here
@@ -140,6 +152,8 @@ int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out);
 int tm_engine_get_ssim_sums(tm_engine *e, uint32_t slot, double out[30]);
 double tm_ssim_from_sums(const double sums[30], uint32_t width, uint32_t height);
 double tm_msssim_from_sums(const double sums[30], uint32_t width, uint32_t height);
+double tm_ssim_channel_from_sums(const double sums[30], uint32_t width, uint32_t height, int channel);
+double tm_msssim_channel_from_sums(const double sums[30], uint32_t width, uint32_t height, int channel);
 void tm_ssim_window(float g[11]);
 
 /* SSIMULACRA2 post-processing (ssimulacra2-cuda/src/lib.rs:449-623) as a pure host function */

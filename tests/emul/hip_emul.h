@@ -47,4 +47,4 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 
 // lanes of one wave run back to back (x fastest), so a running total per wave is enough
 bool tm_wave_sum6(double (&a)[6]);
-bool tm_wave_sum_u32(unsigned &v);
+bool tm_wave_sum_u32x3(unsigned (&v)[3]);

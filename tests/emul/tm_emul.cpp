@@ -6,7 +6,7 @@ thread_local uint3_ threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 
 static double g_acc6[6];
-static unsigned g_accu;
+static unsigned g_accu[3];
 static inline unsigned lane_id() { return (threadIdx.x + threadIdx.y * blockDim.x) & 63; }
 bool tm_wave_sum6(double (&a)[6])
 {
@@ -15,11 +15,11 @@ bool tm_wave_sum6(double (&a)[6])
     if (lane_id() == 63) { for (int k = 0; k < 6; ++k) a[k] = g_acc6[k]; return true; }
     return false;
 }
-bool tm_wave_sum_u32(unsigned &v)
+bool tm_wave_sum_u32x3(unsigned (&v)[3])
 {
-    if (lane_id() == 0) g_accu = 0;
-    g_accu += v;
-    if (lane_id() == 63) { v = g_accu; return true; }
+    if (lane_id() == 0) for (int k = 0; k < 3; ++k) g_accu[k] = 0;
+    for (int k = 0; k < 3; ++k) g_accu[k] += v[k];
+    if (lane_id() == 63) { for (int k = 0; k < 3; ++k) v[k] = g_accu[k]; return true; }
     return false;
 }
 
@@ -113,7 +113,7 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
     TmGeom g; tm_make_geom(&g, w, h);
     out[0] = (unsigned long long)n * 2 * g.pyr; out[1] = out[0];
     out[2] = (unsigned long long)n * 2 * g.pyr_t; out[3] = (unsigned long long)n * 5 * g.pyr_t;
-    out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = (unsigned long long)n * TM_SSE_BINS;
+    out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = (unsigned long long)n * TM_SSE_BINS * 3;
 }
 
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,

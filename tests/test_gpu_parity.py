@@ -294,3 +294,30 @@ def test_ssim_of_identical_frames_is_one_and_size_limits():
     assert ei.value.code == F.TM_ERR_UNSUPPORTED
     with pytest.raises(tm.TmError):
         tm.TurboMetrics(10, 300, tm.Metrics(ssim=True), batch=1)
+
+
+def test_per_channel_values_and_first_channel_mode():
+    """NPP's C3 quality functions may report one value per channel, of which the reference's 4-byte read-back would keep
+    the first: the per-channel SSE / SSIM / MS-SSIM are exposed, and TM_CHANNELS_FIRST reports
+    channel 0 instead of the pooled / averaged value.  Checked against numpy on the oracle's quantised frames."""
+    w, h = 208, 192
+    fr, fd = nv12_frames(w, h, 3)
+    lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+    qa, qb = O.quantize_u8(lin[0]).astype(np.int64), O.quantize_u8(lin[1]).astype(np.int64)
+    sse_c = [int(((qa[c] - qb[c]) ** 2).sum()) for c in range(3)]
+    eng = tm.TurboMetrics(w, h, tm.Metrics(psnr=True, ssim=True, msssim=True), batch=1)
+    pooled = eng.compute_one(fr, fd)
+    assert eng.sse_channels(0) == sse_c and eng.sse(0) == sum(sse_c)
+    sums = eng.ssim_sums(0)
+    L = tm.ffi.lib()
+    import ctypes as C
+    sp = np.ascontiguousarray(sums.ravel()).ctypes.data_as(C.POINTER(C.c_double))
+    ssim_c = [L.tm_ssim_channel_from_sums(sp, w, h, c) for c in range(3)]
+    ms_c = [L.tm_msssim_channel_from_sums(sp, w, h, c) for c in range(3)]
+    assert abs(pooled.ssim - np.mean(ssim_c)) < 1e-6 and abs(pooled.msssim - np.mean(ms_c)) < 1e-6
+    eng.set_channel_mode(True)
+    first = eng.scores(0)
+    assert first.psnr == L.tm_psnr_from_sse(sse_c[0], w * h) and first.psnr == float(np.float32(10 * np.log10(255.0 ** 2 * w * h / sse_c[0])))
+    assert first.ssim == ssim_c[0] and first.msssim == ms_c[0]
+    assert pooled.psnr == L.tm_psnr_from_sse(sum(sse_c), 3 * w * h) == O.psnr(lin[0], lin[1])[1]
+    eng.close()

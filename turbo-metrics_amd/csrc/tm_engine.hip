@@ -87,6 +87,7 @@ struct tm_engine {
     TmGeom g{};
     TmJobs jobs{};
     bool full_sums = false;
+    int channel_mode = TM_CHANNELS_POOLED;
     TmSsimGeom sg{};               // SSIM / MS-SSIM (only when the mask asks for them)
     unsigned char *QU8 = nullptr;  // [slot][side][3] planar u8-quantised linear RGB
     float *SPYR = nullptr;         // [slot][side][3] box pyramid, scales 1..4
@@ -209,11 +210,16 @@ int check_yuv_args(int matrix, int transfer, int full_range)
     return TM_OK;
 }
 
-unsigned long long slot_sse(const tm_engine *e, uint32_t slot)
+unsigned long long slot_sse_channel(const tm_engine *e, uint32_t slot, int c)
 {
     unsigned long long tot = 0;
-    for (int i = 0; i < TM_SSE_BINS; ++i) tot += e->h_sse[(size_t)slot * TM_SSE_BINS + i];
+    for (int i = 0; i < TM_SSE_BINS; ++i) tot += e->h_sse[((size_t)slot * TM_SSE_BINS + i) * 3 + c];
     return tot;
+}
+
+unsigned long long slot_sse(const tm_engine *e, uint32_t slot)
+{
+    return slot_sse_channel(e, slot, 0) + slot_sse_channel(e, slot, 1) + slot_sse_channel(e, slot, 2);
 }
 
 dim3 grid2(int w, int h, int z) { return dim3((unsigned)((w + 63) / 64), (unsigned)h, (unsigned)z); }
@@ -301,7 +307,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->SSE, B * TM_SSE_BINS, true))) return fail(rc);
+    if ((rc = dev_alloc(e, &e->SSE, B * TM_SSE_BINS * 3, true))) return fail(rc);
     if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         float gw[TM_SSIM_TAPS];
         tm_ssim_window(gw);
@@ -326,7 +332,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(hip_fail(he, "k_build_yuv_lut"));
     if ((he = hipHostMalloc((void **)&e->h_desc, B * 2 * sizeof(TmFrameDesc), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     if ((he = hipHostMalloc((void **)&e->h_sums, B * 108 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
-    if ((he = hipHostMalloc((void **)&e->h_sse, B * TM_SSE_BINS * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
+    if ((he = hipHostMalloc((void **)&e->h_sse, B * TM_SSE_BINS * 3 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     for (size_t i = 0; i < B * 2; ++i) { e->h_desc[i] = TmFrameDesc{nullptr, nullptr, 0, TM_KIND_NONE, 0}; }
     e->staging.assign(B * 2, nullptr);
     e->staging_size.assign(B * 2, 0);
@@ -447,7 +453,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
     float *LIN2 = e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane;
     double *PART = e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
-    unsigned long long *SSE = e->SSE + (size_t)slot0 * TM_SSE_BINS;
+    unsigned long long *SSE = e->SSE + (size_t)slot0 * TM_SSE_BINS * 3;
     unsigned char *QU8 = e->QU8 ? e->QU8 + (size_t)slot0 * 2 * 3 * e->sg.qplane : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
@@ -539,7 +545,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     const int n = (int)n_slots;
     HIPCHK(hipMemcpyAsync(e->d_desc, e->h_desc, (size_t)n * 2 * sizeof(TmFrameDesc), hipMemcpyHostToDevice, st));
     const int want_sse = (e->mask & TM_METRIC_PSNR) ? 1 : 0;
-    if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * TM_SSE_BINS * sizeof(unsigned long long), st));
+    if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * TM_SSE_BINS * 3 * sizeof(unsigned long long), st));
     int chunks = (e->variant >> 16) & 15;
     if (chunks < 1) chunks = 1;
     if (chunks > n) chunks = n;
@@ -565,7 +571,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     }
     if (e->mask & TM_METRIC_SSIMULACRA2)
         HIPCHK(hipMemcpyAsync(e->h_sums, e->SUMS, (size_t)n * 108 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (want_sse) HIPCHK(hipMemcpyAsync(e->h_sse, e->SSE, (size_t)n * TM_SSE_BINS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (want_sse) HIPCHK(hipMemcpyAsync(e->h_sse, e->SSE, (size_t)n * TM_SSE_BINS * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM))
         HIPCHK(hipMemcpyAsync(e->h_ssums, e->SSUMS, (size_t)n * 30 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
@@ -639,31 +645,50 @@ void tm_ssim_window(float g[11])
     for (int k = 0; k < TM_SSIM_TAPS; ++k) g[k] = (float)(v[k] / sum);
 }
 
+static double ssim_channel(const double sums[30], uint32_t width, uint32_t height, int c)
+{
+    return sums[(c * TM_SSIM_SCALES + 0) * 2] / ((double)(width - 10) * (double)(height - 10));
+}
+
+static double msssim_channel(const double sums[30], uint32_t width, uint32_t height, int c)
+{
+    static const double wt[TM_SSIM_SCALES] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+    double prod = 1.0;
+    uint32_t sw = width, sh = height;
+    for (int s = 0; s < TM_SSIM_SCALES; ++s) {
+        const double n = (double)(sw - 10) * (double)(sh - 10);
+        const double v = sums[(c * TM_SSIM_SCALES + s) * 2 + (s == TM_SSIM_SCALES - 1 ? 0 : 1)] / n;
+        prod *= std::pow(v > 0.0 ? v : 0.0, wt[s]);
+        sw /= 2; sh /= 2;
+    }
+    return prod;
+}
+
+double tm_ssim_channel_from_sums(const double sums[30], uint32_t width, uint32_t height, int channel)
+{
+    if (width < TM_SSIM_TAPS || height < TM_SSIM_TAPS || channel < 0 || channel > 2) return NAN;
+    return (double)(float)ssim_channel(sums, width, height, channel);
+}
+
+double tm_msssim_channel_from_sums(const double sums[30], uint32_t width, uint32_t height, int channel)
+{
+    if ((width >> 4) < TM_SSIM_TAPS || (height >> 4) < TM_SSIM_TAPS || channel < 0 || channel > 2) return NAN;
+    return (double)(float)msssim_channel(sums, width, height, channel);
+}
+
 double tm_ssim_from_sums(const double sums[30], uint32_t width, uint32_t height)
 {
     if (width < TM_SSIM_TAPS || height < TM_SSIM_TAPS) return NAN;
-    const double n = (double)(width - 10) * (double)(height - 10);
     double acc = 0.0;
-    for (int c = 0; c < 3; ++c) acc += sums[(c * TM_SSIM_SCALES + 0) * 2] / n;
+    for (int c = 0; c < 3; ++c) acc += ssim_channel(sums, width, height, c);
     return (double)(float)(acc / 3.0); // one Npp32f read back (ist.rs:118,133), widened (lib.rs:355-357)
 }
 
 double tm_msssim_from_sums(const double sums[30], uint32_t width, uint32_t height)
 {
-    static const double wt[TM_SSIM_SCALES] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
     if ((width >> 4) < TM_SSIM_TAPS || (height >> 4) < TM_SSIM_TAPS) return NAN;
     double acc = 0.0;
-    for (int c = 0; c < 3; ++c) {
-        double prod = 1.0;
-        uint32_t sw = width, sh = height;
-        for (int s = 0; s < TM_SSIM_SCALES; ++s) {
-            const double n = (double)(sw - 10) * (double)(sh - 10);
-            const double v = sums[(c * TM_SSIM_SCALES + s) * 2 + (s == TM_SSIM_SCALES - 1 ? 0 : 1)] / n;
-            prod *= std::pow(v > 0.0 ? v : 0.0, wt[s]);
-            sw /= 2; sh /= 2;
-        }
-        acc += prod;
-    }
+    for (int c = 0; c < 3; ++c) acc += msssim_channel(sums, width, height, c);
     return (double)(float)(acc / 3.0);
 }
 
@@ -691,6 +716,27 @@ int tm_engine_get_sse(tm_engine *e, uint32_t slot, uint64_t *out)
     return TM_OK;
 }
 
+int tm_engine_get_sse_channels(tm_engine *e, uint32_t slot, uint64_t out[3])
+{
+    if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
+    if (!e->have_results || slot >= e->last_n || !(e->mask & TM_METRIC_PSNR)) return TM_ERR_STATE;
+    for (int c = 0; c < 3; ++c) out[c] = slot_sse_channel(e, slot, c);
+    return TM_OK;
+}
+
+int tm_engine_set_channel_mode(tm_engine *e, int mode)
+{
+    if (!e || (mode != TM_CHANNELS_POOLED && mode != TM_CHANNELS_FIRST)) return TM_ERR_INVALID_ARG;
+    e->channel_mode = mode;
+    return TM_OK;
+}
+
+double tm_psnr_from_sse(uint64_t sse, uint64_t n_samples)
+{
+    const double mse = (double)sse / (double)n_samples;
+    return (double)(float)(10.0 * std::log10(255.0 * 255.0 / mse)); // one Npp32f (ist.rs:118), widened (lib.rs:355)
+}
+
 int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out)
 {
     if (!e || !out || slot >= e->cap) return TM_ERR_INVALID_ARG;
@@ -703,17 +749,19 @@ int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out)
     if (e->mask & TM_METRIC_PSNR) {
         // PSNR of the u8-quantised linear RGB pair (turbo-metrics/src/lib.rs:296-318); NPP returns one
         // Npp32f (cudarse-npp/src/image/ist.rs:118) which the engine widens (lib.rs:355).
-        const double count = 3.0 * (double)e->w * (double)e->h;
-        const double mse = (double)slot_sse(e, slot) / count;
-        out->psnr = (double)(float)(10.0 * std::log10(255.0 * 255.0 / mse));
+        const uint64_t px = (uint64_t)e->w * e->h;
+        out->psnr = e->channel_mode == TM_CHANNELS_FIRST ? tm_psnr_from_sse(slot_sse_channel(e, slot, 0), px)
+                                                         : tm_psnr_from_sse(slot_sse(e, slot), 3 * px);
         out->valid |= TM_METRIC_PSNR;
     }
     if (e->mask & TM_METRIC_SSIM) {
-        out->ssim = tm_ssim_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h);
+        out->ssim = e->channel_mode == TM_CHANNELS_FIRST ? tm_ssim_channel_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h, 0)
+                                                         : tm_ssim_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h);
         out->valid |= TM_METRIC_SSIM;
     }
     if (e->mask & TM_METRIC_MSSSIM) {
-        out->msssim = tm_msssim_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h);
+        out->msssim = e->channel_mode == TM_CHANNELS_FIRST ? tm_msssim_channel_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h, 0)
+                                                           : tm_msssim_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h);
         out->valid |= TM_METRIC_MSSSIM;
     }
     return TM_OK;

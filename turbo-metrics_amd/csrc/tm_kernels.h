@@ -28,10 +28,13 @@ __device__ __forceinline__ bool tm_wave_sum6(double (&a)[6])
     }
     return (threadIdx.x & 63) == 0;
 }
-__device__ __forceinline__ bool tm_wave_sum_u32(unsigned &v)
+__device__ __forceinline__ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] += __shfl_down(v[k], off, 64);
+    }
     return ((threadIdx.x + threadIdx.y * blockDim.x) & 63) == 0;
 }
 #endif
@@ -236,17 +239,18 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
                 for (int c = 0; c < 3; ++c) q[side][iy][ix][c] = (int)rintf(px[iy][ix][c] * 255.0f);
     }
     if (want_sse) {
-        unsigned sse = 0;
+        unsigned sse[3] = {0, 0, 0};
 #pragma unroll
-        for (int iy = 0; iy < 2; ++iy)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int ix = 0; ix < 2; ++ix)
+            for (int iy = 0; iy < 2; ++iy)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int ix = 0; ix < 2; ++ix) {
                     const int dlt = q[0][iy][ix][c] - q[1][iy][ix][c];
-                    sse += (unsigned)(dlt * dlt);
+                    sse[c] += (unsigned)(dlt * dlt);
                 }
-        if (tm_wave_sum_u32(sse)) atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS], (unsigned long long)sse);
+        if (tm_wave_sum_u32x3(sse))
+            for (int c = 0; c < 3; ++c) atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS * 3 + c], (unsigned long long)sse[c]);
     }
 }
 
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
     const int X0 = blockIdx.x * 64 + bx * 4, Y0 = blockIdx.y * 64 + by * 4;
     const int w = g.s[0].w, h = g.s[0].h;
     unsigned qref[12];
-    unsigned sse = 0;
+    unsigned sse3[3] = {0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 12; ++i) qref[i] = 0;
     if (tid < 96) tab[tid] = gtab[tid];
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
                         if (side == 0) qref[k >> 2] |= q << (8 * (k & 3));
                         else {
                             const int dlt = (int)((qref[k >> 2] >> (8 * (k & 3))) & 255u) - (int)q;
-                            sse += (unsigned)(dlt * dlt);
+                            sse3[c] += (unsigned)(dlt * dlt);
                         }
                     }
         }
@@ -478,12 +482,15 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
         }
     }
     if (want_sse) {
-        sse_s[tid] = sse;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long tot = 0;
-            for (int i = 0; i < 256; ++i) tot += sse_s[i];
-            atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS], tot);
+        for (int c = 0; c < 3; ++c) {
+            sse_s[tid] = sse3[c];
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long tot = 0;
+                for (int i = 0; i < 256; ++i) tot += sse_s[i];
+                atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS * 3 + c], tot);
+            }
+            __syncthreads();
         }
     }
 }
@@ -599,7 +606,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     const int w = g.s[0].w, h = g.s[0].h;
     unsigned qref[3] = {0, 0, 0};
-    unsigned sse = 0;
+    unsigned sse3[3] = {0, 0, 0}; // per channel: NPP's C3 quality functions may report per channel
     // YUV kinds: the quad's six samples are fetched one side ahead -- side 0 before the table barrier, side 1 while
     // side 0 is being stored -- so that their latency never sits in front of the arithmetic
     constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016;
@@ -656,7 +663,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
                 if (side == 0) qref[k >> 2] |= q << (8 * (k & 3));
                 else {
                     const int dlt = (int)((qref[k >> 2] >> (8 * (k & 3))) & 255u) - (int)q;
-                    sse += (unsigned)(dlt * dlt);
+                    sse3[k % 3] += (unsigned)(dlt * dlt);
                 }
             }
         }
@@ -718,15 +725,19 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
     }
     if (want_sse) {
         // per-wave sum through LDS (wave-synchronous), one 64-bit integer atomic per wave into one of TM_SSE_BINS
-        // accumulators of the slot (exact and order-free; a single address per slot serialised 8 000 atomics at 1080p and
-        // doubled the kernel's time); the host adds the bins
-        sse_s[tid] = sse;
-        __builtin_amdgcn_wave_barrier();
-        if ((tid & 63) == 0) {
-            unsigned long long tot = 0;
-            for (int i = 0; i < 64; ++i) tot += sse_s[tid + i];
-            const unsigned bin = (blockIdx.x * 4 + (tid >> 6) + blockIdx.y * 29) % TM_SSE_BINS;
-            atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS + bin], tot);
+        // x 3 (channel) accumulators of the slot (exact and order-free; a single address per slot serialised 8 000 atomics
+        // at 1080p and doubled the kernel's time); the host adds the bins
+        const unsigned bin = (blockIdx.x * 4 + (tid >> 6) + blockIdx.y * 29) % TM_SSE_BINS;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sse_s[tid] = sse3[c];
+            __builtin_amdgcn_wave_barrier();
+            if ((tid & 63) == 0) {
+                unsigned long long tot = 0;
+                for (int i = 0; i < 64; ++i) tot += sse_s[tid + i];
+                atomicAdd(&SSE[((size_t)slot * TM_SSE_BINS + bin) * 3 + c], tot);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -214,6 +214,15 @@ class TurboMetrics:
         _chk(self._L.tm_engine_get_sse(self._h, slot, C.byref(v)), "tm_engine_get_sse")
         return int(v.value)
 
+    def sse_channels(self, slot: int):
+        v = (C.c_uint64 * 3)()
+        _chk(self._L.tm_engine_get_sse_channels(self._h, slot, v), "tm_engine_get_sse_channels")
+        return [int(x) for x in v]
+
+    def set_channel_mode(self, first_channel_only: bool):
+        """PSNR / SSIM / MS-SSIM from channel 0 only instead of pooled / averaged over R, G, B (see the header)"""
+        _chk(self._L.tm_engine_set_channel_mode(self._h, ffi.TM_CHANNELS_FIRST if first_channel_only else ffi.TM_CHANNELS_POOLED), "tm_engine_set_channel_mode")
+
     def compute_one(self, fref: HwFrame, fdis: HwFrame) -> FrameScores:
         """== TurboMetrics::compute_one: convert, compute, block, return FrameScores."""
         self.set_pair(0, fref, fdis)

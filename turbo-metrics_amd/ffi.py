@@ -11,6 +11,7 @@ TM_METRIC_PSNR, TM_METRIC_SSIM, TM_METRIC_MSSSIM, TM_METRIC_SSIMULACRA2 = 1, 2, 
 TM_MATRIX_BT709, TM_MATRIX_BT601_525, TM_MATRIX_BT601_625 = 0, 1, 2
 TM_TRANSFER_BT709 = 0
 TM_SIDE_REF, TM_SIDE_DIS = 0, 1
+TM_CHANNELS_POOLED, TM_CHANNELS_FIRST = 0, 1
 TM_MEM_HOST, TM_MEM_DEVICE, TM_MEM_HOST_PINNED = 0, 1, 2
 TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_COUNT = 0, 1, 2, 3
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
@@ -43,6 +44,11 @@ SYMBOLS = {
     "tm_engine_set_full_sums": (_i, [_vp, _i]),
     "tm_engine_get_job_modes": (_i, [_vp, C.POINTER(C.c_int)]),
     "tm_engine_get_sse": (_i, [_vp, _u32, C.POINTER(C.c_uint64)]),
+    "tm_engine_get_sse_channels": (_i, [_vp, _u32, C.POINTER(C.c_uint64)]),
+    "tm_psnr_from_sse": (C.c_double, [C.c_uint64, C.c_uint64]),
+    "tm_engine_set_channel_mode": (_i, [_vp, _i]),
+    "tm_ssim_channel_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32, _i]),
+    "tm_msssim_channel_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32, _i]),
     "tm_engine_get_ssim_sums": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
     "tm_ssim_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
     "tm_msssim_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
