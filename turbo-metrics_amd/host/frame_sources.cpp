@@ -1,6 +1,8 @@
 // frame_sources.cpp -- see frame_sources.hpp
 #include "frame_sources.hpp"
 
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -251,13 +253,25 @@ YuvStreamSource::YuvStreamSource(FILE *in, bool y4m, uint32_t w, uint32_t h, int
     : in_(in), y4m_(y4m), w_(w), h_(h), bits_(bits), cc_(cc), cr_(cr), frame_count_(frame_count), codec_(std::move(codec))
 {
     const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
-    planar_.resize(((size_t)w_ * h_ + 2 * cw * ch) * bps);
+    planar_bytes_ = ((size_t)w_ * h_ + 2 * cw * ch) * bps;
     pitch_ = round_up(std::max((size_t)w_, cw * 2) * bps, 256);
     surface_bytes_ = pitch_ * (round_up(h_, 2) + ch);
+    // a regular file is mapped: pictures are repacked straight out of the page cache
+    struct stat st;
+    const int fd = fileno(in_);
+    const long at = ftell(in_);
+    if (fd >= 0 && at >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            map_ = (const unsigned char *)m; map_size_ = (size_t)st.st_size; map_pos_ = (size_t)at;
+            madvise(m, map_size_, MADV_SEQUENTIAL);
+        }
+    }
 }
 
 YuvStreamSource::~YuvStreamSource()
 {
+    if (map_) munmap(const_cast<unsigned char *>(map_), map_size_);
     if (in_ && in_ != stdin) fclose(in_);
     for (unsigned char *p : ring_) {
         if (ring_pinned_) tm_host_free(p);
@@ -299,30 +313,56 @@ FormatIdentifier YuvStreamSource::format_id() const
     return FormatIdentifier{y4m_ ? std::optional<std::string>("Y4M") : std::nullopt, codec_, "turbo-metrics-hip"};
 }
 
-bool YuvStreamSource::read_picture(unsigned char *surface)
+// next picture's planar samples: a pointer into the file mapping (regular files: no copy out of the page cache) or into
+// planar_ (pipes); nullptr at the end of the stream
+const unsigned char *YuvStreamSource::acquire_picture()
 {
-    const bool keep = surface != nullptr;
+    if (map_) {
+        if (map_pos_ >= map_size_) return nullptr;
+        if (y4m_) {
+            if (map_size_ - map_pos_ < 6 || memcmp(map_ + map_pos_, "FRAME", 5)) fail("Y4M: expected a FRAME header");
+            const void *nl = memchr(map_ + map_pos_, '\n', std::min<size_t>(map_size_ - map_pos_, 256));
+            if (!nl) fail("Y4M: truncated FRAME header");
+            map_pos_ = (size_t)((const unsigned char *)nl - map_) + 1;
+        }
+        if (map_size_ - map_pos_ < planar_bytes_) {
+            if (!y4m_) return nullptr; // a trailing partial picture of a raw stream is ignored
+            fail("truncated picture in the YUV stream");
+        }
+        const unsigned char *p = map_ + map_pos_;
+        map_pos_ += planar_bytes_;
+        return p;
+    }
     if (y4m_) {
         char tag[6];
         const size_t got = fread(tag, 1, 5, in_);
-        if (got == 0) return false;
+        if (got == 0) return nullptr;
         if (got != 5 || memcmp(tag, "FRAME", 5)) fail("Y4M: expected a FRAME header");
         int c;
         while ((c = fgetc(in_)) != '\n')
             if (c == EOF) fail("Y4M: truncated FRAME header");
     }
+    if (planar_.size() != planar_bytes_) planar_.resize(planar_bytes_);
     const size_t got = fread(planar_.data(), 1, planar_.size(), in_);
-    if (got == 0 && !y4m_) return false;
+    if (got == 0 && !y4m_) return nullptr;
     if (got != planar_.size()) {
-        if (!y4m_ && feof(in_)) return false; // a trailing partial picture of a raw stream is ignored
+        if (!y4m_ && feof(in_)) return nullptr; // a trailing partial picture of a raw stream is ignored
         fail("truncated picture in the YUV stream");
     }
+    return planar_.data();
+}
+
+bool YuvStreamSource::read_picture(unsigned char *surface)
+{
+    const bool keep = surface != nullptr;
+    const unsigned char *planar = acquire_picture();
+    if (!planar) return false;
     if (!keep) return true;
     // planar I420 -> the NVDEC surface contract: luma rows at `pitch`, then interleaved CbCr rows at the same pitch
     const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
     unsigned char *luma = surface, *uv = surface + pitch_ * round_up(h_, 2);
     if (bits_ == 8) {
-        const unsigned char *y = planar_.data(), *u = y + (size_t)w_ * h_, *v = u + cw * ch;
+        const unsigned char *y = planar, *u = y + (size_t)w_ * h_, *v = u + cw * ch;
         for (uint32_t r = 0; r < h_; ++r) memcpy(luma + r * pitch_, y + (size_t)r * w_, w_);
         for (size_t r = 0; r < ch; ++r) {
             unsigned char *o = uv + r * pitch_;
@@ -330,7 +370,7 @@ bool YuvStreamSource::read_picture(unsigned char *surface)
         }
     } else {
         const int sh = 16 - bits_; // P016: the value sits in the high bits (cudarse-video/src/dec.rs:398-400)
-        const uint16_t *y = (const uint16_t *)planar_.data(), *u = y + (size_t)w_ * h_, *v = u + cw * ch;
+        const uint16_t *y = (const uint16_t *)planar, *u = y + (size_t)w_ * h_, *v = u + cw * ch;
         for (uint32_t r = 0; r < h_; ++r) {
             uint16_t *o = (uint16_t *)(luma + r * pitch_);
             for (uint32_t x = 0; x < w_; ++x) o[x] = (uint16_t)(y[(size_t)r * w_ + x] << sh);

@@ -75,6 +75,7 @@ public:
 
 private:
     bool read_picture(unsigned char *surface);
+    const unsigned char *acquire_picture();
     FILE *in_;
     bool y4m_;
     uint32_t w_, h_;
@@ -83,8 +84,10 @@ private:
     ColorRange cr_;
     size_t frame_count_;
     std::string codec_;
-    size_t pitch_ = 0, surface_bytes_ = 0;
-    std::vector<unsigned char> planar_;
+    size_t pitch_ = 0, surface_bytes_ = 0, planar_bytes_ = 0;
+    std::vector<unsigned char> planar_;         // pipes: one picture read with fread
+    const unsigned char *map_ = nullptr;        // regular files: the whole file mapped
+    size_t map_size_ = 0, map_pos_ = 0;
     // ring of page-locked surfaces (tm_host_alloc): a frame stays valid for `lookahead` further next_frame calls, which
     // lets the engine pull it by asynchronous DMA; plain memory when page-locking fails
     std::vector<unsigned char *> ring_;
