@@ -21,11 +21,7 @@
 
 namespace tmdev {
 
-#ifdef TM_EXP_NOINLINE
-#define TM_MATH_INLINE __attribute__((noinline))
-#else
 #define TM_MATH_INLINE __forceinline__
-#endif
 
 __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
@@ -83,9 +79,6 @@ __device__ __forceinline__ tm_f2 cbrt_core2(tm_f2 a)
 // [2^-100, 2^100] are brought into range by an exact power-of-eight scaling
 __device__ TM_MATH_INLINE float cbrt_pos(float a)
 {
-#ifdef TM_EXP_NOCBRT
-    return a * 0.5f + 0.1f;
-#endif
     if (!(a > 0.0f) || !(a < __builtin_inff())) return a;
     float sc = 1.0f;
     if (a < 0x1p-100f) { a *= 0x1p96f; sc = 0x1p-32f; }
@@ -97,10 +90,6 @@ __device__ TM_MATH_INLINE float cbrt_pos(float a)
 // (same operations as cbrt_pos with sc = 1 -> same bits) and the general routine is only a fallback
 template <int N> __device__ __forceinline__ void cbrt_pos_n(float (&v)[N])
 {
-#ifdef TM_EXP_NOCBRT
-    for (int i = 0; i < N; ++i) v[i] = v[i] * 0.5f + 0.1f;
-    return;
-#endif
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -126,9 +115,6 @@ template <int N> __device__ __forceinline__ void cbrt_pos_n(float (&v)[N])
 // |rr| <= ln2/64, degree-5 series.  ~20 f64 operations, no division.
 __device__ TM_MATH_INLINE float pow_pos(float xf, double y, const double *__restrict__ tab)
 {
-#ifdef TM_EXP_NOPOW
-    return xf * xf;
-#endif
     if (!(xf > 0.0f)) return xf != xf ? xf : 0.0f;
     const double x = (double)xf;
     const uint64_t b = d2u(x);

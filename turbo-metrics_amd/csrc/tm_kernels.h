@@ -48,12 +48,6 @@ __device__ __forceinline__ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 #define TM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
-#ifdef TM_EXP_NOLUT
-#define TM_EXP_NOLUT_V 1
-#else
-#define TM_EXP_NOLUT_V 0
-#endif
-
 namespace tmk {
 
 __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, int nrows, int pitch)
@@ -103,7 +97,7 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
             const unsigned ys = yv[iy][ix];
             const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
             px[iy][ix][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
-            if (BITS == 8 && rb != nullptr && !TM_EXP_NOLUT_V) {
+            if (BITS == 8 && rb != nullptr) {
                 const float *t = rb + (size_t)d.matrix * 2 * 65536;
                 px[iy][ix][0] = t[(ys << 8) | ucr];
                 px[iy][ix][2] = t[65536 + ((ys << 8) | ucb)];
@@ -145,7 +139,7 @@ __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const uns
         const unsigned ys = raw[q];
         const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
         px[q >> 1][q & 1][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
-        if (BITS == 8 && rb != nullptr && !TM_EXP_NOLUT_V) {
+        if (BITS == 8 && rb != nullptr) {
             const float *t = rb + (size_t)d.matrix * 2 * 65536;
             px[q >> 1][q & 1][0] = t[(ys << 8) | ucr];
             px[q >> 1][q & 1][2] = t[65536 + ((ys << 8) | ucb)];
@@ -557,16 +551,12 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
         const int r = tid >> 3, q4 = (tid & 7) * 4;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-#ifndef TM_EXP_NOSTORE_N
             if (ty0 + r < sa.h && tx0 + q4 < sa.w)
                 *(float4 *)(xyb + sa.off + c * sa.plane + (size_t)(ty0 + r) * sa.pitch + tx0 + q4) =
                     make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
-#endif
-#ifndef TM_EXP_NOSTORE_T
             if (tx0 + r < sa.w && ty0 + q4 < sa.h)
                 *(float4 *)(xybt + sa.off_t + c * sa.plane_t + (size_t)(tx0 + r) * sa.pitch_t + ty0 + q4) =
                     make_float4(L.t0[c][q4][r], L.t0[c][q4 + 1][r], L.t0[c][q4 + 2][r], L.t0[c][q4 + 3][r]);
-#endif
         }
     }
     if (tid < 192) {
