@@ -321,3 +321,32 @@ def test_per_channel_values_and_first_channel_mode():
     assert first.ssim == ssim_c[0] and first.msssim == ms_c[0]
     assert pooled.psnr == L.tm_psnr_from_sse(sum(sse_c), 3 * w * h) == O.psnr(lin[0], lin[1])[1]
     eng.close()
+
+
+def test_graph_replay_equals_direct_launches():
+    """The per-batch sequence is replayed from a captured hipGraph; frame pointers, batch size, input kind and the
+    full_sums switch may change between computes (re-capture) without changing a bit of the results."""
+    w, h = 200, 120
+    nv = [nv12_frames(w, h, n) for n in range(3)]
+    r8, d8 = tm.synth.rgb8_pair(w, h)
+    rgb = (tm.HwFrame.rgb(r8), tm.HwFrame.rgb(d8))
+    m = tm.Metrics(ssimulacra2=True, psnr=True, ssim=True)
+
+    def run(eng, seq):
+        out = []
+        for frames, full in seq:
+            eng.set_full_sums(full)
+            for slot, (fr, fd) in enumerate(frames):
+                eng.set_pair(slot, fr, fd)
+            eng.compute_async(len(frames)); eng.sync()
+            out.append([(eng.raw_sums(i).copy(), eng.scores(i), eng.sse(i)) for i in range(len(frames))])
+        return out
+    seq = [(nv, False), (nv[::-1], False), (nv[:2], False), ([rgb, rgb, rgb], False), (nv, True), ([nv[0], rgb], False), (nv, False)]
+    a, b = tm.TurboMetrics(w, h, m, batch=3), tm.TurboMetrics(w, h, m, batch=3)
+    b.set_graph(False)
+    ra, rb = run(a, seq), run(b, seq)
+    for x, y in zip(ra, rb):
+        for (sa, ca, ea), (sb, cb, eb) in zip(x, y):
+            assert np.array_equal(sa, sb) and ca == cb and ea == eb
+    assert [s for s, _, _ in ra[0]][0].tolist() == [s for s, _, _ in ra[6]][0].tolist()   # replay after re-captures
+    a.close(); b.close()

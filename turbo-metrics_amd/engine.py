@@ -281,6 +281,9 @@ class TurboMetrics:
         _chk(self._L.tm_engine_get_job_modes(self._h, out), "tm_engine_get_job_modes")
         return np.array(out, np.int32).reshape(6, 3)
 
+    def set_graph(self, on: bool):
+        _chk(self._L.tm_engine_set_graph(self._h, int(bool(on))), "tm_engine_set_graph")
+
     def set_variant(self, v: int):
         _chk(self._L.tm_engine_set_variant(self._h, int(v)), "tm_engine_set_variant")
 

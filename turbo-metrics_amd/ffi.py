@@ -56,6 +56,7 @@ SYMBOLS = {
     "tm_ssimulacra2_score_from_sums": (C.c_double, [C.POINTER(C.c_double), _u32, _u32]),
     "tm_engine_set_profiling": (_i, [_vp, _i]),
     "tm_engine_get_stage_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), _i]),
+    "tm_engine_set_graph": (_i, [_vp, _i]),
     "tm_engine_set_variant": (_i, [_vp, _i]),
     "tm_engine_debug_read_plane": (_i, [_vp, _u32, _i, _i, _i, _i, C.POINTER(C.c_float), _sz]),
     "tm_strerror": (C.c_char_p, [_i]),
