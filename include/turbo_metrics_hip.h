@@ -165,8 +165,10 @@ enum { TM_STAGE_INGEST = 0, TM_STAGE_BLUR_V = 1, TM_STAGE_BLUR_H = 2, TM_STAGE_C
 int tm_engine_set_profiling(tm_engine *e, int on);
 /* Accumulated since the last reset: milliseconds per stage and number of computes measured. */
 int tm_engine_get_stage_ms(tm_engine *e, double ms[TM_STAGE_COUNT], uint64_t *n_computes, int reset);
-/* 1 (default): the per-batch sequence (descriptor upload, kernels, result download) is captured once into a hipGraph and
- * replayed -- the counterpart of the reference's recorded CUDA graph (ssimulacra2-cuda/src/lib.rs:140-229); 0: direct launches */
+/* 1: the per-batch sequence (descriptor upload, kernels, result download) is captured once into a hipGraph and replayed --
+ * the counterpart of the reference's recorded CUDA graph (ssimulacra2-cuda/src/lib.rs:140-229).  0 (default): direct
+ * launches; with ~10 submissions per batch instead of the reference's 305 the graph has nothing left to hide and measured
+ * 1-6 % slower on ROCm 7.2. */
 int tm_engine_set_graph(tm_engine *e, int on);
 /* select the kernel generation (0 = simple reference kernels, 1 = tuned); for A/B tests */
 int tm_engine_set_variant(tm_engine *e, int variant);

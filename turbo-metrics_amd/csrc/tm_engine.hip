@@ -88,7 +88,7 @@ struct tm_engine {
     TmJobs jobs{};
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
-    bool use_graph = true;          // replay the per-batch launch sequence from a captured hipGraph
+    bool use_graph = false;         // replay the per-batch launch sequence from a captured hipGraph (measured slower than direct launches: off)
     hipGraphExec_t gexec = nullptr;
     long long gkey = -1;
     TmSsimGeom sg{};               // SSIM / MS-SSIM (only when the mask asks for them)
