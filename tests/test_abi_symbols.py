@@ -95,3 +95,14 @@ def test_ssim_host_functions_match_oracle():
     g = (C.c_float * 11)()
     tm.ffi.lib().tm_ssim_window(g)
     assert np.array_equal(np.array(g, np.float32), O.ssim_window()) and abs(sum(g) - 1.0) < 1e-6
+
+
+def test_header_is_plain_c_and_host_entry_points_work(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_c_check")
+    lib_dir = os.path.join(ROOT, "turbo-metrics_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "host", "abi_c_check.c"),
+                           "-L" + lib_dir, "-lturbometrics_hip", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.startswith("abi ok: turbo-metrics-hip")
