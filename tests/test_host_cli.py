@@ -377,3 +377,23 @@ def test_cli_error_paths(tmp_path):
     write_y4m(y, [tm.synth.yuv420_pair(48, 32, 0, 8)[0]], 48, 32, 8, " XCOLORRANGE=FULL")
     rc, _, err = cli(y, y, "-m", "ssimulacra2")
     assert rc == 1 and "unsupported" in err                      # full-range YUV: todo!() in the reference
+
+
+@pytest.mark.gpu
+def test_cli_baseline_config_1_full_hd_png_pair(tmp_path):
+    """BASELINE.json configs[0]: one 1080p PNG pair.  The CLI's score equals the committed golden (oracle, GPU arithmetic) to
+    1e-4 and lies within the reference's own 0.25 band of its CPU path (examples/cpu.rs restated, examples/compare.rs:72)."""
+    from PIL import Image
+    case = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "scores_r01.json")))["cases"]
+            if c["kind"] == "rgb8" and c["width"] == 1920][0]
+    r8, d8 = tm.synth.rgb8_pair(1920, 1080)
+    pr, pd = str(tmp_path / "r.png"), str(tmp_path / "d.png")
+    Image.fromarray(r8).save(pr, compress_level=1)
+    Image.fromarray(d8).save(pd, compress_level=1)
+    rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "-m", "ssim", "-m", "msssim", "--output", "json")
+    assert rc == 0, err
+    d = json.loads(out)
+    assert abs(d["ssimulacra2"]["scores"][0] - case["ssimulacra2"]) <= 1e-4
+    assert abs(d["ssimulacra2"]["scores"][0] - case["cpu_path_ssimulacra2"]) < 0.25
+    assert d["psnr"]["scores"][0] == case["psnr"]
+    assert abs(d["ssim"]["scores"][0] - case["ssim"]) <= 1e-6 and abs(d["msssim"]["scores"][0] - case["msssim"]) <= 1e-6

@@ -16,7 +16,8 @@ from oracle import oracle as O  # noqa: E402
 from tm_pkg import tm  # noqa: E402
 
 CASES = [("nv12", 160, 96, 1, 0), ("nv12", 333, 203, 4, 1), ("nv12", 640, 360, 7, 0), ("p016", 320, 200, 2, 0), ("rgb8", 256, 192, 0, 0),
-         ("nv12", 1920, 1080, 2, 0)]
+         ("nv12", 1920, 1080, 2, 0),
+         ("rgb8", 1920, 1080, 0, 0)]  # BASELINE config 1: single 1080p RGB8 (PNG) pair; `cpu_path_ssimulacra2` = the reference's CPU path restated
 
 
 def linear_pair(kind, w, h, n, matrix):
