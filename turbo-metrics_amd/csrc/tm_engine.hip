@@ -132,6 +132,10 @@ template <typename T> int dev_alloc(tm_engine *e, T **p, size_t count, bool zero
     return TM_OK;
 }
 
+// an engine lives on the device that was current when it was created; calls may come from a thread whose current device
+// is another one (one process driving several GPUs)
+#define TM_BIND(e) do { if ((e) && hipSetDevice((e)->device) != hipSuccess) return hip_fail(hipGetLastError(), "hipSetDevice"); } while (0)
+
 int check_slot_side(const tm_engine *e, uint32_t slot, int side)
 {
     if (!e || slot >= e->cap || (side != TM_SIDE_REF && side != TM_SIDE_DIS)) return TM_ERR_INVALID_ARG;
@@ -167,6 +171,7 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
 {
     int rc = check_slot_side(e, slot, side);
     if (rc) return rc;
+    TM_BIND(e);
     if (!p0 || (mem != TM_MEM_HOST && mem != TM_MEM_DEVICE && mem != TM_MEM_HOST_PINNED)) return TM_ERR_INVALID_ARG;
     const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016;
     if (yuv && !p1) return TM_ERR_INVALID_ARG;
@@ -351,6 +356,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
 void tm_engine_destroy(tm_engine *e)
 {
     if (!e) return;
+    (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
@@ -546,6 +552,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
 int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
 {
     if (!e || n_slots == 0 || n_slots > e->cap) return TM_ERR_INVALID_ARG;
+    TM_BIND(e);
     for (uint32_t i = 0; i < n_slots * 2; ++i)
         if (e->h_desc[i].kind == TM_KIND_NONE) return TM_ERR_STATE;
     if (e->ev_pending) { // fold the previous compute's timings before the events are reused
@@ -628,6 +635,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
 int tm_engine_sync(tm_engine *e)
 {
     if (!e) return TM_ERR_INVALID_ARG;
+    TM_BIND(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->ev_pending) {
         for (int i = 0; i < TM_STAGE_COUNT; ++i) {
@@ -817,6 +825,7 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     const TmGeom &g = e->g;
     const TmScaleGeom &sg = g.s[scale];
     if (out_count < (size_t)sg.w * sg.h) return TM_ERR_INVALID_ARG;
+    TM_BIND(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     const float *src = nullptr;
     size_t pitch = 0, width = 0, rows = 0;
