@@ -267,6 +267,14 @@ def test_y4m_is_repacked_to_the_nvdec_surface_contract(helper, tmp_path, w, h, b
     head, frames, data2 = read_dump(helper, raw, str(tmp_path / "r.bin"), "--width", w, "--height", h, "--bits", bits, "--cp", 1, "--mc", 1, "--tc", 1)
     assert head[3:6] == ["BT709", "BT709", "BT709"] and len(frames) == 3 and np.array_equal(data2, data)
     assert "not a PNG" in run(helper, "source", raw, str(tmp_path / "n.bin"))
+    # the same streams through a pipe (stdin): the probe bytes are handed back to the source, nothing is buffered whole
+    for path, extra in ((p, ()), (raw, ("--width", w, "--height", h, "--bits", bits))):
+        outp = str(tmp_path / "pipe.bin")
+        if path == p:
+            write_y4m(p, [pr[0] for pr in pairs], w, h, bits)
+        r = subprocess.run([helper, "source", "-", outp] + [str(a) for a in extra], stdin=open(path, "rb"), capture_output=True, text=True)
+        assert r.stdout.strip().split("\n")[0].split()[1:3] == [str(w), str(h)] and len(r.stdout.strip().split("\n")) == 4, r.stdout
+        assert np.array_equal(np.fromfile(outp, np.uint8), data)
 
 
 def test_y4m_rejects_what_the_reference_cannot_represent(helper, tmp_path):

@@ -279,6 +279,25 @@ YuvStreamSource::~YuvStreamSource()
     }
 }
 
+void YuvStreamSource::set_prefix(std::vector<unsigned char> bytes)
+{
+    prefix_ = std::move(bytes);
+    prefix_pos_ = 0;
+    if (!prefix_.empty() && map_) { munmap(const_cast<unsigned char *>(map_), map_size_); map_ = nullptr; } // never both
+}
+
+size_t YuvStreamSource::read_bytes(unsigned char *dst, size_t n)
+{
+    size_t done = 0;
+    if (prefix_pos_ < prefix_.size()) {
+        done = std::min(n, prefix_.size() - prefix_pos_);
+        memcpy(dst, prefix_.data() + prefix_pos_, done);
+        prefix_pos_ += done;
+    }
+    if (done < n) done += fread(dst + done, 1, n - done, in_);
+    return done;
+}
+
 void YuvStreamSource::set_lookahead(size_t frames)
 {
     if (ring_.empty()) lookahead_ = frames ? frames : 1;
@@ -334,19 +353,20 @@ const unsigned char *YuvStreamSource::acquire_picture()
         return p;
     }
     if (y4m_) {
-        char tag[6];
-        const size_t got = fread(tag, 1, 5, in_);
+        unsigned char tag[6];
+        const size_t got = read_bytes(tag, 5);
         if (got == 0) return nullptr;
         if (got != 5 || memcmp(tag, "FRAME", 5)) fail("Y4M: expected a FRAME header");
-        int c;
-        while ((c = fgetc(in_)) != '\n')
-            if (c == EOF) fail("Y4M: truncated FRAME header");
+        unsigned char c;
+        do {
+            if (read_bytes(&c, 1) != 1) fail("Y4M: truncated FRAME header");
+        } while (c != '\n');
     }
     if (planar_.size() != planar_bytes_) planar_.resize(planar_bytes_);
-    const size_t got = fread(planar_.data(), 1, planar_.size(), in_);
+    const size_t got = read_bytes(planar_.data(), planar_.size());
     if (got == 0 && !y4m_) return nullptr;
     if (got != planar_.size()) {
-        if (!y4m_ && feof(in_)) return nullptr; // a trailing partial picture of a raw stream is ignored
+        if (!y4m_) return nullptr; // a trailing partial picture of a raw stream is ignored
         fail("truncated picture in the YUV stream");
     }
     return planar_.data();
@@ -474,54 +494,35 @@ std::unique_ptr<FrameSource> create_source(const std::string &path, const Source
         const size_t pp = cs.find('p', 3);
         if (pp != std::string::npos && pp + 1 < cs.size() && isdigit((unsigned char)cs[pp + 1])) bits = std::stoi(cs.substr(pp + 1));
         if (bits != 8 && bits != 10 && bits != 12 && bits != 14 && bits != 16) { close(); fail("Y4M: unsupported bit depth in C" + cs); }
-        // put the over-read bytes back: only possible on a seekable file; on a pipe we re-feed them through a memory stream
+        // the probe may have swallowed the beginning of the first FRAME: a seekable file is rewound, a pipe gets the
+        // over-read bytes handed to the source as a prefix that it consumes before touching the stream again
+        std::vector<unsigned char> prefix;
         FILE *in = f;
-        if (!rest.empty()) {
-            if (!is_stdin && fseek(f, (long)(nl + 1), SEEK_SET) == 0) {
-                // rewound
-            } else {
-                // non-seekable: splice `rest` in front of the remaining stream with a cookie-less trick: a pipe-free
-                // approach is to read everything left into memory
-                std::vector<unsigned char> all(rest.begin(), rest.end());
-                unsigned char buf[1 << 16];
-                size_t n;
-                while ((n = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + n);
-                in = fmemopen(nullptr, all.size() ? all.size() : 1, "w+b");
-                if (!in) { close(); fail("Y4M: could not buffer the stream"); }
-                fwrite(all.data(), 1, all.size(), in);
-                rewind(in);
-                close();
-            }
-        }
+        if (!rest.empty() && (is_stdin || fseek(f, (long)(nl + 1), SEEK_SET) != 0)) prefix.assign(rest.begin(), rest.end());
         const size_t bps = bits > 8 ? 2 : 1, cw = (w + 1) / 2, ch = (h + 1) / 2;
         const size_t pic = ((size_t)w * h + 2 * cw * ch) * bps + 6;
-        const long total = in == f && !is_stdin ? file_size_or_zero(f) : 0;
+        const long total = !is_stdin ? file_size_or_zero(f) : 0;
         const size_t count = total > (long)(nl + 1) ? ((size_t)total - (nl + 1)) / pic : 0;
         const ColorCharacteristics cc = ColorCharacteristics::from_codes(hints.cp, hints.mc, hints.tc).or_(color_characteristics_fallback(h));
-        return std::make_unique<YuvStreamSource>(in, true, w, h, bits, cc, full ? ColorRange::Full : ColorRange::Limited, count,
-                                                 "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
+        auto src = std::make_unique<YuvStreamSource>(in, true, w, h, bits, cc, full ? ColorRange::Full : ColorRange::Limited, count,
+                                                     "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
+        src->set_prefix(std::move(prefix));
+        return src;
     }
 
     if (hints.width && hints.height) { // headerless planar 4:2:0
         FILE *in = f;
-        if (is_stdin || fseek(f, 0, SEEK_SET) != 0) {
-            std::vector<unsigned char> all(probe, probe + got);
-            unsigned char buf[1 << 16];
-            size_t n;
-            while ((n = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + n);
-            in = fmemopen(nullptr, all.size() ? all.size() : 1, "w+b");
-            if (!in) { close(); fail("could not buffer the raw stream"); }
-            fwrite(all.data(), 1, all.size(), in);
-            rewind(in);
-            close();
-        }
+        std::vector<unsigned char> prefix;
+        if (is_stdin || fseek(f, 0, SEEK_SET) != 0) prefix.assign(probe, probe + got); // a pipe: the probe bytes come first
         const int bits = hints.bits;
         const size_t bps = bits > 8 ? 2 : 1, cw = (hints.width + 1) / 2, ch = (hints.height + 1) / 2;
         const size_t pic = ((size_t)hints.width * hints.height + 2 * cw * ch) * bps;
-        const long total = in == f ? file_size_or_zero(f) : 0;
+        const long total = !is_stdin ? file_size_or_zero(f) : 0;
         const ColorCharacteristics cc = ColorCharacteristics::from_codes(hints.cp, hints.mc, hints.tc).or_(color_characteristics_fallback(hints.height));
-        return std::make_unique<YuvStreamSource>(in, false, hints.width, hints.height, bits, cc, hints.full_range ? ColorRange::Full : ColorRange::Limited,
-                                                 total > 0 ? (size_t)total / pic : 0, "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
+        auto src = std::make_unique<YuvStreamSource>(in, false, hints.width, hints.height, bits, cc, hints.full_range ? ColorRange::Full : ColorRange::Limited,
+                                                     total > 0 ? (size_t)total / pic : 0, "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
+        src->set_prefix(std::move(prefix));
+        return src;
     }
     close();
     fail("'" + path + "': not a PNG / PPM / PFM image nor a Y4M stream (for headerless planar YUV give --width/--height); "

@@ -72,8 +72,13 @@ public:
     void skip_frames(uint32_t n) override;
     bool next_frame(HwFrame &out) override;
     void set_lookahead(size_t frames) override;
+    // bytes that were read from the stream before this source took it over (the format probe of a pipe)
+    void set_prefix(std::vector<unsigned char> bytes);
 
 private:
+    size_t read_bytes(unsigned char *dst, size_t n);
+    std::vector<unsigned char> prefix_;
+    size_t prefix_pos_ = 0;
     bool read_picture(unsigned char *surface);
     const unsigned char *acquire_picture();
     FILE *in_;
