@@ -350,3 +350,17 @@ def test_graph_replay_equals_direct_launches():
             assert np.array_equal(sa, sb) and ca == cb and ea == eb
     assert [s for s, _, _ in ra[0]][0].tolist() == [s for s, _, _ in ra[6]][0].tolist()   # replay after re-captures
     a.close(); b.close()
+
+
+def test_psnr_and_ssim_without_ssimulacra2_skip_the_xyb_machinery():
+    """PSNR / SSIM / MS-SSIM alone: no XYB pyramid is computed or allocated; the values equal those of the fused pass."""
+    w, h = 640, 360
+    fr, fd = nv12_frames(w, h, 4)
+    fused = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True, ssim=True, msssim=True), batch=1)
+    light = tm.TurboMetrics(w, h, tm.Metrics(psnr=True, ssim=True, msssim=True), batch=1)
+    a, b = fused.compute_one(fr, fd), light.compute_one(fr, fd)
+    assert (a.psnr, a.ssim, a.msssim) == (b.psnr, b.ssim, b.msssim) and b.ssimulacra2 is None
+    assert light.mem_usage() < fused.mem_usage() / 4
+    with pytest.raises(tm.TmError):
+        light.raw_sums(0)
+    fused.close(); light.close()

@@ -309,12 +309,14 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
     const size_t B = batch_capacity;
     const TmGeom &g = e->g;
-    if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->LIN2, B * 2 * 3 * g.s[2].plane, true))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->XYBT, B * 2 * g.pyr_t, true))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
+    if (metrics_mask & TM_METRIC_SSIMULACRA2) { // PSNR / SSIM / MS-SSIM alone need none of the XYB machinery
+        if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->LIN2, B * 2 * 3 * g.s[2].plane, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->XYBT, B * 2 * g.pyr_t, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
+    }
     if ((rc = dev_alloc(e, &e->SSE, B * TM_SSE_BINS * 3, true))) return fail(rc);
     if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         float gw[TM_SSIM_TAPS];
@@ -424,6 +426,7 @@ int tm_engine_set_variant(tm_engine *e, int variant)
     if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 2 || (variant >> 22) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) != 2) return TM_ERR_INVALID_ARG; // only tile32 writes the u8 planes
+    if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) != 2) return TM_ERR_INVALID_ARG; // only tile32 can run without the XYB arenas
     if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
         int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
@@ -465,11 +468,12 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     const TmGeom &g = e->g;
     const TmFrameDesc *h_desc = e->h_desc + (size_t)slot0 * 2;
     const TmFrameDesc *d_desc = e->d_desc + (size_t)slot0 * 2;
-    float *XYB = e->XYB + (size_t)slot0 * 2 * g.pyr, *XYBT = e->XYBT + (size_t)slot0 * 2 * g.pyr_t;
-    float *V = e->V + (size_t)slot0 * 5 * g.pyr_t;
+    const bool ssimu2 = (e->mask & TM_METRIC_SSIMULACRA2) != 0;
+    float *XYB = ssimu2 ? e->XYB + (size_t)slot0 * 2 * g.pyr : nullptr, *XYBT = ssimu2 ? e->XYBT + (size_t)slot0 * 2 * g.pyr_t : nullptr;
+    float *V = ssimu2 ? e->V + (size_t)slot0 * 5 * g.pyr_t : nullptr;
     float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
-    float *LIN2 = e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane;
-    double *PART = e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6, *SUMS = e->SUMS + (size_t)slot0 * 108;
+    float *LIN2 = ssimu2 ? e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane : nullptr;
+    double *PART = ssimu2 ? e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6 : nullptr, *SUMS = ssimu2 ? e->SUMS + (size_t)slot0 * 108 : nullptr;
     unsigned long long *SSE = e->SSE + (size_t)slot0 * TM_SSE_BINS * 3;
     unsigned char *QU8 = e->QU8 ? e->QU8 + (size_t)slot0 * 2 * 3 * e->sg.qplane : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
@@ -502,7 +506,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         default: TM_LAUNCH_T32(-1); break;
         }
 #undef TM_LAUNCH_T32
-        hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT);
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     if (ev_ingest_done) HIPCHK(hipEventRecord(ev_ingest_done, st));
@@ -825,6 +829,7 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     const TmGeom &g = e->g;
     const TmScaleGeom &sg = g.s[scale];
     if (out_count < (size_t)sg.w * sg.h) return TM_ERR_INVALID_ARG;
+    if (!(e->mask & TM_METRIC_SSIMULACRA2)) return TM_ERR_STATE; // no XYB / pass-1 planes without SSIMULACRA2
     TM_BIND(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     const float *src = nullptr;

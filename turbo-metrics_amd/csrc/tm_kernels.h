@@ -668,8 +668,8 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
                 }
         }
         // ---- level-0 XYB into the LDS tile, level-1 linear pixel of this quad and its XYB (five pixels = 15 cube
-        // roots, evaluated pairwise)
-        {
+        // roots, evaluated pairwise).  XYB == nullptr: SSIMULACRA2 is not asked for (PSNR / SSIM only): no pyramid at all.
+        if (XYB != nullptr) {
             const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
             float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
 #pragma unroll
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
         }
         TM_LDS_BARRIER();
         // ---- levels 0 and 1 out of their tiles
-        store_tiles_both(L, g.s[0], g.s[1], xyb, xybt, tx0, ty0, tid);
+        if (XYB != nullptr) store_tiles_both(L, g.s[0], g.s[1], xyb, xybt, tx0, ty0, tid);
         if (QU8 != nullptr && tid < 192) { // the u8 tile: 16 pixels = one 16-B store per lane, two lanes per row
             const int c = tid >> 6, r = (tid & 63) >> 1, half = tid & 1;
             if (ty0 + r < h && tx0 + 16 * half < w)
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
         }
         // ---- level-2 LINEAR pixels of this tile (8x8) go to HBM: levels 2..5 are finished by k_ingest_upper.
         // (Doing them here cost four more barriers per side with 3/4 .. 255/256 of the workgroup idle.)
-        if (tid < 64) {
+        if (XYB != nullptr && tid < 64) {
             const TmScaleGeom s1 = g.s[1], s2 = g.s[2];
             const int ox = tid & 7, oy = tid >> 3;
             const int XL = (tx0 >> 2) + ox, YL = (ty0 >> 2) + oy;
