@@ -364,3 +364,52 @@ def test_psnr_and_ssim_without_ssimulacra2_skip_the_xyb_machinery():
     with pytest.raises(tm.TmError):
         light.raw_sums(0)
     fused.close(); light.close()
+
+
+def test_extreme_samples_match_oracle():
+    """Out-of-range and degenerate samples: NV12 / P016 code values 0 and max (below black, above white, saturated chroma),
+    flat frames, linear f32 input with negatives, zeros, huge values and denormals (the cube root's range fallback)."""
+    w, h = 96, 80
+    rng = np.random.default_rng(12)
+    frames = []
+    # NV12 with every code value, including the ones outside the limited range
+    for seed in range(2):
+        pl = lambda shape: rng.integers(0, 256, shape)
+        ref = (pl((h, w)), pl((h // 2, w // 2)), pl((h // 2, w // 2)))
+        dis = tuple(np.clip(p + rng.integers(-3, 4, p.shape), 0, 255) for p in ref)
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.pack_biplanar(ref, w, h, 8), tm.synth.pack_biplanar(dis, w, h, 8)
+        frames.append((tm.HwFrame.nv12(rs, rp, rch, tm.ColorMatrix(seed)), tm.HwFrame.nv12(ds, dp, dch, tm.ColorMatrix(seed))))
+    # P016 using all 16 bits (the reference kernel takes the full 16-bit value, biplanar.rs:89-101)
+    ref = (rng.integers(0, 65536, (h, w)), rng.integers(0, 65536, (h // 2, w // 2)), rng.integers(0, 65536, (h // 2, w // 2)))
+    dis = tuple(np.clip(p + rng.integers(-300, 301, p.shape), 0, 65535) for p in ref)
+    (rs, rp, rch), (ds, dp, dch) = tm.synth.pack_biplanar(ref, w, h, 16), tm.synth.pack_biplanar(dis, w, h, 16)
+    frames.append((tm.HwFrame.p016(rs, rp, rch), tm.HwFrame.p016(ds, dp, dch)))
+    # flat black against flat white
+    z, o = np.zeros((h, w, 3), np.uint8), np.full((h, w, 3), 255, np.uint8)
+    frames.append((tm.HwFrame.rgb(z), tm.HwFrame.rgb(o)))
+    # linear f32 far outside [0, 1]
+    lf = (rng.standard_normal((h, w, 3)) * 2).astype(np.float32)
+    lf[0, :8] = [0.0, -0.0, 1e-45, 1e-38, 1e30, 3e38, -1e30, 65504.0][:8][0]  # one row of specials, channel-wise below
+    specials = np.array([0.0, -0.0, 1e-45, 1e-38, 1e30, 3e38, -1e30, 1e-20], np.float32)
+    lf[1, :8, 0] = specials; lf[2, :8, 1] = specials; lf[3, :8, 2] = specials
+    ld = (lf * np.float32(0.9)).astype(np.float32)
+    frames.append((tm.HwFrame.linear(lf), tm.HwFrame.linear(ld)))
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=len(frames), full_sums=True)
+    for slot, (fr, fd) in enumerate(frames):
+        eng.set_pair(slot, fr, fd)
+    eng.compute_async(); eng.sync()
+    for slot, (fr, fd) in enumerate(frames):
+        lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+        sums, pyr = O.ssimulacra2_sums(lin[0], lin[1], want_xyb=True)
+        for s in range(6):
+            for side in range(2):
+                for c in range(3):
+                    got, want = eng.read_plane(slot, F.TM_PLANE_XYB, s, side, c), pyr[s][side][c]
+                    assert np.array_equal(got, want, equal_nan=True), ("xyb", slot, s, side, c)
+        got_s = eng.raw_sums(slot)
+        ok = np.isfinite(sums)
+        np.testing.assert_allclose(got_s[ok], sums[ok], rtol=1e-11, atol=1e-300)
+        assert np.array_equal(np.isfinite(got_s), ok)
+        if slot < 4:
+            assert eng.sse(slot) == O.psnr(lin[0], lin[1])[0]
+    eng.close()

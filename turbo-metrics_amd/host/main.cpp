@@ -4,6 +4,7 @@
 // Additions (no counterpart in the reference, all optional): --batch, --device, --no-pipeline, --full-sums, and the
 // description of headerless YUV input (--width, --height, --bits, --color-primaries, --matrix-coefficients,
 // --transfer-characteristics, --full-range).
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -199,6 +200,9 @@ int main(int argc, char **argv)
     std::unique_ptr<TurboMetrics> turbo;
     try {
         if (metrics.mask() == 0) throw std::runtime_error("no metric selected (-m psnr|ssim|msssim|ssimulacra2)");
+        // a source that knows its length never needs more slots than it has pairs (a single image pair: one slot, one engine)
+        const size_t known = std::min(source_ref->frame_count(), source_dis->frame_count());
+        if (known > 0 && known <= batch) { batch = (uint32_t)known; pipeline = false; }
         turbo = std::make_unique<TurboMetrics>(source_ref->width(), source_ref->height(), metrics, batch, pipeline);
         if (full_sums) turbo->set_full_sums(true);
     } catch (const std::exception &e) {
