@@ -48,3 +48,4 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 // lanes of one wave run back to back (x fastest), so a running total per wave is enough
 bool tm_wave_sum6(double (&a)[6]);
 bool tm_wave_sum_u32x3(unsigned (&v)[3]);
+float tm_shfl_xor(float v, int mask); // lockstep wave emulation only

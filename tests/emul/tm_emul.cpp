@@ -15,8 +15,20 @@ bool tm_wave_sum6(double (&a)[6])
     if (lane_id() == 63) { for (int k = 0; k < 6; ++k) a[k] = g_acc6[k]; return true; }
     return false;
 }
+void tm_emul_wave_barrier();
+static bool lockstep_on();
 bool tm_wave_sum_u32x3(unsigned (&v)[3])
 {
+    if (lockstep_on()) { // the 64 lanes are concurrent host threads: sum through memory
+        static unsigned buf[3][64];
+        const unsigned l = lane_id();
+        for (int k = 0; k < 3; ++k) buf[k][l] = v[k];
+        tm_emul_wave_barrier();
+        if (l == 0)
+            for (int k = 0; k < 3; ++k) { unsigned t = 0; for (int i = 0; i < 64; ++i) t += buf[k][i]; v[k] = t; }
+        tm_emul_wave_barrier();
+        return l == 0;
+    }
     if (lane_id() == 0) for (int k = 0; k < 3; ++k) g_accu[k] = 0;
     for (int k = 0; k < 3; ++k) g_accu[k] += v[k];
     if (lane_id() == 63) { for (int k = 0; k < 3; ++k) v[k] = g_accu[k]; return true; }
@@ -29,6 +41,7 @@ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 static pthread_barrier_t g_wave_bar;       // all host threads of the workgroup (__syncthreads)
 static pthread_barrier_t g_per_wave_bar[16]; // the 64 host threads of one wavefront (wave-synchronous code)
 static bool g_lockstep = false, g_per_wave = false;
+static bool lockstep_on() { return g_lockstep; }
 void tm_emul_wave_barrier()
 {
     if (!g_lockstep) return;
@@ -36,6 +49,19 @@ void tm_emul_wave_barrier()
     else pthread_barrier_wait(&g_wave_bar);
 }
 void tm_emul_syncthreads() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
+
+// wave shuffle for the lockstep emulation (64 host threads = the lanes of one wave): exchange through memory
+static float g_shfl[64];
+float tm_shfl_xor(float v, int mask)
+{
+    const unsigned l = threadIdx.x & 63;
+    tm_emul_wave_barrier();
+    g_shfl[l] = v;
+    tm_emul_wave_barrier();
+    const float r = g_shfl[l ^ (unsigned)mask];
+    tm_emul_wave_barrier();
+    return r;
+}
 
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
 #include "../../turbo-metrics_amd/csrc/tm_ssim_kernels.h"
@@ -133,6 +159,16 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
     } else if (ingest_gen == 1) {
         launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, tab, XYB, XYBT, SSE, want_sse); });
+    } else if (ingest_gen == 3) {
+        std::vector<float> yuvlut((size_t)3 * 2 * 65536);
+        std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
+        launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
+        launch_wave_lockstep(dim3((w + 31) / 32, (h + 7) / 8, n), [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
+          switch (kind) {
+          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
+        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr); });
     } else {
         std::vector<float> yuvlut((size_t)3 * 2 * 65536);
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
@@ -158,7 +194,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     case 10: launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 1); }, 5); break;
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
-    if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
+    if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x(g, jobs, XYB, V, PART, 0); });
+    else if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
     else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });
 }

@@ -20,7 +20,7 @@ def oracle_linear(f, w, h):
     return {"rgb8": O.rgb8_to_linear, "rgb16": O.rgb16_to_linear, "rgbf32": O.rgbf32_to_linear, "linear_f32": O.linear_packed_to_planar}[k](f["data"])
 
 
-def check_against_oracle(em, frames, w, h, have_linear=True):
+def check_against_oracle(em, frames, w, h, have_linear=True, have_xybt=True):
     for slot, (fr, fd) in enumerate(frames):
         lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
         sums, pyr = O.ssimulacra2_sums(lin[0], lin[1], want_xyb=True)
@@ -33,8 +33,9 @@ def check_against_oracle(em, frames, w, h, have_linear=True):
                 for c in range(3):
                     got = em.plane(em.XYB, slot, s, side, c)
                     assert np.array_equal(got, pyr[s][side][c]), ("xyb", slot, s, side, c)
-                    got_t = em.plane(em.XYBT, slot, s, side, c, transposed=True)
-                    assert np.array_equal(got_t, pyr[s][side][c].T), ("xybt", slot, s, side, c)
+                    if have_xybt:
+                        got_t = em.plane(em.XYBT, slot, s, side, c, transposed=True)
+                        assert np.array_equal(got_t, pyr[s][side][c].T), ("xybt", slot, s, side, c)
             _, cap = O.process_scale(pyr[s][0], pyr[s][1], capture=True)
             for p in range(5):
                 for c in range(3):
@@ -140,3 +141,28 @@ def test_ssim_kernels_match_oracle(w, h, streamed):
         assert abs(got_ssim - O.ssim_from_sums(want, w, h)) <= 1e-7
         a, b = tm.engine.msssim_from_sums(em.ssim_sums(slot), w, h), O.msssim_from_sums(em.ssim_sums(slot), w, h)
         assert (a == b) or (np.isnan(a) and np.isnan(b))   # NaN below 176x176
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (200, 9)])
+def test_wave_ingest_and_transposing_row_pass_match_oracle(w, h):
+    """ingest generation 3 (no LDS, no transposed XYB copy) + k_blur_h_jobs_x (the row pass transposes ref / dis itself)"""
+    frames = []
+    for n in range(2):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
+        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=n % 3),
+                       dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
+    r8, d8 = tm.synth.rgb8_pair(w, h)
+    frames.append((dict(kind="rgb8", data=r8), dict(kind="rgb8", data=d8)))
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=3 * 256 + 9, weights=O.weights(), full_sums=True,
+                    ssim_window=O.ssim_window() if min(w, h) >= 11 else None)
+    check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
+    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=3 * 256 + 9, weights=O.weights(), full_sums=False)
+    m = weight_mask()
+    for slot in range(len(frames)):
+        assert np.array_equal(em.sums(slot)[m], pr.sums(slot)[m])
+        if em.sg is not None:
+            lin = [oracle_linear(frames[slot][0], w, h), oracle_linear(frames[slot][1], w, h)]
+            for side in range(2):
+                q = O.quantize_u8(lin[side])
+                for c in range(3):
+                    assert np.array_equal(em.qplane(slot, side, c), q[c])

@@ -423,10 +423,11 @@ int tm_engine_set_variant(tm_engine *e, int variant)
 {
     // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
     // dispatch order of the two blur passes (default: slot-major), bit 21: LDS-tiled SSIM statistics kernel (default: streaming)
-    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 2 || (variant >> 22) != 0) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 3 || (variant >> 22) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
-    if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) != 2) return TM_ERR_INVALID_ARG; // only tile32 writes the u8 planes
-    if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) != 2) return TM_ERR_INVALID_ARG; // only tile32 can run without the XYB arenas
+    if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 write the u8 planes
+    if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 can run without the XYB arenas
+    if ((variant >> 8 & 255) == 3 && (variant & 255) != 9) return TM_ERR_INVALID_ARG; // no transposed XYB copy: needs the job-driven column pass
     if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
         int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
@@ -491,6 +492,23 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     } else if ((e->variant >> 8 & 255) == 1) { // generation 1: one kernel, 64x64 tiles, 4x4 pixels per lane
         dim3 grid((unsigned)((e->w + 63) / 64), (unsigned)((e->h + 63) / 64), (unsigned)n);
         hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, XYB, XYBT, SSE, want_sse);
+    } else if ((e->variant >> 8 & 255) == 3) { // generation 3 (experiment): wave-private tiles, no LDS, no transposed copy
+        dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
+        int kind = h_desc[0].kind;
+        for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
+#define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
+        switch (kind) {
+        case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
+        case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
+        case TM_KIND_RGB8: TM_LAUNCH_W(TM_KIND_RGB8); break;
+        case TM_KIND_RGB16: TM_LAUNCH_W(TM_KIND_RGB16); break;
+        case TM_KIND_RGBF32: TM_LAUNCH_W(TM_KIND_RGBF32); break;
+        case TM_KIND_LINEARF32: TM_LAUNCH_W(TM_KIND_LINEARF32); break;
+        default: TM_LAUNCH_W(-1); break;
+        }
+#undef TM_LAUNCH_W
+        // levels 2..5; no transposed copy (the row pass k_blur_h_jobs_x transposes ref / dis itself)
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr);
     } else { // generation 2: 32x32 tiles, one quad per lane, LDS-staged stores
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
@@ -530,7 +548,9 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         }
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
-        hipLaunchKernelGGL(tmk::k_blur_h_jobs, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART, sm);
+        if ((e->variant >> 8 & 255) == 3)
+            hipLaunchKernelGGL(tmk::k_blur_h_jobs_x, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
+        else hipLaunchKernelGGL(tmk::k_blur_h_jobs, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART, sm);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, e->jobs, PART, SUMS);
     } else if (ev) {

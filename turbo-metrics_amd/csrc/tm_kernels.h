@@ -28,6 +28,7 @@ __device__ __forceinline__ bool tm_wave_sum6(double (&a)[6])
     }
     return (threadIdx.x & 63) == 0;
 }
+__device__ __forceinline__ float tm_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 {
 #pragma unroll
@@ -530,7 +531,7 @@ __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__r
         tmdev::linear_to_xyb(lin[0], lin[1], lin[2], a, b, c);
         const size_t o = sg.off + (size_t)Y * sg.pitch + X, ot = sg.off_t + (size_t)X * sg.pitch_t + Y;
         xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c;
-        xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c;
+        if (xybt != nullptr) { xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c; }
     }
 }
 
@@ -554,7 +555,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
             if (ty0 + r < sa.h && tx0 + q4 < sa.w)
                 *(float4 *)(xyb + sa.off + c * sa.plane + (size_t)(ty0 + r) * sa.pitch + tx0 + q4) =
                     make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
-            if (tx0 + r < sa.w && ty0 + q4 < sa.h)
+            if (xybt != nullptr && tx0 + r < sa.w && ty0 + q4 < sa.h)
                 *(float4 *)(xybt + sa.off_t + c * sa.plane_t + (size_t)(tx0 + r) * sa.pitch_t + ty0 + q4) =
                     make_float4(L.t0[c][q4][r], L.t0[c][q4 + 1][r], L.t0[c][q4 + 2][r], L.t0[c][q4 + 3][r]);
         }
@@ -565,7 +566,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
         if (y1 + r < sb.h && x1 + q4 < sb.w)
             *(float4 *)(xyb + sb.off + c * sb.plane + (size_t)(y1 + r) * sb.pitch + x1 + q4) =
                 make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
-        if (x1 + r < sb.w && y1 + q4 < sb.h)
+        if (xybt != nullptr && x1 + r < sb.w && y1 + q4 < sb.h)
             *(float4 *)(xybt + sb.off_t + c * sb.plane_t + (size_t)(x1 + r) * sb.pitch_t + y1 + q4) =
                 make_float4(L.t1[c][q4][r], L.t1[c][q4 + 1][r], L.t1[c][q4 + 2][r], L.t1[c][q4 + 3][r]);
     }
@@ -732,6 +733,129 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ingest, generation 3 ("wave"): no LDS tile, no barrier.  One wave = one 32 x 8 pixel tile (16 x 4 quads, lane = quad),
+// both sides.  Rows are stored straight from registers: a lane's float2 per row and 16 lanes along x make whole 128-B lines
+// in the normal orientation; the level-2 linear pixels (8 x 2 per tile) come from the level-1 pixels of four neighbouring
+// lanes through wave shuffles.  No transposed copy is written: the row pass k_blur_h_jobs_x transposes ref / dis itself.
+// grid (ceil(w/32), ceil(h/8), slots), block 64.
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
+                                                    const float *__restrict__ coef, const double *__restrict__ gtab,
+                                                    const float *__restrict__ yuvlut, float *__restrict__ XYB,
+                                                    float *__restrict__ LIN2, unsigned long long *__restrict__ SSE, int want_sse,
+                                                    unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch)
+{
+    __shared__ double tab[96];
+    const int lane = threadIdx.x;
+    const int qx = lane & 15, qy = lane >> 4;
+    const int slot = blockIdx.z;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
+    const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
+    const int w = g.s[0].w, h = g.s[0].h;
+    unsigned qref[3] = {0, 0, 0};
+    unsigned sse3[3] = {0, 0, 0};
+    tab[lane] = gtab[lane];
+    if (lane < 32) tab[64 + lane] = gtab[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const TmFrameDesc d = desc[slot * 2 + side];
+        const int kind = KIND >= 0 ? KIND : d.kind;
+        float px[2][2][3];
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
+        if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
+            if (X0 + 1 < w && Y0 + 1 < h) { // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
+                if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px, yuvlut);
+                else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
+            }
+        } else {
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix)
+                    if (X0 + ix < w && Y0 + iy < h) ingest_px_rgb(d, kind, lut, tab, X0 + ix, Y0 + iy, px[iy][ix]);
+        }
+        if (want_sse) { // sample_conv.rs:6-35 quantisation; out-of-image samples are 0 on both sides
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const unsigned q = (unsigned)(int)rintf(px[k / 6][(k / 3) & 1][k % 3] * 255.0f) & 255u;
+                if (side == 0) qref[k >> 2] |= q << (8 * (k & 3));
+                else {
+                    const int dlt = (int)((qref[k >> 2] >> (8 * (k & 3))) & 255u) - (int)q;
+                    sse3[k % 3] += (unsigned)(dlt * dlt);
+                }
+            }
+        }
+        if (QU8 != nullptr && X0 < w) { // u8-quantised planes for SSIM / MS-SSIM: two pixels = one 16-bit store per row
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+                    if (Y0 + iy < h) {
+                        const unsigned q0 = (unsigned)(int)rintf(px[iy][0][c] * 255.0f) & 255u;
+                        const unsigned q1 = (unsigned)(int)rintf(px[iy][1][c] * 255.0f) & 255u;
+                        *(unsigned short *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(Y0 + iy) * qpitch + X0) = (unsigned short)(q0 | (q1 << 8));
+                    }
+        }
+        if (XYB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
+        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
+        const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
+        float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lr[k] = px[k >> 1][k & 1][0]; lg[k] = px[k >> 1][k & 1][1]; lb[k] = px[k >> 1][k & 1][2]; }
+        lr[4] = ds4(px[0][0][0], px[0][1][0], px[1][0][0], px[1][1][0], okx, oky);
+        lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
+        lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
+        tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
+        // ---- level 0: two rows of two pixels; level 1: one pixel
+        {
+            const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
+            const float *xv[3] = {xa, xb, xc};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+                    if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
+                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
+                if (X0 / 2 < s1.w && Y0 / 2 < s1.h) xyb[s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2] = xv[c][4];
+            }
+        }
+        // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
+        {
+            const TmScaleGeom s1 = g.s[1], s2 = g.s[2];
+            const int XL = X0 >> 2, YL = Y0 >> 2;
+            const bool ok2x = 2 * XL + 1 < s1.w, ok2y = 2 * YL + 1 < s1.h;
+            float v[3];
+            const float l1[3] = {lr[4], lg[4], lb[4]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // lanes are (qy, qx) row-major 4 x 16: the right neighbour is lane ^ 1, the lower one lane ^ 16
+                const float v01 = tm_shfl_xor(l1[c], 1), v10 = tm_shfl_xor(l1[c], 16), v11 = tm_shfl_xor(l1[c], 17);
+                v[c] = ds4(l1[c], v01, v10, v11, ok2x, ok2y);
+            }
+            if (!(qx & 1) && !(qy & 1) && XL < s2.w && YL < s2.h) {
+                float *l2 = LIN2 + (size_t)(slot * 2 + side) * 3 * s2.plane + (size_t)YL * s2.pitch + XL;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) l2[c * s2.plane] = v[c];
+            }
+        }
+    }
+    if (want_sse) {
+        if (tm_wave_sum_u32x3(sse3)) {
+            const unsigned bin = (blockIdx.x + blockIdx.y * 29) % TM_SSE_BINS;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&SSE[((size_t)slot * TM_SSE_BINS + bin) * 3 + c], (unsigned long long)sse3[c]);
+        }
+    }
+}
+
 // Levels 2..5 of the pyramid from the level-2 linear RGB that k_ingest_tile32 leaves in LIN2 (1/16 of the
 // pixels): XYB of level 2, then 2x2 box downscales (downscale.rs:5-35) and XYB for levels 3, 4, 5.
 // Workgroup = 32x32 tile of level 2 (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad.
@@ -745,7 +869,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     const int img = blockIdx.z; // slot*2 + side
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
     const TmScaleGeom s2 = g.s[2];
-    float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT + (size_t)img * g.pyr_t;
+    float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
     const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     {
@@ -1362,6 +1486,147 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = acc[k];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row pass without a transposed XYB copy ("x" = transposes ref / dis itself).  The blurred planes still come from the
+// transposed V arena (lanes = consecutive y: coalesced); the two edge-term inputs ref(x, y), dis(x, y) are read from the
+// NORMAL planes in blocks of 16 columns: one load fetches 4 rows x 16 columns (64-B runs), 16 loads make a 64 x 16 block,
+// which goes through a double-buffered [64][17] LDS tile per plane and is read back one column per step, one row per lane.
+// Loads run D steps ahead of their LDS write and a whole block ahead of their use: element e = 16 * block + row group is
+// requested at step u = e - 16 - D, written at u = e - 16, consumed during steps 16 * block .. + 15 (u = t - 4 = the column
+// whose maps are evaluated at step t).  Everything stays inside the wave: LDS operations of one wave execute in order.
+// 17.4 KB of LDS per wave -> 9 waves per CU.
+// ------------------------------------------------------------------------------------------------
+template <bool FULL, int WN, int D>
+__device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][17], const float *__restrict__ refn,
+                                             const float *__restrict__ disn, const float *__restrict__ v0,
+                                             const float *__restrict__ v1, const float *__restrict__ v2,
+                                             const float *__restrict__ v3, const float *__restrict__ v4, int y0, int w, int h,
+                                             int pitch, int pt, bool valid, double (&acc)[6])
+{
+    // refn, disn: normal planes of this channel (row y at y * pitch); v0..v4: transposed planes + this lane's row
+    static_assert(WN % D == 0 && D <= 16, "queue depth");
+    constexpr int P = WN - 10; // load distance of the blurred planes, in rows of the transposed arena
+    constexpr int NF = FULL ? WN : 1;
+    const int lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
+    float w0[NF], w1[NF], w2[NF], w3[WN], w4[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        w3[j] = j < P ? ld_row(v3, j, w, pt) : 0.0f;
+        w4[j] = j < P ? ld_row(v4, j, w, pt) : 0.0f;
+        if (FULL) {
+            w0[j] = j < P ? ld_row(v0, j, w, pt) : 0.0f;
+            w1[j] = j < P ? ld_row(v1, j, w, pt) : 0.0f;
+            w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
+        }
+    }
+    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, column 16 * (e >> 4) + lc
+    auto fetch = [&](const float *plane, int e) -> float {
+        const int x = 16 * (e >> 4) + lc, y = y0 + 4 * (e & 15) + lr;
+        const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
+        return plane[(size_t)yc * pitch + xc];
+    };
+    auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + lr][lc] = v; };
+    // prologue: block 0 complete in LDS, elements 16 .. 16 + D - 1 in flight
+    {
+        float a[16], b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a[i] = fetch(refn, i); b[i] = fetch(disn, i); }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { put(0, i, a[i]); put(1, i, b[i]); }
+    }
+    float qa[D], qb[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { qa[i] = fetch(refn, 16 + i); qb[i] = fetch(disn, 16 + i); }
+    __builtin_amdgcn_wave_barrier();
+    tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
+    const int T = w + 4;
+    for (int t0 = 0; t0 < T; t0 += WN) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int t = t0 + j; // row t lives in slot j, row t-10 in slot (j+P) % WN, which row t+P then takes over
+            float s11 = 0.0f, s22 = 0.0f, s12 = 0.0f;
+            if (FULL) {
+                s11 = tmdev::iir_step(f0, w0[(j + P) % NF] + w0[j % NF]);
+                s22 = tmdev::iir_step(f1, w1[(j + P) % NF] + w1[j % NF]);
+                s12 = tmdev::iir_step(f2, w2[(j + P) % NF] + w2[j % NF]);
+            }
+            const float mu1 = tmdev::iir_step(f3, w3[(j + P) % WN] + w3[j]);
+            const float mu2 = tmdev::iir_step(f4, w4[(j + P) % WN] + w4[j]);
+            if (FULL) {
+                w0[(j + P) % NF] = ld_row(v0, t + P, w, pt);
+                w1[(j + P) % NF] = ld_row(v1, t + P, w, pt);
+                w2[(j + P) % NF] = ld_row(v2, t + P, w, pt);
+            }
+            w3[(j + P) % WN] = ld_row(v3, t + P, w, pt);
+            w4[(j + P) % WN] = ld_row(v4, t + P, w, pt);
+            if (t >= 4 && t < T) {
+                const int u = t - 4;                 // the column whose maps are evaluated now
+                const int slot = (j + WN - 4) % D;   // == u % D because D divides WN
+                // element u + 16 (requested D steps ago) into its buffer, element u + 16 + D requested in its place
+                __builtin_amdgcn_wave_barrier();
+                put(0, u + 16, qa[slot]); put(1, u + 16, qb[slot]);
+                qa[slot] = fetch(refn, u + 16 + D); qb[slot] = fetch(disn, u + 16 + D);
+                __builtin_amdgcn_wave_barrier();
+                const float src = tile[0][(u >> 4) & 1][lane][u & 15], dsv = tile[1][(u >> 4) & 1][lane][u & 15];
+                float ssim = 0.0f, art, det;
+                if (FULL) tmdev::error_maps(src, dsv, mu1, mu2, s11, s22, s12, ssim, art, det);
+                else tmdev::edge_maps(src, dsv, mu1, mu2, art, det);
+                if (valid) {
+                    float q;
+                    if (FULL) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
+                    acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
+                    acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
+                                                      const float *__restrict__ V, double *__restrict__ PART, int slot_major)
+{
+    __shared__ float tile[2][2][64][17];
+    const int b = slot_major ? blockIdx.y : blockIdx.x;
+    const int j = tm_find_job(jobs.hstart, b);
+    const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
+    const TmScaleGeom sg = g.s[s];
+    const int y0 = (b - jobs.hstart[j]) * 64;
+    const int y = y0 + threadIdx.x;
+    const bool valid = y < sg.h;
+    const int yy = valid ? y : sg.h - 1;
+    const int slot = slot_major ? blockIdx.x : blockIdx.z;
+    const size_t to = sg.off_t + c * sg.plane_t + yy;
+    const float *refn = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *disn = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to;
+    const float *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to;
+    const float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
+    const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
+    const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    else blur_h_job_x<false, 16, 8>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+#ifdef TM_EMULATE
+    { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
+        __shared__ double redl[6][64];
+        for (int k = 0; k < 6; ++k) redl[k][threadIdx.x] = acc[k];
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0) {
+            double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
+            for (int k = 0; k < 6; ++k) { double tsum = 0.0; for (int i = 0; i < 64; ++i) tsum += redl[k][i]; o[k] = tsum; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#else
+    if (tm_wave_sum6(acc)) {
+        double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = acc[k];
+    }
+#endif
 }
 
 // fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no
