@@ -150,6 +150,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     variant &= 255;
     TmGeom g; tm_make_geom(&g, w, h);
     TmJobs jobs; tm_make_jobs(&jobs, &g, weights, full_sums);
+    std::vector<float> xybb(ingest_gen == 3 ? (size_t)n * 2 * g.pyr_b : 1, 0.0f); // blocked XYB copy (generation 3 only)
     const int qw = (w + 1) / 2, qh = (h + 1) / 2;
     if (ingest_gen == 0) {
         launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, tab, LIN, SSE, want_sse); });
@@ -165,10 +166,10 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
         launch_wave_lockstep(dim3((w + 31) / 32, (h + 7) / 8, n), [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
           switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
-        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr); });
+          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, xybb.data(), lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, xybb.data(), lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, xybb.data(), lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
+        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr, xybb.data()); });
     } else {
         std::vector<float> yuvlut((size_t)3 * 2 * 65536);
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
@@ -178,7 +179,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
           case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
           case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
           default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
-        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, XYBT); });
+        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, XYBT, (float *)nullptr); });
     }
     const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
     switch (variant) {
@@ -194,7 +195,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     case 10: launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 1); }, 5); break;
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
-    if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x(g, jobs, XYB, V, PART, 0); });
+    if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x(g, jobs, xybb.data(), V, PART, 0); });
     else if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
     else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });

@@ -27,12 +27,19 @@ struct TmScaleGeom {
     unsigned long long plane_t; // round_up(w,64) * pitch_t
     unsigned long long off;     // float offset of this scale inside a normal pyramid
     unsigned long long off_t;   // float offset inside a transposed pyramid
+    // "blocked" orientation (ingest generation 3 -> row pass k_blur_h_jobs_x): blocks of 64 rows x 16 columns stored
+    // contiguously (4 KB), element (x, y) at ((y >> 6) * cb + (x >> 4)) * 1024 + (y & 63) * 16 + (x & 15); cb includes
+    // three padding blocks so that the row pass may prefetch past the right edge without a test
+    int cb, rb;
+    unsigned long long plane_b; // rb * cb * 1024
+    unsigned long long off_b;   // float offset inside a blocked pyramid
 };
 
 struct TmGeom {
     TmScaleGeom s[TM_SCALES];
     unsigned long long pyr;   // floats per normal pyramid     (sum over scales of 3*plane)
     unsigned long long pyr_t; // floats per transposed pyramid (sum over scales of 3*plane_t)
+    unsigned long long pyr_b; // floats per blocked pyramid
     int vblk[TM_SCALES + 1];  // prefix sums: 64-column blocks of the column pass, per (slot, channel)
     int hblk[TM_SCALES + 1];  // prefix sums: 64-row blocks of the row pass, per (slot, channel)
 };
@@ -73,7 +80,7 @@ static inline int tm_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static inline void tm_make_geom(TmGeom *g, int w, int h)
 {
-    unsigned long long off = 0, off_t = 0;
+    unsigned long long off = 0, off_t = 0, off_b = 0;
     g->vblk[0] = 0;
     g->hblk[0] = 0;
     for (int i = 0; i < TM_SCALES; ++i) {
@@ -85,12 +92,15 @@ static inline void tm_make_geom(TmGeom *g, int w, int h)
         s->plane_t = (unsigned long long)tm_round_up(w, 64) * s->pitch_t; // rows padded: see blur_v_flush
         s->off = off; s->off_t = off_t;
         off += 3 * s->plane; off_t += 3 * s->plane_t;
+        s->cb = (w + 15) / 16 + 3; s->rb = (h + 63) / 64;
+        s->plane_b = (unsigned long long)s->rb * s->cb * 1024;
+        s->off_b = off_b; off_b += 3 * s->plane_b;
         g->vblk[i + 1] = g->vblk[i] + (w + 63) / 64;
         g->hblk[i + 1] = g->hblk[i] + (h + 63) / 64;
         // scale sizes: ssimulacra2-cuda/src/lib.rs:62-66
         w = (w + 1) / 2; h = (h + 1) / 2;
     }
-    g->pyr = off; g->pyr_t = off_t;
+    g->pyr = off; g->pyr_t = off_t; g->pyr_b = off_b;
 }
 
 // weights: the reference's table [channel][scale][ssim1, art1, det1, ssim4, art4, det4]

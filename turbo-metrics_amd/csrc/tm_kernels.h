@@ -523,8 +523,14 @@ __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, co
     }
 }
 
+// float offset of (x, y) inside a blocked plane (tm_geom.h)
+__device__ __forceinline__ size_t tm_boff(const TmScaleGeom &sg, int x, int y)
+{
+    return ((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)((y & 63) * 16 + (x & 15));
+}
+
 __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__restrict__ xybt, const TmScaleGeom &sg,
-                                             int X, int Y, const float (&lin)[3])
+                                             int X, int Y, const float (&lin)[3], float *__restrict__ xybb = nullptr)
 {
     if (X < sg.w && Y < sg.h) {
         float a, b, c;
@@ -532,6 +538,10 @@ __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__r
         const size_t o = sg.off + (size_t)Y * sg.pitch + X, ot = sg.off_t + (size_t)X * sg.pitch_t + Y;
         xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c;
         if (xybt != nullptr) { xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c; }
+        if (xybb != nullptr) {
+            const size_t ob = sg.off_b + tm_boff(sg, X, Y);
+            xybb[ob] = a; xybb[ob + sg.plane_b] = b; xybb[ob + 2 * sg.plane_b] = c;
+        }
     }
 }
 
@@ -744,7 +754,8 @@ template <int KIND>
 __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
                                                     const float *__restrict__ yuvlut, float *__restrict__ XYB,
-                                                    float *__restrict__ LIN2, unsigned long long *__restrict__ SSE, int want_sse,
+                                                    float *__restrict__ XYBB, float *__restrict__ LIN2,
+                                                    unsigned long long *__restrict__ SSE, int want_sse,
                                                     unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch)
 {
     __shared__ double tab[96];
@@ -806,6 +817,7 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
         }
         if (XYB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
         float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
+        float *xybb = XYBB + (size_t)(slot * 2 + side) * g.pyr_b;
         const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
         float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
 #pragma unroll
@@ -822,9 +834,17 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
             for (int c = 0; c < 3; ++c) {
 #pragma unroll
                 for (int iy = 0; iy < 2; ++iy)
-                    if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
-                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
-                if (X0 / 2 < s1.w && Y0 / 2 < s1.h) xyb[s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2] = xv[c][4];
+                    if (X0 < w && Y0 + iy < h) { // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
+                        const float2 v2 = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
+                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = v2;
+                        // blocked copy for the row pass: the 8 lanes of a 16-column block and the two rows of the quad fill
+                        // whole 128-B lines (two rows of a block are 64 B apart)
+                        *(float2 *)(xybb + s0.off_b + c * s0.plane_b + tm_boff(s0, X0, Y0 + iy)) = v2;
+                    }
+                if (X0 / 2 < s1.w && Y0 / 2 < s1.h) {
+                    xyb[s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2] = xv[c][4];
+                    xybb[s1.off_b + c * s1.plane_b + tm_boff(s1, X0 / 2, Y0 / 2)] = xv[c][4];
+                }
             }
         }
         // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
@@ -861,7 +881,7 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
 // Workgroup = 32x32 tile of level 2 (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad.
 // grid (ceil(w2/32), ceil(h2/32), slots*2), block 256.
 __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB,
-                                                      float *__restrict__ XYBT)
+                                                      float *__restrict__ XYBT, float *__restrict__ XYBB)
 {
     __shared__ IngestSideLds L; // t0: level-2 XYB tile, t1: level-3 XYB tile, lin1: level-3 linear RGB
     __shared__ float lin4[3][8][9];
@@ -870,6 +890,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
     const TmScaleGeom s2 = g.s[2];
     float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
+    float *xybb = XYBB != nullptr ? XYBB + (size_t)img * g.pyr_b : nullptr; // blocked copy instead of the transposed one
     const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     {
@@ -898,6 +919,18 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     }
     TM_LDS_BARRIER();
     store_tiles_both(L, s2, g.s[3], xyb, xybt, tx0, ty0, tid);
+    if (xybb != nullptr) { // levels 2 and 3 are 1/16 and 1/64 of the pixels: plain per-pixel stores
+        const TmScaleGeom s3 = g.s[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = X0 + (k & 1), y = Y0 + (k >> 1);
+                if (x < s2.w && y < s2.h) xybb[s2.off_b + c * s2.plane_b + tm_boff(s2, x, y)] = L.t0[c][2 * qy + (k >> 1)][2 * qx + (k & 1)];
+            }
+            if (X0 / 2 < s3.w && Y0 / 2 < s3.h) xybb[s3.off_b + c * s3.plane_b + tm_boff(s3, X0 / 2, Y0 / 2)] = L.t1[c][qy][qx];
+        }
+    }
     if (tid < 64) { // level 4: 8x8 per tile
         const TmScaleGeom s3 = g.s[3];
         const int ox = tid & 7, oy = tid >> 3;
@@ -909,7 +942,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
             v[c] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox], L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
             lin4[c][oy][ox] = v[c];
         }
-        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v);
+        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v, xybb);
     }
     TM_LDS_BARRIER();
     if (tid < 16) { // level 5: 4x4 per tile
@@ -921,7 +954,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             v[c] = ds4(lin4[c][2 * oy][2 * ox], lin4[c][2 * oy][2 * ox + 1], lin4[c][2 * oy + 1][2 * ox], lin4[c][2 * oy + 1][2 * ox + 1], okx, oky);
-        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v);
+        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v, xybb);
     }
 }
 
@@ -1491,8 +1524,10 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const
 // ------------------------------------------------------------------------------------------------
 // Row pass without a transposed XYB copy ("x" = transposes ref / dis itself).  The blurred planes still come from the
 // transposed V arena (lanes = consecutive y: coalesced); the two edge-term inputs ref(x, y), dis(x, y) are read from the
-// NORMAL planes in blocks of 16 columns: one load fetches 4 rows x 16 columns (64-B runs), 16 loads make a 64 x 16 block,
-// which goes through a double-buffered [64][17] LDS tile per plane and is read back one column per step, one row per lane.
+// BLOCKED planes the generation-3 ingest writes (tm_geom.h: 64 rows x 16 columns per 4-KB block): one load fetches 4 rows x
+// 16 columns = one contiguous 256-B run, 16 loads make a block, which goes through a double-buffered [64][17] LDS tile per
+// plane and is read back one column per step, one row per lane.  (Reading the normal planes in 64-B runs instead fetched
+// every line twice from HBM: +2 GB per 32 pairs.)
 // Loads run D steps ahead of their LDS write and a whole block ahead of their use: element e = 16 * block + row group is
 // requested at step u = e - 16 - D, written at u = e - 16, consumed during steps 16 * block .. + 15 (u = t - 4 = the column
 // whose maps are evaluated at step t).  Everything stays inside the wave: LDS operations of one wave execute in order.
@@ -1502,10 +1537,10 @@ template <bool FULL, int WN, int D>
 __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][17], const float *__restrict__ refn,
                                              const float *__restrict__ disn, const float *__restrict__ v0,
                                              const float *__restrict__ v1, const float *__restrict__ v2,
-                                             const float *__restrict__ v3, const float *__restrict__ v4, int y0, int w, int h,
-                                             int pitch, int pt, bool valid, double (&acc)[6])
+                                             const float *__restrict__ v3, const float *__restrict__ v4, int w, int pt, bool valid,
+                                             double (&acc)[6])
 {
-    // refn, disn: normal planes of this channel (row y at y * pitch); v0..v4: transposed planes + this lane's row
+    // refn, disn: first block of this wave's row block in the BLOCKED planes; v0..v4: transposed planes + this lane's row
     static_assert(WN % D == 0 && D <= 16, "queue depth");
     constexpr int P = WN - 10; // load distance of the blurred planes, in rows of the transposed arena
     constexpr int NF = FULL ? WN : 1;
@@ -1522,12 +1557,10 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
             w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
         }
     }
-    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, column 16 * (e >> 4) + lc
-    auto fetch = [&](const float *plane, int e) -> float {
-        const int x = 16 * (e >> 4) + lc, y = y0 + 4 * (e & 15) + lr;
-        const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
-        return plane[(size_t)yc * pitch + xc];
-    };
+    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, column 16 * (e >> 4) + lc: in the blocked planes
+    // that is one contiguous 256-B run (block e >> 4 of this row block, floats 64 * (e & 15) + lane); the three padding
+    // blocks past the right edge make every prefetch legal without a test
+    auto fetch = [&](const float *rowblock, int e) -> float { return rowblock[(size_t)(e >> 4) * 1024 + 64 * (e & 15) + lane]; };
     auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + lr][lc] = v; };
     // prologue: block 0 complete in LDS, elements 16 .. 16 + D - 1 in flight
     {
@@ -1585,7 +1618,7 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     }
 }
 
-__global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
+__global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYBB,
                                                       const float *__restrict__ V, double *__restrict__ PART, int slot_major)
 {
     __shared__ float tile[2][2][64][17];
@@ -1599,16 +1632,17 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     const int yy = valid ? y : sg.h - 1;
     const int slot = slot_major ? blockIdx.x : blockIdx.z;
     const size_t to = sg.off_t + c * sg.plane_t + yy;
-    const float *refn = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *disn = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const size_t rbo = sg.off_b + c * sg.plane_b + (size_t)(y0 >> 6) * sg.cb * 1024; // this wave's row block
+    const float *refn = XYBB + (size_t)(slot * 2 + 0) * g.pyr_b + rbo;
+    const float *disn = XYBB + (size_t)(slot * 2 + 1) * g.pyr_b + rbo;
     const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to;
     const float *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to;
     const float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
     const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
     const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
-    else blur_h_job_x<false, 16, 8>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6>(tile, refn, disn, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
+    else blur_h_job_x<false, 16, 8>(tile, refn, disn, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
         __shared__ double redl[6][64];
