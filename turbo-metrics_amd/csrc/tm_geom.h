@@ -28,8 +28,10 @@ struct TmScaleGeom {
     unsigned long long off;     // float offset of this scale inside a normal pyramid
     unsigned long long off_t;   // float offset inside a transposed pyramid
     // "blocked" orientation (ingest generation 3 -> row pass k_blur_h_jobs_x): blocks of 64 rows x 16 columns stored
-    // contiguously (4 KB), element (x, y) at ((y >> 6) * cb + (x >> 4)) * 1024 + (y & 63) * 16 + (x & 15); cb includes
-    // three padding blocks so that the row pass may prefetch past the right edge without a test
+    // contiguously (4 KB); inside a block the 2x2 quads are the unit: [row pair 32][column pair 8][row in pair][column in
+    // pair], so that a lane's quad is one 16-B store and 8 lanes fill a 128-B line.  Element (x, y) at
+    // ((y >> 6) * cb + (x >> 4)) * 1024 + ((y & 63) >> 1) * 32 + ((x & 15) >> 1) * 4 + (y & 1) * 2 + (x & 1); cb includes three
+    // padding blocks so that the row pass may prefetch past the right edge without a test
     int cb, rb;
     unsigned long long plane_b; // rb * cb * 1024
     unsigned long long off_b;   // float offset inside a blocked pyramid

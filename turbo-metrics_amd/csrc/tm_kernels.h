@@ -526,7 +526,7 @@ __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, co
 // float offset of (x, y) inside a blocked plane (tm_geom.h)
 __device__ __forceinline__ size_t tm_boff(const TmScaleGeom &sg, int x, int y)
 {
-    return ((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)((y & 63) * 16 + (x & 15));
+    return ((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)(((y & 63) >> 1) * 32 + ((x & 15) >> 1) * 4 + (y & 1) * 2 + (x & 1));
 }
 
 __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__restrict__ xybt, const TmScaleGeom &sg,
@@ -826,25 +826,26 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
         lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
         lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
         tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
-        // ---- level 0: two rows of two pixels; level 1: one pixel
+        // ---- level 0: two rows of two pixels (normal planes: float2 per row; blocked planes: the quad is one float4, 8
+        // lanes fill a 128-B line); level 1: one pixel per lane, the 2 x 2 lane group's four pixels leave as one float4 in
+        // the blocked planes
         {
             const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
             const float *xv[3] = {xa, xb, xc};
+            const bool group_lead = !(qx & 1) && !(qy & 1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
 #pragma unroll
                 for (int iy = 0; iy < 2; ++iy)
-                    if (X0 < w && Y0 + iy < h) { // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
-                        const float2 v2 = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
-                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = v2;
-                        // blocked copy for the row pass: the 8 lanes of a 16-column block and the two rows of the quad fill
-                        // whole 128-B lines (two rows of a block are 64 B apart)
-                        *(float2 *)(xybb + s0.off_b + c * s0.plane_b + tm_boff(s0, X0, Y0 + iy)) = v2;
-                    }
-                if (X0 / 2 < s1.w && Y0 / 2 < s1.h) {
-                    xyb[s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2] = xv[c][4];
-                    xybb[s1.off_b + c * s1.plane_b + tm_boff(s1, X0 / 2, Y0 / 2)] = xv[c][4];
-                }
+                    if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
+                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
+                if (X0 < w && Y0 < h) // rows / columns past the image inside the quad land in the block's own padding
+                    *(float4 *)(xybb + s0.off_b + c * s0.plane_b + tm_boff(s0, X0, Y0)) = make_float4(xv[c][0], xv[c][1], xv[c][2], xv[c][3]);
+                const int X1 = X0 / 2, Y1 = Y0 / 2;
+                if (X1 < s1.w && Y1 < s1.h) xyb[s1.off + c * s1.plane + (size_t)Y1 * s1.pitch + X1] = xv[c][4];
+                const float r1 = tm_shfl_xor(xv[c][4], 1), d1 = tm_shfl_xor(xv[c][4], 16), rd1 = tm_shfl_xor(xv[c][4], 17);
+                if (group_lead && X1 < s1.w && Y1 < s1.h)
+                    *(float4 *)(xybb + s1.off_b + c * s1.plane_b + tm_boff(s1, X1, Y1)) = make_float4(xv[c][4], r1, d1, rd1);
             }
         }
         // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
@@ -1545,7 +1546,6 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     constexpr int P = WN - 10; // load distance of the blurred planes, in rows of the transposed arena
     constexpr int NF = FULL ? WN : 1;
     const int lane = threadIdx.x & 63;
-    const int lr = lane >> 4, lc = lane & 15;
     float w0[NF], w1[NF], w2[NF], w3[WN], w4[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -1557,11 +1557,14 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
             w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
         }
     }
-    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, column 16 * (e >> 4) + lc: in the blocked planes
-    // that is one contiguous 256-B run (block e >> 4 of this row block, floats 64 * (e & 15) + lane); the three padding
+    // element e of the ref / dis stream = rows 4 * (e & 15) .. + 3 of this row block, columns 16 * (e >> 4) .. + 15: in the
+    // blocked planes that is one contiguous 256-B run (block e >> 4 of this row block, floats 64 * (e & 15) + lane); the three padding
     // blocks past the right edge make every prefetch legal without a test
     auto fetch = [&](const float *rowblock, int e) -> float { return rowblock[(size_t)(e >> 4) * 1024 + 64 * (e & 15) + lane]; };
-    auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + lr][lc] = v; };
+    // float 64 * (e & 15) + lane of a block = row pair 2 * (e & 15) + (lane >> 5), column pair (lane >> 2) & 7, row lane >> 1 & 1
+    // and column lane & 1 inside the quad
+    const int er = 2 * (lane >> 5) + ((lane >> 1) & 1), ec = 2 * ((lane >> 2) & 7) + (lane & 1);
+    auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + er][ec] = v; };
     // prologue: block 0 complete in LDS, elements 16 .. 16 + D - 1 in flight
     {
         float a[16], b[16];
