@@ -503,7 +503,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
         int kind = h_desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, XYBB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
+#define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYBB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
@@ -515,7 +515,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         }
 #undef TM_LAUNCH_W
         // levels 2..5; no transposed copy (the row pass k_blur_h_jobs_x transposes ref / dis itself)
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr, XYBB);
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, (float *)nullptr, (float *)nullptr, XYBB);
     } else { // generation 2: 32x32 tiles, one quad per lane, LDS-staged stores
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
@@ -549,7 +549,8 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
             case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 8: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm); break;
+            case 9: if ((e->variant >> 8 & 255) == 3) { hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYBB, V, sm); break; }
+                    hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
             }
         }
@@ -865,12 +866,23 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     case TM_PLANE_LINEAR:
     case TM_PLANE_XYB:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
+        if (kind == TM_PLANE_XYB && (e->variant >> 8 & 255) == 3) { // generation 3 keeps only the blocked copy: de-block on the host
+            if (!e->XYBB) return TM_ERR_STATE;
+            std::vector<float> blk((size_t)sg.plane_b);
+            HIPCHK(hipMemcpy(blk.data(), e->XYBB + (size_t)(slot * 2 + index) * g.pyr_b + sg.off_b + channel * sg.plane_b,
+                             blk.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (int y = 0; y < sg.h; ++y)
+                for (int x = 0; x < sg.w; ++x)
+                    out[(size_t)y * sg.w + x] = blk[((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)((y & 63) * 16 + (x & 15))];
+            return TM_OK;
+        }
         if (kind == TM_PLANE_LINEAR && (!e->LIN || (e->variant >> 8 & 255) != 0)) return TM_ERR_STATE; // only the gen-0 ingest stores it
         src = (kind == TM_PLANE_LINEAR ? e->LIN : e->XYB) + (size_t)(slot * 2 + index) * g.pyr + sg.off + channel * sg.plane;
         pitch = sg.pitch; width = sg.w; rows = sg.h;
         break;
     case TM_PLANE_XYB_T:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
+        if ((e->variant >> 8 & 255) == 3) return TM_ERR_STATE; // no transposed copy in generation 3
         src = e->XYBT + (size_t)(slot * 2 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
         pitch = sg.pitch_t; width = sg.h; rows = sg.w;
         break;

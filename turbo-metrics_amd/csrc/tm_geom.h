@@ -27,11 +27,12 @@ struct TmScaleGeom {
     unsigned long long plane_t; // round_up(w,64) * pitch_t
     unsigned long long off;     // float offset of this scale inside a normal pyramid
     unsigned long long off_t;   // float offset inside a transposed pyramid
-    // "blocked" orientation (ingest generation 3 -> row pass k_blur_h_jobs_x): blocks of 64 rows x 16 columns stored
-    // contiguously (4 KB); inside a block the 2x2 quads are the unit: [row pair 32][column pair 8][row in pair][column in
-    // pair], so that a lane's quad is one 16-B store and 8 lanes fill a 128-B line.  Element (x, y) at
-    // ((y >> 6) * cb + (x >> 4)) * 1024 + ((y & 63) >> 1) * 32 + ((x & 15) >> 1) * 4 + (y & 1) * 2 + (x & 1); cb includes three
-    // padding blocks so that the row pass may prefetch past the right edge without a test
+    // "blocked" orientation (ingest generation 3, the only XYB copy it writes): blocks of 64 rows x 16 columns stored
+    // contiguously (4 KB, rows of 64 B).  Element (x, y) at ((y >> 6) * cb + (x >> 4)) * 1024 + (y & 63) * 16 + (x & 15).
+    // One layout serves all three users: the ingest kernel stores 4 columns x 1 row per lane (8 lanes = two rows of a block
+    // = one 128-B line), the column pass reads 64 consecutive columns of a row as four 64-B runs whose other half is the
+    // next row (the same wave, one step later), the row pass fetches 4 rows x 16 columns as one 256-B run.  cb includes
+    // three padding blocks so that the row pass may prefetch past the right edge without a test.
     int cb, rb;
     unsigned long long plane_b; // rb * cb * 1024
     unsigned long long off_b;   // float offset inside a blocked pyramid

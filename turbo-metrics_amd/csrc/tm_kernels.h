@@ -526,7 +526,7 @@ __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, co
 // float offset of (x, y) inside a blocked plane (tm_geom.h)
 __device__ __forceinline__ size_t tm_boff(const TmScaleGeom &sg, int x, int y)
 {
-    return ((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)(((y & 63) >> 1) * 32 + ((x & 15) >> 1) * 4 + (y & 1) * 2 + (x & 1));
+    return ((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)((y & 63) * 16 + (x & 15));
 }
 
 __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__restrict__ xybt, const TmScaleGeom &sg,
@@ -536,7 +536,7 @@ __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__r
         float a, b, c;
         tmdev::linear_to_xyb(lin[0], lin[1], lin[2], a, b, c);
         const size_t o = sg.off + (size_t)Y * sg.pitch + X, ot = sg.off_t + (size_t)X * sg.pitch_t + Y;
-        xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c;
+        if (xyb != nullptr) { xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c; }
         if (xybt != nullptr) { xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c; }
         if (xybb != nullptr) {
             const size_t ob = sg.off_b + tm_boff(sg, X, Y);
@@ -562,7 +562,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
         const int r = tid >> 3, q4 = (tid & 7) * 4;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (ty0 + r < sa.h && tx0 + q4 < sa.w)
+            if (xyb != nullptr && ty0 + r < sa.h && tx0 + q4 < sa.w)
                 *(float4 *)(xyb + sa.off + c * sa.plane + (size_t)(ty0 + r) * sa.pitch + tx0 + q4) =
                     make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
             if (xybt != nullptr && tx0 + r < sa.w && ty0 + q4 < sa.h)
@@ -573,7 +573,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
     if (tid < 192) {
         const int c = tid >> 6, r = (tid & 63) >> 2, q4 = (tid & 3) * 4;
         const int x1 = tx0 / 2, y1 = ty0 / 2;
-        if (y1 + r < sb.h && x1 + q4 < sb.w)
+        if (xyb != nullptr && y1 + r < sb.h && x1 + q4 < sb.w)
             *(float4 *)(xyb + sb.off + c * sb.plane + (size_t)(y1 + r) * sb.pitch + x1 + q4) =
                 make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
         if (xybt != nullptr && x1 + r < sb.w && y1 + q4 < sb.h)
@@ -753,8 +753,8 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
 template <int KIND>
 __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
-                                                    const float *__restrict__ yuvlut, float *__restrict__ XYB,
-                                                    float *__restrict__ XYBB, float *__restrict__ LIN2,
+                                                    const float *__restrict__ yuvlut, float *__restrict__ XYBB,
+                                                    float *__restrict__ LIN2,
                                                     unsigned long long *__restrict__ SSE, int want_sse,
                                                     unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch)
 {
@@ -815,8 +815,7 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
                         *(unsigned short *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(Y0 + iy) * qpitch + X0) = (unsigned short)(q0 | (q1 << 8));
                     }
         }
-        if (XYB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
-        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
+        if (XYBB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
         float *xybb = XYBB + (size_t)(slot * 2 + side) * g.pyr_b;
         const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
         float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
@@ -826,26 +825,22 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
         lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
         lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
         tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
-        // ---- level 0: two rows of two pixels (normal planes: float2 per row; blocked planes: the quad is one float4, 8
-        // lanes fill a 128-B line); level 1: one pixel per lane, the 2 x 2 lane group's four pixels leave as one float4 in
-        // the blocked planes
+        // ---- level 0.  A lane holds a 2 x 2 quad; neighbouring lanes swap one row so that the even lane owns 4 columns of the
+        // upper row and the odd lane 4 columns of the lower row: one float4 each, and 8 lanes (two 64-B rows of a block) fill
+        // a 128-B line of the blocked plane.  Level 1: one pixel per lane, 16 lanes = one 64-B block row.
         {
             const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
             const float *xv[3] = {xa, xb, xc};
-            const bool group_lead = !(qx & 1) && !(qy & 1);
+            const bool odd = qx & 1;
+            const int xs = odd ? X0 - 2 : X0, ys = odd ? Y0 + 1 : Y0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int iy = 0; iy < 2; ++iy)
-                    if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
-                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
-                if (X0 < w && Y0 < h) // rows / columns past the image inside the quad land in the block's own padding
-                    *(float4 *)(xybb + s0.off_b + c * s0.plane_b + tm_boff(s0, X0, Y0)) = make_float4(xv[c][0], xv[c][1], xv[c][2], xv[c][3]);
+                const float g0 = tm_shfl_xor(odd ? xv[c][0] : xv[c][2], 1), g1 = tm_shfl_xor(odd ? xv[c][1] : xv[c][3], 1);
+                if (xs < w && ys < h) // columns past the image inside the float4 land in the block's own padding
+                    *(float4 *)(xybb + s0.off_b + c * s0.plane_b + tm_boff(s0, xs, ys)) =
+                        odd ? make_float4(g0, g1, xv[c][2], xv[c][3]) : make_float4(xv[c][0], xv[c][1], g0, g1);
                 const int X1 = X0 / 2, Y1 = Y0 / 2;
-                if (X1 < s1.w && Y1 < s1.h) xyb[s1.off + c * s1.plane + (size_t)Y1 * s1.pitch + X1] = xv[c][4];
-                const float r1 = tm_shfl_xor(xv[c][4], 1), d1 = tm_shfl_xor(xv[c][4], 16), rd1 = tm_shfl_xor(xv[c][4], 17);
-                if (group_lead && X1 < s1.w && Y1 < s1.h)
-                    *(float4 *)(xybb + s1.off_b + c * s1.plane_b + tm_boff(s1, X1, Y1)) = make_float4(xv[c][4], r1, d1, rd1);
+                if (X1 < s1.w && Y1 < s1.h) xybb[s1.off_b + c * s1.plane_b + tm_boff(s1, X1, Y1)] = xv[c][4];
             }
         }
         // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
@@ -890,7 +885,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     const int img = blockIdx.z; // slot*2 + side
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
     const TmScaleGeom s2 = g.s[2];
-    float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
+    float *xyb = XYB != nullptr ? XYB + (size_t)img * g.pyr : nullptr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
     float *xybb = XYBB != nullptr ? XYBB + (size_t)img * g.pyr_b : nullptr; // blocked copy instead of the transposed one
     const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
@@ -1239,17 +1234,20 @@ template <typename T> __device__ __forceinline__ TM_GLOBAL_AS T *tm_uniform_ptr(
     return (TM_GLOBAL_AS T *)v;
 }
 
+template <bool BLK = false>
 __device__ __forceinline__ float ld_row_u(const float *__restrict__ plane, unsigned xb, int row, int nrows, int pitch)
 {
     // xb = this lane's BYTE offset inside the row (a zero-extended 32-bit VGPR offset is what the
-    // scalar-base form of global_load takes)
+    // scalar-base form of global_load takes).  BLK: blocked plane (tm_geom.h), `pitch` = its column-block count cb and
+    // xb = ((x >> 4) * 1024 + (x & 15)) * 4
     const int rc = row < nrows ? row : nrows - 1;
-    TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(plane + (size_t)rc * pitch);
+    const size_t roff = BLK ? (size_t)(rc >> 6) * pitch * 1024 + (size_t)(rc & 63) * 16 : (size_t)rc * pitch;
+    TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(plane + roff);
     const float v = *(TM_GLOBAL_AS const float *)(rowp + xb);
     return row < nrows ? v : 0.0f;
 }
 
-template <int R, int W, bool TWO, bool COPY, bool NT = false>
+template <int R, int W, bool TWO, bool COPY, bool NT = false, bool BLK = false>
 __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, float *__restrict__ tile_copy,
                                                   const float *__restrict__ pa, const float *__restrict__ pb, unsigned x,
                                                   float *__restrict__ dst, float *__restrict__ dst_copy, int h, int pitch,
@@ -1266,16 +1264,16 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
     float wa[W], wb[TWO ? W : 1];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        wa[j] = j < P ? ld_row_u(pa, x, j, h, pitch) : 0.0f;
-        if (TWO) wb[j] = j < P ? ld_row_u(pb, x, j, h, pitch) : 0.0f;
+        wa[j] = j < P ? ld_row_u<BLK>(pa, x, j, h, pitch) : 0.0f;
+        if (TWO) wb[j] = j < P ? ld_row_u<BLK>(pb, x, j, h, pitch) : 0.0f;
     }
     tmdev::Iir f = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; ++t) { // no output row yet
         const float a = wa[t], aold = wa[(t + P) % W];
         const float b = TWO ? wb[t] : a, bold = TWO ? wb[(t + P) % W] : aold;
-        wa[(t + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
-        if (TWO) wb[(t + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+        wa[(t + P) % W] = ld_row_u<BLK>(pa, x, t + P, h, pitch);
+        if (TWO) wb[(t + P) % W] = ld_row_u<BLK>(pb, x, t + P, h, pitch);
         (void)tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
     }
     const int T = (h + U - 1) / U * U + 4;
@@ -1291,8 +1289,8 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
             const float a = wa[(j + 4) % W], aold = wa[(j + 4 + P) % W];
             const float b = TWO ? wb[(j + 4) % W] : a, bold = TWO ? wb[(j + 4 + P) % W] : aold;
             const float a4 = wa[j % W]; // input row t-4 == output row: its transposed copy rides along
-            wa[(j + 4 + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
-            if (TWO) wb[(j + 4 + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+            wa[(j + 4 + P) % W] = ld_row_u<BLK>(pa, x, t + P, h, pitch);
+            if (TWO) wb[(j + 4 + P) % W] = ld_row_u<BLK>(pb, x, t + P, h, pitch);
             const float o = tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
             tile[(j % R) * TT::S + lane] = o;
             if (COPY) tile_copy[(j % R) * TT::S + lane] = a4;
@@ -1376,7 +1374,7 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
     return j;
 }
 
-template <int R, int W>
+template <int R, int W, bool BLK = false>
 __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V,
                                                         int slot_major)
 {
@@ -1398,19 +1396,22 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
     }
     const int x0 = blk * 64;
     const int lane = threadIdx.x & 63;
-    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u;
+    // BLK: XYB is the blocked pyramid of ingest generation 3 (the only copy it writes)
+    const int xcol = min(x0 + lane, sg.w - 1);
+    const unsigned x = BLK ? (unsigned)((xcol >> 4) * 1024 + (xcol & 15)) * 4u : (unsigned)xcol * 4u;
     const int slot = slot_major ? blockIdx.x : blockIdx.z;
-    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const float *ref = BLK ? XYB + (size_t)(slot * 2 + 0) * g.pyr_b + sg.off_b + c * sg.plane_b : XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *dis = BLK ? XYB + (size_t)(slot * 2 + 1) * g.pyr_b + sg.off_b + c * sg.plane_b : XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const int in_pitch = BLK ? sg.cb : sg.pitch;
     const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
     float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
     float *tile = tiles + wave * R * TT::S;
     if (role == 2)
-        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, true, false, true, BLK>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
     else if (role < 2)
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, false, false, true, BLK>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
     else
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, false);
+        blur_v_split_role<R, W, false, false, true, BLK>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1561,9 +1562,7 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     // blocked planes that is one contiguous 256-B run (block e >> 4 of this row block, floats 64 * (e & 15) + lane); the three padding
     // blocks past the right edge make every prefetch legal without a test
     auto fetch = [&](const float *rowblock, int e) -> float { return rowblock[(size_t)(e >> 4) * 1024 + 64 * (e & 15) + lane]; };
-    // float 64 * (e & 15) + lane of a block = row pair 2 * (e & 15) + (lane >> 5), column pair (lane >> 2) & 7, row lane >> 1 & 1
-    // and column lane & 1 inside the quad
-    const int er = 2 * (lane >> 5) + ((lane >> 1) & 1), ec = 2 * ((lane >> 2) & 7) + (lane & 1);
+    const int er = lane >> 4, ec = lane & 15; // float 64 * (e & 15) + lane of a block = row 4 * (e & 15) + er, column ec
     auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + er][ec] = v; };
     // prologue: block 0 complete in LDS, elements 16 .. 16 + D - 1 in flight
     {
