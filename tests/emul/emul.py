@@ -33,12 +33,11 @@ def product_pow_tables():
 
 class ScaleGeom(C.Structure):
     _fields_ = [("w", C.c_int), ("h", C.c_int), ("pitch", C.c_int), ("pitch_t", C.c_int), ("plane", C.c_ulonglong),
-                ("plane_t", C.c_ulonglong), ("off", C.c_ulonglong), ("off_t", C.c_ulonglong), ("cb", C.c_int), ("rb", C.c_int),
-                ("plane_b", C.c_ulonglong), ("off_b", C.c_ulonglong)]
+                ("plane_t", C.c_ulonglong), ("off", C.c_ulonglong), ("off_t", C.c_ulonglong)]
 
 
 class Geom(C.Structure):
-    _fields_ = [("s", ScaleGeom * 6), ("pyr", C.c_ulonglong), ("pyr_t", C.c_ulonglong), ("pyr_b", C.c_ulonglong), ("vblk", C.c_int * 7), ("hblk", C.c_int * 7)]
+    _fields_ = [("s", ScaleGeom * 6), ("pyr", C.c_ulonglong), ("pyr_t", C.c_ulonglong), ("vblk", C.c_int * 7), ("hblk", C.c_int * 7)]
 
 
 class SsimGeom(C.Structure):

@@ -98,7 +98,6 @@ struct tm_engine {
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t ev_pipe[4] = {};
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr;
-    float *XYBB = nullptr; // blocked copy of the XYB pyramid (ingest generation 3 -> k_blur_h_jobs_x), allocated on first use
     float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_tile32 -> k_ingest_upper
     double *PART = nullptr, *SUMS = nullptr;
     unsigned long long *SSE = nullptr;
@@ -365,7 +364,7 @@ void tm_engine_destroy(tm_engine *e)
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
     for (int i = 0; i < 4; ++i) if (e->ev_pipe[i]) (void)hipEventDestroy(e->ev_pipe[i]);
     for (void *p : e->staging) if (p) (void)hipFree(p);
-    (void)hipFree(e->XYBB); (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
+    (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
     (void)hipFree(e->QU8); (void)hipFree(e->SPYR); (void)hipFree(e->SPART); (void)hipFree(e->SSUMS);
     if (e->h_ssums) (void)hipHostFree(e->h_ssums);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
@@ -434,11 +433,6 @@ int tm_engine_set_variant(tm_engine *e, int variant)
         int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
         if (rc) return rc;
     }
-    if ((variant >> 8 & 255) == 3 && !e->XYBB && (e->mask & TM_METRIC_SSIMULACRA2)) { // generation-3 ingest writes a blocked copy
-        if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
-        int rc = dev_alloc(e, &e->XYBB, (size_t)e->cap * 2 * e->g.pyr_b, true);
-        if (rc) return rc;
-    }
     e->variant = variant;
     return TM_OK;
 }
@@ -478,7 +472,6 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     const bool ssimu2 = (e->mask & TM_METRIC_SSIMULACRA2) != 0;
     float *XYB = ssimu2 ? e->XYB + (size_t)slot0 * 2 * g.pyr : nullptr, *XYBT = ssimu2 ? e->XYBT + (size_t)slot0 * 2 * g.pyr_t : nullptr;
     float *V = ssimu2 ? e->V + (size_t)slot0 * 5 * g.pyr_t : nullptr;
-    float *XYBB = e->XYBB ? e->XYBB + (size_t)slot0 * 2 * g.pyr_b : nullptr;
     float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
     float *LIN2 = ssimu2 ? e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane : nullptr;
     double *PART = ssimu2 ? e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6 : nullptr, *SUMS = ssimu2 ? e->SUMS + (size_t)slot0 * 108 : nullptr;
@@ -503,7 +496,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
         int kind = h_desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYBB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
+#define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
@@ -515,7 +508,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         }
 #undef TM_LAUNCH_W
         // levels 2..5; no transposed copy (the row pass k_blur_h_jobs_x transposes ref / dis itself)
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, (float *)nullptr, (float *)nullptr, XYBB);
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr);
     } else { // generation 2: 32x32 tiles, one quad per lane, LDS-staged stores
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
@@ -531,7 +524,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         default: TM_LAUNCH_T32(-1); break;
         }
 #undef TM_LAUNCH_T32
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT, (float *)nullptr);
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     if (ev_ingest_done) HIPCHK(hipEventRecord(ev_ingest_done, st));
@@ -549,15 +542,14 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
             case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 8: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 9: if ((e->variant >> 8 & 255) == 3) { hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYBB, V, sm); break; }
-                    hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm); break;
+            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
             }
         }
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
         if ((e->variant >> 8 & 255) == 3)
-            hipLaunchKernelGGL(tmk::k_blur_h_jobs_x, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBB, V, PART, sm);
+            hipLaunchKernelGGL(tmk::k_blur_h_jobs_x, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
         else hipLaunchKernelGGL(tmk::k_blur_h_jobs, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART, sm);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, e->jobs, PART, SUMS);
@@ -866,23 +858,12 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     case TM_PLANE_LINEAR:
     case TM_PLANE_XYB:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
-        if (kind == TM_PLANE_XYB && (e->variant >> 8 & 255) == 3) { // generation 3 keeps only the blocked copy: de-block on the host
-            if (!e->XYBB) return TM_ERR_STATE;
-            std::vector<float> blk((size_t)sg.plane_b);
-            HIPCHK(hipMemcpy(blk.data(), e->XYBB + (size_t)(slot * 2 + index) * g.pyr_b + sg.off_b + channel * sg.plane_b,
-                             blk.size() * sizeof(float), hipMemcpyDeviceToHost));
-            for (int y = 0; y < sg.h; ++y)
-                for (int x = 0; x < sg.w; ++x)
-                    out[(size_t)y * sg.w + x] = blk[((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)((y & 63) * 16 + (x & 15))];
-            return TM_OK;
-        }
         if (kind == TM_PLANE_LINEAR && (!e->LIN || (e->variant >> 8 & 255) != 0)) return TM_ERR_STATE; // only the gen-0 ingest stores it
         src = (kind == TM_PLANE_LINEAR ? e->LIN : e->XYB) + (size_t)(slot * 2 + index) * g.pyr + sg.off + channel * sg.plane;
         pitch = sg.pitch; width = sg.w; rows = sg.h;
         break;
     case TM_PLANE_XYB_T:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
-        if ((e->variant >> 8 & 255) == 3) return TM_ERR_STATE; // no transposed copy in generation 3
         src = e->XYBT + (size_t)(slot * 2 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
         pitch = sg.pitch_t; width = sg.h; rows = sg.w;
         break;

@@ -27,22 +27,12 @@ struct TmScaleGeom {
     unsigned long long plane_t; // round_up(w,64) * pitch_t
     unsigned long long off;     // float offset of this scale inside a normal pyramid
     unsigned long long off_t;   // float offset inside a transposed pyramid
-    // "blocked" orientation (ingest generation 3, the only XYB copy it writes): blocks of 64 rows x 16 columns stored
-    // contiguously (4 KB, rows of 64 B).  Element (x, y) at ((y >> 6) * cb + (x >> 4)) * 1024 + (y & 63) * 16 + (x & 15).
-    // One layout serves all three users: the ingest kernel stores 4 columns x 1 row per lane (8 lanes = two rows of a block
-    // = one 128-B line), the column pass reads 64 consecutive columns of a row as four 64-B runs whose other half is the
-    // next row (the same wave, one step later), the row pass fetches 4 rows x 16 columns as one 256-B run.  cb includes
-    // three padding blocks so that the row pass may prefetch past the right edge without a test.
-    int cb, rb;
-    unsigned long long plane_b; // rb * cb * 1024
-    unsigned long long off_b;   // float offset inside a blocked pyramid
 };
 
 struct TmGeom {
     TmScaleGeom s[TM_SCALES];
     unsigned long long pyr;   // floats per normal pyramid     (sum over scales of 3*plane)
     unsigned long long pyr_t; // floats per transposed pyramid (sum over scales of 3*plane_t)
-    unsigned long long pyr_b; // floats per blocked pyramid
     int vblk[TM_SCALES + 1];  // prefix sums: 64-column blocks of the column pass, per (slot, channel)
     int hblk[TM_SCALES + 1];  // prefix sums: 64-row blocks of the row pass, per (slot, channel)
 };
@@ -83,7 +73,7 @@ static inline int tm_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static inline void tm_make_geom(TmGeom *g, int w, int h)
 {
-    unsigned long long off = 0, off_t = 0, off_b = 0;
+    unsigned long long off = 0, off_t = 0;
     g->vblk[0] = 0;
     g->hblk[0] = 0;
     for (int i = 0; i < TM_SCALES; ++i) {
@@ -95,15 +85,12 @@ static inline void tm_make_geom(TmGeom *g, int w, int h)
         s->plane_t = (unsigned long long)tm_round_up(w, 64) * s->pitch_t; // rows padded: see blur_v_flush
         s->off = off; s->off_t = off_t;
         off += 3 * s->plane; off_t += 3 * s->plane_t;
-        s->cb = (w + 15) / 16 + 3; s->rb = (h + 63) / 64;
-        s->plane_b = (unsigned long long)s->rb * s->cb * 1024;
-        s->off_b = off_b; off_b += 3 * s->plane_b;
         g->vblk[i + 1] = g->vblk[i] + (w + 63) / 64;
         g->hblk[i + 1] = g->hblk[i] + (h + 63) / 64;
         // scale sizes: ssimulacra2-cuda/src/lib.rs:62-66
         w = (w + 1) / 2; h = (h + 1) / 2;
     }
-    g->pyr = off; g->pyr_t = off_t; g->pyr_b = off_b;
+    g->pyr = off; g->pyr_t = off_t;
 }
 
 // weights: the reference's table [channel][scale][ssim1, art1, det1, ssim4, art4, det4]

@@ -523,25 +523,15 @@ __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, co
     }
 }
 
-// float offset of (x, y) inside a blocked plane (tm_geom.h)
-__device__ __forceinline__ size_t tm_boff(const TmScaleGeom &sg, int x, int y)
-{
-    return ((size_t)(y >> 6) * sg.cb + (x >> 4)) * 1024 + (size_t)((y & 63) * 16 + (x & 15));
-}
-
 __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__restrict__ xybt, const TmScaleGeom &sg,
-                                             int X, int Y, const float (&lin)[3], float *__restrict__ xybb = nullptr)
+                                             int X, int Y, const float (&lin)[3])
 {
     if (X < sg.w && Y < sg.h) {
         float a, b, c;
         tmdev::linear_to_xyb(lin[0], lin[1], lin[2], a, b, c);
         const size_t o = sg.off + (size_t)Y * sg.pitch + X, ot = sg.off_t + (size_t)X * sg.pitch_t + Y;
-        if (xyb != nullptr) { xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c; }
+        xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c;
         if (xybt != nullptr) { xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c; }
-        if (xybb != nullptr) {
-            const size_t ob = sg.off_b + tm_boff(sg, X, Y);
-            xybb[ob] = a; xybb[ob + sg.plane_b] = b; xybb[ob + 2 * sg.plane_b] = c;
-        }
     }
 }
 
@@ -562,7 +552,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
         const int r = tid >> 3, q4 = (tid & 7) * 4;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (xyb != nullptr && ty0 + r < sa.h && tx0 + q4 < sa.w)
+            if (ty0 + r < sa.h && tx0 + q4 < sa.w)
                 *(float4 *)(xyb + sa.off + c * sa.plane + (size_t)(ty0 + r) * sa.pitch + tx0 + q4) =
                     make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
             if (xybt != nullptr && tx0 + r < sa.w && ty0 + q4 < sa.h)
@@ -573,7 +563,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
     if (tid < 192) {
         const int c = tid >> 6, r = (tid & 63) >> 2, q4 = (tid & 3) * 4;
         const int x1 = tx0 / 2, y1 = ty0 / 2;
-        if (xyb != nullptr && y1 + r < sb.h && x1 + q4 < sb.w)
+        if (y1 + r < sb.h && x1 + q4 < sb.w)
             *(float4 *)(xyb + sb.off + c * sb.plane + (size_t)(y1 + r) * sb.pitch + x1 + q4) =
                 make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
         if (xybt != nullptr && x1 + r < sb.w && y1 + q4 < sb.h)
@@ -753,9 +743,8 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
 template <int KIND>
 __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
-                                                    const float *__restrict__ yuvlut, float *__restrict__ XYBB,
-                                                    float *__restrict__ LIN2,
-                                                    unsigned long long *__restrict__ SSE, int want_sse,
+                                                    const float *__restrict__ yuvlut, float *__restrict__ XYB,
+                                                    float *__restrict__ LIN2, unsigned long long *__restrict__ SSE, int want_sse,
                                                     unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch)
 {
     __shared__ double tab[96];
@@ -815,8 +804,8 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
                         *(unsigned short *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(Y0 + iy) * qpitch + X0) = (unsigned short)(q0 | (q1 << 8));
                     }
         }
-        if (XYBB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
-        float *xybb = XYBB + (size_t)(slot * 2 + side) * g.pyr_b;
+        if (XYB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
+        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
         const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
         float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
 #pragma unroll
@@ -825,22 +814,17 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
         lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
         lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
         tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
-        // ---- level 0.  A lane holds a 2 x 2 quad; neighbouring lanes swap one row so that the even lane owns 4 columns of the
-        // upper row and the odd lane 4 columns of the lower row: one float4 each, and 8 lanes (two 64-B rows of a block) fill
-        // a 128-B line of the blocked plane.  Level 1: one pixel per lane, 16 lanes = one 64-B block row.
+        // ---- level 0: two rows of two pixels; level 1: one pixel
         {
             const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
             const float *xv[3] = {xa, xb, xc};
-            const bool odd = qx & 1;
-            const int xs = odd ? X0 - 2 : X0, ys = odd ? Y0 + 1 : Y0;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float g0 = tm_shfl_xor(odd ? xv[c][0] : xv[c][2], 1), g1 = tm_shfl_xor(odd ? xv[c][1] : xv[c][3], 1);
-                if (xs < w && ys < h) // columns past the image inside the float4 land in the block's own padding
-                    *(float4 *)(xybb + s0.off_b + c * s0.plane_b + tm_boff(s0, xs, ys)) =
-                        odd ? make_float4(g0, g1, xv[c][2], xv[c][3]) : make_float4(xv[c][0], xv[c][1], g0, g1);
-                const int X1 = X0 / 2, Y1 = Y0 / 2;
-                if (X1 < s1.w && Y1 < s1.h) xybb[s1.off_b + c * s1.plane_b + tm_boff(s1, X1, Y1)] = xv[c][4];
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+                    if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
+                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
+                if (X0 / 2 < s1.w && Y0 / 2 < s1.h) xyb[s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2] = xv[c][4];
             }
         }
         // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
@@ -877,7 +861,7 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
 // Workgroup = 32x32 tile of level 2 (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad.
 // grid (ceil(w2/32), ceil(h2/32), slots*2), block 256.
 __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB,
-                                                      float *__restrict__ XYBT, float *__restrict__ XYBB)
+                                                      float *__restrict__ XYBT)
 {
     __shared__ IngestSideLds L; // t0: level-2 XYB tile, t1: level-3 XYB tile, lin1: level-3 linear RGB
     __shared__ float lin4[3][8][9];
@@ -885,8 +869,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     const int img = blockIdx.z; // slot*2 + side
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
     const TmScaleGeom s2 = g.s[2];
-    float *xyb = XYB != nullptr ? XYB + (size_t)img * g.pyr : nullptr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
-    float *xybb = XYBB != nullptr ? XYBB + (size_t)img * g.pyr_b : nullptr; // blocked copy instead of the transposed one
+    float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
     const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     {
@@ -915,18 +898,6 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     }
     TM_LDS_BARRIER();
     store_tiles_both(L, s2, g.s[3], xyb, xybt, tx0, ty0, tid);
-    if (xybb != nullptr) { // levels 2 and 3 are 1/16 and 1/64 of the pixels: plain per-pixel stores
-        const TmScaleGeom s3 = g.s[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x = X0 + (k & 1), y = Y0 + (k >> 1);
-                if (x < s2.w && y < s2.h) xybb[s2.off_b + c * s2.plane_b + tm_boff(s2, x, y)] = L.t0[c][2 * qy + (k >> 1)][2 * qx + (k & 1)];
-            }
-            if (X0 / 2 < s3.w && Y0 / 2 < s3.h) xybb[s3.off_b + c * s3.plane_b + tm_boff(s3, X0 / 2, Y0 / 2)] = L.t1[c][qy][qx];
-        }
-    }
     if (tid < 64) { // level 4: 8x8 per tile
         const TmScaleGeom s3 = g.s[3];
         const int ox = tid & 7, oy = tid >> 3;
@@ -938,7 +909,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
             v[c] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox], L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
             lin4[c][oy][ox] = v[c];
         }
-        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v, xybb);
+        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v);
     }
     TM_LDS_BARRIER();
     if (tid < 16) { // level 5: 4x4 per tile
@@ -950,7 +921,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             v[c] = ds4(lin4[c][2 * oy][2 * ox], lin4[c][2 * oy][2 * ox + 1], lin4[c][2 * oy + 1][2 * ox], lin4[c][2 * oy + 1][2 * ox + 1], okx, oky);
-        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v, xybb);
+        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v);
     }
 }
 
@@ -1234,20 +1205,17 @@ template <typename T> __device__ __forceinline__ TM_GLOBAL_AS T *tm_uniform_ptr(
     return (TM_GLOBAL_AS T *)v;
 }
 
-template <bool BLK = false>
 __device__ __forceinline__ float ld_row_u(const float *__restrict__ plane, unsigned xb, int row, int nrows, int pitch)
 {
     // xb = this lane's BYTE offset inside the row (a zero-extended 32-bit VGPR offset is what the
-    // scalar-base form of global_load takes).  BLK: blocked plane (tm_geom.h), `pitch` = its column-block count cb and
-    // xb = ((x >> 4) * 1024 + (x & 15)) * 4
+    // scalar-base form of global_load takes)
     const int rc = row < nrows ? row : nrows - 1;
-    const size_t roff = BLK ? (size_t)(rc >> 6) * pitch * 1024 + (size_t)(rc & 63) * 16 : (size_t)rc * pitch;
-    TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(plane + roff);
+    TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(plane + (size_t)rc * pitch);
     const float v = *(TM_GLOBAL_AS const float *)(rowp + xb);
     return row < nrows ? v : 0.0f;
 }
 
-template <int R, int W, bool TWO, bool COPY, bool NT = false, bool BLK = false>
+template <int R, int W, bool TWO, bool COPY, bool NT = false>
 __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, float *__restrict__ tile_copy,
                                                   const float *__restrict__ pa, const float *__restrict__ pb, unsigned x,
                                                   float *__restrict__ dst, float *__restrict__ dst_copy, int h, int pitch,
@@ -1264,16 +1232,16 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
     float wa[W], wb[TWO ? W : 1];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        wa[j] = j < P ? ld_row_u<BLK>(pa, x, j, h, pitch) : 0.0f;
-        if (TWO) wb[j] = j < P ? ld_row_u<BLK>(pb, x, j, h, pitch) : 0.0f;
+        wa[j] = j < P ? ld_row_u(pa, x, j, h, pitch) : 0.0f;
+        if (TWO) wb[j] = j < P ? ld_row_u(pb, x, j, h, pitch) : 0.0f;
     }
     tmdev::Iir f = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; ++t) { // no output row yet
         const float a = wa[t], aold = wa[(t + P) % W];
         const float b = TWO ? wb[t] : a, bold = TWO ? wb[(t + P) % W] : aold;
-        wa[(t + P) % W] = ld_row_u<BLK>(pa, x, t + P, h, pitch);
-        if (TWO) wb[(t + P) % W] = ld_row_u<BLK>(pb, x, t + P, h, pitch);
+        wa[(t + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
+        if (TWO) wb[(t + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
         (void)tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
     }
     const int T = (h + U - 1) / U * U + 4;
@@ -1289,8 +1257,8 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
             const float a = wa[(j + 4) % W], aold = wa[(j + 4 + P) % W];
             const float b = TWO ? wb[(j + 4) % W] : a, bold = TWO ? wb[(j + 4 + P) % W] : aold;
             const float a4 = wa[j % W]; // input row t-4 == output row: its transposed copy rides along
-            wa[(j + 4 + P) % W] = ld_row_u<BLK>(pa, x, t + P, h, pitch);
-            if (TWO) wb[(j + 4 + P) % W] = ld_row_u<BLK>(pb, x, t + P, h, pitch);
+            wa[(j + 4 + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
+            if (TWO) wb[(j + 4 + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
             const float o = tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
             tile[(j % R) * TT::S + lane] = o;
             if (COPY) tile_copy[(j % R) * TT::S + lane] = a4;
@@ -1374,7 +1342,7 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
     return j;
 }
 
-template <int R, int W, bool BLK = false>
+template <int R, int W>
 __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V,
                                                         int slot_major)
 {
@@ -1396,22 +1364,19 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
     }
     const int x0 = blk * 64;
     const int lane = threadIdx.x & 63;
-    // BLK: XYB is the blocked pyramid of ingest generation 3 (the only copy it writes)
-    const int xcol = min(x0 + lane, sg.w - 1);
-    const unsigned x = BLK ? (unsigned)((xcol >> 4) * 1024 + (xcol & 15)) * 4u : (unsigned)xcol * 4u;
+    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u;
     const int slot = slot_major ? blockIdx.x : blockIdx.z;
-    const float *ref = BLK ? XYB + (size_t)(slot * 2 + 0) * g.pyr_b + sg.off_b + c * sg.plane_b : XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *dis = BLK ? XYB + (size_t)(slot * 2 + 1) * g.pyr_b + sg.off_b + c * sg.plane_b : XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
-    const int in_pitch = BLK ? sg.cb : sg.pitch;
+    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
     const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
     float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
     float *tile = tiles + wave * R * TT::S;
     if (role == 2)
-        blur_v_split_role<R, W, true, false, true, BLK>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
     else if (role < 2)
-        blur_v_split_role<R, W, false, false, true, BLK>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
     else
-        blur_v_split_role<R, W, false, false, true, BLK>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, false);
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1526,10 +1491,8 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const
 // ------------------------------------------------------------------------------------------------
 // Row pass without a transposed XYB copy ("x" = transposes ref / dis itself).  The blurred planes still come from the
 // transposed V arena (lanes = consecutive y: coalesced); the two edge-term inputs ref(x, y), dis(x, y) are read from the
-// BLOCKED planes the generation-3 ingest writes (tm_geom.h: 64 rows x 16 columns per 4-KB block): one load fetches 4 rows x
-// 16 columns = one contiguous 256-B run, 16 loads make a block, which goes through a double-buffered [64][17] LDS tile per
-// plane and is read back one column per step, one row per lane.  (Reading the normal planes in 64-B runs instead fetched
-// every line twice from HBM: +2 GB per 32 pairs.)
+// NORMAL planes in blocks of 16 columns: one load fetches 4 rows x 16 columns (64-B runs), 16 loads make a 64 x 16 block,
+// which goes through a double-buffered [64][17] LDS tile per plane and is read back one column per step, one row per lane.
 // Loads run D steps ahead of their LDS write and a whole block ahead of their use: element e = 16 * block + row group is
 // requested at step u = e - 16 - D, written at u = e - 16, consumed during steps 16 * block .. + 15 (u = t - 4 = the column
 // whose maps are evaluated at step t).  Everything stays inside the wave: LDS operations of one wave execute in order.
@@ -1539,14 +1502,15 @@ template <bool FULL, int WN, int D>
 __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][17], const float *__restrict__ refn,
                                              const float *__restrict__ disn, const float *__restrict__ v0,
                                              const float *__restrict__ v1, const float *__restrict__ v2,
-                                             const float *__restrict__ v3, const float *__restrict__ v4, int w, int pt, bool valid,
-                                             double (&acc)[6])
+                                             const float *__restrict__ v3, const float *__restrict__ v4, int y0, int w, int h,
+                                             int pitch, int pt, bool valid, double (&acc)[6])
 {
-    // refn, disn: first block of this wave's row block in the BLOCKED planes; v0..v4: transposed planes + this lane's row
+    // refn, disn: normal planes of this channel (row y at y * pitch); v0..v4: transposed planes + this lane's row
     static_assert(WN % D == 0 && D <= 16, "queue depth");
     constexpr int P = WN - 10; // load distance of the blurred planes, in rows of the transposed arena
     constexpr int NF = FULL ? WN : 1;
     const int lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
     float w0[NF], w1[NF], w2[NF], w3[WN], w4[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -1558,12 +1522,13 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
             w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
         }
     }
-    // element e of the ref / dis stream = rows 4 * (e & 15) .. + 3 of this row block, columns 16 * (e >> 4) .. + 15: in the
-    // blocked planes that is one contiguous 256-B run (block e >> 4 of this row block, floats 64 * (e & 15) + lane); the three padding
-    // blocks past the right edge make every prefetch legal without a test
-    auto fetch = [&](const float *rowblock, int e) -> float { return rowblock[(size_t)(e >> 4) * 1024 + 64 * (e & 15) + lane]; };
-    const int er = lane >> 4, ec = lane & 15; // float 64 * (e & 15) + lane of a block = row 4 * (e & 15) + er, column ec
-    auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + er][ec] = v; };
+    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, column 16 * (e >> 4) + lc
+    auto fetch = [&](const float *plane, int e) -> float {
+        const int x = 16 * (e >> 4) + lc, y = y0 + 4 * (e & 15) + lr;
+        const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
+        return plane[(size_t)yc * pitch + xc];
+    };
+    auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + lr][lc] = v; };
     // prologue: block 0 complete in LDS, elements 16 .. 16 + D - 1 in flight
     {
         float a[16], b[16];
@@ -1620,7 +1585,7 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     }
 }
 
-__global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYBB,
+__global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
                                                       const float *__restrict__ V, double *__restrict__ PART, int slot_major)
 {
     __shared__ float tile[2][2][64][17];
@@ -1634,17 +1599,16 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     const int yy = valid ? y : sg.h - 1;
     const int slot = slot_major ? blockIdx.x : blockIdx.z;
     const size_t to = sg.off_t + c * sg.plane_t + yy;
-    const size_t rbo = sg.off_b + c * sg.plane_b + (size_t)(y0 >> 6) * sg.cb * 1024; // this wave's row block
-    const float *refn = XYBB + (size_t)(slot * 2 + 0) * g.pyr_b + rbo;
-    const float *disn = XYBB + (size_t)(slot * 2 + 1) * g.pyr_b + rbo;
+    const float *refn = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *disn = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
     const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to;
     const float *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to;
     const float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
     const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
     const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6>(tile, refn, disn, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
-    else blur_h_job_x<false, 16, 8>(tile, refn, disn, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
+    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    else blur_h_job_x<false, 16, 8>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
         __shared__ double redl[6][64];
