@@ -157,8 +157,7 @@ def main():
         # (= 84 B/px summed over the 6 scales) when all five blurred planes of every channel are computed (full_sums).
         # With the zero-weight sums skipped a (scale, channel) image costs 7 (all maps), 4 (edge terms only: mu1, mu2 +
         # ref, dis) or 0 f32 per pixel and pass -- `job_bytes` is what THIS configuration must move.
-        # Ingest reads the two surfaces and writes the planar XYB pyramid once (24 B/px; the kernel additionally writes a
-        # transposed copy, which shows up in `traffic`, not here).
+        # Ingest reads the two surfaces and writes the planar XYB pyramid once (24 B/px for the two sides).
         sizes, ww, hh = [], w, h
         for _ in range(6):
             sizes.append(ww * hh)
@@ -173,12 +172,12 @@ def main():
 
         traffic = load_pmc_traffic(args.workload, B, args.full_sums)
         per_kernel = {
-            "k_ingest_tile32": roof(stage_ms[tm.ffi.TM_STAGE_INGEST], (in_bytes + 24 * spx) * B),
+            "k_ingest_wave": roof(stage_ms[tm.ffi.TM_STAGE_INGEST], (in_bytes + 24 * spx) * B),
             "k_blur_v_jobs": roof(stage_ms[tm.ffi.TM_STAGE_BLUR_V], job_bytes * B),
             "k_blur_h_jobs": roof(stage_ms[tm.ffi.TM_STAGE_BLUR_H], job_bytes * B),
         }
         for name in per_kernel:
-            per_kernel[name]["traffic"] = traffic.get(name)
+            per_kernel[name]["traffic"] = traffic.get(name if name != "k_blur_h_jobs" else "k_blur_h_jobs_x", traffic.get(name))
         dom = max(("k_blur_v_jobs", "k_blur_h_jobs"), key=lambda k: per_kernel[k]["avg_launch_ms"])
         ms_v, ms_h = per_kernel["k_blur_v_jobs"]["avg_launch_ms"], per_kernel["k_blur_h_jobs"]["avg_launch_ms"]
         stage_ach = 2 * job_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0

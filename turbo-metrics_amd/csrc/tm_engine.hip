@@ -116,7 +116,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = (2 << 8) | 9; // tile32 fused ingest + job-driven split column pass, non-temporal stores
+    int variant = (3 << 8) | 9; // wave ingest (no transposed copy) + job-driven split column pass + transposing row pass
 };
 
 namespace {
@@ -312,7 +312,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (metrics_mask & TM_METRIC_SSIMULACRA2) { // PSNR / SSIM / MS-SSIM alone need none of the XYB machinery
         if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->LIN2, B * 2 * 3 * g.s[2].plane, true))) return fail(rc);
-        if ((rc = dev_alloc(e, &e->XYBT, B * 2 * g.pyr_t, true))) return fail(rc);
+        // XYBT (the transposed copy) is only written by ingest generations 0-2: allocated when such a variant is selected
         if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
@@ -428,6 +428,11 @@ int tm_engine_set_variant(tm_engine *e, int variant)
     if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 write the u8 planes
     if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 can run without the XYB arenas
     if ((variant >> 8 & 255) == 3 && (variant & 255) != 9) return TM_ERR_INVALID_ARG; // no transposed XYB copy: needs the job-driven column pass
+    if ((variant >> 8 & 255) < 3 && !e->XYBT && (e->mask & TM_METRIC_SSIMULACRA2)) { // generations 0-2 write a transposed XYB copy
+        if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+        int rc = dev_alloc(e, &e->XYBT, (size_t)e->cap * 2 * e->g.pyr_t, true);
+        if (rc) return rc;
+    }
     if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
         int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
@@ -470,7 +475,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     const TmFrameDesc *h_desc = e->h_desc + (size_t)slot0 * 2;
     const TmFrameDesc *d_desc = e->d_desc + (size_t)slot0 * 2;
     const bool ssimu2 = (e->mask & TM_METRIC_SSIMULACRA2) != 0;
-    float *XYB = ssimu2 ? e->XYB + (size_t)slot0 * 2 * g.pyr : nullptr, *XYBT = ssimu2 ? e->XYBT + (size_t)slot0 * 2 * g.pyr_t : nullptr;
+    float *XYB = ssimu2 ? e->XYB + (size_t)slot0 * 2 * g.pyr : nullptr, *XYBT = (ssimu2 && e->XYBT) ? e->XYBT + (size_t)slot0 * 2 * g.pyr_t : nullptr;
     float *V = ssimu2 ? e->V + (size_t)slot0 * 5 * g.pyr_t : nullptr;
     float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
     float *LIN2 = ssimu2 ? e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane : nullptr;
@@ -864,6 +869,7 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
         break;
     case TM_PLANE_XYB_T:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
+        if ((e->variant >> 8 & 255) == 3 || !e->XYBT) return TM_ERR_STATE; // ingest generation 3 writes no transposed copy
         src = e->XYBT + (size_t)(slot * 2 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
         pitch = sg.pitch_t; width = sg.h; rows = sg.w;
         break;
