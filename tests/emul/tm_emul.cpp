@@ -159,16 +159,21 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
     } else if (ingest_gen == 1) {
         launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, tab, XYB, XYBT, SSE, want_sse); });
-    } else if (ingest_gen == 3) {
+    } else if (ingest_gen >= 3) {
+        const bool rd = ingest_gen == 4;
         std::vector<float> yuvlut((size_t)3 * 2 * 65536);
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
         launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
         launch_wave_lockstep(dim3((w + 31) / 32, (h + 7) / 8, n), [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
-          switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
-        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr); });
+          if (rd) switch (kind) {
+          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          default: tmk::k_ingest_wave<-1, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; }
+          else switch (kind) {
+          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+          default: tmk::k_ingest_wave<-1, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
+        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr, rd ? 1 : 0); });
     } else {
         std::vector<float> yuvlut((size_t)3 * 2 * 65536);
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
@@ -178,7 +183,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
           case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
           case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
           default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
-        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, XYBT); });
+        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, XYBT, 0); });
     }
     const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
     switch (variant) {
@@ -190,14 +195,23 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     case 6: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, true>(g, XYB, XYBT, V); }, 5); break;
     case 7: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false>(g, XYB, XYBT, V); }, 5); break;
     case 8: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false, true>(g, XYB, XYBT, V); }, 5); break;
-    case 9: launch_wave_lockstep(dim3(jobs.vstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 0); }, 5); break;
-    case 10: launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 1); }, 5); break;
+    case 9: launch_wave_lockstep(dim3(jobs.vstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 0, ingest_gen == 4); }, 5); break;
+    case 10: launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 1, 0); }, 5); break;
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
-    if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x(g, jobs, XYB, V, PART, 0); });
+    if (ingest_gen == 4) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true>(g, jobs, XYB, V, PART, 0); });
+    else if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<false>(g, jobs, XYB, V, PART, 0); });
     else if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
     else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });
+    if (ingest_gen == 4) { // test convenience: turn the interleaved pyramid back into two plain ones for the plane checks
+        std::vector<float> tmp((size_t)2 * g.pyr);
+        for (int sl = 0; sl < n; ++sl) {
+            float *base = XYB + (size_t)sl * 2 * g.pyr;
+            for (size_t i = 0; i < g.pyr; ++i) { tmp[i] = base[2 * i]; tmp[g.pyr + i] = base[2 * i + 1]; }
+            for (size_t i = 0; i < 2 * g.pyr; ++i) base[i] = tmp[i];
+        }
+    }
 }
 
 size_t emul_ssim_geom_size(void) { return sizeof(TmSsimGeom); }

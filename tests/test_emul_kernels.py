@@ -143,9 +143,11 @@ def test_ssim_kernels_match_oracle(w, h, streamed):
         assert (a == b) or (np.isnan(a) and np.isnan(b))   # NaN below 176x176
 
 
+@pytest.mark.parametrize("gen", [3, 4])
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (200, 9)])
-def test_wave_ingest_and_transposing_row_pass_match_oracle(w, h):
-    """ingest generation 3 (no LDS, no transposed XYB copy) + k_blur_h_jobs_x (the row pass transposes ref / dis itself)"""
+def test_wave_ingest_and_transposing_row_pass_match_oracle(w, h, gen):
+    """ingest generation 3 (no LDS, no transposed XYB copy) + k_blur_h_jobs_x (the row pass transposes ref / dis itself);
+    generation 4: the same with ref and dis interleaved in one plane"""
     frames = []
     for n in range(2):
         (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
@@ -153,10 +155,10 @@ def test_wave_ingest_and_transposing_row_pass_match_oracle(w, h):
                        dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
     r8, d8 = tm.synth.rgb8_pair(w, h)
     frames.append((dict(kind="rgb8", data=r8), dict(kind="rgb8", data=d8)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=3 * 256 + 9, weights=O.weights(), full_sums=True,
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=True,
                     ssim_window=O.ssim_window() if min(w, h) >= 11 else None)
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
-    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=3 * 256 + 9, weights=O.weights(), full_sums=False)
+    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=False)
     m = weight_mask()
     for slot in range(len(frames)):
         assert np.array_equal(em.sums(slot)[m], pr.sums(slot)[m])

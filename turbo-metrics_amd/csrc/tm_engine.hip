@@ -423,11 +423,11 @@ int tm_engine_set_variant(tm_engine *e, int variant)
 {
     // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
     // dispatch order of the two blur passes (default: slot-major), bit 21: LDS-tiled SSIM statistics kernel (default: streaming)
-    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 3 || (variant >> 22) != 0) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 22) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 write the u8 planes
     if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 can run without the XYB arenas
-    if ((variant >> 8 & 255) == 3 && (variant & 255) != 9) return TM_ERR_INVALID_ARG; // no transposed XYB copy: needs the job-driven column pass
+    if ((variant >> 8 & 255) >= 3 && (variant & 255) != 9) return TM_ERR_INVALID_ARG; // no transposed XYB copy: needs the job-driven column pass
     if ((variant >> 8 & 255) < 3 && !e->XYBT && (e->mask & TM_METRIC_SSIMULACRA2)) { // generations 0-2 write a transposed XYB copy
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
         int rc = dev_alloc(e, &e->XYBT, (size_t)e->cap * 2 * e->g.pyr_t, true);
@@ -497,11 +497,15 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     } else if ((e->variant >> 8 & 255) == 1) { // generation 1: one kernel, 64x64 tiles, 4x4 pixels per lane
         dim3 grid((unsigned)((e->w + 63) / 64), (unsigned)((e->h + 63) / 64), (unsigned)n);
         hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, XYB, XYBT, SSE, want_sse);
-    } else if ((e->variant >> 8 & 255) == 3) { // generation 3 (experiment): wave-private tiles, no LDS, no transposed copy
+    } else if ((e->variant >> 8 & 255) >= 3) {
+        // generation 3: wave-private tiles, no LDS tile, no transposed copy; generation 4: the same with ref and dis
+        // interleaved in one plane (the XYB arena is then read as [slot][scale][channel][y][x][side])
+        const bool rd = (e->variant >> 8 & 255) == 4;
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
         int kind = h_desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
+#define TM_LAUNCH_W(K) do { if (rd) hipLaunchKernelGGL((tmk::k_ingest_wave<K, true>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); \
+                        else hipLaunchKernelGGL((tmk::k_ingest_wave<K, false>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); } while (0)
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
@@ -513,7 +517,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         }
 #undef TM_LAUNCH_W
         // levels 2..5; no transposed copy (the row pass k_blur_h_jobs_x transposes ref / dis itself)
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr);
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr, rd ? 1 : 0);
     } else { // generation 2: 32x32 tiles, one quad per lane, LDS-staged stores
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
@@ -529,7 +533,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         default: TM_LAUNCH_T32(-1); break;
         }
 #undef TM_LAUNCH_T32
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT);
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT, 0);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     if (ev_ingest_done) HIPCHK(hipEventRecord(ev_ingest_done, st));
@@ -547,14 +551,16 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
             case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 8: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm); break;
+            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm, (e->variant >> 8 & 255) == 4 ? 1 : 0); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
             }
         }
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
-        if ((e->variant >> 8 & 255) == 3)
-            hipLaunchKernelGGL(tmk::k_blur_h_jobs_x, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
+        if ((e->variant >> 8 & 255) == 4)
+            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
+        else if ((e->variant >> 8 & 255) == 3)
+            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<false>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
         else hipLaunchKernelGGL(tmk::k_blur_h_jobs, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART, sm);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, e->jobs, PART, SUMS);
@@ -863,13 +869,20 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     case TM_PLANE_LINEAR:
     case TM_PLANE_XYB:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
+        if (kind == TM_PLANE_XYB && (e->variant >> 8 & 255) == 4) { // ref/dis-interleaved pyramid: de-interleave on the host
+            std::vector<float> rows((size_t)sg.h * sg.pitch * 2);
+            HIPCHK(hipMemcpy(rows.data(), e->XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + channel * sg.plane), rows.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (int y = 0; y < sg.h; ++y)
+                for (int x = 0; x < sg.w; ++x) out[(size_t)y * sg.w + x] = rows[2 * ((size_t)y * sg.pitch + x) + index];
+            return TM_OK;
+        }
         if (kind == TM_PLANE_LINEAR && (!e->LIN || (e->variant >> 8 & 255) != 0)) return TM_ERR_STATE; // only the gen-0 ingest stores it
         src = (kind == TM_PLANE_LINEAR ? e->LIN : e->XYB) + (size_t)(slot * 2 + index) * g.pyr + sg.off + channel * sg.plane;
         pitch = sg.pitch; width = sg.w; rows = sg.h;
         break;
     case TM_PLANE_XYB_T:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
-        if ((e->variant >> 8 & 255) == 3 || !e->XYBT) return TM_ERR_STATE; // ingest generation 3 writes no transposed copy
+        if ((e->variant >> 8 & 255) >= 3 || !e->XYBT) return TM_ERR_STATE; // ingest generations 3, 4 write no transposed copy
         src = e->XYBT + (size_t)(slot * 2 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
         pitch = sg.pitch_t; width = sg.h; rows = sg.w;
         break;

@@ -524,14 +524,15 @@ __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, co
 }
 
 __device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__restrict__ xybt, const TmScaleGeom &sg,
-                                             int X, int Y, const float (&lin)[3])
+                                             int X, int Y, const float (&lin)[3], float *__restrict__ xi = nullptr)
 {
     if (X < sg.w && Y < sg.h) {
         float a, b, c;
         tmdev::linear_to_xyb(lin[0], lin[1], lin[2], a, b, c);
         const size_t o = sg.off + (size_t)Y * sg.pitch + X, ot = sg.off_t + (size_t)X * sg.pitch_t + Y;
-        xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c;
+        if (xyb != nullptr) { xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c; }
         if (xybt != nullptr) { xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c; }
+        if (xi != nullptr) { xi[2 * o] = a; xi[2 * (o + sg.plane)] = b; xi[2 * (o + 2 * sg.plane)] = c; } // interleaved pyramid, this side's lane
     }
 }
 
@@ -552,7 +553,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
         const int r = tid >> 3, q4 = (tid & 7) * 4;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (ty0 + r < sa.h && tx0 + q4 < sa.w)
+            if (xyb != nullptr && ty0 + r < sa.h && tx0 + q4 < sa.w)
                 *(float4 *)(xyb + sa.off + c * sa.plane + (size_t)(ty0 + r) * sa.pitch + tx0 + q4) =
                     make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
             if (xybt != nullptr && tx0 + r < sa.w && ty0 + q4 < sa.h)
@@ -563,7 +564,7 @@ __device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const T
     if (tid < 192) {
         const int c = tid >> 6, r = (tid & 63) >> 2, q4 = (tid & 3) * 4;
         const int x1 = tx0 / 2, y1 = ty0 / 2;
-        if (y1 + r < sb.h && x1 + q4 < sb.w)
+        if (xyb != nullptr && y1 + r < sb.h && x1 + q4 < sb.w)
             *(float4 *)(xyb + sb.off + c * sb.plane + (size_t)(y1 + r) * sb.pitch + x1 + q4) =
                 make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
         if (xybt != nullptr && x1 + r < sb.w && y1 + q4 < sb.h)
@@ -740,7 +741,10 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
 // lanes through wave shuffles.  No transposed copy is written: the row pass k_blur_h_jobs_x transposes ref / dis itself.
 // grid (ceil(w/32), ceil(h/8), slots), block 64.
 // ------------------------------------------------------------------------------------------------
-template <int KIND>
+// RD: ref and dis share one plane, interleaved per pixel ([y][x][side], rows of 2 * pitch floats): the row pass then fetches
+// both inputs of the edge terms with one load of whole 128-B lines.  The wave keeps side 0's XYB in registers and stores
+// {ref, dis} pairs when side 1 is done: float4 per row (two pixels x two sides), 16 lanes = 256 contiguous bytes.
+template <int KIND, bool RD = false>
 __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
                                                     const float *__restrict__ yuvlut, float *__restrict__ XYB,
@@ -759,6 +763,11 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
     tab[lane] = gtab[lane];
     if (lane < 32) tab[64 + lane] = gtab[64 + lane];
     __builtin_amdgcn_wave_barrier();
+    float keep[3][5]; // RD: side 0's XYB (four level-0 pixels + the level-1 pixel) until side 1 is done
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) keep[c][k] = 0.0f;
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
         const TmFrameDesc d = desc[slot * 2 + side];
@@ -815,7 +824,7 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
         lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
         tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
         // ---- level 0: two rows of two pixels; level 1: one pixel
-        {
+        if (!RD) {
             const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
             const float *xv[3] = {xa, xb, xc};
 #pragma unroll
@@ -825,6 +834,23 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
                     if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
                         *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
                 if (X0 / 2 < s1.w && Y0 / 2 < s1.h) xyb[s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2] = xv[c][4];
+            }
+        } else if (side == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { keep[0][k] = xa[k]; keep[1][k] = xb[k]; keep[2][k] = xc[k]; }
+        } else {
+            const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
+            const float *xv[3] = {xa, xb, xc};
+            float *xi = XYB + (size_t)slot * 2 * g.pyr; // the slot's interleaved pyramid (same size as its two plain ones)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+                    if (X0 < w && Y0 + iy < h)
+                        *(float4 *)(xi + 2 * (s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0)) =
+                            make_float4(keep[c][2 * iy], xv[c][2 * iy], keep[c][2 * iy + 1], xv[c][2 * iy + 1]);
+                if (X0 / 2 < s1.w && Y0 / 2 < s1.h)
+                    *(float2 *)(xi + 2 * (s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2)) = make_float2(keep[c][4], xv[c][4]);
             }
         }
         // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
@@ -860,8 +886,9 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
 // pixels): XYB of level 2, then 2x2 box downscales (downscale.rs:5-35) and XYB for levels 3, 4, 5.
 // Workgroup = 32x32 tile of level 2 (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad.
 // grid (ceil(w2/32), ceil(h2/32), slots*2), block 256.
+// rd: the XYB arena is the ref/dis-interleaved pyramid of ingest generation 4 (element (x, y, side) at 2 * plain offset + side)
 __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB,
-                                                      float *__restrict__ XYBT)
+                                                      float *__restrict__ XYBT, int rd)
 {
     __shared__ IngestSideLds L; // t0: level-2 XYB tile, t1: level-3 XYB tile, lin1: level-3 linear RGB
     __shared__ float lin4[3][8][9];
@@ -869,7 +896,8 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     const int img = blockIdx.z; // slot*2 + side
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
     const TmScaleGeom s2 = g.s[2];
-    float *xyb = XYB + (size_t)img * g.pyr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
+    float *xyb = rd ? nullptr : XYB + (size_t)img * g.pyr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
+    float *xi = rd ? XYB + (size_t)(img >> 1) * 2 * g.pyr + (img & 1) : nullptr; // interleaved pyramid of the slot, this side's lane
     const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     {
@@ -898,6 +926,18 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
     }
     TM_LDS_BARRIER();
     store_tiles_both(L, s2, g.s[3], xyb, xybt, tx0, ty0, tid);
+    if (xi != nullptr) { // levels 2 and 3 are 1/16 and 1/64 of the pixels: plain per-pixel stores at stride 2
+        const TmScaleGeom s3 = g.s[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = X0 + (k & 1), y = Y0 + (k >> 1);
+                if (x < s2.w && y < s2.h) xi[2 * (s2.off + c * s2.plane + (size_t)y * s2.pitch + x)] = L.t0[c][2 * qy + (k >> 1)][2 * qx + (k & 1)];
+            }
+            if (X0 / 2 < s3.w && Y0 / 2 < s3.h) xi[2 * (s3.off + c * s3.plane + (size_t)(Y0 / 2) * s3.pitch + X0 / 2)] = L.t1[c][qy][qx];
+        }
+    }
     if (tid < 64) { // level 4: 8x8 per tile
         const TmScaleGeom s3 = g.s[3];
         const int ox = tid & 7, oy = tid >> 3;
@@ -909,7 +949,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
             v[c] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox], L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
             lin4[c][oy][ox] = v[c];
         }
-        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v);
+        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v, xi);
     }
     TM_LDS_BARRIER();
     if (tid < 16) { // level 5: 4x4 per tile
@@ -921,7 +961,7 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             v[c] = ds4(lin4[c][2 * oy][2 * ox], lin4[c][2 * oy][2 * ox + 1], lin4[c][2 * oy + 1][2 * ox], lin4[c][2 * oy + 1][2 * ox + 1], okx, oky);
-        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v);
+        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v, xi);
     }
 }
 
@@ -1344,7 +1384,7 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
 
 template <int R, int W>
 __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V,
-                                                        int slot_major)
+                                                        int slot_major, int rd)
 {
     // slot_major: grid (slots, blocks) instead of (blocks, 1, slots) -- workgroups are dispatched x-fastest, so the
     // long jobs (scale 0) of ALL slots start first and the short scales fill the tail (longest-processing-time order)
@@ -1364,19 +1404,22 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
     }
     const int x0 = blk * 64;
     const int lane = threadIdx.x & 63;
-    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u;
+    // rd: XYB is the ref/dis-interleaved pyramid (ingest generation 4): a lane's pixel is 8 bytes wide, dis sits 4 bytes
+    // after ref, rows are 2 * pitch floats
+    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * (rd ? 8u : 4u);
     const int slot = slot_major ? blockIdx.x : blockIdx.z;
-    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const float *ref = rd ? XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane) : XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *dis = rd ? ref + 1 : XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const int in_pitch = rd ? 2 * sg.pitch : sg.pitch;
     const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
     float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
     float *tile = tiles + wave * R * TT::S;
     if (role == 2)
-        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
     else if (role < 2)
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
     else
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, false);
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1498,7 +1541,7 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const
 // whose maps are evaluated at step t).  Everything stays inside the wave: LDS operations of one wave execute in order.
 // 17.4 KB of LDS per wave -> 9 waves per CU.
 // ------------------------------------------------------------------------------------------------
-template <bool FULL, int WN, int D>
+template <bool FULL, int WN, int D, bool RD>
 __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][17], const float *__restrict__ refn,
                                              const float *__restrict__ disn, const float *__restrict__ v0,
                                              const float *__restrict__ v1, const float *__restrict__ v2,
@@ -1522,24 +1565,32 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
             w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
         }
     }
-    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, column 16 * (e >> 4) + lc
-    auto fetch = [&](const float *plane, int e) -> float {
+    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, columns 16 * (e >> 4) + lc.  !RD: two plain planes,
+    // 64-B runs per row (the other half of each 128-B line is fetched again one block later); RD: one interleaved plane,
+    // a lane loads its {ref, dis} pair with one 8-B load and a row of the block is one whole 128-B line.
+    auto fetch2 = [&](int e, float &a, float &b) {
         const int x = 16 * (e >> 4) + lc, y = y0 + 4 * (e & 15) + lr;
         const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
-        return plane[(size_t)yc * pitch + xc];
+        if (RD) {
+            const float2 v = *(const float2 *)(refn + 2 * ((size_t)yc * pitch + xc));
+            a = v.x; b = v.y;
+        } else {
+            a = refn[(size_t)yc * pitch + xc];
+            b = disn[(size_t)yc * pitch + xc];
+        }
     };
     auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + lr][lc] = v; };
     // prologue: block 0 complete in LDS, elements 16 .. 16 + D - 1 in flight
     {
         float a[16], b[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { a[i] = fetch(refn, i); b[i] = fetch(disn, i); }
+        for (int i = 0; i < 16; ++i) fetch2(i, a[i], b[i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { put(0, i, a[i]); put(1, i, b[i]); }
     }
     float qa[D], qb[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { qa[i] = fetch(refn, 16 + i); qb[i] = fetch(disn, 16 + i); }
+    for (int i = 0; i < D; ++i) fetch2(16 + i, qa[i], qb[i]);
     __builtin_amdgcn_wave_barrier();
     tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
     const int T = w + 4;
@@ -1568,7 +1619,7 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
                 // element u + 16 (requested D steps ago) into its buffer, element u + 16 + D requested in its place
                 __builtin_amdgcn_wave_barrier();
                 put(0, u + 16, qa[slot]); put(1, u + 16, qb[slot]);
-                qa[slot] = fetch(refn, u + 16 + D); qb[slot] = fetch(disn, u + 16 + D);
+                fetch2(u + 16 + D, qa[slot], qb[slot]);
                 __builtin_amdgcn_wave_barrier();
                 const float src = tile[0][(u >> 4) & 1][lane][u & 15], dsv = tile[1][(u >> 4) & 1][lane][u & 15];
                 float ssim = 0.0f, art, det;
@@ -1585,6 +1636,7 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     }
 }
 
+template <bool RD>
 __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
                                                       const float *__restrict__ V, double *__restrict__ PART, int slot_major)
 {
@@ -1599,16 +1651,17 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     const int yy = valid ? y : sg.h - 1;
     const int slot = slot_major ? blockIdx.x : blockIdx.z;
     const size_t to = sg.off_t + c * sg.plane_t + yy;
-    const float *refn = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *disn = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    // RD: refn = this channel's interleaved plane ({ref, dis} pairs, rows of 2 * pitch floats); disn unused
+    const float *refn = RD ? XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane) : XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *disn = RD ? refn : XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
     const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to;
     const float *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to;
     const float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
     const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
     const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
-    else blur_h_job_x<false, 16, 8>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6, RD>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    else blur_h_job_x<false, 16, 8, RD>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
         __shared__ double redl[6][64];
