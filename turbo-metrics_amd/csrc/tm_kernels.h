@@ -1255,33 +1255,63 @@ __device__ __forceinline__ float ld_row_u(const float *__restrict__ plane, unsig
     return row < nrows ? v : 0.0f;
 }
 
-template <int R, int W, bool TWO, bool COPY, bool NT = false>
+#ifdef TM_EMULATE
+struct alignas(8) tm_g2 { float x, y; };
+#else
+typedef float tm_g2 __attribute__((ext_vector_type(2)));
+#endif
+__device__ __forceinline__ void ld_row_u2(const float *__restrict__ plane, unsigned xb, int row, int nrows, int pitch, float &a, float &b)
+{
+    // the {ref, dis} pair of the interleaved pyramid (ingest generation 4): one 8-byte load per lane
+    const int rc = row < nrows ? row : nrows - 1;
+    TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(plane + (size_t)rc * pitch);
+    const tm_g2 v = *(TM_GLOBAL_AS const tm_g2 *)(rowp + xb);
+    a = row < nrows ? v.x : 0.0f;
+    b = row < nrows ? v.y : 0.0f;
+}
+
+// RDM (ref/dis-interleaved input, ingest generation 4): 0 = plain planes; 1 = "pair lanes": the wave covers 32 columns, lane =
+// (column, side), one coalesced 256-B load per row feeds the ref AND the dis recurrence, and the flush sends the odd tile
+// columns to the next output plane (side_delta floats further); 2 = the product wave: 64 columns, one 8-byte load per lane.
+template <int R, int W, bool TWO, bool COPY, bool NT = false, int RDM = 0>
 __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, float *__restrict__ tile_copy,
                                                   const float *__restrict__ pa, const float *__restrict__ pb, unsigned x,
                                                   float *__restrict__ dst, float *__restrict__ dst_copy, int h, int pitch,
-                                                  int pitch_t, bool product)
+                                                  int pitch_t, bool product, unsigned side_delta = 0)
 {
     // pa/pb: wave-uniform input plane bases; x: this lane's column as a BYTE offset; dst/dst_copy: wave-uniform pointers to
     // transposed row x0 of the output planes
     using TT = BlurVTile<R>;
+    static_assert(RDM == 0 || (!COPY && TT::CPI % 2 == 0 && (RDM == 2) == TWO), "interleaved input: roles");
     constexpr int P = W - 10;
     constexpr int U = W > R ? W : R;
+    constexpr int XS = RDM == 1 ? 2 : 1; // tile columns per image column
     const int lane = threadIdx.x & 63;
     const int xl = lane / TT::LPC, yq = lane % TT::LPC;
-    const unsigned voff = (unsigned)(xl * pitch_t + 4 * yq) * 4u; // per-lane BYTE part of every flush address
+    // per-lane BYTE part of every flush address
+    const unsigned voff = RDM == 1 ? (unsigned)((xl >> 1) * pitch_t + 4 * yq) * 4u + (unsigned)(xl & 1) * side_delta * 4u
+                                   : (unsigned)(xl * pitch_t + 4 * yq) * 4u;
     float wa[W], wb[TWO ? W : 1];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        wa[j] = j < P ? ld_row_u(pa, x, j, h, pitch) : 0.0f;
-        if (TWO) wb[j] = j < P ? ld_row_u(pb, x, j, h, pitch) : 0.0f;
+        if (RDM == 2) {
+            if (j < P) ld_row_u2(pa, x, j, h, pitch, wa[j], wb[j]);
+            else wa[j] = wb[j] = 0.0f;
+        } else {
+            wa[j] = j < P ? ld_row_u(pa, x, j, h, pitch) : 0.0f;
+            if (TWO) wb[j] = j < P ? ld_row_u(pb, x, j, h, pitch) : 0.0f;
+        }
     }
     tmdev::Iir f = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; ++t) { // no output row yet
         const float a = wa[t], aold = wa[(t + P) % W];
         const float b = TWO ? wb[t] : a, bold = TWO ? wb[(t + P) % W] : aold;
-        wa[(t + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
-        if (TWO) wb[(t + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+        if (RDM == 2) ld_row_u2(pa, x, t + P, h, pitch, wa[(t + P) % W], wb[(t + P) % W]);
+        else {
+            wa[(t + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
+            if (TWO) wb[(t + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+        }
         (void)tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
     }
     const int T = (h + U - 1) / U * U + 4;
@@ -1297,8 +1327,11 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
             const float a = wa[(j + 4) % W], aold = wa[(j + 4 + P) % W];
             const float b = TWO ? wb[(j + 4) % W] : a, bold = TWO ? wb[(j + 4 + P) % W] : aold;
             const float a4 = wa[j % W]; // input row t-4 == output row: its transposed copy rides along
-            wa[(j + 4 + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
-            if (TWO) wb[(j + 4 + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+            if (RDM == 2) ld_row_u2(pa, x, t + P, h, pitch, wa[(j + 4 + P) % W], wb[(j + 4 + P) % W]);
+            else {
+                wa[(j + 4 + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
+                if (TWO) wb[(j + 4 + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
+            }
             const float o = tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
             tile[(j % R) * TT::S + lane] = o;
             if (COPY) tile_copy[(j % R) * TT::S + lane] = a4;
@@ -1309,7 +1342,7 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
                 for (int i = 0; i < 64 / TT::CPI; ++i) {
                     const int xc = i * TT::CPI + xl;
                     const float *tp = tile + (4 * yq) * TT::S + xc;
-                    TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst + (size_t)(i * TT::CPI) * pitch_t + y0);
+                    TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst + (size_t)(i * TT::CPI / XS) * pitch_t + y0);
                     if (NT) __builtin_nontemporal_store(tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]), (TM_GLOBAL_AS tm_f4 *)(ub + voff));
                     else *(TM_GLOBAL_AS tm_f4 *)(ub + voff) = tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]);
                     if (COPY) {
@@ -1395,6 +1428,34 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
     const TmScaleGeom sg = g.s[s];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
+    const int slot = slot_major ? blockIdx.x : blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    float *tile = tiles + wave * R * TT::S;
+    if (rd) {
+        // XYB is the ref/dis-interleaved pyramid (ingest generation 4): a pixel is the 8-byte pair {ref, dis}, rows are
+        // 2 * pitch floats.  FULL: waves 0, 1 = squares of columns 0..31 / 32..63 (lane = (column, side) -> planes 0 and 1),
+        // wave 2 = the product (64 columns, pair loads -> plane 2), waves 3, 4 = plain values -> planes 3 and 4.  EDGE: waves
+        // 0..3 = plain values of four neighbouring 32-column blocks.  Every row load is a whole run of 256 or 512 bytes.
+        const float *in = XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane);
+        int blk = b - jobs.vstart[j], half, role;
+        if (mode == TM_MODE_FULL) { role = wave == 2 ? 2 : (wave < 2 ? 0 : 3); half = wave == 2 ? 0 : (wave < 2 ? wave : wave - 3); }
+        else {
+            if (wave == 4) return; // a retired wave no longer counts at s_barrier
+            role = 3; half = wave & 1; blk = blk * 2 + (wave >> 1);
+            if (blk * 64 >= sg.w) return;
+        }
+        const int x0 = blk * 64;
+        float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + sg.off_t + c * sg.plane_t + (size_t)(x0 + 32 * half) * sg.pitch_t;
+        if (role == 2) {
+            const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 8u;
+            blur_v_split_role<R, W, true, false, true, 2>(tile, nullptr, in, nullptr, x, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, true);
+        } else {
+            const unsigned x = (unsigned)min(x0 + 32 * half + (lane >> 1), sg.w - 1) * 8u + (unsigned)(lane & 1) * 4u;
+            blur_v_split_role<R, W, false, false, true, 1>(tile, nullptr, in, nullptr, x, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t,
+                                                           role == 0, (unsigned)g.pyr_t);
+        }
+        return;
+    }
     int role = wave, blk = b - jobs.vstart[j];
     if (mode != TM_MODE_FULL) {
         if (wave == 4) return; // a retired wave no longer counts at s_barrier
@@ -1403,23 +1464,17 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
         if (blk * 64 >= sg.w) return;
     }
     const int x0 = blk * 64;
-    const int lane = threadIdx.x & 63;
-    // rd: XYB is the ref/dis-interleaved pyramid (ingest generation 4): a lane's pixel is 8 bytes wide, dis sits 4 bytes
-    // after ref, rows are 2 * pitch floats
-    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * (rd ? 8u : 4u);
-    const int slot = slot_major ? blockIdx.x : blockIdx.z;
-    const float *ref = rd ? XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane) : XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *dis = rd ? ref + 1 : XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
-    const int in_pitch = rd ? 2 * sg.pitch : sg.pitch;
+    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u;
+    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
+    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
     const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
     float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
-    float *tile = tiles + wave * R * TT::S;
     if (role == 2)
-        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
     else if (role < 2)
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, true);
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
     else
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, in_pitch, sg.pitch_t, false);
+        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, false);
 }
 
 // ------------------------------------------------------------------------------------------------
