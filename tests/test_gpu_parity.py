@@ -91,7 +91,7 @@ def test_kernel_generations_are_bit_identical(variant):
     eng.compute_async()
     eng.sync()
     for slot, (fr, fd) in enumerate(frames):
-        lin, sums = check_planes(eng, slot, fr, fd, w, h, have_linear=variant < 256, have_xybt=(variant >> 8 & 255) != 3)  # generations 0-2 also write a transposed XYB copy
+        lin, sums = check_planes(eng, slot, fr, fd, w, h, have_linear=variant < 256, have_xybt=(variant >> 8 & 255) < 3)  # generations 0-2 also write a transposed XYB copy
         check_scores(eng, slot, lin, sums, w, h)
     eng.close()
 

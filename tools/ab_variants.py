@@ -8,7 +8,7 @@ from tm_pkg import tm
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="1080p"); ap.add_argument("--batch", type=int, default=32)
-ap.add_argument("--variants", default="777,521"); ap.add_argument("--rounds", type=int, default=3); ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--variants", default="1033,777"); ap.add_argument("--rounds", type=int, default=3); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--full-sums", action="store_true")
 a = ap.parse_args()
 w, h, gen, mk = (1920, 1080, tm.synth.nv12_pair, tm.HwFrame.nv12) if a.workload == "1080p" else (3840, 2160, tm.synth.p016_pair, tm.HwFrame.p016)

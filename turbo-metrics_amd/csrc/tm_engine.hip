@@ -116,7 +116,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = (3 << 8) | 9; // wave ingest (no transposed copy) + job-driven split column pass + transposing row pass
+    int variant = (4 << 8) | 9; // wave ingest into the ref/dis-interleaved pyramid (no transposed copy) + job-driven split column pass + transposing row pass
 };
 
 namespace {
