@@ -44,6 +44,11 @@ __device__ __forceinline__ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 // store of the wave (s_waitcnt vmcnt(0)); the ingest kernel only ever exchanges data through LDS, and
 // waiting ~2 us for store acknowledgements at each of its 12 barriers was most of a workgroup's lifetime.
 #ifdef TM_EMULATE
+#define TM_WAVES_PER_SIMD(n)
+#else
+#define TM_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n))) // holds the register allocation to 512 / n VGPRs
+#endif
+#ifdef TM_EMULATE
 #define TM_LDS_BARRIER() __syncthreads()
 #else
 #define TM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -745,7 +750,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
 // both inputs of the edge terms with one load of whole 128-B lines.  The wave keeps side 0's XYB in registers and stores
 // {ref, dis} pairs when side 1 is done: float4 per row (two pixels x two sides), 16 lanes = 256 contiguous bytes.
 template <int KIND, bool RD = false>
-__global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
+__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
                                                     const float *__restrict__ yuvlut, float *__restrict__ XYB,
                                                     float *__restrict__ LIN2, unsigned long long *__restrict__ SSE, int want_sse,
@@ -763,11 +768,9 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
     tab[lane] = gtab[lane];
     if (lane < 32) tab[64 + lane] = gtab[64 + lane];
     __builtin_amdgcn_wave_barrier();
-    float keep[3][5]; // RD: side 0's XYB (four level-0 pixels + the level-1 pixel) until side 1 is done
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) keep[c][k] = 0.0f;
+    // RD: side 0's XYB (four level-0 pixels + the level-1 pixel) waits in LDS until side 1 is done ([value][lane]: wave-private,
+    // conflict-free; holding it in 15 VGPRs cost the fifth wave per SIMD)
+    __shared__ float keep_s[RD ? 15 : 1][64];
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
         const TmFrameDesc d = desc[slot * 2 + side];
@@ -837,20 +840,23 @@ __global__ void __launch_bounds__(64) k_ingest_wave(TmGeom g, const TmFrameDesc 
             }
         } else if (side == 0) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { keep[0][k] = xa[k]; keep[1][k] = xb[k]; keep[2][k] = xc[k]; }
+            for (int k = 0; k < 5; ++k) { keep_s[k][lane] = xa[k]; keep_s[5 + k][lane] = xb[k]; keep_s[10 + k][lane] = xc[k]; }
         } else {
             const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
             const float *xv[3] = {xa, xb, xc};
             float *xi = XYB + (size_t)slot * 2 * g.pyr; // the slot's interleaved pyramid (same size as its two plain ones)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
+                float keep[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) keep[k] = keep_s[5 * c + k][lane];
 #pragma unroll
                 for (int iy = 0; iy < 2; ++iy)
                     if (X0 < w && Y0 + iy < h)
                         *(float4 *)(xi + 2 * (s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0)) =
-                            make_float4(keep[c][2 * iy], xv[c][2 * iy], keep[c][2 * iy + 1], xv[c][2 * iy + 1]);
+                            make_float4(keep[2 * iy], xv[c][2 * iy], keep[2 * iy + 1], xv[c][2 * iy + 1]);
                 if (X0 / 2 < s1.w && Y0 / 2 < s1.h)
-                    *(float2 *)(xi + 2 * (s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2)) = make_float2(keep[c][4], xv[c][4]);
+                    *(float2 *)(xi + 2 * (s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2)) = make_float2(keep[4], xv[c][4]);
             }
         }
         // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
