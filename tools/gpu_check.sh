@@ -11,11 +11,11 @@ timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee gpurun_out
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/${TAG}_smoke.log
 echo "== bench 1080p"
-timeout 600 python bench.py --steps 10 --warmup 2 2>&1 | tail -3 | tee gpurun_out/${TAG}_bench_1080p.json
+timeout 600 python bench.py 2>&1 | tail -3 | tee gpurun_out/${TAG}_bench_1080p.json
 echo "== bench 4k"
-timeout 600 python bench.py --workload 4k_p016 --steps 5 --warmup 1 --no-cpu-baseline 2>&1 | tail -3 | tee gpurun_out/${TAG}_bench_4k.json
+timeout 600 python bench.py --workload 4k_p016 --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | tail -3 | tee gpurun_out/${TAG}_bench_4k.json
 echo "== rocprof"
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-compare > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_bench.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-compare > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/${TAG}_prof -name "*kernel_stats*.csv" | head -3
 for f in $(find gpurun_out/${TAG}_prof -name "*kernel_stats*.csv" | head -1); do head -12 $f; done

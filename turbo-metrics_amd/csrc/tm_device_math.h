@@ -88,16 +88,20 @@ __device__ TM_MATH_INLINE float cbrt_pos(float a)
 
 // N cube roots in place; pixel data is always inside [2^-100, 2^100], so the pairs go through cbrt_core2 directly
 // (same operations as cbrt_pos with sc = 1 -> same bits) and the general routine is only a fallback
-template <int N> __device__ __forceinline__ void cbrt_pos_n(float (&v)[N])
+// BOUNDED: the caller guarantees every value is inside that range (linear RGB in [0, 1] -> mixed in [0.0037, 1.004]), so
+// the range test (two integer min / max per value) is not compiled at all
+template <int N, bool BOUNDED = false> __device__ __forceinline__ void cbrt_pos_n(float (&v)[N])
 {
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    if (!BOUNDED) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint32_t u = f2u(v[i]);
-        lo = u < lo ? u : lo;
-        hi = u > hi ? u : hi;
+        for (int i = 0; i < N; ++i) {
+            const uint32_t u = f2u(v[i]);
+            lo = u < lo ? u : lo;
+            hi = u > hi ? u : hi;
+        }
     }
-    if (lo >= 0x0D800000u && hi <= 0x71800000u) { // all in [2^-100, 2^100]: positive, normal, finite
+    if (BOUNDED || (lo >= 0x0D800000u && hi <= 0x71800000u)) { // all in [2^-100, 2^100]: positive, normal, finite
 #pragma unroll
         for (int i = 0; i + 1 < N; i += 2) {
             const tm_f2 y = cbrt_core2(f2_make(v[i], v[i + 1]));
@@ -142,14 +146,27 @@ __device__ TM_MATH_INLINE float pow_pos(float xf, double y, const double *__rest
     return (float)u2d(d2u(res) + ((uint64_t)(long long)(ki >> 5) << 52));
 }
 
+// x / c for a positive constant c, as IEEE division rounds it, in 4 operations instead of the ~11 of the hardware division
+// sequence: q1 = RN(x RN(1/c)), the exact remainder x - q1 c (one fma), one correction, the sign of x (so that -0 stays -0).
+// For each c used below the three-operation core was compared with x / c over ALL 2^23 mantissas of x (tools/check_div_const.c:
+// 0 mismatches; the uncorrected product alone is wrong for 3-10 % of them); the quotient's mantissa does not depend on the
+// exponent of x, so the result holds wherever nothing under- or overflows: 2^-100 < |x| < 2^100 and x = +-0.  Callers: only
+// the YUV transfer function, whose argument is a sum of two products of integer samples (|x| in {0} U [2^-40, 4]).
+__device__ __forceinline__ float div_const(float x, float c, float rc)
+{
+    const float q1 = x * rc;
+    const float r = __builtin_fmaf(-q1, c, x);
+    return __builtin_copysignf(__builtin_fmaf(r, rc, q1), x);
+}
+
 // BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs)
 __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ tab)
 {
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
     const float THRESHOLD = 0.08124285829863521110029445797874f;
-    if (v >= THRESHOLD) return pow_pos((v + (ALPHA - 1.0f)) / ALPHA, (double)(1.0f / 0.45f), tab);
-    return v / 4.5f;
+    if (v >= THRESHOLD) return pow_pos(div_const(v + (ALPHA - 1.0f), ALPHA, 1.0f / ALPHA), (double)(1.0f / 0.45f), tab);
+    return div_const(v, 4.5f, 1.0f / 4.5f);
 }
 
 // srgb_inverse_oetf, cuda-colorspace-kernel/src/srgb.rs:40-48
@@ -165,7 +182,7 @@ __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f),
 
 // px_linear_rgb_to_positive_xyb, ssimulacra2-cuda-kernel/src/xyb.rs:42-79, for N pixels at once (the 3N cube roots
 // are evaluated pairwise)
-template <int N>
+template <int N, bool BOUNDED = false>
 __device__ __forceinline__ void linear_to_xyb_n(const float (&r)[N], const float (&g)[N], const float (&b)[N], float (&X)[N],
                                                 float (&Y)[N], float (&B)[N])
 {
@@ -181,7 +198,7 @@ __device__ __forceinline__ void linear_to_xyb_n(const float (&r)[N], const float
         m[3 * i + 1] = fmaxf(__builtin_fmaf(K_M10, r[i], __builtin_fmaf(K_M11, g[i], __builtin_fmaf(K_M12, b[i], K_B0))), 0.0f);
         m[3 * i + 2] = fmaxf(__builtin_fmaf(K_M20, r[i], __builtin_fmaf(K_M21, g[i], __builtin_fmaf(K_M22, b[i], K_B0))), 0.0f);
     }
-    cbrt_pos_n<3 * N>(m);
+    cbrt_pos_n<3 * N, BOUNDED>(m);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float rg = m[3 * i + 0] - K_B0_ROOT, gr = m[3 * i + 1] - K_B0_ROOT, bb = m[3 * i + 2] - K_B0_ROOT;

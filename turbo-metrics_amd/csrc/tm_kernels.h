@@ -127,6 +127,32 @@ __device__ __forceinline__ void yuv_quad_load(const TmFrameDesc &d, int qx, int 
     raw[0] = yrow0[0]; raw[1] = yrow0[1]; raw[2] = yrow1[0]; raw[3] = yrow1[1];
 }
 
+// The same six samples as three pair loads (two luma rows, one CbCr pair): half the load instructions and half the
+// registers, which is what lets k_ingest_wave hold BOTH sides' samples from the start.  raw[i] = first | second << bits.
+// Pair loads need the plane pointers and the pitch to be multiples of the pair size; otherwise single loads are packed.
+template <typename T>
+__device__ __forceinline__ void yuv_quad_load_pairs(const TmFrameDesc &d, int qx, int qy, unsigned (&raw)[3])
+{
+    const char *uv = (const char *)d.p1 + (size_t)qy * d.pitch + (size_t)(2 * qx) * sizeof(T);
+    const char *y0 = (const char *)d.p0 + (size_t)(2 * qy) * d.pitch + (size_t)(2 * qx) * sizeof(T);
+    const char *y1 = y0 + d.pitch;
+    const bool aligned = (((unsigned long long)d.p0 | (unsigned long long)d.p1 | (unsigned long long)d.pitch) & (2 * sizeof(T) - 1)) == 0; // wave-uniform
+    if (aligned) {
+        if (sizeof(T) == 1) { raw[0] = *(const unsigned short *)y0; raw[1] = *(const unsigned short *)y1; raw[2] = *(const unsigned short *)uv; }
+        else { raw[0] = *(const unsigned *)y0; raw[1] = *(const unsigned *)y1; raw[2] = *(const unsigned *)uv; }
+    } else {
+        const int sh = 8 * (int)sizeof(T);
+        raw[0] = (unsigned)((const T *)y0)[0] | ((unsigned)((const T *)y0)[1] << sh);
+        raw[1] = (unsigned)((const T *)y1)[0] | ((unsigned)((const T *)y1)[1] << sh);
+        raw[2] = (unsigned)((const T *)uv)[0] | ((unsigned)((const T *)uv)[1] << sh);
+    }
+}
+template <int BITS> __device__ __forceinline__ void yuv_quad_unpack(const unsigned (&pr)[3], unsigned (&raw)[6])
+{
+    const unsigned m = BITS == 8 ? 0xFFu : 0xFFFFu;
+    raw[0] = pr[0] & m; raw[1] = pr[0] >> BITS; raw[2] = pr[1] & m; raw[3] = pr[1] >> BITS; raw[4] = pr[2] & m; raw[5] = pr[2] >> BITS;
+}
+
 template <int BITS>
 __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const unsigned (&raw)[6], const float *__restrict__ coef,
                                                  const double *__restrict__ tab, float (&px)[2][2][3], const float *__restrict__ rb)
@@ -771,9 +797,19 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     // RD: side 0's XYB (four level-0 pixels + the level-1 pixel) waits in LDS until side 1 is done ([value][lane]: wave-private,
     // conflict-free; holding it in 15 VGPRs cost the fifth wave per SIMD)
     __shared__ float keep_s[RD ? 15 : 1][64];
+    // YUV kinds: the samples of BOTH sides are requested before anything else (three pair loads per side), so that side 1's
+    // never sit behind side 0's arithmetic
+    constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016;
+    const TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
+    const bool quad_ok = X0 + 1 < w && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
+    unsigned pr0[3] = {0, 0, 0}, pr1[3] = {0, 0, 0};
+    if (YUV && quad_ok) {
+        if (KIND == TM_KIND_NV12) { yuv_quad_load_pairs<unsigned char>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned char>(dd1, X0 / 2, Y0 / 2, pr1); }
+        else { yuv_quad_load_pairs<unsigned short>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned short>(dd1, X0 / 2, Y0 / 2, pr1); }
+    }
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
-        const TmFrameDesc d = desc[slot * 2 + side];
+        const TmFrameDesc d = side ? dd1 : dd0;
         const int kind = KIND >= 0 ? KIND : d.kind;
         float px[2][2][3];
 #pragma unroll
@@ -782,8 +818,16 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
             for (int ix = 0; ix < 2; ++ix)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
-        if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
-            if (X0 + 1 < w && Y0 + 1 < h) { // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
+        if (YUV) {
+            if (quad_ok) {
+                const unsigned prs[3] = {side ? pr1[0] : pr0[0], side ? pr1[1] : pr0[1], side ? pr1[2] : pr0[2]};
+                unsigned raw[6];
+                yuv_quad_unpack<KIND == TM_KIND_NV12 ? 8 : 16>(prs, raw);
+                if (KIND == TM_KIND_NV12) yuv_quad_convert<8>(d, raw, coef, tab, px, yuvlut);
+                else yuv_quad_convert<16>(d, raw, coef, tab, px, nullptr);
+            }
+        } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
+            if (quad_ok) {
                 if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px, yuvlut);
                 else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
             }
@@ -825,7 +869,9 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
         lr[4] = ds4(px[0][0][0], px[0][1][0], px[1][0][0], px[1][1][0], okx, oky);
         lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
         lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
-        tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
+        // 8- and 16-bit kinds give linear RGB in [0, 1] (clamp01 / the sRGB tables): the cube roots need no range test
+        constexpr bool UNIT = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_RGB8 || KIND == TM_KIND_RGB16;
+        tmdev::linear_to_xyb_n<5, UNIT>(lr, lg, lb, xa, xb, xc);
         // ---- level 0: two rows of two pixels; level 1: one pixel
         if (!RD) {
             const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
