@@ -105,8 +105,8 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
             px[iy][ix][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
             if (BITS == 8 && rb != nullptr) {
                 const float *t = rb + (size_t)d.matrix * 2 * 65536;
-                px[iy][ix][0] = t[(ys << 8) | ucr];
-                px[iy][ix][2] = t[65536 + ((ys << 8) | ucb)];
+                px[iy][ix][0] = t[(ucr << 8) | ys];
+                px[iy][ix][2] = t[65536 + ((ucb << 8) | ys)];
             } else {
                 px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
                 px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
@@ -173,8 +173,8 @@ __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const uns
         px[q >> 1][q & 1][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
         if (BITS == 8 && rb != nullptr) {
             const float *t = rb + (size_t)d.matrix * 2 * 65536;
-            px[q >> 1][q & 1][0] = t[(ys << 8) | ucr];
-            px[q >> 1][q & 1][2] = t[65536 + ((ys << 8) | ucb)];
+            px[q >> 1][q & 1][0] = t[(ucr << 8) | ys];
+            px[q >> 1][q & 1][2] = t[65536 + ((ucb << 8) | ys)];
         } else {
             px[q >> 1][q & 1][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
             px[q >> 1][q & 1][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
@@ -182,7 +182,8 @@ __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const uns
     }
 }
 
-// out[matrix][0][Y<<8|Cr] = R, out[matrix][1][Y<<8|Cb] = B of an 8-bit limited-range sample pair; grid (256, 2, 3) x 256
+// out[matrix][0][Cr<<8|Y] = R, out[matrix][1][Cb<<8|Y] = B of an 8-bit limited-range sample pair (chroma-major: the 256 luma
+// values of one chroma value share 1 KB, and a wave sees few chroma values); grid (256, 2, 3) x 256
 __global__ void __launch_bounds__(256) k_build_yuv_lut(const float *__restrict__ coef, const double *__restrict__ tab,
                                                        float *__restrict__ out)
 {
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(256) k_build_yuv_lut(const float *__restrict__
     const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
     const float ch = (float)(c - 128);
     const float add = (which == 0 ? k[1] : k[2]) * ch; // r_ = r_coeff*cr, b_ = b_coeff*cb (biplanar.rs:36-38)
-    out[((size_t)matrix * 2 + which) * 65536 + ((y << 8) | c)] = tmdev::clamp01(tmdev::bt709_eotf(luma + add, tab));
+    out[((size_t)matrix * 2 + which) * 65536 + ((c << 8) | y)] = tmdev::clamp01(tmdev::bt709_eotf(luma + add, tab));
 }
 
 __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__restrict__ desc,
