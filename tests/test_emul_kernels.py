@@ -89,6 +89,36 @@ def test_p016_and_rgb_kinds_match_oracle(variant):
     check_against_oracle(em, frames, w, h, have_linear=variant < 256)
 
 
+@pytest.mark.parametrize("gen", [3, 4])
+def test_wave_ingest_p016_launch_and_unaligned_pitch(gen):
+    """all-P016 launches of the wave ingest (KIND-specialised kernel, pair loads): slot 0 = 10-bit samples in the upper bits,
+    slot 1 = full 16-bit content, slot 2 = a BT.601 matrix; NV12 with an odd pitch goes through the unaligned branch of the pair loads"""
+    w, h = 46, 30
+    frames = []
+    for n, matrix in ((3, 0), (4, 0), (5, 2)):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.p016_pair(w, h, n)
+        if n == 4:
+            rs = rs.copy(); ds = ds.copy()
+            rs.view(np.uint16)[::7] |= 0x21; ds.view(np.uint16)[::5] |= 0x3F  # 16-bit content
+        frames.append((dict(kind="p016", data=rs, pitch=rp, coded_height=rch, matrix=matrix), dict(kind="p016", data=ds, pitch=dp, coded_height=dch, matrix=matrix)))
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=True)
+    check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
+    # NV12, pitch not a multiple of 2
+    frames = []
+    for n in range(2):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
+        def repitch(buf, pitch, rows, newp):
+            a = np.asarray(buf, np.uint8)[: pitch * rows].reshape(rows, pitch)
+            out = np.zeros((rows, newp), np.uint8); out[:, : min(pitch, newp)] = a[:, : min(pitch, newp)]
+            return out.reshape(-1).copy()
+        rows = rch * 3 // 2
+        newp = w + 1 if (w + 1) % 2 else w + 3
+        frames.append((dict(kind="nv12", data=repitch(rs, rp, rows, newp), pitch=newp, coded_height=rch, matrix=1),
+                       dict(kind="nv12", data=repitch(ds, dp, rows, newp), pitch=newp, coded_height=dch, matrix=1)))
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=True)
+    check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
+
+
 def weight_mask():
     """(6 scales, 6 kinds, 3 channels) bool: sums that carry a non-zero weight (table layout [channel][scale][kind])"""
     return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)

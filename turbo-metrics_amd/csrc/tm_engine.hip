@@ -106,7 +106,7 @@ struct tm_engine {
     unsigned long long *h_sse = nullptr;
     float *d_lut = nullptr, *d_coef = nullptr;
     double *d_powtab = nullptr;
-    float *d_yuvlut = nullptr; // [matrix 3][R|B][Y<<8|C]: memoised 8-bit YUV -> linear R,B (k_build_yuv_lut)
+    float *d_yuvlut = nullptr; // [matrix 3][R|B][C<<8|Y]: memoised 8-bit YUV -> linear R,B (k_build_yuv_lut)
     std::vector<void *> staging;      // [slot*2+side], lazily allocated
     std::vector<size_t> staging_size;
     size_t mem_bytes = 0;
@@ -504,8 +504,9 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
         int kind = h_desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_W(K) do { if (rd) hipLaunchKernelGGL((tmk::k_ingest_wave<K, true>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); \
-                        else hipLaunchKernelGGL((tmk::k_ingest_wave<K, false>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); } while (0)
+#define TM_LAUNCH_W(K) do { const float *ytab = e->d_yuvlut; \
+                        if (rd) hipLaunchKernelGGL((tmk::k_ingest_wave<K, true>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); \
+                        else hipLaunchKernelGGL((tmk::k_ingest_wave<K, false>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); } while (0)
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
