@@ -170,7 +170,12 @@ int tm_engine_get_stage_ms(tm_engine *e, double ms[TM_STAGE_COUNT], uint64_t *n_
  * launches; with ~10 submissions per batch instead of the reference's 305 the graph has nothing left to hide and measured
  * 1-6 % slower on ROCm 7.2. */
 int tm_engine_set_graph(tm_engine *e, int on);
-/* select the kernel generation (0 = simple reference kernels, 1 = tuned); for A/B tests */
+/* Select the kernel generation, for A/B tests (every combination reproduces the oracle bit for bit, tests/test_gpu_parity.py):
+ * bits 0-7 column pass (0 = simple reference kernel ... 9 = job-table driven, the default), bits 8-15 ingest (0 = separate
+ * straight-line kernels, 1 = fused 64x64 tiles, 2 = 32x32 LDS tiles + transposed copy, 3 = wave-private tiles, two plain
+ * pyramids, 4 = wave-private tiles, ref/dis-interleaved pyramid: the default), bits 16-19 chunks of the two-stream pipeline
+ * (0 = off), bit 20 block-major instead of slot-major dispatch, bit 21 LDS-tiled SSIM statistics.  Default (4 << 8) | 9.
+ * TM_ERR_INVALID_ARG for combinations that do not exist (generations 3, 4 need column pass 9). */
 int tm_engine_set_variant(tm_engine *e, int variant);
 
 /* ---- test hooks: read back intermediate planes of one slot (blocking) ------------------ */

@@ -10,6 +10,9 @@
 //   k_blur_v_jobs grid (jobs.vstart[n], 1, slots) block 320   the tuned column pass, job table driven
 //   k_blur_h_jobs grid (jobs.hstart[n], 1, slots) block 64    one lane per image ROW, job table driven
 //   k_finish_jobs grid (slots)                                          block 128
+// The default pipeline (engine variant (4 << 8) | 9) is k_ingest_wave<KIND, true> + k_ingest_upper -> k_blur_v_jobs<32, 16>
+// (rd = 1) -> k_blur_h_jobs_x<true> -> k_finish_jobs over the ref/dis-interleaved pyramid, slot-major grids (x = slot);
+// everything else in this file is an older generation kept selectable for A/B runs and as on-device cross-checks.
 //
 // Arithmetic follows the reference kernels operation for operation (cited per function); the
 // file must be compiled with -ffp-contract=off so that only the explicit fmaf calls fuse.
