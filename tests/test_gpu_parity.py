@@ -148,6 +148,43 @@ def weight_mask():
     return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
 
 
+@pytest.mark.parametrize("kind", ["nv12", "p016"])
+def test_unaligned_device_surfaces_and_16bit_content(kind):
+    """device-resident surfaces whose base pointer and pitch are not multiples of a sample pair (the ingest kernel's pair loads
+    must fall back to single loads), and P016 words that use all 16 bits"""
+    torch = pytest.importorskip("torch")
+    w, h = 150, 70
+    bps = 1 if kind == "nv12" else 2
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=3, full_sums=True)
+    host, keep = [], []
+    for slot in range(3):
+        (rs, rp, rch), (ds, dp, dch) = (tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair)(w, h, slot)
+        pair_h, pair_d = [], []
+        for buf, pitch, ch in ((rs, rp, rch), (ds, dp, dch)):
+            rows = ch * 3 // 2
+            a = np.asarray(buf, np.uint8)[: pitch * rows].reshape(rows, pitch)
+            newp = w * bps + (bps if slot else 2 * bps)  # slot 0: pair-aligned pitch, odd base; slots 1, 2: pitch = odd number of samples
+            b = np.zeros((rows, newp), np.uint8)
+            b[:, : w * bps] = a[:, : w * bps]
+            if kind == "p016" and slot == 2:
+                b.reshape(-1).view(np.uint16)[::3] |= 0x3F  # not 10-bit-in-16 any more
+            flat = b.reshape(-1)
+            off = bps if slot != 1 else 2 * bps  # slots 0, 2: base not pair-aligned
+            t = torch.zeros(flat.size + off, dtype=torch.uint8, device="cuda")
+            t[off:] = torch.from_numpy(flat).cuda()
+            keep.append(t)
+            mk = tm.HwFrame.nv12 if kind == "nv12" else tm.HwFrame.p016
+            pair_h.append(mk(flat.copy(), newp, ch)); pair_d.append(mk(t[off:], newp, ch))
+        host.append(pair_h)
+        eng.set_pair(slot, pair_d[0], pair_d[1])
+    eng.compute_async()
+    eng.sync()
+    for slot, (fr, fd) in enumerate(host):
+        lin, sums = check_planes(eng, slot, fr, fd, w, h)
+        check_scores(eng, slot, lin, sums, w, h)
+    eng.close()
+
+
 @pytest.mark.parametrize("w,h", [(70, 38), (333, 203), (1, 1), (129, 20), (640, 360)])
 def test_weight_pruned_sums_equal_full_sums(w, h):
     """Default mode skips the 56 sums whose weight is 0.0: the 52 weighted sums and the score must be bit-identical
