@@ -146,7 +146,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
                    int variant, const double *weights, int full_sums, unsigned char *QU8, unsigned long long qplane, int qpitch)
 {
-    const int ingest_gen = variant >> 8;
+    const int xcd_order = (variant >> 22) & 1; // ingest: XCD-aware tile order
+    const int ingest_gen = (variant >> 8) & 255;
     variant &= 255;
     TmGeom g; tm_make_geom(&g, w, h);
     TmJobs jobs; tm_make_jobs(&jobs, &g, weights, full_sums);
@@ -166,13 +167,13 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
         launch_wave_lockstep(dim3((w + 31) / 32, (h + 7) / 8, n), [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
           if (rd) switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          default: tmk::k_ingest_wave<-1, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; }
+          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
+          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
+          default: tmk::k_ingest_wave<-1, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break; }
           else switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          default: tmk::k_ingest_wave<-1, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
+          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
+          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
+          default: tmk::k_ingest_wave<-1, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break; } } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr, rd ? 1 : 0); });
     } else {
         std::vector<float> yuvlut((size_t)3 * 2 * 65536);

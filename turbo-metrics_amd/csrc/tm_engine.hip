@@ -423,7 +423,7 @@ int tm_engine_set_variant(tm_engine *e, int variant)
 {
     // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
     // dispatch order of the two blur passes (default: slot-major), bit 21: LDS-tiled SSIM statistics kernel (default: streaming)
-    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 22) != 0) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 23) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 write the u8 planes
     if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 can run without the XYB arenas
@@ -504,9 +504,9 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
         int kind = h_desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_W(K) do { const float *ytab = e->d_yuvlut; \
-                        if (rd) hipLaunchKernelGGL((tmk::k_ingest_wave<K, true>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); \
-                        else hipLaunchKernelGGL((tmk::k_ingest_wave<K, false>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0]); } while (0)
+#define TM_LAUNCH_W(K) do { const float *ytab = e->d_yuvlut; const int xcd = (e->variant >> 22) & 1; \
+                        if (rd) hipLaunchKernelGGL((tmk::k_ingest_wave<K, true>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], xcd); \
+                        else hipLaunchKernelGGL((tmk::k_ingest_wave<K, false>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], xcd); } while (0)
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;

@@ -786,13 +786,25 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
                                                     const float *__restrict__ yuvlut, float *__restrict__ XYB,
                                                     float *__restrict__ LIN2, unsigned long long *__restrict__ SSE, int want_sse,
-                                                    unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch)
+                                                    unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch, int xcd_order)
 {
     __shared__ double tab[96];
     const int lane = threadIdx.x;
     const int qx = lane & 15, qy = lane >> 4;
     const int slot = blockIdx.z;
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
+    // xcd_order (A/B option, off: measured 8 % slower at 1080p): workgroups are dealt round-robin to the 8 XCDs (each with its
+    // own L2), and four neighbouring tiles share every 128-B line of an 8-bit luma / chroma row (two tiles for 16-bit samples).
+    // Inside each run of 32 workgroups, XCD r (= workgroup id mod 8) takes tiles 4r .. 4r+3: a line goes to one L2, not four.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const unsigned ntx = gridDim.x, total = gridDim.x * gridDim.y;
+        const unsigned L = blockIdx.x + blockIdx.y * ntx, base = L & ~31u;
+        if (xcd_order && base + 32 <= total) {
+            const unsigned T = base + 4 * (L & 7) + ((L >> 3) & 3);
+            bx = (int)(T % ntx); by = (int)(T / ntx);
+        }
+    }
+    const int tx0 = bx * 32, ty0 = by * 8;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     const int w = g.s[0].w, h = g.s[0].h;
     unsigned qref[3] = {0, 0, 0};
