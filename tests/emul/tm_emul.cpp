@@ -147,6 +147,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
                    int variant, const double *weights, int full_sums, unsigned char *QU8, unsigned long long qplane, int qpitch)
 {
     const int xcd_order = (variant >> 22) & 1; // ingest: XCD-aware tile order
+    const int blocked_v = (variant >> 23) & 1; // generation 4: column-pass output in 64 x 32 tiles
     const int ingest_gen = (variant >> 8) & 255;
     variant &= 255;
     TmGeom g; tm_make_geom(&g, w, h);
@@ -196,15 +197,30 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     case 6: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, true>(g, XYB, XYBT, V); }, 5); break;
     case 7: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false>(g, XYB, XYBT, V); }, 5); break;
     case 8: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false, true>(g, XYB, XYBT, V); }, 5); break;
-    case 9: launch_wave_lockstep(dim3(jobs.vstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 0, ingest_gen == 4); }, 5); break;
+    case 9: launch_wave_lockstep(dim3(jobs.vstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 0, ingest_gen == 4 ? (blocked_v ? 2 : 1) : 0); }, 5); break;
     case 10: launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 1, 0); }, 5); break;
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
-    if (ingest_gen == 4) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true>(g, jobs, XYB, V, PART, 0); });
+    if (ingest_gen == 4 && blocked_v) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true, true>(g, jobs, XYB, V, PART, 0); });
+    else if (ingest_gen == 4) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true>(g, jobs, XYB, V, PART, 0); });
     else if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<false>(g, jobs, XYB, V, PART, 0); });
     else if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
     else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });
+    if (blocked_v) { // test convenience: blocked column-pass planes back into plain transposed ones
+        for (int sl = 0; sl < n; ++sl)
+            for (int pl = 0; pl < 5; ++pl)
+                for (int sc = 0; sc < TM_SCALES; ++sc)
+                    for (int c = 0; c < 3; ++c) {
+                        const TmScaleGeom sg = g.s[sc];
+                        float *base = V + (size_t)(sl * 5 + pl) * g.pyr_t + sg.off_t + (size_t)c * sg.plane_t;
+                        std::vector<float> tmp(base, base + sg.plane_t);
+                        const size_t nby = (size_t)sg.pitch_t >> 5, nx = sg.plane_t / sg.pitch_t;
+                        for (size_t x = 0; x < nx; ++x)
+                            for (size_t y = 0; y < (size_t)sg.pitch_t; ++y)
+                                base[x * sg.pitch_t + y] = tmp[((x >> 6) * nby + (y >> 5)) * 2048 + (x & 63) * 32 + (y & 31)];
+                    }
+    }
     if (ingest_gen == 4) { // test convenience: turn the interleaved pyramid back into two plain ones for the plane checks
         std::vector<float> tmp((size_t)2 * g.pyr);
         for (int sl = 0; sl < n; ++sl) {

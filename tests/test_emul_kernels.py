@@ -173,7 +173,7 @@ def test_ssim_kernels_match_oracle(w, h, streamed):
         assert (a == b) or (np.isnan(a) and np.isnan(b))   # NaN below 176x176
 
 
-@pytest.mark.parametrize("gen", [3, 4, 4 + (1 << 14)])  # 1 << 14 here = variant bit 22: XCD-aware tile order of the ingest kernel
+@pytest.mark.parametrize("gen", [3, 4, 4 + (1 << 14), 4 + (1 << 15)])  # here 1 << 14 = variant bit 22 (XCD-aware ingest tile order), 1 << 15 = bit 23 (blocked column-pass planes)
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (200, 9)])
 def test_wave_ingest_and_transposing_row_pass_match_oracle(w, h, gen):
     """ingest generation 3 (no LDS, no transposed XYB copy) + k_blur_h_jobs_x (the row pass transposes ref / dis itself);

@@ -423,10 +423,11 @@ int tm_engine_set_variant(tm_engine *e, int variant)
 {
     // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
     // dispatch order of the two blur passes (default: slot-major), bit 21: LDS-tiled SSIM statistics kernel (default: streaming)
-    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 23) != 0) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 24) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 write the u8 planes
     if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 can run without the XYB arenas
+    if (((variant >> 23) & 1) && (variant >> 8 & 255) != 4) return TM_ERR_INVALID_ARG; // blocked V planes exist for the interleaved pipeline only
     if ((variant >> 8 & 255) >= 3 && (variant & 255) != 9) return TM_ERR_INVALID_ARG; // no transposed XYB copy: needs the job-driven column pass
     if ((variant >> 8 & 255) < 3 && !e->XYBT && (e->mask & TM_METRIC_SSIMULACRA2)) { // generations 0-2 write a transposed XYB copy
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
@@ -552,13 +553,15 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
             case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
             case 8: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm, (e->variant >> 8 & 255) == 4 ? 1 : 0); break;
+            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm, (e->variant >> 8 & 255) == 4 ? ((e->variant >> 23) & 1 ? 2 : 1) : 0); break;
             default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
             }
         }
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
-        if ((e->variant >> 8 & 255) == 4)
+        if ((e->variant >> 8 & 255) == 4 && ((e->variant >> 23) & 1))
+            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
+        else if ((e->variant >> 8 & 255) == 4)
             hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
         else if ((e->variant >> 8 & 255) == 3)
             hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<false>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
@@ -889,6 +892,15 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
         break;
     case TM_PLANE_PASS1_T:
         if (index < 0 || index > 4) return TM_ERR_INVALID_ARG;
+        if ((e->variant >> 23) & 1) { // blocked planes (64 x 32 tiles): gather on the host
+            std::vector<float> pl((size_t)sg.plane_t);
+            HIPCHK(hipMemcpy(pl.data(), e->V + (size_t)(slot * 5 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t, pl.size() * sizeof(float), hipMemcpyDeviceToHost));
+            const size_t nby = (size_t)sg.pitch_t >> 5;
+            for (int x = 0; x < sg.w; ++x)
+                for (int y = 0; y < sg.h; ++y)
+                    out[(size_t)x * sg.h + y] = pl[(((size_t)x >> 6) * nby + ((size_t)y >> 5)) * 2048 + ((size_t)x & 63) * 32 + ((size_t)y & 31)];
+            return TM_OK;
+        }
         src = e->V + (size_t)(slot * 5 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
         pitch = sg.pitch_t; width = sg.h; rows = sg.w;
         break;

@@ -1343,7 +1343,11 @@ __device__ __forceinline__ void ld_row_u2(const float *__restrict__ plane, unsig
 // RDM (ref/dis-interleaved input, ingest generation 4): 0 = plain planes; 1 = "pair lanes": the wave covers 32 columns, lane =
 // (column, side), one coalesced 256-B load per row feeds the ref AND the dis recurrence, and the flush sends the odd tile
 // columns to the next output plane (side_delta floats further); 2 = the product wave: 64 columns, one 8-byte load per lane.
-template <int R, int W, bool TWO, bool COPY, bool NT = false, int RDM = 0>
+// BLK: the output planes are stored as 64-column x 32-row tiles of 2048 contiguous floats (element (x, y) of a plane at
+// ((x >> 6) * (pitch_t >> 5) + (y >> 5)) * 2048 + (x & 63) * 32 + (y & 31)): one flush of this wave is ONE contiguous run of
+// 8 KB (4 KB per side for the pair-lane waves) instead of 64 lines 4 KB apart, and the row pass walks a tile front to back.
+// dst then points at the wave's first column inside tile row 0.
+template <int R, int W, bool TWO, bool COPY, bool NT = false, int RDM = 0, bool BLK = false>
 __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, float *__restrict__ tile_copy,
                                                   const float *__restrict__ pa, const float *__restrict__ pb, unsigned x,
                                                   float *__restrict__ dst, float *__restrict__ dst_copy, int h, int pitch,
@@ -1359,8 +1363,10 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
     const int lane = threadIdx.x & 63;
     const int xl = lane / TT::LPC, yq = lane % TT::LPC;
     // per-lane BYTE part of every flush address
-    const unsigned voff = RDM == 1 ? (unsigned)((xl >> 1) * pitch_t + 4 * yq) * 4u + (unsigned)(xl & 1) * side_delta * 4u
-                                   : (unsigned)(xl * pitch_t + 4 * yq) * 4u;
+    static_assert(!BLK || (R == 32 && !COPY), "blocked output: 32-row tiles");
+    const int cpitch = BLK ? 32 : pitch_t; // floats between two columns of the output
+    const unsigned voff = RDM == 1 ? (unsigned)((xl >> 1) * cpitch + 4 * yq) * 4u + (unsigned)(xl & 1) * side_delta * 4u
+                                   : (unsigned)(xl * cpitch + 4 * yq) * 4u;
     float wa[W], wb[TWO ? W : 1];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
@@ -1412,7 +1418,8 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
                 for (int i = 0; i < 64 / TT::CPI; ++i) {
                     const int xc = i * TT::CPI + xl;
                     const float *tp = tile + (4 * yq) * TT::S + xc;
-                    TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst + (size_t)(i * TT::CPI / XS) * pitch_t + y0);
+                    TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(BLK ? dst + (size_t)(y0 >> 5) * 2048 + (i * TT::CPI / XS) * 32
+                                                                                        : dst + (size_t)(i * TT::CPI / XS) * pitch_t + y0);
                     if (NT) __builtin_nontemporal_store(tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]), (TM_GLOBAL_AS tm_f4 *)(ub + voff));
                     else *(TM_GLOBAL_AS tm_f4 *)(ub + voff) = tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]);
                     if (COPY) {
@@ -1515,14 +1522,17 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
             if (blk * 64 >= sg.w) return;
         }
         const int x0 = blk * 64;
-        float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + sg.off_t + c * sg.plane_t + (size_t)(x0 + 32 * half) * sg.pitch_t;
-        if (role == 2) {
-            const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 8u;
-            blur_v_split_role<R, W, true, false, true, 2>(tile, nullptr, in, nullptr, x, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, true);
+        float *vplane = V + (size_t)(slot * 5 + role) * g.pyr_t + sg.off_t + c * sg.plane_t;
+        const unsigned xc = (unsigned)min(x0 + lane, sg.w - 1) * 8u;
+        const unsigned xp = (unsigned)min(x0 + 32 * half + (lane >> 1), sg.w - 1) * 8u + (unsigned)(lane & 1) * 4u;
+        if (rd == 2) { // blocked V planes (rd: 1 = interleaved input, 2 = interleaved input + blocked output)
+            float *vdst = vplane + (size_t)blk * (sg.pitch_t >> 5) * 2048 + (size_t)(32 * half) * 32;
+            if (role == 2) blur_v_split_role<R, W, true, false, true, 2, true>(tile, nullptr, in, nullptr, xc, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, true);
+            else blur_v_split_role<R, W, false, false, true, 1, true>(tile, nullptr, in, nullptr, xp, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, role == 0, (unsigned)g.pyr_t);
         } else {
-            const unsigned x = (unsigned)min(x0 + 32 * half + (lane >> 1), sg.w - 1) * 8u + (unsigned)(lane & 1) * 4u;
-            blur_v_split_role<R, W, false, false, true, 1>(tile, nullptr, in, nullptr, x, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t,
-                                                           role == 0, (unsigned)g.pyr_t);
+            float *vdst = vplane + (size_t)(x0 + 32 * half) * sg.pitch_t;
+            if (role == 2) blur_v_split_role<R, W, true, false, true, 2>(tile, nullptr, in, nullptr, xc, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, true);
+            else blur_v_split_role<R, W, false, false, true, 1>(tile, nullptr, in, nullptr, xp, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, role == 0, (unsigned)g.pyr_t);
         }
         return;
     }
@@ -1666,7 +1676,7 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const
 // whose maps are evaluated at step t).  Everything stays inside the wave: LDS operations of one wave execute in order.
 // 17.4 KB of LDS per wave -> 9 waves per CU.
 // ------------------------------------------------------------------------------------------------
-template <bool FULL, int WN, int D, bool RD>
+template <bool FULL, int WN, int D, bool RD, bool BLK>
 __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][17], const float *__restrict__ refn,
                                              const float *__restrict__ disn, const float *__restrict__ v0,
                                              const float *__restrict__ v1, const float *__restrict__ v2,
@@ -1679,6 +1689,14 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     constexpr int NF = FULL ? WN : 1;
     const int lane = threadIdx.x & 63;
     const int lr = lane >> 4, lc = lane & 15;
+    // column x of a blurred plane, this lane's row: transposed planes x * pt floats further, blocked planes (BLK, see
+    // blur_v_split_role) in tile column x >> 6, 32 floats per column inside the tile
+    const size_t tcol = (size_t)(pt >> 5) * 2048;
+    auto ld_row = [&](const float *__restrict__ p, int x, int nx, int) {
+        const int rc = x < nx ? x : nx - 1;
+        const float v = BLK ? p[(size_t)(rc >> 6) * tcol + (size_t)(rc & 63) * 32] : p[(size_t)rc * pt];
+        return x < nx ? v : 0.0f;
+    };
     float w0[NF], w1[NF], w2[NF], w3[WN], w4[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -1761,7 +1779,7 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     }
 }
 
-template <bool RD>
+template <bool RD, bool BLK = false>
 __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
                                                       const float *__restrict__ V, double *__restrict__ PART, int slot_major)
 {
@@ -1775,7 +1793,7 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     const bool valid = y < sg.h;
     const int yy = valid ? y : sg.h - 1;
     const int slot = slot_major ? blockIdx.x : blockIdx.z;
-    const size_t to = sg.off_t + c * sg.plane_t + yy;
+    const size_t to = sg.off_t + c * sg.plane_t + (BLK ? (size_t)(yy >> 5) * 2048 + (yy & 31) : (size_t)yy);
     // RD: refn = this channel's interleaved plane ({ref, dis} pairs, rows of 2 * pitch floats); disn unused
     const float *refn = RD ? XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane) : XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
     const float *disn = RD ? refn : XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
@@ -1785,8 +1803,8 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
     const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6, RD>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
-    else blur_h_job_x<false, 16, 8, RD>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    else blur_h_job_x<false, 16, 8, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
         __shared__ double redl[6][64];
