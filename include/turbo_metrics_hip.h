@@ -175,7 +175,8 @@ int tm_engine_set_graph(tm_engine *e, int on);
  * straight-line kernels, 1 = fused 64x64 tiles, 2 = 32x32 LDS tiles + transposed copy, 3 = wave-private tiles, two plain
  * pyramids, 4 = wave-private tiles, ref/dis-interleaved pyramid: the default), bits 16-19 chunks of the two-stream pipeline
  * (0 = off), bit 20 block-major instead of slot-major dispatch, bit 21 LDS-tiled SSIM statistics, bit 22 XCD-aware tile
- * order in the ingest kernel (measured slower, off).  Default (4 << 8) | 9.
+ * order in the ingest kernel (measured slower, off), bit 23 column-pass planes stored as 64 x 32 tiles (generation 4 only;
+ * measured slower, off).  Default (4 << 8) | 9.
  * TM_ERR_INVALID_ARG for combinations that do not exist (generations 3, 4 need column pass 9). */
 int tm_engine_set_variant(tm_engine *e, int variant);
 
