@@ -9,7 +9,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
-_LIB = os.path.join(_HERE, "libtm_emul.so")
+# TM_EMUL_ASAN=1: AddressSanitizer build of the kernel source (GPU ASan is not available on the pool; every arena the kernels
+# touch is a numpy allocation of exactly the engine's size, so out-of-bounds accesses of any kernel show up here).  Run with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 -- see tools/asan_emul.sh
+_ASAN = os.environ.get("TM_EMUL_ASAN") == "1"
+_LIB = os.path.join(_HERE, "libtm_emul_asan.so" if _ASAN else "libtm_emul.so")
 _SRCS = [os.path.join(_HERE, "tm_emul.cpp"), os.path.join(_HERE, "hip_emul.h")] + [
     os.path.join(_ROOT, "turbo-metrics_amd", "csrc", f) for f in ("tm_kernels.h", "tm_ssim_kernels.h", "tm_device_math.h", "tm_geom.h", "tm_math_tables.inc")]
 
@@ -17,8 +21,9 @@ _SRCS = [os.path.join(_HERE, "tm_emul.cpp"), os.path.join(_HERE, "hip_emul.h")] 
 def build():
     if os.path.exists(_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(_LIB) for s in _SRCS):
         return _LIB
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-march=x86-64-v3", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
-                           "-shared", "-pthread", "-Wno-unknown-pragmas", "-I", _HERE, "-o", _LIB, _SRCS[0]])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-march=x86-64-v3", "-ffp-contract=off", "-fno-fast-math", "-fPIC"]
+                          + (["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if _ASAN else [])
+                          + ["-shared", "-pthread", "-Wno-unknown-pragmas", "-I", _HERE, "-o", _LIB, _SRCS[0]])
     return _LIB
 
 
