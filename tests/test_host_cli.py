@@ -17,7 +17,9 @@ from tm_pkg import tm
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "turbo-metrics_amd", "host")
-HELPER = os.path.join(ROOT, "tests", "host", "tm_host_test")
+# TM_HOST_SANITIZE=1: the helper (decoders, stream readers, formatters) built with AddressSanitizer + UBSan, aborting on the first report
+SANITIZE = os.environ.get("TM_HOST_SANITIZE") == "1"
+HELPER = os.path.join(ROOT, "tests", "host", "tm_host_test_san" if SANITIZE else "tm_host_test")
 CLI = os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")
 
 
@@ -26,7 +28,8 @@ def helper():
     srcs = [os.path.join(ROOT, "tests", "host", "tm_host_test.cpp")] + [os.path.join(HOST, f) for f in ("frame_sources.cpp", "output.cpp", "turbo_metrics.cpp")]
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
     if not os.path.exists(HELPER) or any(os.path.getmtime(d) > os.path.getmtime(HELPER) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", HELPER] + srcs + ["-L" + os.path.join(ROOT, "turbo-metrics_amd"),
+        subprocess.check_call(["g++", "-O1", "-std=c++17"] + (["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"] if SANITIZE else [])
+                              + ["-o", HELPER] + srcs + ["-L" + os.path.join(ROOT, "turbo-metrics_amd"),
                               "-lturbometrics_hip", "-lz", "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "turbo-metrics_amd")])
     return HELPER
 
@@ -281,6 +284,30 @@ def test_y4m_rejects_what_the_reference_cannot_represent(helper, tmp_path):
     p = str(tmp_path / "v.y4m")
     open(p, "wb").write(b"YUV4MPEG2 W64 H64 F30:1 Ip A1:1 C444\nFRAME\n" + bytes(64 * 64 * 3))
     assert "not implemented" in run(helper, "source", p, str(tmp_path / "o.bin"))
+
+
+def test_corrupt_headers_end_in_errors_not_allocations(helper, tmp_path):
+    """found by tools/fuzz_sources.py: a PNG whose IHDR promises 21 x 889 192 461 pixels asked for a 57 GB buffer"""
+    import struct, zlib
+    good = png_bytes(np.zeros((8, 8, 3), np.uint8))
+    ihdr = bytearray(good[16:29])
+    for w, h in ((21, 889192461), (70000, 8), (8, 70000)):
+        ihdr[0:8] = struct.pack(">II", w, h)
+        bad = good[:16] + bytes(ihdr) + struct.pack(">I", zlib.crc32(b"IHDR" + bytes(ihdr))) + good[33:]
+        p = str(tmp_path / "bad.png")
+        open(p, "wb").write(bad)
+        assert run(helper, "source", p, str(tmp_path / "o.bin")).startswith("ERROR")
+    # a plausible size that the 60 compressed bytes cannot possibly inflate to
+    ihdr[0:8] = struct.pack(">II", 4000, 4000)
+    open(p, "wb").write(good[:16] + bytes(ihdr) + struct.pack(">I", zlib.crc32(b"IHDR" + bytes(ihdr))) + good[33:])
+    assert "corrupt" in run(helper, "source", p, str(tmp_path / "o.bin"))
+    for blob in (b"P6\n99999999 3\n255\n" + bytes(64), b"PF\n4000000000 4000000000\n-1.0\n" + bytes(64)):
+        q = str(tmp_path / ("bad.ppm" if blob[1:2] == b"6" else "bad.pfm"))
+        open(q, "wb").write(blob)
+        assert run(helper, "source", q, str(tmp_path / "o.bin")).startswith("ERROR")
+    y = str(tmp_path / "bad.y4m")
+    open(y, "wb").write(b"YUV4MPEG2 W100000 H64 F30:1 Ip A1:1 C420jpeg\nFRAME\n" + bytes(256))
+    assert run(helper, "source", y, str(tmp_path / "o.bin")).startswith("ERROR")
 
 
 # ---- the command line on the device ------------------------------------------------------------------------------------

@@ -14,6 +14,13 @@ namespace tm_host {
 namespace {
 
 [[noreturn]] void fail(const std::string &m) { throw std::runtime_error(m); }
+// Dimension sanity shared by every reader: a corrupt header must end in an error, not in a 50 GB allocation (found by
+// tools/fuzz_sources.py); 65 536 is far above anything the engine can hold and keeps w * h * 6 inside size_t arithmetic.
+constexpr uint32_t MAX_DIM = 65536;
+void check_dims(const char *what, uint64_t w, uint64_t h)
+{
+    if (w > MAX_DIM || h > MAX_DIM) fail(std::string(what) + ": implausible size " + std::to_string(w) + "x" + std::to_string(h));
+}
 
 uint32_t be32(const unsigned char *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 
@@ -111,6 +118,7 @@ CpuImg decode_png(const unsigned char *d, size_t len)
         pos += 12 + (size_t)clen;
     }
     if (ctype < 0 || w == 0 || h == 0) fail("PNG: no IHDR");
+    check_dims("PNG", w, h);
     // the reference accepts RGB sample layouts only (turbo-metrics/src/img.rs:17-37: anything else is todo!())
     if (ctype != 2) fail("not implemented: PNG colour type " + std::to_string(ctype) + " (only RGB is supported, as in the reference)");
     if (depth != 8 && depth != 16) fail("PNG: RGB must be 8 or 16 bits per sample");
@@ -128,6 +136,9 @@ CpuImg decode_png(const unsigned char *d, size_t len)
         const size_t ph = (h > passes[p].y0) ? (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
         if (pw && ph) raw_size += ph * (1 + pw * bpp);
     }
+    // deflate expands at most ~1032:1: a header that promises more than the IDAT bytes can hold is corrupt (checked BEFORE
+    // the allocation)
+    if (raw_size / 1032 > idat.size() + 1) fail("PNG: corrupt image data");
     std::vector<unsigned char> raw(raw_size);
     {
         z_stream zs;
@@ -180,8 +191,10 @@ CpuImg decode_pnm(const unsigned char *d, size_t len)
     };
     const bool pfm = d[1] == 'F';
     CpuImg img;
-    img.width = (uint32_t)std::stoul(token());
-    img.height = (uint32_t)std::stoul(token());
+    const unsigned long pw = std::stoul(token()), ph = std::stoul(token());
+    check_dims("PNM", pw, ph);
+    img.width = (uint32_t)pw;
+    img.height = (uint32_t)ph;
     const std::string third = token();
     ++pos; // the single whitespace byte after the header
     if (img.width == 0 || img.height == 0) fail("PNM: empty image");
@@ -390,14 +403,17 @@ bool YuvStreamSource::read_picture(unsigned char *surface)
         }
     } else {
         const int sh = 16 - bits_; // P016: the value sits in the high bits (cudarse-video/src/dec.rs:398-400)
-        const uint16_t *y = (const uint16_t *)planar, *u = y + (size_t)w_ * h_, *v = u + cw * ch;
+        // the samples sit wherever the stream's headers left them (a file mapping: any byte offset): read them bytewise
+        // through memcpy (one unaligned 16-bit load each once compiled), little endian like the Y4M / raw formats
+        auto ld16 = [](const unsigned char *p) { uint16_t v; memcpy(&v, p, 2); return v; };
+        const unsigned char *y = planar, *u = y + (size_t)w_ * h_ * 2, *v = u + cw * ch * 2;
         for (uint32_t r = 0; r < h_; ++r) {
             uint16_t *o = (uint16_t *)(luma + r * pitch_);
-            for (uint32_t x = 0; x < w_; ++x) o[x] = (uint16_t)(y[(size_t)r * w_ + x] << sh);
+            for (uint32_t x = 0; x < w_; ++x) o[x] = (uint16_t)(ld16(y + ((size_t)r * w_ + x) * 2) << sh);
         }
         for (size_t r = 0; r < ch; ++r) {
             uint16_t *o = (uint16_t *)(uv + r * pitch_);
-            for (size_t x = 0; x < cw; ++x) { o[2 * x] = (uint16_t)(u[r * cw + x] << sh); o[2 * x + 1] = (uint16_t)(v[r * cw + x] << sh); }
+            for (size_t x = 0; x < cw; ++x) { o[2 * x] = (uint16_t)(ld16(u + (r * cw + x) * 2) << sh); o[2 * x + 1] = (uint16_t)(ld16(v + (r * cw + x) * 2) << sh); }
         }
     }
     return true;
@@ -490,6 +506,7 @@ std::unique_ptr<FrameSource> create_source(const std::string &path, const Source
             else if (tok == "XCOLORRANGE=LIMITED") full = false;
         }
         if (w == 0 || h == 0) { close(); fail("Y4M: missing W/H"); }
+        if (w > MAX_DIM || h > MAX_DIM) { close(); check_dims("Y4M", w, h); }
         if (cs.rfind("420", 0) != 0) { close(); fail("not implemented: Y4M colourspace C" + cs + " (only 4:2:0 reaches the NV12 / P016 surfaces of the reference)"); }
         const size_t pp = cs.find('p', 3);
         if (pp != std::string::npos && pp + 1 < cs.size() && isdigit((unsigned char)cs[pp + 1])) bits = std::stoi(cs.substr(pp + 1));
