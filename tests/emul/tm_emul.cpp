@@ -148,6 +148,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
 {
     const int xcd_order = (variant >> 22) & 1; // ingest: XCD-aware tile order
     const int blocked_v = (variant >> 23) & 1; // generation 4: column-pass output in 64 x 32 tiles
+    const int wide_rows = (variant >> 24) & 1; // generation 4: the row-pass instantiation the engine uses above 2560 pixels
     const int ingest_gen = (variant >> 8) & 255;
     variant &= 255;
     TmGeom g; tm_make_geom(&g, w, h);
@@ -202,7 +203,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
     default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
     }
     if (ingest_gen == 4 && blocked_v) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true, true>(g, jobs, XYB, V, PART, 0); });
-    else if (ingest_gen == 4) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true>(g, jobs, XYB, V, PART, 0); });
+    else if (ingest_gen == 4 && wide_rows) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true, false, 16, 8, 16, 8>(g, jobs, XYB, V, PART, 0); });
+    else if (ingest_gen == 4) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true, false, 16, 8, 32, 16>(g, jobs, XYB, V, PART, 0); });
     else if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<false>(g, jobs, XYB, V, PART, 0); });
     else if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
     else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });

@@ -423,7 +423,7 @@ int tm_engine_set_variant(tm_engine *e, int variant)
 {
     // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
     // dispatch order of the two blur passes (default: slot-major), bit 21: LDS-tiled SSIM statistics kernel (default: streaming)
-    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 24) != 0) return TM_ERR_INVALID_ARG;
+    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 25) != 0) return TM_ERR_INVALID_ARG;
     if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
     if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 write the u8 planes
     if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 can run without the XYB arenas
@@ -561,8 +561,10 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         // ---- stage BLUR_H: row pass + error maps + reductions
         if ((e->variant >> 8 & 255) == 4 && ((e->variant >> 23) & 1))
             hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
+        else if ((e->variant >> 8 & 255) == 4 && (g.s[0].w > 2560 || ((e->variant >> 24) & 1))) // wide frames (bit 24 forces this instantiation, for tests)
+            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 16, 8>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
         else if ((e->variant >> 8 & 255) == 4)
-            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
+            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
         else if ((e->variant >> 8 & 255) == 3)
             hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<false>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
         else hipLaunchKernelGGL(tmk::k_blur_h_jobs, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART, sm);

@@ -1779,7 +1779,11 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
     }
 }
 
-template <bool RD, bool BLK = false>
+// WNF / DF, WNE / DE: register window (rows of the blurred planes in flight = window - 10) and ref/dis queue depth of the
+// FULL and the EDGE path.  The engine runs <16, 8, 32, 16> up to 2560 pixels wide and <16, 8, 16, 8> above (measured: FULL 12 ->
+// 16 is worth 10 % of this pass at 4K and nothing at 1080p, EDGE 16 -> 32 3.5 % at 1080p and -5 % at 4K); at 217 VGPRs the
+// kernel holds 2 waves per SIMD = 8 per CU, one fewer than its LDS would allow, which by itself measured 3.6 % faster.
+template <bool RD, bool BLK = false, int WNF = 12, int DF = 6, int WNE = 16, int DE = 8>
 __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
                                                       const float *__restrict__ V, double *__restrict__ PART, int slot_major)
 {
@@ -1803,8 +1807,8 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
     const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (mode == TM_MODE_FULL) blur_h_job_x<true, 12, 6, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
-    else blur_h_job_x<false, 16, 8, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    if (mode == TM_MODE_FULL) blur_h_job_x<true, WNF, DF, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    else blur_h_job_x<false, WNE, DE, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
         __shared__ double redl[6][64];
