@@ -361,6 +361,27 @@ def test_per_channel_values_and_first_channel_mode():
     eng.close()
 
 
+def test_placement_search_changes_nothing_but_the_address():
+    """tm_set_placement_candidates: engine creation keeps the fastest of a few allocations of the pass-1 arena (only for arenas
+    of 1 GiB and more: 8 slots of 1080p).  Scores, raw sums and the memory accounting must not depend on it."""
+    w, h, B = 1920, 1080, 8
+    frames = [nv12_frames(w, h, n) for n in range(2)]
+    out = []
+    try:
+        for cand in (1, 3):
+            tm.set_placement_candidates(cand)
+            eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B)
+            for slot in range(B):
+                eng.set_pair(slot, *frames[slot % 2])
+            eng.compute_async()
+            eng.sync()
+            out.append((eng.mem_usage(), [eng.scores(s).ssimulacra2 for s in range(B)], [eng.raw_sums(s).tobytes() for s in range(B)]))
+            eng.close()
+    finally:
+        tm.set_placement_candidates(6)
+    assert out[0] == out[1]
+
+
 def test_graph_replay_equals_direct_launches():
     """The per-batch sequence is replayed from a captured hipGraph; frame pointers, batch size, input kind and the
     full_sums switch may change between computes (re-capture) without changing a bit of the results."""

@@ -10,4 +10,4 @@ the operators raise.
 """
 from . import ffi, shard, synth  # noqa: F401
 from .engine import (ColorMatrix, FrameScores, HwFrame, Metrics, Ssimulacra2, TmError,  # noqa: F401
-                     TurboMetrics, init_hip)
+                     TurboMetrics, init_hip, set_placement_candidates)

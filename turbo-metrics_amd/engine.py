@@ -40,6 +40,12 @@ def init_hip(device: int = 0):
     _chk(ffi.lib().tm_init(int(device)), "tm_init")
 
 
+def set_placement_candidates(n: int):
+    """tm_set_placement_candidates: allocations of the pass-1 arena that engine creation tries (it keeps the one on which the
+    column pass runs fastest); 1 = off.  Process-wide, applies to engines created afterwards."""
+    ffi.lib().tm_set_placement_candidates(int(n))
+
+
 class ColorMatrix(enum.IntEnum):
     BT709 = ffi.TM_MATRIX_BT709
     BT601_525 = ffi.TM_MATRIX_BT601_525

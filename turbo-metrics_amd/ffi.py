@@ -28,6 +28,7 @@ SYMBOLS = {
     "tm_init": (_i, [_i]),
     "tm_host_alloc": (_vp, [_sz]),
     "tm_host_free": (None, [_vp]),
+    "tm_set_placement_candidates": (None, [_i]),
     "tm_engine_create": (_i, [C.POINTER(_vp), _u32, _u32, _u32, _u32]),
     "tm_engine_destroy": (None, [_vp]),
     "tm_engine_mem_usage": (_sz, [_vp]),
