@@ -309,7 +309,7 @@ static int placement_search(tm_engine *e)
         for (int rep = 0; rep < 3; ++rep) { // the first run warms the instruction cache; the faster of the other two counts
             float m = 0.0f;
             (void)hipEventRecord(e0, e->stream);
-            hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), dim3((unsigned)e->cap, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), dim3(320), 0, e->stream,
+            hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), dim3(320), 0, e->stream,
                                e->g, e->jobs, e->XYB, e->V, 1, 1);
             (void)hipEventRecord(e1, e->stream);
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&m, e0, e1) != hipSuccess) { rc = hip_fail(hipGetLastError(), "placement search"); break; }

@@ -1492,7 +1492,9 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
     return j;
 }
 
-template <int R, int W>
+// PROBE: a second instantiation of the same code for the placement search of tm_engine_create, so that profilers list the
+// search's launches (cold caches, zeros) apart from the batch launches
+template <int R, int W, int PROBE = 0>
 __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V,
                                                         int slot_major, int rd)
 {

@@ -203,6 +203,8 @@ int main(int argc, char **argv)
         // a source that knows its length never needs more slots than it has pairs (a single image pair: one slot, one engine)
         const size_t known = std::min(source_ref->frame_count(), source_dis->frame_count());
         if (known > 0 && known <= batch) { batch = (uint32_t)known; pipeline = false; }
+        // the placement search of tm_engine_create (~10 ms per candidate and engine) pays off on long streams only
+        if (known > 0 && known < 20000) tm_set_placement_candidates(1);
         turbo = std::make_unique<TurboMetrics>(source_ref->width(), source_ref->height(), metrics, batch, pipeline);
         if (full_sums) turbo->set_full_sums(true);
     } catch (const std::exception &e) {
