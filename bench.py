@@ -72,12 +72,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # TM_BENCH_BACKEND=gloo (testing only): run the multi-rank path on a box with fewer GPUs than ranks -- the ranks share the
+    # devices round-robin and the one collective goes through gloo on host tensors.  The driver's runs use RCCL ("nccl").
+    backend = os.environ.get("TM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
+    cdev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     tm.init_hip(local_rank)
 
     w, h, kind, default_b, cfg_name = WORKLOADS[args.workload]
@@ -135,9 +144,9 @@ def main():
     # ---- the single collective of the path: per-frame scores reduced (sum) to rank 0
     scores_local = np.array([eng.scores(i).ssimulacra2 or 0.0 for i in range(B)], np.float64)
     lo, hi = tm.shard.shard_range(world * B, rank, world)  # this rank's block of the stream: [rank*B, (rank+1)*B)
-    all_scores = tm.shard.reduce_scores(scores_local, lo, world * B, 1, dist, "cuda" if dist is not None else "cpu")
+    all_scores = tm.shard.reduce_scores(scores_local, lo, world * B, 1, dist, cdev if dist is not None else "cpu")
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
