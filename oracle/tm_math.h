@@ -100,4 +100,23 @@ static inline float tmo_powf(float xf, double y)
     return (float)tmo_u2d(tmo_d2u(res) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
 
+/* BT.709 transfer function, power branch: ((v + a) / A)^(1/0.45) for v in [0.0812, 1) as one of 128 cubics in t = 128 v - k,
+ * k = floor(128 v) -- both exact in f32 --, coefficients from tools/gen_math_tables.py, c0 = hi + lo so that the last addition
+ * is the only rounding that matters.  8 f32 operations instead of a division and the ~45 of tmo_powf; the product runs the
+ * same sequence (tm_device_math.h bt709_eotf).  Error against the exact function: tmo_bt709_eotf_max_ulp() scans every
+ * float of the interval (tests/test_oracle_pins.py).  v >= 1: the exact value is >= 1 and every caller clamps to 1. */
+static const float tmo_eotf_c[512] = {TM_EOTF_C};
+static const float tmo_eotf_c0lo[128] = {TM_EOTF_C0LO};
+static inline float tmo_bt709_power(float v)
+{
+    if (v >= 1.0f) return 1.0f;
+    const float s = v * 128.0f;
+    const int k = (int)s;
+    const float t = s - (float)k;
+    const float *c = tmo_eotf_c + 4 * k;
+    float q = fmaf(c[3], t, c[2]);
+    q = fmaf(q, t, c[1]);
+    return fmaf(q, t, tmo_eotf_c0lo[k]) + c[0];
+}
+
 #endif

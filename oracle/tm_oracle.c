@@ -168,10 +168,33 @@ static inline float bt709_eotf(float v)
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
     const float THRESHOLD = 0.08124285829863521110029445797874f;
-    if (v >= THRESHOLD) return tmo_powf((v + (ALPHA - 1.0f)) / ALPHA, (double)(1.0f / 0.45f));
+    /* the reference: powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (fast_powf = exp2(y log2 x), ~8 ulp); here the piecewise
+     * cubic of tm_math.h (< 1 ulp from the exact value of that expression) */
+    (void)ALPHA;
+    if (v >= THRESHOLD) return tmo_bt709_power(v);
     return v / 4.5f;
 }
 float tmo_bt709_eotf(float v) { return bt709_eotf(v); }
+
+/* largest error of the power branch, in ulps of the exact result, over EVERY float v in [threshold, 1); exact = powl in long
+ * double of the reference's expression with its f32 constants.  worst_v receives the argument of the maximum. */
+double tmo_bt709_eotf_max_ulp(float *worst_v)
+{
+    const float BETA = 0.018053968510807f;
+    const float ALPHA = 1.0f + 5.5f * BETA;
+    const float AM1 = ALPHA - 1.0f;
+    const float EXPO = 1.0f / 0.45f;
+    const float THRESHOLD = 0.08124285829863521110029445797874f;
+    double worst = 0.0;
+    for (float v = THRESHOLD; v < 1.0f; v = nextafterf(v, 2.0f)) {
+        const long double exact = powl(((long double)v + (long double)AM1) / (long double)ALPHA, (long double)EXPO);
+        int e;
+        (void)frexpl(exact, &e); /* exact = m 2^e, m in [0.5, 1): ulp = 2^(e - 24) */
+        const double err = (double)(fabsl((long double)bt709_eotf(v) - exact) / ldexpl(1.0L, e - 24));
+        if (err > worst) { worst = err; if (worst_v) *worst_v = v; }
+    }
+    return worst;
+}
 
 static inline float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 

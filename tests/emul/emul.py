@@ -28,12 +28,18 @@ def build():
 
 
 def product_pow_tables():
-    """the 96 doubles of turbo-metrics_amd/csrc/tm_math_tables.inc (rcp, nlog, exp2)"""
+    """the math table buffer of turbo-metrics_amd/csrc/tm_math_tables.inc as the kernels expect it (TM_TAB_DOUBLES = 416 doubles):
+    96 doubles (rcp, nlog, exp2 of pow_pos), then the BT.709 transfer-function cubics as 512 + 128 floats"""
     import re
     txt = open(os.path.join(_ROOT, "turbo-metrics_amd", "csrc", "tm_math_tables.inc")).read()
-    vals = [float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[-+]?[0-9]+", txt)]
-    assert len(vals) == 96
-    return np.array(vals, np.float64)
+    lits = re.findall(r"(-?0x[0-9a-f.]+p[-+]?[0-9]+)(f?)", txt)
+    dbl = [float.fromhex(v) for v, f in lits if not f]
+    flt = [float.fromhex(v) for v, f in lits if f]
+    assert len(dbl) == 96 and len(flt) == 640, (len(dbl), len(flt))
+    buf = np.zeros(416, np.float64)
+    buf[:96] = dbl
+    buf[96:].view(np.float32)[:] = np.array(flt, np.float32)
+    return buf
 
 
 class ScaleGeom(C.Structure):

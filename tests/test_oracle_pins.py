@@ -103,6 +103,20 @@ def test_powf_is_correctly_rounded_on_samples():
         assert bad.sum() == 0
 
 
+def test_bt709_transfer_function_is_within_0p7_ulp_everywhere():
+    """the power branch ((v + a) / A)^(1/0.45) is a table of 128 cubics (oracle/tm_math.h == tm_device_math.h): scanned over EVERY
+    float of [threshold, 1) against long-double powl of the reference's expression with its f32 constants"""
+    worst, at = O.bt709_eotf_max_ulp()
+    assert worst < 0.70, (worst, at)
+    v = np.array([0.0, 0.01, 0.0812, 0.08124286, 0.5, 0.99999994, 1.0, 1.3], np.float32)
+    got = O.bt709_eotf(v)
+    assert got[0] == 0.0 and got[1] == np.float32(0.01) / np.float32(4.5) and got[2] == np.float32(0.0812) / np.float32(4.5)  # linear branch: IEEE division
+    assert got[6] == 1.0 and got[7] == 1.0 and got[5] < 1.0  # v >= 1: exactly 1 (the callers clamp)
+    x = np.linspace(0.0813, 0.9999, 20001).astype(np.float32)
+    y = O.bt709_eotf(x)
+    assert (np.diff(y.astype(np.float64)) >= 0).all()  # monotone across the 128 segment joints
+
+
 def test_yuv_matrix_constants():
     # SURVEY 8a/A2: Kr,Kb derived from chromaticities in f32
     exp = {0: (0.212639, 0.072192), 1: (0.212376, 0.086564), 2: (0.222004, 0.071341)}

@@ -159,13 +159,30 @@ __device__ __forceinline__ float div_const(float x, float c, float rc)
     return __builtin_copysignf(__builtin_fmaf(r, rc, q1), x);
 }
 
-// BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs)
+// Layout of the math table buffer every ingest kernel stages in LDS: 96 doubles of pow_pos, then (as floats) the BT.709
+// transfer-function table: 128 x {c0hi, c1, c2, c3}, then 128 x c0lo (tools/gen_math_tables.py -> tm_math_tables.inc)
+#define TM_TAB_DOUBLES 416
+
+// BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs).  Power branch: the reference
+// evaluates powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (exp2(y log2 x), ~8 ulp); here ((v + a) / A)^(1/0.45) on [0.0812, 1) is
+// one of 128 cubics in t = 128 v - k, k = floor(128 v) -- both exact in f32 --, c0 = hi + lo so that the last addition is the only
+// rounding that matters: 8 f32 operations instead of a division and the ~45 of pow_pos, at most 0.68 ulp from the exact value
+// of that expression over every float of the interval (oracle/tm_oracle.c tmo_bt709_eotf_max_ulp, tests/test_oracle_pins.py).
+// v >= 1: the exact value is >= 1 and every caller clamps to 1.
 __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ tab)
 {
-    const float BETA = 0.018053968510807f;
-    const float ALPHA = 1.0f + 5.5f * BETA;
     const float THRESHOLD = 0.08124285829863521110029445797874f;
-    if (v >= THRESHOLD) return pow_pos(div_const(v + (ALPHA - 1.0f), ALPHA, 1.0f / ALPHA), (double)(1.0f / 0.45f), tab);
+    if (v >= THRESHOLD) {
+        if (v >= 1.0f) return 1.0f;
+        const float *__restrict__ et = (const float *)(tab + 96);
+        const float s = v * 128.0f;
+        const int k = (int)s;
+        const float t = s - (float)k;
+        const float c0 = et[4 * k], c1 = et[4 * k + 1], c2 = et[4 * k + 2], c3 = et[4 * k + 3], c0lo = et[512 + k];
+        float q = __builtin_fmaf(c3, t, c2);
+        q = __builtin_fmaf(q, t, c1);
+        return __builtin_fmaf(q, t, c0lo) + c0;
+    }
     return div_const(v, 4.5f, 1.0f / 4.5f);
 }
 

@@ -41,7 +41,14 @@ int hip_fail(hipError_t e, const char *what)
 
 const uint32_t k_lut_bits[256] = {TM_SRGB_LUT_BITS};
 const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
-const double k_powtab[96] = {TM_POW_RCP, TM_POW_NLOG, TM_POW_EXP2};
+// the math table buffer of tm_device_math.h (TM_TAB_DOUBLES): pow_pos tables, then the transfer-function cubics as floats
+struct TmMathTab {
+    double pow[96];
+    float eotf_c[512];
+    float eotf_c0lo[128];
+};
+static_assert(sizeof(TmMathTab) == TM_TAB_DOUBLES * sizeof(double), "math table layout");
+const TmMathTab k_powtab = {{TM_POW_RCP, TM_POW_NLOG, TM_POW_EXP2}, {TM_EOTF_C}, {TM_EOTF_C0LO}};
 
 // ---- colour coefficients: same f32 operation order as the reference's const evaluation -----------
 struct V3 { float x, y, z; };
@@ -379,8 +386,8 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((rc = dev_alloc(e, &e->d_desc, B * 2, true))) return fail(rc);
     if ((rc = dev_alloc(e, &e->d_lut, 256, false))) return fail(rc);
     if ((rc = dev_alloc(e, &e->d_coef, 3 * 2 * 5, false))) return fail(rc);
-    if ((rc = dev_alloc(e, &e->d_powtab, 96, false))) return fail(rc);
-    if ((he = hipMemcpy(e->d_powtab, k_powtab, sizeof k_powtab, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(powtab)"));
+    if ((rc = dev_alloc(e, &e->d_powtab, TM_TAB_DOUBLES, false))) return fail(rc);
+    if ((he = hipMemcpy(e->d_powtab, &k_powtab, sizeof k_powtab, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(powtab)"));
     float coef[3][2][5];
     for (int m = 0; m < 3; ++m) { yuv_coefficients(m, 8, coef[m][0]); yuv_coefficients(m, 16, coef[m][1]); }
     if ((he = hipMemcpy(e->d_coef, coef, sizeof coef, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(coef)"));

@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
                                                       float *__restrict__ XYBT, unsigned long long *__restrict__ SSE,
                                                       int want_sse)
 {
-    __shared__ double tab[96]; // pow tables: 32 entries x 8 B = one LDS bank row each, conflict-free for any index mix
+    __shared__ double tab[TM_TAB_DOUBLES]; // pow tables: 32 entries x 8 B = one LDS bank row each, conflict-free for any index mix
     __shared__ float l2s[3][16][17];
     __shared__ float l3s[3][8][9];
     __shared__ float l4s[3][4][5];
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDes
     unsigned sse3[3] = {0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 12; ++i) qref[i] = 0;
-    if (tid < 96) tab[tid] = gtab[tid];
+    for (int i = tid; i < TM_TAB_DOUBLES; i += 256) tab[i] = gtab[i];
     __syncthreads();
 
 #pragma unroll 1
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
                                                        int want_sse, unsigned char *__restrict__ QU8, unsigned long long qplane,
                                                        int qpitch)
 {
-    __shared__ double tab[96];
+    __shared__ double tab[TM_TAB_DOUBLES];
     __shared__ IngestSideLds L;
     __shared__ unsigned sse_s[256];
     __shared__ __attribute__((aligned(16))) unsigned short qt[3][32][16]; // u8 tile, two pixels per entry (SSIM / MS-SSIM only)
@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g
         if (KIND == TM_KIND_NV12) yuv_quad_load<unsigned char>(dd0, X0 / 2, Y0 / 2, raw);
         else yuv_quad_load<unsigned short>(dd0, X0 / 2, Y0 / 2, raw);
     }
-    if (tid < 96) tab[tid] = gtab[tid];
+    for (int i = tid; i < TM_TAB_DOUBLES; i += 256) tab[i] = gtab[i];
     TM_LDS_BARRIER();
 
 #pragma unroll 1
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                                                     float *__restrict__ LIN2, unsigned long long *__restrict__ SSE, int want_sse,
                                                     unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch, int xcd_order)
 {
-    __shared__ double tab[96];
+    __shared__ double tab[TM_TAB_DOUBLES];
     const int lane = threadIdx.x;
     const int qx = lane & 15, qy = lane >> 4;
     const int slot = blockIdx.z;
@@ -809,8 +809,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     const int w = g.s[0].w, h = g.s[0].h;
     unsigned qref[3] = {0, 0, 0};
     unsigned sse3[3] = {0, 0, 0};
-    tab[lane] = gtab[lane];
-    if (lane < 32) tab[64 + lane] = gtab[64 + lane];
+    for (int i = lane; i < TM_TAB_DOUBLES; i += 64) tab[i] = gtab[i];
     __builtin_amdgcn_wave_barrier();
     // RD: side 0's XYB (four level-0 pixels + the level-1 pixel) waits in LDS until side 1 is done ([value][lane]: wave-private,
     // conflict-free; holding it in 15 VGPRs cost the fifth wave per SIMD)
