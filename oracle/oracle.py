@@ -106,6 +106,14 @@ def bt709_eotf(v):
     return np.array([L.tmo_bt709_eotf(float(x)) for x in v.ravel()], np.float32).reshape(v.shape)
 
 
+def cbrtf_scan(lo, hi):
+    """(largest error in ulps, number of not correctly rounded results) over every float of [lo, hi)"""
+    L = lib()
+    L.tmo_cbrtf_scan.restype = C.c_double; L.tmo_cbrtf_scan.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_longlong)]
+    n = C.c_longlong()
+    return float(L.tmo_cbrtf_scan(float(lo), float(hi), C.byref(n))), int(n.value)
+
+
 def bt709_eotf_max_ulp():
     """(largest error in ulps of the exact result over every float of the power branch, the argument where it occurs)"""
     w = C.c_float()

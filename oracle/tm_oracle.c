@@ -52,6 +52,24 @@ void tmo_weights(double out[108]) { memcpy(out, k_weights, sizeof k_weights); }
 
 /* exported scalar math so tests can pin it */
 float tmo_math_cbrtf(float a) { return tmo_cbrtf(a); }
+/* every float of [lo, hi): largest error in ulps of the exact result (long double cbrtl) and the number of results that are
+ * not the correctly rounded value */
+double tmo_cbrtf_scan(float lo, float hi, long long *not_correctly_rounded)
+{
+    double worst = 0.0;
+    long long bad = 0;
+    for (float a = lo; a < hi; a = nextafterf(a, 1e30f)) {
+        const float got = tmo_cbrtf(a);
+        const long double exact = cbrtl((long double)a);
+        int e;
+        (void)frexpl(exact, &e);
+        const double err = (double)(fabsl((long double)got - exact) / ldexpl(1.0L, e - 24));
+        if (err > worst) worst = err;
+        bad += got != (float)exact;
+    }
+    if (not_correctly_rounded) *not_correctly_rounded = bad;
+    return worst;
+}
 float tmo_math_powf(float x, float y) { return tmo_powf(x, (double)y); }
 
 /* ------------------------------------------------------------------------------------------
