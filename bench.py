@@ -153,7 +153,7 @@ def main():
     # ---- the same batch with the other setting of full_sums (a few steps, outside the headline timing): by default the
     # engine skips the 56 of 108 per-scale sums whose weight in the reference's table is 0.0; --full-sums computes all
     other = None
-    if world == 1 and not args.no_compare:
+    if world == 1 and not args.no_compare and "ssimulacra2" in mets:
         eng.set_full_sums(not args.full_sums)
         step()
         k = max(2, min(5, args.steps))
@@ -186,19 +186,24 @@ def main():
             ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": ach, "frac": ach / HBM_PEAK_GBS}
 
-        traffic = load_pmc_traffic(args.workload, B, args.full_sums)
-        per_kernel = {
-            "k_ingest_wave": roof(stage_ms[tm.ffi.TM_STAGE_INGEST], (in_bytes + 24 * spx) * B),
-            "k_blur_v_jobs": roof(stage_ms[tm.ffi.TM_STAGE_BLUR_V], job_bytes * B),
-            "k_blur_h_jobs_x": roof(stage_ms[tm.ffi.TM_STAGE_BLUR_H], job_bytes * B),
-        }
+        # the PMC profiles were taken with SSIMULACRA2 alone: only then do they describe this run
+        traffic = load_pmc_traffic(args.workload, B, args.full_sums) if mets == {"ssimulacra2"} else {}
+        has_s2 = "ssimulacra2" in mets
+        # without SSIMULACRA2 the ingest kernel writes no pyramid (only the u8 planes when SSIM / MS-SSIM ask for them) and the
+        # blur kernels are not launched at all
+        ingest_bytes = (in_bytes + (24 * spx if has_s2 else 0) + (6 * w * h if mets & {"ssim", "msssim"} else 0)) * B
+        per_kernel = {"k_ingest_wave": roof(stage_ms[tm.ffi.TM_STAGE_INGEST], ingest_bytes)}
+        if has_s2:
+            per_kernel["k_blur_v_jobs"] = roof(stage_ms[tm.ffi.TM_STAGE_BLUR_V], job_bytes * B)
+            per_kernel["k_blur_h_jobs_x"] = roof(stage_ms[tm.ffi.TM_STAGE_BLUR_H], job_bytes * B)
         for name in per_kernel:
             per_kernel[name]["traffic"] = traffic.get(name)
-        dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"])
-        ms_v, ms_h = per_kernel["k_blur_v_jobs"]["avg_launch_ms"], per_kernel["k_blur_h_jobs_x"]["avg_launch_ms"]
+        dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else "k_ingest_wave"
+        ms_v = per_kernel["k_blur_v_jobs"]["avg_launch_ms"] if has_s2 else 0.0
+        ms_h = per_kernel["k_blur_h_jobs_x"]["avg_launch_ms"] if has_s2 else 0.0
         stage_ach = 2 * job_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
         out = {
-            "metric": "ssimulacra2_frame_pairs_per_sec",
+            "metric": "ssimulacra2_frame_pairs_per_sec" if has_s2 else "frame_pairs_per_sec",
             "value": pairs / elapsed,
             "unit": "frame-pairs/s",
             "n_gpus": world,
@@ -225,7 +230,8 @@ def main():
                        "blur_reduce_stage_bytes_per_pair": 2 * job_bytes,
                        "survey_8d_model_bytes_per_pair": 2 * model_bytes,
                        "survey_8d_model_frac": 2 * model_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_v + ms_h > 0 else 0.0,
-                       "full_pipeline_GBs": (pairs / elapsed) * (2 * job_bytes + 24 * spx + in_bytes) / 1e9 / world},
+                       "full_pipeline_GBs": (pairs / elapsed) * (2 * job_bytes + 24 * spx + in_bytes) / 1e9 / world}
+            if has_s2 else {"full_pipeline_GBs": (pairs / elapsed) * (ingest_bytes / B) / 1e9 / world},
             "score_mean": float(np.mean(all_scores)),
         }
         if other is not None:
