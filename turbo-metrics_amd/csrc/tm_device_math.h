@@ -3,12 +3,12 @@
 // The reference kernels call two libdevice routines whose bit-level behaviour is NVIDIA's:
 //   __nv_cbrtf     in linear_to_xyb            (ssimulacra2-cuda-kernel/src/xyb.rs:44-46)
 //   __nv_fast_powf in the BT.709 / sRGB EOTFs  (cuda-colorspace-kernel/src/lib.rs:228, srgb.rs:46)
-// Here both are evaluated as a fixed sequence of IEEE-754 operations (pow: v_fma_f64 / v_mul_f64 / v_add_f64,
-// v_rndne_f64, integer ops on the exponent field, three 32-entry tables, one rounding to f32; cbrt: f32 mul / sub /
-// fma only).  The result is within 0.50001 ulp of the exact value, deterministic, and reproducible on any IEEE
-// machine -- which is what lets the parity tests demand bit equality for every plane.
-// Cost matters: the ingest kernel is ALU bound (MI355X runs f64 FMA at half the f32 rate), so both
-// routines avoid division; pow is ~20 f64 operations, cbrt 27 f32 operations evaluated on pairs (v_pk_*_f32).
+// Here they are fixed sequences of IEEE-754 operations, deterministic and reproducible on any IEEE machine -- which is what
+// lets the parity tests demand bit equality for every plane:
+//   cbrt              f32 mul / sub / fma only, 20 operations, evaluated on pairs (v_pk_*_f32); <= 0.5003 ulp
+//   BT.709 transfer   the power branch is a table of 128 cubics, 8 f32 operations; <= 0.68 ulp (the reference's fast_powf: ~8 ulp)
+//   pow (sRGB path of 16-bit / f32 RGB frames)  ~20 f64 operations, three 32-entry tables, one rounding to f32; <= 0.50001 ulp
+// Cost matters: the ingest kernel is bound by its arithmetic, so none of the routines divides.
 //
 // Must be compiled with -ffp-contract=off: the fma() calls are the only fused operations.
 #pragma once
