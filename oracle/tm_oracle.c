@@ -18,6 +18,11 @@
  * end-to-end score is NOT pinned by any reference fixture (the only known answer,
  * 17.398505 in ssimulacra2-cuda/examples/compare.rs:70-90, is for an image pair that is not
  * in the repository): "parity unpinned" for the final score.
+ * The two libdevice routines of the path are closed NVIDIA code (__nv_cbrtf, ~1 ulp; __nv_fast_powf, ~8 ulp): tm_math.h
+ * restates them as fixed IEEE sequences that are CLOSER to the exact functions than the originals (cube root <= 0.5003 ulp,
+ * BT.709 transfer function <= 0.68 ulp, sRGB pow <= 0.50001 ulp; each scanned exhaustively by tests/test_oracle_pins.py).
+ * The score reacts to such last-bit differences at the 1e-3 .. 2e-2 level (tools/score_sensitivity.py), the reference's own
+ * GPU-vs-CPU check allows +-0.25.
  *
  * Layout convention here: planar f32, 3 planes of w*h each (plane c at p + c*w*h), row-major,
  * no padding.  The reference uses packed C3; every operation on the path is per-sample or
