@@ -95,7 +95,7 @@ void tm_host_free(void *p);
  * The column pass stores transposed 128-B lines over the whole pass-1 arena, and how fast that goes depends on where the
  * arena lands physically: the same kernel on the same box takes 1.04 ... 1.24 ms per 32 1080p pairs from one allocation to the
  * next.  For arenas of 1 GiB and more tm_engine_create therefore allocates up to `n` candidates, times
- * the column pass on each (the kernel has no data-dependent branch) and keeps the fastest; the others are freed before it
+ * the column pass and the row pass on each (neither has a data-dependent branch) and keeps the fastest; the others are freed before it
  * returns.  Costs ~10 ms per candidate and, while it runs, n times the arena's memory (it stops early when less than twice the
  * arena is free). */
 void tm_set_placement_candidates(int n);

@@ -316,8 +316,16 @@ static int placement_search(tm_engine *e)
         for (int rep = 0; rep < 3; ++rep) { // the first run warms the instruction cache; the faster of the other two counts
             float m = 0.0f;
             (void)hipEventRecord(e0, e->stream);
+            // both kernels that touch the arena: the column pass writes it, the row pass reads it, and they do not always agree
+            // on a placement (row pass 1.89 ... 1.98 ms per 64 pairs across candidates) -- the sum decides
             hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), dim3(320), 0, e->stream,
                                e->g, e->jobs, e->XYB, e->V, 1, 1);
+            if (e->g.s[0].w > 2560)
+                hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 16, 8, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
+                                   e->g, e->jobs, e->XYB, e->V, e->PART, 1);
+            else
+                hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
+                                   e->g, e->jobs, e->XYB, e->V, e->PART, 1);
             (void)hipEventRecord(e1, e->stream);
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&m, e0, e1) != hipSuccess) { rc = hip_fail(hipGetLastError(), "placement search"); break; }
             if (rep > 0 && m < ms) ms = m;

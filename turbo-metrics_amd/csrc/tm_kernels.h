@@ -1784,7 +1784,8 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
 // FULL and the EDGE path.  The engine runs <16, 8, 32, 16> up to 2560 pixels wide and <16, 8, 16, 8> above (measured: FULL 12 ->
 // 16 is worth 10 % of this pass at 4K and nothing at 1080p, EDGE 16 -> 32 3.5 % at 1080p and -5 % at 4K); at 217 VGPRs the
 // kernel holds 2 waves per SIMD = 8 per CU, one fewer than its LDS would allow, which by itself measured 3.6 % faster.
-template <bool RD, bool BLK = false, int WNF = 12, int DF = 6, int WNE = 16, int DE = 8>
+// PROBE: second instantiation for the placement search of tm_engine_create (listed apart by profilers, like k_blur_v_jobs').
+template <bool RD, bool BLK = false, int WNF = 12, int DF = 6, int WNE = 16, int DE = 8, int PROBE = 0>
 __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
                                                       const float *__restrict__ V, double *__restrict__ PART, int slot_major)
 {
