@@ -176,7 +176,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
           case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
           case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
           default: tmk::k_ingest_wave<-1, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break; } } });
-        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr, rd ? 1 : 0); });
+        if (rd) launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
+        else launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr, 0); });
     } else {
         std::vector<float> yuvlut((size_t)3 * 2 * 65536);
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);

@@ -583,7 +583,8 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         }
 #undef TM_LAUNCH_W
         // levels 2..5; no transposed copy (the row pass k_blur_h_jobs_x transposes ref / dis itself)
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr, rd ? 1 : 0);
+        if (ssimu2 && rd) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
+        else if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr, 0);
     } else { // generation 2: 32x32 tiles, one quad per lane, LDS-staged stores
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel

@@ -10,7 +10,7 @@
 //   k_blur_v_jobs grid (jobs.vstart[n], 1, slots) block 320   the tuned column pass, job table driven
 //   k_blur_h_jobs grid (jobs.hstart[n], 1, slots) block 64    one lane per image ROW, job table driven
 //   k_finish_jobs grid (slots)                                          block 128
-// The default pipeline (engine variant (4 << 8) | 9) is k_ingest_wave<KIND, true> + k_ingest_upper -> k_blur_v_jobs<32, 16>
+// The default pipeline (engine variant (4 << 8) | 9) is k_ingest_wave<KIND, true> + k_ingest_upper_rd -> k_blur_v_jobs<32, 16>
 // (rd = 1) -> k_blur_h_jobs_x<true> -> k_finish_jobs over the ref/dis-interleaved pyramid, slot-major grids (x = slot);
 // everything else in this file is an older generation kept selectable for A/B runs and as on-device cross-checks.
 //
@@ -1031,6 +1031,108 @@ __global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__r
         for (int c = 0; c < 3; ++c)
             v[c] = ds4(lin4[c][2 * oy][2 * ox], lin4[c][2 * oy][2 * ox + 1], lin4[c][2 * oy + 1][2 * ox], lin4[c][2 * oy + 1][2 * ox + 1], okx, oky);
         store_xyb_px(xyb, xybt, g.s[5], XL, YL, v, xi);
+    }
+}
+
+// The same for the ref/dis-interleaved pyramid (ingest generation 4), both sides in one workgroup: side 0's XYB values (five
+// per lane for levels 2 and 3, one each for the lanes that own a level-4 / level-5 pixel) wait in registers and side 1 stores
+// whole {ref, dis} pairs -- a float4 per level-2 row (two pixels x two sides: 16 lanes = 256 contiguous bytes) -- instead of
+// 4-byte stores at stride 8 from two workgroups.  Same arithmetic calls as k_ingest_upper -> same bits.
+// grid (ceil(w2/32), ceil(h2/32), slots), block 256.
+__global__ void __launch_bounds__(256) k_ingest_upper_rd(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB)
+{
+    __shared__ float lin3[3][16][17]; // level-3 linear RGB of this tile
+    __shared__ float lin4[3][8][9];
+    const int tid = threadIdx.x, qx = tid & 15, qy = tid >> 4;
+    const int slot = blockIdx.z;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
+    const TmScaleGeom s2 = g.s[2], s3 = g.s[3], s4 = g.s[4], s5 = g.s[5];
+    float *xi = XYB + (size_t)slot * 2 * g.pyr;
+    const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
+    float k23[3][5], k4[3] = {0, 0, 0}, k5[3] = {0, 0, 0}; // side 0
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) k23[c][k] = 0.0f;
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const float *l2 = LIN2 + (size_t)(slot * 2 + side) * 3 * s2.plane;
+        float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = X0 + (k & 1), y = Y0 + (k >> 1);
+            const bool in = x < s2.w && y < s2.h;
+            const size_t o = (size_t)(in ? y : 0) * s2.pitch + (in ? x : 0);
+            const float a = l2[o], b = l2[s2.plane + o], c = l2[2 * s2.plane + o];
+            lr[k] = in ? a : 0.0f; lg[k] = in ? b : 0.0f; lb[k] = in ? c : 0.0f;
+        }
+        const bool okx = X0 + 1 < s2.w, oky = Y0 + 1 < s2.h;
+        lr[4] = ds4(lr[0], lr[1], lr[2], lr[3], okx, oky);
+        lg[4] = ds4(lg[0], lg[1], lg[2], lg[3], okx, oky);
+        lb[4] = ds4(lb[0], lb[1], lb[2], lb[3], okx, oky);
+        lin3[0][qy][qx] = lr[4]; lin3[1][qy][qx] = lg[4]; lin3[2][qy][qx] = lb[4];
+        tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
+        const float *xv[3] = {xa, xb, xc};
+        if (side == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) k23[c][k] = xv[c][k];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+                    if (X0 < s2.w && Y0 + iy < s2.h) // X0 is even and the pitch a multiple of 64 floats: the pair of pixels stays inside the row
+                        *(float4 *)(xi + 2 * (s2.off + c * s2.plane + (size_t)(Y0 + iy) * s2.pitch + X0)) =
+                            make_float4(k23[c][2 * iy], xv[c][2 * iy], k23[c][2 * iy + 1], xv[c][2 * iy + 1]);
+                if (X0 / 2 < s3.w && Y0 / 2 < s3.h)
+                    *(float2 *)(xi + 2 * (s3.off + c * s3.plane + (size_t)(Y0 / 2) * s3.pitch + X0 / 2)) = make_float2(k23[c][4], xv[c][4]);
+            }
+        }
+        TM_LDS_BARRIER();
+        if (tid < 64) { // level 4: 8x8 per tile
+            const int ox = tid & 7, oy = tid >> 3;
+            const int XL = (tx0 >> 2) + ox, YL = (ty0 >> 2) + oy;
+            const bool ok4x = 2 * XL + 1 < s3.w, ok4y = 2 * YL + 1 < s3.h;
+            float v[3], a, b, c;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                v[ch] = ds4(lin3[ch][2 * oy][2 * ox], lin3[ch][2 * oy][2 * ox + 1], lin3[ch][2 * oy + 1][2 * ox], lin3[ch][2 * oy + 1][2 * ox + 1], ok4x, ok4y);
+                lin4[ch][oy][ox] = v[ch];
+            }
+            if (XL < s4.w && YL < s4.h) {
+                tmdev::linear_to_xyb(v[0], v[1], v[2], a, b, c);
+                if (side == 0) { k4[0] = a; k4[1] = b; k4[2] = c; }
+                else {
+                    const size_t o = s4.off + (size_t)YL * s4.pitch + XL;
+                    *(float2 *)(xi + 2 * o) = make_float2(k4[0], a);
+                    *(float2 *)(xi + 2 * (o + s4.plane)) = make_float2(k4[1], b);
+                    *(float2 *)(xi + 2 * (o + 2 * s4.plane)) = make_float2(k4[2], c);
+                }
+            }
+        }
+        TM_LDS_BARRIER();
+        if (tid < 16) { // level 5: 4x4 per tile
+            const int ox = tid & 3, oy = tid >> 2;
+            const int XL = (tx0 >> 3) + ox, YL = (ty0 >> 3) + oy;
+            const bool ok5x = 2 * XL + 1 < s4.w, ok5y = 2 * YL + 1 < s4.h;
+            float v[3], a, b, c;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                v[ch] = ds4(lin4[ch][2 * oy][2 * ox], lin4[ch][2 * oy][2 * ox + 1], lin4[ch][2 * oy + 1][2 * ox], lin4[ch][2 * oy + 1][2 * ox + 1], ok5x, ok5y);
+            if (XL < s5.w && YL < s5.h) {
+                tmdev::linear_to_xyb(v[0], v[1], v[2], a, b, c);
+                if (side == 0) { k5[0] = a; k5[1] = b; k5[2] = c; }
+                else {
+                    const size_t o = s5.off + (size_t)YL * s5.pitch + XL;
+                    *(float2 *)(xi + 2 * o) = make_float2(k5[0], a);
+                    *(float2 *)(xi + 2 * (o + s5.plane)) = make_float2(k5[1], b);
+                    *(float2 *)(xi + 2 * (o + 2 * s5.plane)) = make_float2(k5[2], c);
+                }
+            }
+        }
+        TM_LDS_BARRIER(); // lin3 / lin4 are reused by the next side
     }
 }
 
