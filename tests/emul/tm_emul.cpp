@@ -38,10 +38,16 @@ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 #include <pthread.h>
 #include <thread>
 #include <vector>
-static pthread_barrier_t g_wave_bar;       // all host threads of the workgroup (__syncthreads)
-static pthread_barrier_t g_per_wave_bar[16]; // the 64 host threads of one wavefront (wave-synchronous code)
+#include <cstdlib>
+#include <cstdio>
 static bool g_lockstep = false, g_per_wave = false;
 static bool lockstep_on() { return g_lockstep; }
+
+#if defined(__SANITIZE_ADDRESS__) || !defined(__x86_64__)
+// ---- lanes as host threads, pthread barriers (AddressSanitizer build: it cannot follow hand-made stack switches) ------------
+#define TM_EMUL_FIBERS 0
+static pthread_barrier_t g_wave_bar;       // all host threads of the workgroup (__syncthreads)
+static pthread_barrier_t g_per_wave_bar[16]; // the 64 host threads of one wavefront (wave-synchronous code)
 void tm_emul_wave_barrier()
 {
     if (!g_lockstep) return;
@@ -49,6 +55,84 @@ void tm_emul_wave_barrier()
     else pthread_barrier_wait(&g_wave_bar);
 }
 void tm_emul_syncthreads() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
+#else
+// ---- lanes as cooperative fibers on ONE host thread: a barrier is a yield to the scheduler, a context switch is six pushes.
+// (64 .. 320 host threads meeting at pthread barriers millions of times cost minutes of futex traffic per test.)
+#define TM_EMUL_FIBERS 1
+extern "C" void tm_ctx_switch(void **save_sp, void *new_sp);
+asm(".text\n.globl tm_ctx_switch\n.type tm_ctx_switch,@function\ntm_ctx_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size tm_ctx_switch,.-tm_ctx_switch\n");
+struct TmFiber { void *sp; char *stack; bool done; int wait_bar; unsigned wait_gen, tid; };
+struct TmFiberBar { unsigned need, arrived, gen; };
+static constexpr size_t kFiberStack = 512 * 1024;
+static std::vector<TmFiber> g_fibers;
+static TmFiberBar g_fbar[17]; // 0..15: the waves of the workgroup, 16: the whole workgroup
+static void *g_sched_sp;
+static int g_cur = -1;
+static void (*g_fiber_body)(void *);
+static void *g_fiber_arg;
+static void fiber_barrier(int b)
+{
+    TmFiberBar &B = g_fbar[b];
+    if (++B.arrived == B.need) { B.arrived = 0; ++B.gen; return; } // the last one in releases the others and goes on
+    TmFiber &f = g_fibers[g_cur];
+    f.wait_bar = b; f.wait_gen = B.gen;
+    tm_ctx_switch(&f.sp, g_sched_sp);
+}
+void tm_emul_wave_barrier()
+{
+    if (!g_lockstep) return;
+    fiber_barrier(g_per_wave ? (int)(threadIdx.x >> 6) : 16);
+}
+void tm_emul_syncthreads() { if (g_lockstep) fiber_barrier(16); }
+static void fiber_entry()
+{
+    g_fiber_body(g_fiber_arg);
+    TmFiber &f = g_fibers[g_cur];
+    f.done = true;
+    tm_ctx_switch(&f.sp, g_sched_sp);
+    abort(); // never resumed
+}
+// run `n` fibers (thread ids 0..n-1 of the current block) to completion
+static void run_fibers(unsigned n, unsigned tid0, void (*body)(void *), void *arg)
+{
+    if (g_fibers.size() < n) {
+        const size_t old = g_fibers.size();
+        g_fibers.resize(n);
+        for (size_t i = old; i < n; ++i) g_fibers[i].stack = (char *)aligned_alloc(64, kFiberStack);
+    }
+    g_fiber_body = body; g_fiber_arg = arg;
+    for (unsigned i = 0; i < n; ++i) {
+        TmFiber &f = g_fibers[i];
+        f.done = false; f.wait_bar = -1; f.tid = tid0 + i;
+        void **sp = (void **)(f.stack + kFiberStack - 64); // 16-byte aligned; entry sees rsp = 8 mod 16 after the `ret`
+        *--sp = nullptr;                 // fake return address of fiber_entry (keeps the ABI alignment)
+        *--sp = (void *)fiber_entry;     // `ret` target of the first switch
+        for (int k = 0; k < 6; ++k) *--sp = nullptr; // rbp rbx r12 r13 r14 r15
+        f.sp = sp;
+    }
+    unsigned live = n;
+    while (live) {
+        bool progressed = false;
+        for (unsigned i = 0; i < n; ++i) {
+            TmFiber &f = g_fibers[i];
+            if (f.done) continue;
+            if (f.wait_bar >= 0 && g_fbar[f.wait_bar].gen == f.wait_gen) continue; // its barrier is not complete yet
+            f.wait_bar = -1;
+            g_cur = (int)i;
+            threadIdx = {f.tid, 0, 0};
+            tm_ctx_switch(&g_sched_sp, f.sp);
+            progressed = true;
+            if (f.done) --live;
+        }
+        if (!progressed) { fprintf(stderr, "tm_emul: lanes wait at a barrier that can never complete\n"); abort(); }
+    }
+    g_cur = -1;
+}
+#endif
 
 // wave shuffle for the lockstep emulation (64 host threads = the lanes of one wave): exchange through memory
 static float g_shfl[64];
@@ -66,9 +150,22 @@ float tm_shfl_xor(float v, int mask)
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
 #include "../../turbo-metrics_amd/csrc/tm_ssim_kernels.h"
 
-// a whole workgroup of `nthreads` host threads; __syncthreads() is a real barrier
+// a whole workgroup of `nthreads` lanes; __syncthreads() is a real barrier
 template <typename F> static void launch_wg_lockstep(dim3 grid, unsigned nthreads, F f)
 {
+#if TM_EMUL_FIBERS
+    g_lockstep = true; g_per_wave = true;
+    gridDim = grid; blockDim = dim3(nthreads);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx = {bx, by, bz};
+                for (unsigned i = 0; i < nthreads / 64; ++i) g_fbar[i] = {64u, 0u, 0u};
+                g_fbar[16] = {nthreads, 0u, 0u};
+                run_fibers(nthreads, 0, [](void *p) { (*(F *)p)(); }, (void *)&f);
+            }
+    g_lockstep = false; g_per_wave = false;
+#else
     pthread_barrier_init(&g_wave_bar, nullptr, nthreads);
     for (unsigned i = 0; i < nthreads / 64; ++i) pthread_barrier_init(&g_per_wave_bar[i], nullptr, 64);
     g_lockstep = true; g_per_wave = true;
@@ -89,11 +186,25 @@ template <typename F> static void launch_wg_lockstep(dim3 grid, unsigned nthread
     g_lockstep = false; g_per_wave = false;
     pthread_barrier_destroy(&g_wave_bar);
     for (unsigned i = 0; i < nthreads / 64; ++i) pthread_barrier_destroy(&g_per_wave_bar[i]);
+#endif
 }
 
-// one workgroup == one wavefront of 64 lanes running as 64 host threads in lockstep-by-barrier
+// one workgroup == `nwaves` wavefronts that never talk to each other: one after the other, 64 lanes in lockstep-by-barrier
 template <typename F> static void launch_wave_lockstep(dim3 grid, F f, unsigned nwaves = 1)
 {
+#if TM_EMUL_FIBERS
+    g_lockstep = true;
+    gridDim = grid; blockDim = dim3(64 * nwaves);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx)
+                for (unsigned wv = 0; wv < nwaves; ++wv) {
+                    blockIdx = {bx, by, bz};
+                    g_fbar[16] = {64u, 0u, 0u};
+                    run_fibers(64, wv * 64, [](void *p) { (*(F *)p)(); }, (void *)&f);
+                }
+    g_lockstep = false;
+#else
     pthread_barrier_init(&g_wave_bar, nullptr, 64);
     g_lockstep = true;
     std::vector<std::thread> th;
@@ -113,6 +224,7 @@ template <typename F> static void launch_wave_lockstep(dim3 grid, F f, unsigned 
     for (auto &t : th) t.join();
     g_lockstep = false;
     pthread_barrier_destroy(&g_wave_bar);
+#endif
 }
 
 template <typename F> static void launch(dim3 grid, dim3 block, F f)

@@ -174,10 +174,9 @@ def test_ssim_kernels_match_oracle(w, h, streamed):
 
 
 # gen: ingest generation + A/B option bits shifted down by 8: 1 << 14 = variant bit 22 (XCD-aware ingest tile order),
-# 1 << 15 = bit 23 (blocked column-pass planes), 1 << 16 = bit 24 (the wide-frame row-pass instantiation); these and the
-# older generation 3 run on three sizes each (CPU time)
-@pytest.mark.parametrize("w,h,gen", [(w, h, 4) for (w, h) in [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (200, 9)]]
-                         + [(w, h, g) for g in (3, 4 + (1 << 14), 4 + (1 << 15), 4 + (1 << 16)) for (w, h) in [(70, 38), (129, 20), (65, 130)]])
+# 1 << 15 = bit 23 (blocked column-pass planes), 1 << 16 = bit 24 (the wide-frame row-pass instantiation)
+@pytest.mark.parametrize("gen", [3, 4, 4 + (1 << 14), 4 + (1 << 15), 4 + (1 << 16)])
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (200, 9), (257, 131)])
 def test_wave_ingest_and_transposing_row_pass_match_oracle(w, h, gen):
     """ingest generation 3 (no LDS, no transposed XYB copy) + k_blur_h_jobs_x (the row pass transposes ref / dis itself);
     generation 4: the same with ref and dis interleaved in one plane"""
