@@ -119,6 +119,19 @@ def test_wave_ingest_p016_launch_and_unaligned_pitch(gen):
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
 
 
+def test_default_pipeline_on_a_multi_tile_frame():
+    """640x360 through the default pipeline (generation 4): 20 x 45 ingest tiles, 10 column blocks, 6 row blocks at scale 0, every
+    scale with partial tiles somewhere; planes bit-exact, pruned sums and score equal to the full computation"""
+    w, h = 640, 360
+    (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, 7)
+    frames = [(dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=0), dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0))]
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=4 * 256 + 9, weights=O.weights(), full_sums=True)
+    check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
+    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=4 * 256 + 9, weights=O.weights(), full_sums=False)
+    m = weight_mask()
+    assert np.array_equal(pr.sums(0).reshape(6, 6, 3)[m], em.sums(0).reshape(6, 6, 3)[m])
+
+
 def weight_mask():
     """(6 scales, 6 kinds, 3 channels) bool: sums that carry a non-zero weight (table layout [channel][scale][kind])"""
     return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
