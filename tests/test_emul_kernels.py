@@ -119,6 +119,21 @@ def test_wave_ingest_p016_launch_and_unaligned_pitch(gen):
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
 
 
+def test_default_pipeline_on_random_frame_sizes():
+    """twenty seeded random sizes (1 .. 300 pixels each way, mostly odd) through the default pipeline, two slots each"""
+    rng = np.random.default_rng(20250101)
+    for _ in range(20):
+        w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        frames = []
+        for n in range(2):
+            (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, int(rng.integers(0, 50)))
+            frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=int(rng.integers(0, 3))),
+                           dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0)))
+            frames[-1][1]["matrix"] = frames[-1][0]["matrix"]
+        em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=4 * 256 + 9, weights=O.weights(), full_sums=True)
+        check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
+
+
 def test_default_pipeline_on_a_multi_tile_frame():
     """640x360 through the default pipeline (generation 4): 20 x 45 ingest tiles, 10 column blocks, 6 row blocks at scale 0, every
     scale with partial tiles somewhere; planes bit-exact, pruned sums and score equal to the full computation"""
