@@ -255,6 +255,26 @@ def test_4k_p016_pair_against_oracle():
     eng.close()
 
 
+def test_8k_pair_against_oracle():
+    """7680x4320: one slot's arenas pass 2 GB (several kernels carry 32-bit lane offsets inside a plane), two slots so that the
+    second one starts beyond 4 GB of the pass-1 arena"""
+    w, h = 7680, 4320
+    fr, fd = nv12_frames(w, h, 3)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2)
+    eng.set_pair(0, fd, fr)
+    eng.set_pair(1, fr, fd)
+    eng.compute_async()
+    eng.sync()
+    lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+    want, sums = O.ssimulacra2_from_linear(lin[0], lin[1])
+    m = weight_mask()
+    np.testing.assert_allclose(eng.raw_sums(1)[m], sums[m], rtol=1e-12, atol=1e-300)
+    assert abs(eng.scores(1).ssimulacra2 - want) <= 1e-9
+    assert eng.scores(0).ssimulacra2 != eng.scores(1).ssimulacra2  # the metric is not symmetric: slot 0 really is the swapped pair
+    assert eng.sse(0) == eng.sse(1)
+    eng.close()
+
+
 def test_reference_mirror_types_and_errors():
     w, h = 96, 64
     r8, d8 = tm.synth.rgb8_pair(w, h)
