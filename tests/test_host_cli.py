@@ -238,7 +238,7 @@ def write_y4m(path, frames, w, h, bits, extra=""):
                 f.write(pl.astype(np.uint8 if bits == 8 else "<u2").tobytes())
 
 
-@pytest.mark.parametrize("w,h,bits", [(70, 38, 8), (33, 67, 8), (46, 30, 10)])
+@pytest.mark.parametrize("w,h,bits", [(70, 38, 8), (33, 67, 8), (46, 30, 10), (322, 271, 8), (318, 258, 10)])  # >= 256 rows: the row workers split the picture
 def test_y4m_is_repacked_to_the_nvdec_surface_contract(helper, tmp_path, w, h, bits):
     pairs = [tm.synth.yuv420_pair(w, h, n, bits) for n in range(3)]
     p = str(tmp_path / "v.y4m")
