@@ -267,7 +267,7 @@ def load_pmc_traffic(workload, batch, full_sums=False):
 
 
 def cpu_baseline(tm, w, h, kind, n_pairs):
-    """CPU baselines on this host, bounded to a few seconds each (reported, never the target):
+    """CPU baselines on this host, bounded to 10-15 s in total (reported, never the target):
     the restated reference CPU path (oracle/tm_cpu_path.c == examples/cpu.rs, single-threaded like the original)
     after the same YUV->linear conversion the GPU path applies, timed on 1 thread and with frame-level
     parallelism on the host cores; plus the GPU-arithmetic oracle on 1 thread."""
@@ -284,7 +284,7 @@ def cpu_baseline(tm, w, h, kind, n_pairs):
         return fn(lr, ld)
 
     if n_pairs <= 0:
-        n_pairs = 6 if w * h <= 1920 * 1080 else 2
+        n_pairs = 12 if w * h <= 1920 * 1080 else 3  # ~5 s on one core; with the two other legs the whole baseline is 10-15 s
     t0 = time.perf_counter()
     for i in range(n_pairs):
         one(i, O.cpu_path_score_linear)
