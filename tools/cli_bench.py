@@ -7,9 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from tm_pkg import tm
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=256); ap.add_argument("--size", default="1080p"); ap.add_argument("--dir", default="/tmp")
+ap.add_argument("--frames", type=int, default=0, help="pairs per clip (0 = 1536 at 1080p, 256 at 4K: long enough that ring page-locking and first-touch of the mapping stop dominating)"); ap.add_argument("--size", default="1080p"); ap.add_argument("--dir", default="/tmp")
 a = ap.parse_args()
 w, h, bits = (1920, 1080, 8) if a.size == "1080p" else (3840, 2160, 10)
+if a.frames <= 0:
+    a.frames = 1536 if a.size == "1080p" else 256
 cli = os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")
 paths = [os.path.join(a.dir, f"tm_cli_{a.size}_{s}.y4m") for s in ("ref", "dis")]
 distinct = 4
