@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- SSIMULACRA2 frame-pairs/s on synthetic decoded streams, one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p_nv12|4k_p016] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p_nv12|4k_p016] [--batch B] [--metrics ...]
 
 A "step" is one pass of the hot path (ingest -> XYB pyramid -> column pass -> row pass + error maps +
 reductions -> 108 sums per pair -> scores) over one batch of B frame pairs whose decoded surfaces are
 already resident in HBM.  value = pairs processed by all ranks / wall time of the K timed steps
 (barrier + device sync on both sides, max over ranks).  Prints ONE JSON line on rank 0.
 
-Extra objects on the line:
-  roofline      the dominant kernel against the HBM roofline: algorithmic bytes per launch (SURVEY 8d:
-                7 f32 per pixel-channel per blur pass = 84 B/px per pass) / its mean launch duration,
-                measured with HIP events on the engine's own stream inside the timed region.
-  cpu_baseline  the CPU oracle (oracle/tm_oracle.c, a single-thread C restatement of the same
-                arithmetic) timed on this host on a bounded sample of the same workload (rank 0, N=1).
+--gpus N > 1 without a torchrun environment: this process -- before it imports torch or touches the GPU --
+starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, turbo-metrics_amd/launch.py),
+forwards rank 0's line and exits non-zero when any rank fails.  Under torchrun (WORLD_SIZE set) it is a rank.
+
+Objects on the line (besides the contract fields, which describe the headline workload = BASELINE configs[1]):
+  roofline      the dominant kernel against the HBM roofline: algorithmic bytes per launch / its mean launch
+                duration, measured with HIP events on the engine's own stream inside the timed region.
+  workloads     the other configurations BASELINE.json's metric names, each with value / ms_per_step / roofline:
+                4K P016 (configs[2]) and the fused PSNR + MS-SSIM + SSIMULACRA2 pass at 1080p and 4K (configs[4]);
+                shorter runs of the same code (min(K, 10) steps).  Skipped with --no-extras or an explicit --workload.
+  fixed_stream  BASELINE configs[3] / SURVEY 8d config 4: a stream of 2048 1080p pairs (fixed total = strong scaling),
+                contiguous shards, wall clock from the first submit to rank 0 holding all 2048 scores (one reduce).
+  host_fed      SURVEY 8d config 2 (ii): the same pairs uploaded from page-locked host memory for every step
+                (two engines ping-pong: the upload of batch k+1 overlaps the kernels of batch k).  Never `value`.
+  cpu_baseline  the restated reference CPU path timed on this host on a bounded sample (rank 0, N=1).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,100 +41,169 @@ WORKLOADS = {
     "1080p_nv12": (1920, 1080, "nv12", 64, "configs[1]: synthetic 1080p yuv420p frame-pair stream, SSIMULACRA2"),
     "4k_p016": (3840, 2160, "p016", 24, "configs[2]: synthetic 4K yuv420p10 stream, SSIMULACRA2"),
 }
+FUSED = "psnr,msssim,ssimulacra2"  # BASELINE configs[4]
+EXTRAS = [("4k_p016", "ssimulacra2"), ("1080p_nv12", FUSED), ("4k_p016", FUSED)]
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec; 6.29 TB/s measured copy ceiling)
+STREAM_PAIRS = 2048
 
 
-def scale_pixels(w, h):
-    tot = 0
-    for _ in range(6):
-        tot += w * h
-        w, h = (w + 1) // 2, (h + 1) // 2
-    return tot
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--settle-ms", type=float, default=400.0, help="setup, before the W warmup steps: run the path for this long so the device "
                     "reaches its steady clock (the first ~100 ms after idle run 10-15 %% slower); never timed, reported in config")
-    ap.add_argument("--workload", default="1080p_nv12", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="run only this workload (default: 1080p_nv12 headline + the extras)")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled over the batch)")
     ap.add_argument("--metrics", default="ssimulacra2", help="comma list: ssimulacra2,psnr,ssim,msssim")
     ap.add_argument("--full-sums", action="store_true", help="compute all 108 per-scale sums like the reference (default: only the 52 with a non-zero weight; same score)")
     ap.add_argument("--no-compare", action="store_true", help="skip the short extra run with the other full_sums setting")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only (no `workloads`, `fixed_stream`, `host_fed` objects)")
+    ap.add_argument("--stream-pairs", type=int, default=STREAM_PAIRS, help="pairs of the fixed-size stream (strong scaling leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed for cpu_baseline (0 = auto, ~15 s)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
 
-    import torch
-    from tm_pkg import tm
+def scale_sizes(w, h):
+    out = []
+    for _ in range(6):
+        out.append(w * h)
+        w, h = (w + 1) // 2, (h + 1) // 2
+    return out
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    # TM_BENCH_BACKEND=gloo (testing only): run the multi-rank path on a box with fewer GPUs than ranks -- the ranks share the
-    # devices round-robin and the one collective goes through gloo on host tensors.  The driver's runs use RCCL ("nccl").
-    backend = os.environ.get("TM_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
-    cdev = "cuda" if backend == "nccl" else "cpu"
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    tm.init_hip(local_rank)
 
-    w, h, kind, default_b, cfg_name = WORKLOADS[args.workload]
-    B = args.batch or default_b
-    mets = set(args.metrics.split(","))
+def csrc_sha16():
+    """content hash of the kernel sources: a PMC traffic profile describes exactly one version of them"""
+    d = os.path.join(ROOT, "turbo-metrics_amd", "csrc")
+    hh = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".inc")):
+            hh.update(name.encode())
+            hh.update(open(os.path.join(d, name), "rb").read())
+    return hh.hexdigest()[:16]
+
+
+class Ctx:
+    """what every leg needs: rank layout, torch, the package, the (optional) process group"""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"WORLD_SIZE={self.world} but --gpus {args.gpus}")
+        import numpy as np
+        import torch
+        from tm_pkg import tm
+        self.np, self.torch, self.tm = np, torch, tm
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+        # TM_BENCH_BACKEND=gloo (testing only): run the multi-rank path on a box with fewer GPUs than ranks -- the ranks share the
+        # devices round-robin and the one collective goes through gloo on host tensors.  The driver's runs use RCCL ("nccl").
+        self.backend = os.environ.get("TM_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if self.backend == "nccl" and ndev < self.world:
+            raise SystemExit(f"--gpus {self.world} but only {ndev} device(s) visible")
+        if self.backend != "nccl":
+            self.local_rank %= max(1, ndev)
+        self.cdev = "cuda" if self.backend == "nccl" else "cpu"
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+        tm.init_hip(self.local_rank)
+        self._surfaces = {}
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def surfaces(self, name, distinct, pinned=False):
+        """`distinct` synthetic pairs of the workload (the same on every rank: pair i of a stream has content i % distinct),
+        resident in HBM -- or in page-locked host memory for the host-fed leg.  Cached: 4K pairs take seconds to generate."""
+        key = (name, distinct, pinned)
+        if key not in self._surfaces:
+            w, h, kind, _, _ = WORKLOADS[name]
+            gen = self.tm.synth.nv12_pair if kind == "nv12" else self.tm.synth.p016_pair
+            host = self._surfaces.get((name, distinct, "host"))
+            if host is None:
+                host = self._surfaces[(name, distinct, "host")] = [gen(w, h, n) for n in range(distinct)]
+            put = (lambda a: self.torch.from_numpy(a).pin_memory()) if pinned else (lambda a: self.torch.from_numpy(a).cuda())
+            self._surfaces[key] = [((put(rs), rp, rch), (put(ds), dp, dch)) for (rs, rp, rch), (ds, dp, dch) in host]
+            self.torch.cuda.synchronize()
+        return self._surfaces[key]
+
+    def fill_slots(self, eng, name, distinct, first_pair, n, pinned=False):
+        """slots [0, n) <- pairs first_pair .. first_pair + n - 1 of the stream"""
+        kind = WORKLOADS[name][2]
+        mk = self.tm.HwFrame.nv12 if kind == "nv12" else self.tm.HwFrame.p016
+        sf = self.surfaces(name, distinct, pinned)
+        for slot in range(n):
+            (rt, rp, rch), (dt, dp, dch) = sf[(first_pair + slot) % distinct]
+            eng.set_pair(slot, mk(rt, rp, rch), mk(dt, dp, dch))
+
+
+def load_pmc_traffic(workload, batch, full_sums=False):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_<workload>_b<B>.json, made by
+    tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md, which the row pass' known read volume confirms).  A profile describes ONE version of the kernels: it
+    carries the content hash of csrc/ it was taken with, and a profile of another version is not reported."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}_b{batch}{'_full' if full_sums else ''}.json")
+    if not os.path.exists(path):
+        return {}, "no PMC profile for this workload / batch"
+    d = json.load(open(path))
+    if d.get("csrc_sha16") != csrc_sha16():
+        return {}, f"PMC profile is of another kernel version (csrc {d.get('csrc_sha16')}, this run {csrc_sha16()})"
+    out = {}
+    for k, v in d.get("kernels", {}).items():
+        name = k.replace("void ", "").replace("tmk::", "").split("<")[0]
+        f, wr = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
+        if f is not None and wr is not None:
+            out[name] = int((2 * f + wr) * 1024)
+    return out, None
+
+
+def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, keep_engine=False):
+    """K timed steps of one workload on every rank; returns (result dict on every rank, engine or None)."""
+    tm, np, torch = ctx.tm, ctx.np, ctx.torch
+    w, h, kind, _, cfg_name = WORKLOADS[name]
     metrics = tm.Metrics(ssimulacra2="ssimulacra2" in mets, psnr="psnr" in mets, ssim="ssim" in mets, msssim="msssim" in mets)
     eng = tm.TurboMetrics(w, h, metrics, batch=B)
-
-    # ---- synthetic decoded surfaces, resident in HBM before the timed region (weak scaling: every rank
-    # owns its own shard of the stream: pair index = rank*B + slot, cycled over `distinct` generated pairs)
-    gen = tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair
-    distinct = max(1, min(args.distinct, B))
-    surfaces = []
-    for n in range(distinct):
-        (rs, rp, rch), (ds, dp, dch) = gen(w, h, rank * distinct + n)
-        surfaces.append(((torch.from_numpy(rs).cuda(), rp, rch), (torch.from_numpy(ds).cuda(), dp, dch)))
-    mk = tm.HwFrame.nv12 if kind == "nv12" else tm.HwFrame.p016
-    for slot in range(B):
-        (rt, rp, rch), (dt, dp, dch) = surfaces[slot % distinct]
-        eng.set_pair(slot, mk(rt, rp, rch), mk(dt, dp, dch))
+    distinct = max(1, min(args.distinct if w * h <= 1920 * 1080 else 2, B))
+    # weak scaling: every rank owns its own block of the stream, [rank * B, (rank + 1) * B)
+    ctx.fill_slots(eng, name, distinct, ctx.rank * B, B)
     torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
 
     def step():
         eng.compute_async(B)
         eng.sync()
 
-    def timed(steps):
+    def timed(k):
         eng.set_profiling(True)
         eng.stage_ms(reset=True)
-        barrier()
+        ctx.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(k):
             step()
         torch.cuda.synchronize()
-        barrier()
+        ctx.barrier()
         dt = time.perf_counter() - t0
         ms, n = eng.stage_ms(reset=True)
         eng.set_profiling(False)
@@ -134,136 +211,193 @@ def main():
 
     eng.set_full_sums(args.full_sums)
     t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+    while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
         step()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    elapsed, stage_ms = timed(args.steps)
+    elapsed, stage_ms = timed(steps)
+    elapsed = ctx.max_over_ranks(elapsed)
     modes = eng.job_modes()
+    has_s2 = "ssimulacra2" in mets
+    sc = eng.scores_batch(B)
+    scores_local = np.array([(s.ssimulacra2 if has_s2 else s.psnr) or 0.0 for s in sc], np.float64)
+    # the single collective of the path: per-frame scores reduced (sum into zeros) to rank 0
+    all_scores = tm.shard.reduce_scores(scores_local, ctx.rank * B, ctx.world * B, 1, ctx.dist, ctx.cdev if ctx.dist is not None else "cpu")
 
-    # ---- the single collective of the path: per-frame scores reduced (sum) to rank 0
-    scores_local = np.array([eng.scores(i).ssimulacra2 or 0.0 for i in range(B)], np.float64)
-    lo, hi = tm.shard.shard_range(world * B, rank, world)  # this rank's block of the stream: [rank*B, (rank+1)*B)
-    all_scores = tm.shard.reduce_scores(scores_local, lo, world * B, 1, dist, cdev if dist is not None else "cpu")
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # ---- the same batch with the other setting of full_sums (a few steps, outside the headline timing): by default the
-    # engine skips the 56 of 108 per-scale sums whose weight in the reference's table is 0.0; --full-sums computes all
     other = None
-    if world == 1 and not args.no_compare and "ssimulacra2" in mets:
+    if compare and ctx.world == 1 and has_s2:
+        # the same batch with the other setting of full_sums (a few steps, outside the headline timing): by default the engine
+        # skips the 56 of 108 per-scale sums whose weight in the reference's table is 0.0; --full-sums computes all
         eng.set_full_sums(not args.full_sums)
         step()
-        k = max(2, min(5, args.steps))
+        k = max(2, min(5, steps))
         dt_o, ms_o = timed(k)
         modes_o = eng.job_modes()
-        scores_o = np.array([eng.scores(i).ssimulacra2 or 0.0 for i in range(B)], np.float64)
+        scores_o = np.array([s.ssimulacra2 or 0.0 for s in eng.scores_batch(B)], np.float64)
         other = {"full_sums": not args.full_sums, "value": B * k / dt_o, "ms_per_step": dt_o / k * 1e3,
                  "stage_ms": {"ingest": ms_o[0], "blur_v": ms_o[1], "blur_h": ms_o[2]},
                  "scores_bit_identical": bool(np.array_equal(scores_o, scores_local)), "_modes": modes_o}
         eng.set_full_sums(args.full_sums)
 
-    if rank == 0:
-        pairs = world * B * args.steps
-        spx = scale_pixels(w, h)
-        in_bytes = w * h * 3 // 2 * (1 if kind == "nv12" else 2) * 2  # both frames of a pair
-        # ALGORITHMIC bytes per launch (B pairs).  SURVEY 8d model: each blur pass moves 7 f32 per pixel-channel
-        # (= 84 B/px summed over the 6 scales) when all five blurred planes of every channel are computed (full_sums).
-        # With the zero-weight sums skipped a (scale, channel) image costs 7 (all maps), 4 (edge terms only: mu1, mu2 +
-        # ref, dis) or 0 f32 per pixel and pass -- `job_bytes` is what THIS configuration must move.
-        # Ingest reads the two surfaces and writes the planar XYB pyramid once (24 B/px for the two sides).
-        sizes, ww, hh = [], w, h
-        for _ in range(6):
-            sizes.append(ww * hh)
-            ww, hh = (ww + 1) // 2, (hh + 1) // 2
-        units = {0: 0, 1: 4, 2: 7}
-        job_bytes = sum(4 * units[int(modes[sc, c])] * sizes[sc] for sc in range(6) for c in range(3))
-        model_bytes = 84 * spx
+    pairs = ctx.world * B * steps
+    sizes = scale_sizes(w, h)
+    spx = sum(sizes)
+    in_bytes = w * h * 3 // 2 * (1 if kind == "nv12" else 2) * 2  # both frames of a pair
+    # ALGORITHMIC bytes per launch (B pairs).  SURVEY 8d model: each blur pass moves 7 f32 per pixel-channel (= 84 B/px summed
+    # over the 6 scales) when all five blurred planes of every channel are computed (full_sums).  With the zero-weight sums
+    # skipped a (scale, channel) image costs 7 (all maps), 4 (edge terms only: mu1, mu2 + ref, dis) or 0 f32 per pixel and
+    # pass -- `job_bytes` is what THIS configuration must move.  Ingest reads the two surfaces and writes the planar XYB
+    # pyramid once (24 B/px for the two sides).  The SSIM / MS-SSIM stage reads the u8-quantised planes (6 B/px per pair) and,
+    # for MS-SSIM, builds and reads back the dyadic pyramid of box sums (u16, scales 1-4: 2 x 0.332 x 2 B per sample).
+    units = {0: 0, 1: 4, 2: 7}
+    job_bytes = sum(4 * units[int(modes[s, c])] * sizes[s] for s in range(6) for c in range(3))
+    model_bytes = 84 * spx
+    has_ssim = bool(mets & {"ssim", "msssim"})
+    ssim_bytes = int((6 + (6 * 0.332 * 2 * 2 if "msssim" in mets else 0)) * w * h)
 
-        def roof(ms, nbytes):
-            ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": ach, "frac": ach / HBM_PEAK_GBS}
+    def roof(ms, nbytes):
+        ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": ach, "frac": ach / HBM_PEAK_GBS}
 
-        # the PMC profiles were taken with SSIMULACRA2 alone: only then do they describe this run
-        traffic = load_pmc_traffic(args.workload, B, args.full_sums) if mets == {"ssimulacra2"} else {}
-        has_s2 = "ssimulacra2" in mets
-        # without SSIMULACRA2 the ingest kernel writes no pyramid (only the u8 planes when SSIM / MS-SSIM ask for them) and the
-        # blur kernels are not launched at all
-        ingest_bytes = (in_bytes + (24 * spx if has_s2 else 0) + (6 * w * h if mets & {"ssim", "msssim"} else 0)) * B
-        per_kernel = {"k_ingest_wave": roof(stage_ms[tm.ffi.TM_STAGE_INGEST], ingest_bytes)}
-        if has_s2:
-            per_kernel["k_blur_v_jobs"] = roof(stage_ms[tm.ffi.TM_STAGE_BLUR_V], job_bytes * B)
-            per_kernel["k_blur_h_jobs_x"] = roof(stage_ms[tm.ffi.TM_STAGE_BLUR_H], job_bytes * B)
-        for name in per_kernel:
-            per_kernel[name]["traffic"] = traffic.get(name)
-        dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else "k_ingest_wave"
-        ms_v = per_kernel["k_blur_v_jobs"]["avg_launch_ms"] if has_s2 else 0.0
-        ms_h = per_kernel["k_blur_h_jobs_x"]["avg_launch_ms"] if has_s2 else 0.0
-        stage_ach = 2 * job_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
-        out = {
-            "metric": "ssimulacra2_frame_pairs_per_sec" if has_s2 else "frame_pairs_per_sec",
-            "value": pairs / elapsed,
-            "unit": "frame-pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "baseline_config": cfg_name, "width": w, "height": h, "input": kind,
-                       "pairs_per_step_per_gpu": B, "metrics": sorted(mets), "inputs_resident_in_hbm": True, "settle_ms_before_warmup": args.settle_ms,
-                       "full_sums": bool(args.full_sums),
-                       "parallelism": f"frame-pair sharding x{world}, one RCCL reduce of scores"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
-                         "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
-                         "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
-                         "bytes_model": "SURVEY 8d (84 B/px/pass)" if args.full_sums else
-                                        "SURVEY 8d restricted to the planes that carry weight (job table)"},
-            "kernels": per_kernel,
-            "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
-                       "blur_reduce_stage_bytes_per_pair": 2 * job_bytes,
-                       "survey_8d_model_bytes_per_pair": 2 * model_bytes,
-                       "survey_8d_model_frac": 2 * model_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_v + ms_h > 0 else 0.0,
-                       "full_pipeline_GBs": (pairs / elapsed) * (2 * job_bytes + 24 * spx + in_bytes) / 1e9 / world}
-            if has_s2 else {"full_pipeline_GBs": (pairs / elapsed) * (ingest_bytes / B) / 1e9 / world},
-            "score_mean": float(np.mean(all_scores)),
-        }
-        if other is not None:
-            mv, mh = other["stage_ms"]["blur_v"], other["stage_ms"]["blur_h"]
-            modes_o = other.pop("_modes")
-            ob = sum(4 * units[int(modes_o[sc, c])] * sizes[sc] for sc in range(6) for c in range(3))
-            other["blur_reduce_stage_bytes_per_pair"] = 2 * ob
-            other["blur_reduce_stage_frac"] = 2 * ob * B / ((mv + mh) * 1e-3) / 1e9 / HBM_PEAK_GBS if mv + mh > 0 else 0.0
-            out["compare"] = other
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tm, w, h, kind, args.cpu_pairs)
-        print(json.dumps(out), flush=True)
+    # the PMC profiles were taken with SSIMULACRA2 alone: only then do they describe this run
+    traffic, traffic_note = load_pmc_traffic(name, B, args.full_sums) if mets == {"ssimulacra2"} else ({}, "PMC profiles exist for SSIMULACRA2 alone")
+    F = tm.ffi
+    # without SSIMULACRA2 the ingest kernel writes no pyramid (only the u8 planes when SSIM / MS-SSIM ask for them) and the
+    # blur kernels are not launched at all
+    ingest_bytes = (in_bytes + (24 * spx if has_s2 else 0) + (6 * w * h if has_ssim else 0)) * B
+    per_kernel = {"k_ingest_wave": roof(stage_ms[F.TM_STAGE_INGEST], ingest_bytes)}
+    if has_s2:
+        per_kernel["k_blur_v_jobs"] = roof(stage_ms[F.TM_STAGE_BLUR_V], job_bytes * B)
+        per_kernel["k_blur_h_jobs_x"] = roof(stage_ms[F.TM_STAGE_BLUR_H], job_bytes * B)
+    if has_ssim:
+        per_kernel["k_ssim_stage"] = roof(stage_ms[F.TM_STAGE_SSIM], ssim_bytes * B)
+        per_kernel["k_ssim_stage"]["bound"] = "valu (11x11 separable window of 5 quantities: ~100 f32 operations per sample; HBM fraction is informative only)"
+    for kn in per_kernel:
+        per_kernel[kn]["traffic"] = traffic.get(kn)
+    dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else "k_ingest_wave"
+    ms_v = per_kernel["k_blur_v_jobs"]["avg_launch_ms"] if has_s2 else 0.0
+    ms_h = per_kernel["k_blur_h_jobs_x"]["avg_launch_ms"] if has_s2 else 0.0
+    stage_ach = 2 * job_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
+    res = {
+        "value": pairs / elapsed,
+        "unit": "frame-pairs/s",
+        "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps,
+        "config": {"workload": name, "baseline_config": cfg_name if mets == {"ssimulacra2"} else "configs[4] on this many GPUs: PSNR + MSSSIM + SSIMULACRA2 fused pass" if mets == set(FUSED.split(",")) else cfg_name + " + " + ",".join(sorted(mets)),
+                   "width": w, "height": h, "input": kind, "pairs_per_step_per_gpu": B, "metrics": sorted(mets),
+                   "inputs_resident_in_hbm": True, "settle_ms_before_warmup": settle_ms, "full_sums": bool(args.full_sums),
+                   "engine_mem_GB": round(eng.mem_usage() / 1e9, 2),
+                   "parallelism": f"frame-pair sharding x{ctx.world}, one {'RCCL' if ctx.backend == 'nccl' else ctx.backend} reduce of scores"},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"],
+                     "traffic_note": traffic_note,
+                     "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
+                     "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
+                     "bytes_model": "SURVEY 8d (84 B/px/pass)" if args.full_sums else
+                                    "SURVEY 8d restricted to the planes that carry weight (job table)"},
+        "kernels": per_kernel,
+        "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
+                   "blur_reduce_stage_bytes_per_pair": 2 * job_bytes,
+                   "survey_8d_model_bytes_per_pair": 2 * model_bytes,
+                   "survey_8d_model_frac": 2 * model_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_v + ms_h > 0 else 0.0,
+                   "full_pipeline_GBs": (pairs / elapsed) * (2 * job_bytes + 24 * spx + in_bytes) / 1e9 / ctx.world}
+        if has_s2 else {"full_pipeline_GBs": (pairs / elapsed) * (ingest_bytes / B) / 1e9 / ctx.world},
+        "score_mean": float(np.mean(all_scores)) if all_scores is not None else None,
+    }
+    if other is not None:
+        mv, mh = other["stage_ms"]["blur_v"], other["stage_ms"]["blur_h"]
+        modes_o = other.pop("_modes")
+        ob = sum(4 * units[int(modes_o[s, c])] * sizes[s] for s in range(6) for c in range(3))
+        other["blur_reduce_stage_bytes_per_pair"] = 2 * ob
+        other["blur_reduce_stage_frac"] = 2 * ob * B / ((mv + mh) * 1e-3) / 1e9 / HBM_PEAK_GBS if mv + mh > 0 else 0.0
+        res["compare"] = other
+    if keep_engine:
+        return res, eng, distinct
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return res, None, distinct
 
 
-def load_pmc_traffic(workload, batch, full_sums=False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_<workload>_b<B>.json, made by
-    tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md, which the row pass' known read volume confirms).  Empty when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}_b{batch}{'_full' if full_sums else ''}.json")
-    if not os.path.exists(path):
-        return {}
-    d = json.load(open(path))
-    out = {}
-    for k, v in d.get("kernels", {}).items():
-        name = k.replace("void ", "").replace("tmk::", "").split("<")[0]
-        f, wr = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
-        if f is not None and wr is not None:
-            out[name] = int((2 * f + wr) * 1024)
-    return out
+def run_fixed_stream(ctx, eng, name, B, distinct, total):
+    """SURVEY 8d config 4 / BASELINE configs[3]: a stream of `total` pairs (pair i has content i % distinct), contiguous
+    shards (tm.shard.shard_range), each rank runs its shard in batches of B on its own GPU; ONE reduce(sum) of the zero-padded
+    score vector; wall clock from the first submit until rank 0 holds every score.  Strong scaling: total is fixed."""
+    tm, np, torch = ctx.tm, ctx.np, ctx.torch
+    lo, hi = tm.shard.shard_range(total, ctx.rank, ctx.world)
+    first_mod = None
+    ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    local = []
+    for b0 in range(lo, hi, B):
+        n = min(B, hi - b0)
+        if b0 % distinct != first_mod:  # descriptors only change when the batch starts at another phase of the cycle
+            ctx.fill_slots(eng, name, distinct, b0, B)
+            first_mod = b0 % distinct
+        eng.compute_async(n)
+        eng.sync()
+        local.extend(s.ssimulacra2 for s in eng.scores_batch(n))
+    all_scores = tm.shard.reduce_scores(np.array(local, np.float64), lo, total, 1, ctx.dist, ctx.cdev if ctx.dist is not None else "cpu")
+    torch.cuda.synchronize()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
+    if ctx.rank != 0:
+        return None
+    sc = all_scores.ravel()
+    # every rank computed a disjoint block and the reduce added each score to zeros: the vector must be the periodic
+    # continuation of its first `distinct` entries, bit for bit, whatever the number of ranks
+    periodic = bool(np.array_equal(sc, np.resize(sc[:distinct], total)))
+    return {"config": "configs[3] / SURVEY 8d config 4: fixed stream, contiguous shards, one reduce of scores to rank 0",
+            "total_pairs": total, "seconds_first_submit_to_scores_on_rank0": dt, "value": total / dt, "unit": "frame-pairs/s",
+            "scaling": "strong", "ranks_seen": ctx.dist.get_world_size() if ctx.dist is not None else 1,
+            "pairs_per_rank": -(-total // ctx.world), "batch": B,
+            "scores_periodic_bit_identical": periodic, "scores_sha256_16": hashlib.sha256(sc.tobytes()).hexdigest()[:16],
+            "score_mean": float(sc.mean())}
+
+
+def run_host_fed(ctx, args, name, B, steps, warmup):
+    """every step uploads its B pairs from page-locked host memory (TM_MEM_HOST_PINNED: asynchronous
+    DMA on the engine's stream).  Two engines ping-pong, so the upload of batch k+1 overlaps the kernels of batch k -- the
+    arrangement of the CLI's compute_all.  PCIe-inclusive: reported beside `value`, never as `value`."""
+    tm, torch = ctx.tm, ctx.torch
+    w, h, kind, _, _ = WORKLOADS[name]
+    distinct = max(1, min(args.distinct if w * h <= 1920 * 1080 else 2, B))
+    tm.set_placement_candidates(1)
+    engs = [tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B) for _ in range(2)]
+    tm.set_placement_candidates(6)
+    busy = [False, False]
+    n_scores = 0
+
+    def submit(k):
+        nonlocal n_scores
+        e = engs[k & 1]
+        if busy[k & 1]:
+            e.sync()
+            n_scores += len(e.scores_batch(B))
+        ctx.fill_slots(e, name, distinct, k * B, B, pinned=True)
+        e.compute_async(B)
+        busy[k & 1] = True
+
+    for k in range(warmup + 2):
+        submit(k)
+    for e in engs:
+        e.sync()
+    busy[:] = [False, False]
+    ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        submit(k)
+    for i, e in enumerate(engs):
+        if busy[i]:
+            e.sync()
+            n_scores += len(e.scores_batch(B))
+    torch.cuda.synchronize()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
+    for e in engs:
+        e.close()
+    in_bytes = w * h * 3 // 2 * (1 if kind == "nv12" else 2) * 2
+    return {"config": "SURVEY 8d config 2 (ii): pinned host -> H2D every pair, two engines ping-pong", "workload": name,
+            "value": ctx.world * B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3, "pairs_per_step_per_gpu": B,
+            "h2d_GBs_per_gpu": B * steps * in_bytes / dt / 1e9, "note": "PCIe-inclusive; includes the Python loop's 2 x B set_frame calls per step"}
 
 
 def cpu_baseline(tm, w, h, kind, n_pairs):
@@ -304,6 +438,72 @@ def cpu_baseline(tm, w, h, kind, n_pairs):
             "seconds": dt1, "host_cpus": os.cpu_count(),
             "all_cores": {"value": n_par / dtp, "cores": threads, "sample": f"{n_par} pairs, one pair per worker thread", "seconds": dtp},
             "gpu_arithmetic_oracle_1thread_pairs_per_s": 1.0 / dt_gpu_arith}
+
+
+def run_rank(args):
+    ctx = Ctx(args)
+    head_name = args.workload or "1080p_nv12"
+    mets = set(args.metrics.split(","))
+    B = args.batch or WORKLOADS[head_name][3]
+    extras = args.workload is None and not args.no_extras and mets == {"ssimulacra2"}
+    res, eng, distinct = run_workload(ctx, args, head_name, mets, B, args.steps, args.warmup, args.settle_ms,
+                                      compare=not args.no_compare, keep_engine=True)
+    fixed = None
+    if "ssimulacra2" in mets and not args.no_extras:
+        eng.set_full_sums(args.full_sums)
+        fixed = run_fixed_stream(ctx, eng, head_name, B, distinct, args.stream_pairs)
+    eng.close()
+    workloads, host_fed = {}, None
+    if extras:
+        ks, kw = max(2, min(args.steps, 10)), min(args.warmup, 2)
+        for wl, m in EXTRAS:
+            r, _, _ = run_workload(ctx, args, wl, set(m.split(",")), WORKLOADS[wl][3], ks, kw, 150.0, compare=False)
+            for drop in ("unit",):
+                r.pop(drop, None)
+            workloads[wl + ("_fused" if m == FUSED else "")] = r
+        host_fed = {wl: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, ks, kw) for wl in ("1080p_nv12", "4k_p016")}
+    if ctx.rank == 0:
+        out = {
+            "metric": "ssimulacra2_frame_pairs_per_sec" if "ssimulacra2" in mets else "frame_pairs_per_sec",
+            "value": res["value"],
+            "unit": "frame-pairs/s",
+            "n_gpus": ctx.world,
+            "ranks_seen": ctx.dist.get_world_size() if ctx.dist is not None else 1,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+        }
+        for k in ("config", "roofline", "kernels", "stages", "score_mean", "compare"):
+            if k in res:
+                out[k] = res[k]
+        if workloads:
+            out["workloads"] = workloads
+        if fixed is not None:
+            out["fixed_stream"] = fixed
+        if host_fed:
+            out["host_fed"] = host_fed
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            w, h, kind = WORKLOADS[head_name][:3]
+            out["cpu_baseline"] = cpu_baseline(ctx.tm, w, h, kind, args.cpu_pairs)
+        print(json.dumps(out), flush=True)
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: become the launcher.  Nothing has touched the GPU (torch is not even imported yet).
+        from tm_pkg import tm
+        sys.exit(tm.launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    run_rank(args)
 
 
 if __name__ == "__main__":

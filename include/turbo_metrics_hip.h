@@ -129,6 +129,8 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots);
 int tm_engine_sync(tm_engine *e);
 /* FrameScores of one slot of the last completed compute (host-side post-processing happens here) */
 int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out);
+/* the same for slots [first_slot, first_slot + n) in one call: out[0 .. n) (what compute_all collects per batch) */
+int tm_engine_get_scores_batch(tm_engine *e, uint32_t first_slot, uint32_t n, tm_frame_scores *out);
 /* the 108 raw sums [scale][kind][channel] == the reference's `scores` before post_process_scores
  * (ssimulacra2-cuda/src/lib.rs:417-447).  By default the 56 sums whose weight in the reference's table is
  * exactly 0.0 (lib.rs:454-584; they are multiplied away at lib.rs:592-602) are not computed and read 0.0;
@@ -169,7 +171,7 @@ void tm_ssim_window(float g[11]);
 double tm_ssimulacra2_score_from_sums(const double sums[108], uint32_t width, uint32_t height);
 
 /* ---- measurement hooks -------------------------------------------------------------- */
-enum { TM_STAGE_INGEST = 0, TM_STAGE_BLUR_V = 1, TM_STAGE_BLUR_H = 2, TM_STAGE_COUNT = 3 };
+enum { TM_STAGE_INGEST = 0, TM_STAGE_BLUR_V = 1, TM_STAGE_BLUR_H = 2, TM_STAGE_SSIM = 3 /* sum finisher + SSIM / MS-SSIM kernels */, TM_STAGE_COUNT = 4 };
 /* When on, HIP events bracket each stage of every compute_async on the engine's own stream. */
 int tm_engine_set_profiling(tm_engine *e, int on);
 /* Accumulated since the last reset: milliseconds per stage and number of computes measured. */

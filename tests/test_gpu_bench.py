@@ -1,0 +1,49 @@
+"""GPU tier: bench.py's multi-rank path really starts N ranks.  On the 1-GPU test box the two ranks share
+the device and the one collective goes through gloo (TM_BENCH_BACKEND=gloo); the driver's 8-GPU run uses RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--workload", "1080p_nv12", "--steps", "2", "--warmup", "1", "--settle-ms", "0", "--no-cpu-baseline", "--no-compare",
+          "--batch", "8", "--stream-pairs", "72"]
+
+
+def _bench(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + COMMON, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_two_ranks_are_really_started_and_reproduce_the_one_rank_scores():
+    one = _bench(["--gpus", "1"])
+    two = _bench(["--gpus", "2"], {"TM_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["fixed_stream"]["ranks_seen"] == 2
+    assert two["scaling"] == "weak" and two["fixed_stream"]["scaling"] == "strong"
+    # weak leg: every rank ran its own 8 pairs per step
+    assert two["config"]["pairs_per_step_per_gpu"] == 8 and two["value"] > 0
+    # strong leg: 72 pairs = 36 per rank (4 full batches + a short one), contiguous shards, one reduce: the same 72 scores, bit for bit
+    assert two["fixed_stream"]["total_pairs"] == 72 and two["fixed_stream"]["pairs_per_rank"] == 36
+    assert one["fixed_stream"]["scores_periodic_bit_identical"] and two["fixed_stream"]["scores_periodic_bit_identical"]
+    assert one["fixed_stream"]["scores_sha256_16"] == two["fixed_stream"]["scores_sha256_16"]
+    for k in ("roofline", "kernels", "stages"):
+        assert k in two
+
+
+def test_asking_for_more_gpus_than_exist_fails_loudly():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TM_BENCH_BACKEND")}
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + COMMON, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "device(s) visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

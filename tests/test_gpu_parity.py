@@ -255,6 +255,33 @@ def test_4k_p016_pair_against_oracle():
     eng.close()
 
 
+def test_4k_p016_fused_psnr_msssim_ssimulacra2_against_oracle():
+    """BASELINE.json configs[4] on one GPU: 4K P016, `-m psnr -m msssim -m ssimulacra2` in one fused pass, batch > 1 (the second
+    slot holds the swapped pair).  SSIMULACRA2 sums 1e-12 / score 1e-9, PSNR bit-exact, MS-SSIM sums 1e-12 / score 1e-6."""
+    w, h = 3840, 2160
+    fr, fd = p016_frames(w, h, 2)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True, msssim=True), batch=2)
+    eng.set_pair(0, fr, fd)
+    eng.set_pair(1, fd, fr)
+    eng.compute_async()
+    eng.sync()
+    lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+    m = weight_mask()
+    for slot, (a, b) in enumerate([(lin[0], lin[1]), (lin[1], lin[0])]):
+        want, sums = O.ssimulacra2_from_linear(a, b)
+        got = eng.scores(slot)
+        np.testing.assert_allclose(eng.raw_sums(slot)[m], sums[m], rtol=1e-12, atol=1e-300)
+        assert abs(got.ssimulacra2 - want) <= 1e-9
+        sse, psnr = O.psnr(a, b)
+        assert eng.sse(slot) == sse and got.psnr == psnr
+        _, want_ms, ssums = O.ssim_msssim(a, b)
+        np.testing.assert_allclose(eng.ssim_sums(slot), ssums, rtol=1e-12, atol=1e-300)
+        assert abs(got.msssim - want_ms) <= 1e-6 and 0.0 < got.msssim <= 1.0
+        assert got.ssim is None
+    assert eng.scores(0).ssimulacra2 != eng.scores(1).ssimulacra2
+    eng.close()
+
+
 def test_8k_pair_against_oracle():
     """7680x4320: one slot's arenas pass 2 GB (several kernels carry 32-bit lane offsets inside a plane), two slots so that the
     second one starts beyond 4 GB of the pass-1 arena"""

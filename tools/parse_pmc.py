@@ -5,6 +5,9 @@ Counter unit is KiB (rocprofv3 derived metric); gfx950 corrections are applied b
 import csv, glob, json, os, sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16  # the profile is stamped with the kernel sources it was taken with (bench.py refuses another version's)
+
 
 def load(d, counter):
     acc = defaultdict(list)
@@ -17,7 +20,7 @@ def load(d, counter):
 
 fd, wd, wl = sys.argv[1], sys.argv[2], sys.argv[3]
 fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
-out = {"workload": wl, "unit": "KiB per launch (raw counter)", "kernels": {}}
+out = {"workload": wl, "unit": "KiB per launch (raw counter)", "csrc_sha16": csrc_sha16(), "kernels": {}}
 for k in sorted(set(fe) | set(wr)):
     f = fe.get(k, []); w = wr.get(k, [])
     # skip the first (warm-up) launch of each kernel

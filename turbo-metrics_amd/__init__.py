@@ -8,6 +8,6 @@ C ABI) with a host-side mirror of the reference's operator interface.
 There is no CPU implementation in this package: without the HIP library (or without a gfx950 GPU)
 the operators raise.
 """
-from . import ffi, shard, synth  # noqa: F401
+from . import ffi, launch, shard, synth  # noqa: F401
 from .engine import (ColorMatrix, FrameScores, HwFrame, Metrics, Ssimulacra2, TmError,  # noqa: F401
                      TurboMetrics, init_hip, set_placement_candidates)

@@ -119,7 +119,7 @@ struct tm_engine {
     size_t mem_bytes = 0;
     bool profiling = false, ev_pending = false;
     hipEvent_t ev[TM_STAGE_COUNT + 1] = {};
-    double stage_ms[TM_STAGE_COUNT] = {0, 0, 0};
+    double stage_ms[TM_STAGE_COUNT] = {0, 0, 0, 0};
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
@@ -532,7 +532,7 @@ int tm_engine_get_job_modes(const tm_engine *e, int out[18])
 }
 
 // Launch the whole pipeline for slots [slot0, slot0 + n) on stream `st`.  Every arena is slot-major, so a
-// chunk is just the same kernels on offset base pointers.  ev (optional): 4 events bracketing the 3 stages.
+// chunk is just the same kernels on offset base pointers.  ev (optional): 5 events bracketing the 4 stages.
 // ev_ingest_done (optional): recorded right after the ingest stage (lets the next chunk's ingest start).
 static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want_sse, hipEvent_t *ev, hipEvent_t ev_ingest_done)
 {
@@ -652,6 +652,7 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         else hipLaunchKernelGGL(tmk::k_ssim_stats, dim3((unsigned)(n * 3), (unsigned)sg.tile_off[nscales], 1), dim3(256), 0, st, sg, nscales, QU8, SPYR, SPART);
         hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, streamed, SPART, SSUMS);
     }
+    if (ev) HIPCHK(hipEventRecord(ev[4], st));
     return TM_OK;
 }
 
@@ -920,6 +921,16 @@ int tm_engine_get_scores(tm_engine *e, uint32_t slot, tm_frame_scores *out)
         out->msssim = e->channel_mode == TM_CHANNELS_FIRST ? tm_msssim_channel_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h, 0)
                                                            : tm_msssim_from_sums(e->h_ssums + (size_t)slot * 30, e->w, e->h);
         out->valid |= TM_METRIC_MSSSIM;
+    }
+    return TM_OK;
+}
+
+int tm_engine_get_scores_batch(tm_engine *e, uint32_t first_slot, uint32_t n, tm_frame_scores *out)
+{
+    if (!e || !out || first_slot >= e->cap || n > e->cap - first_slot) return TM_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int rc = tm_engine_get_scores(e, first_slot + i, out + i);
+        if (rc) return rc;
     }
     return TM_OK;
 }

@@ -126,7 +126,7 @@ class HwFrame:
 
 def _ptr_and_mem(data):
     if hasattr(data, "data_ptr"):  # torch tensor
-        mem = ffi.TM_MEM_DEVICE if getattr(data, "is_cuda", False) else ffi.TM_MEM_HOST
+        mem = ffi.TM_MEM_DEVICE if getattr(data, "is_cuda", False) else (ffi.TM_MEM_HOST_PINNED if data.is_pinned() else ffi.TM_MEM_HOST)
         return int(data.data_ptr()), mem, data
     a = np.ascontiguousarray(data)
     return a.ctypes.data, ffi.TM_MEM_HOST, a
@@ -203,6 +203,20 @@ class TurboMetrics:
             psnr=s.psnr if v & ffi.TM_METRIC_PSNR else None, ssim=s.ssim if v & ffi.TM_METRIC_SSIM else None,
             msssim=s.msssim if v & ffi.TM_METRIC_MSSSIM else None,
             ssimulacra2=s.ssimulacra2 if v & ffi.TM_METRIC_SSIMULACRA2 else None)
+
+    def scores_batch(self, n: Optional[int] = None, first: int = 0) -> List[FrameScores]:
+        """FrameScores of slots [first, first + n) of the last completed compute, one call across the ABI"""
+        n = self.batch - first if n is None else int(n)
+        arr = (ffi.FrameScoresC * n)()
+        _chk(self._L.tm_engine_get_scores_batch(self._h, first, n, arr), "tm_engine_get_scores_batch")
+        out = []
+        for s in arr:
+            v = s.valid
+            out.append(FrameScores(
+                psnr=s.psnr if v & ffi.TM_METRIC_PSNR else None, ssim=s.ssim if v & ffi.TM_METRIC_SSIM else None,
+                msssim=s.msssim if v & ffi.TM_METRIC_MSSSIM else None,
+                ssimulacra2=s.ssimulacra2 if v & ffi.TM_METRIC_SSIMULACRA2 else None))
+        return out
 
     def raw_sums(self, slot: int) -> np.ndarray:
         out = np.zeros(108, np.float64)

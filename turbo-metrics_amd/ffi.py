@@ -13,7 +13,7 @@ TM_TRANSFER_BT709 = 0
 TM_SIDE_REF, TM_SIDE_DIS = 0, 1
 TM_CHANNELS_POOLED, TM_CHANNELS_FIRST = 0, 1
 TM_MEM_HOST, TM_MEM_DEVICE, TM_MEM_HOST_PINNED = 0, 1, 2
-TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_COUNT = 0, 1, 2, 3
+TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_SSIM, TM_STAGE_COUNT = 0, 1, 2, 3, 4
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
 
 
@@ -41,6 +41,7 @@ SYMBOLS = {
     "tm_engine_compute_async": (_i, [_vp, _u32]),
     "tm_engine_sync": (_i, [_vp]),
     "tm_engine_get_scores": (_i, [_vp, _u32, C.POINTER(FrameScoresC)]),
+    "tm_engine_get_scores_batch": (_i, [_vp, _u32, _u32, C.POINTER(FrameScoresC)]),
     "tm_engine_get_raw_sums": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
     "tm_engine_set_full_sums": (_i, [_vp, _i]),
     "tm_engine_get_job_modes": (_i, [_vp, C.POINTER(C.c_int)]),
