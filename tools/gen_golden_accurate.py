@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/scores_accurate_frozen.json -- FROZEN: generated once from the most accurate evaluation of the reference's
+expressions and never regenerated when the product's arithmetic changes (the regression goldens of
+tools/gen_golden_scores.py follow the oracle, so they cannot bound drift from the upstream arithmetic).
+
+Generator = the numpy twin (oracle/twin_numpy.py, written from the reference's files) with the two closed libdevice functions
+replaced by correctly rounded ones: cbrtf -> float64 cbrt rounded once, __nv_fast_powf -> float64 pow of the reference's
+f32-rounded base, rounded once.  Beside each accurate score the file records, for the same inputs,
+  fast_powf_shape   the twin with the transfer function evaluated like libdevice's fast path, exp2f(y * log2f(x)) in f32
+  oracle_at_freeze  the C oracle (= the HIP kernels, bit for bit) at the time of freezing
+so that the distance between this build and the reference's own arithmetic is a committed number, not prose:
+tests/test_golden_accurate.py asserts that oracle and HIP path stay within BAND of `accurate`.
+The inputs are regenerated from their seeds (turbo-metrics_amd/synth.py); only numbers are stored."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from oracle import twin_numpy as T  # noqa: E402
+from tm_pkg import tm  # noqa: E402
+
+CASES = [("nv12", 160, 96, 1, 0), ("nv12", 333, 203, 4, 1), ("nv12", 640, 360, 7, 0), ("p016", 320, 200, 2, 0), ("rgb8", 256, 192, 0, 0),
+         ("nv12", 1920, 1080, 2, 0), ("rgb8", 1920, 1080, 0, 0)]
+BAND = 5e-2  # |this build - accurate|; the reference's own GPU-vs-CPU check allows 0.25 (ssimulacra2-cuda/examples/compare.rs:70-90)
+OUT = os.path.join(ROOT, "tests", "golden", "scores_accurate_frozen.json")
+
+
+def srgb_lut():
+    bits = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_tables.json")))["srgb_lut_bits"]
+    return np.array(bits, np.uint32).view(np.float32)
+
+
+def twin_linear_pair(kind, w, h, n, matrix, eotf):
+    if kind == "rgb8":  # srgb_to_linear_u8_lookup (cuda-colorspace-kernel/src/srgb.rs:51-66): the reference's own table
+        lut = srgb_lut()
+        r8, d8 = tm.synth.rgb8_pair(w, h)
+        return (np.ascontiguousarray(lut[r8].transpose(2, 0, 1)), np.ascontiguousarray(lut[d8].transpose(2, 0, 1)))
+    gen = tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair
+    (rs, rp, rch), (ds, dp, dch) = gen(w, h, n)
+    bits = 8 if kind == "nv12" else 16
+    return (T.yuv420_biplanar_to_linear(rs, rp, rch, w, h, bits, matrix, eotf=eotf),
+            T.yuv420_biplanar_to_linear(ds, dp, dch, w, h, bits, matrix, eotf=eotf))
+
+
+def oracle_score(kind, w, h, n, matrix):
+    import gen_golden_scores as G
+    lr, ld = G.linear_pair(kind, w, h, n, matrix)
+    return O.ssimulacra2_from_linear(lr, ld)[0]
+
+
+def compute_case(kind, w, h, n, matrix, with_fast=True):
+    out = {"kind": kind, "width": w, "height": h, "pair": n, "matrix": matrix}
+    lr, ld = twin_linear_pair(kind, w, h, n, matrix, "exact")
+    out["accurate"] = T.ssimulacra2_from_linear(lr, ld, cbrt="exact")[0]
+    if with_fast and kind != "rgb8":
+        lr, ld = twin_linear_pair(kind, w, h, n, matrix, "fast_powf")
+        out["fast_powf_shape"] = T.ssimulacra2_from_linear(lr, ld, cbrt="exact")[0]
+    return out
+
+
+def main():
+    if os.path.exists(OUT) and "--force" not in sys.argv:
+        raise SystemExit(f"{OUT} exists and is FROZEN; pass --force only to add cases, never because the product's arithmetic changed")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    cases = []
+    for kind, w, h, n, matrix in CASES:
+        c = compute_case(kind, w, h, n, matrix)
+        c["oracle_at_freeze"] = oracle_score(kind, w, h, n, matrix)
+        c["oracle_minus_accurate"] = c["oracle_at_freeze"] - c["accurate"]
+        if "fast_powf_shape" in c:
+            c["fast_powf_shape_minus_accurate"] = c["fast_powf_shape"] - c["accurate"]
+        print(c, flush=True)
+        cases.append(c)
+    json.dump({"generator": "tools/gen_golden_accurate.py", "frozen": True, "band": BAND, "cases": cases}, open(OUT, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
