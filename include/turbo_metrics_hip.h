@@ -181,21 +181,19 @@ int tm_engine_get_stage_ms(tm_engine *e, double ms[TM_STAGE_COUNT], uint64_t *n_
  * launches; with ~10 submissions per batch instead of the reference's 305 the graph has nothing left to hide and measured
  * 1-6 % slower on ROCm 7.2. */
 int tm_engine_set_graph(tm_engine *e, int on);
-/* Select the kernel generation, for A/B tests (every combination reproduces the oracle bit for bit, tests/test_gpu_parity.py):
- * bits 0-7 column pass (0 = simple reference kernel ... 9 = job-table driven, the default), bits 8-15 ingest (0 = separate
- * straight-line kernels, 1 = fused 64x64 tiles, 2 = 32x32 LDS tiles + transposed copy, 3 = wave-private tiles, two plain
- * pyramids, 4 = wave-private tiles, ref/dis-interleaved pyramid: the default), bits 16-19 chunks of the two-stream pipeline
- * (0 = off), bit 20 block-major instead of slot-major dispatch, bit 21 LDS-tiled SSIM statistics, bit 22 XCD-aware tile
- * order in the ingest kernel (measured slower, off), bit 23 column-pass planes stored as 64 x 32 tiles (generation 4 only;
- * measured slower, off).  Default (4 << 8) | 9.
- * TM_ERR_INVALID_ARG for combinations that do not exist (generations 3, 4 need column pass 9). */
+/* Which kernels run.  TM_VARIANT_DEFAULT: the tuned pipeline (csrc/tm_kernels.h).  TM_VARIANT_REFERENCE: the straight-line,
+ * LDS-free kernels kept as the on-device cross-check (SSIMULACRA2 / PSNR only; they keep the linear pyramid and a transposed
+ * XYB copy in HBM, allocated on first selection) -- the two produce identical bits (tests/test_gpu_parity.py).
+ * TM_VARIANT_WIDE_ROWS (test hook, default pipeline only): the row-pass instantiation that frames wider than 2560 pixels get,
+ * forced on any size.  TM_ERR_INVALID_ARG for any other value. */
+enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100 };
 int tm_engine_set_variant(tm_engine *e, int variant);
 
 /* ---- test hooks: read back intermediate planes of one slot (blocking) ------------------ */
 enum {
-    TM_PLANE_LINEAR = 0, /* index = side,            channel = R,G,B  ; scale 0..5 ; w x h   */
+    TM_PLANE_LINEAR = 0, /* index = side,            channel = R,G,B  ; scale 0..5 ; w x h   (reference pipeline only) */
     TM_PLANE_XYB = 1,    /* index = side,            channel = X,Y,B  ; w x h                 */
-    TM_PLANE_XYB_T = 2,  /* index = side,            transposed: h wide, w tall               */
+    TM_PLANE_XYB_T = 2,  /* index = side,            transposed: h wide, w tall               (reference pipeline only) */
     TM_PLANE_PASS1_T = 3 /* index = 0..4 (s11,s22,s12,mu1,mu2), transposed: h wide, w tall    */
 };
 int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale, int index, int channel,

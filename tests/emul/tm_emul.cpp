@@ -254,89 +254,40 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
     out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = (unsigned long long)n * TM_SSE_BINS * 3;
 }
 
+// variant: 0 = the default pipeline, 1 = the reference pipeline (TM_VARIANT_REFERENCE), 0x100 = default with the wide-frame row pass
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
                    int variant, const double *weights, int full_sums, unsigned char *QU8, unsigned long long qplane, int qpitch)
 {
-    const int xcd_order = (variant >> 22) & 1; // ingest: XCD-aware tile order
-    const int blocked_v = (variant >> 23) & 1; // generation 4: column-pass output in 64 x 32 tiles
-    const int wide_rows = (variant >> 24) & 1; // generation 4: the row-pass instantiation the engine uses above 2560 pixels
-    const int ingest_gen = (variant >> 8) & 255;
-    variant &= 255;
+    const bool reference = (variant & 1) != 0, wide_rows = (variant & 0x100) != 0;
     TmGeom g; tm_make_geom(&g, w, h);
     TmJobs jobs; tm_make_jobs(&jobs, &g, weights, full_sums);
     const int qw = (w + 1) / 2, qh = (h + 1) / 2;
-    if (ingest_gen == 0) {
+    if (reference) {
         launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, tab, LIN, SSE, want_sse); });
         for (int s = 1; s < TM_SCALES; ++s)
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 6), dim3(64), [&] { tmk::k_downscale(g, s, LIN); });
         for (int s = 0; s < TM_SCALES; ++s)
             launch(dim3((g.s[s].w + 63) / 64, g.s[s].h, n * 2), dim3(64), [&] { tmk::k_xyb(g, s, LIN, XYB); });
-    } else if (ingest_gen == 1) {
-        launch_wg_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n), 256, [&] { tmk::k_ingest_fused(g, desc, lut, coef, tab, XYB, XYBT, SSE, want_sse); });
-    } else if (ingest_gen >= 3) {
-        const bool rd = ingest_gen == 4;
-        std::vector<float> yuvlut((size_t)3 * 2 * 65536);
-        std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
-        launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
-        launch_wave_lockstep(dim3((w + 31) / 32, (h + 7) / 8, n), [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
-          if (rd) switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
-          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
-          default: tmk::k_ingest_wave<-1, true>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break; }
-          else switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
-          case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break;
-          default: tmk::k_ingest_wave<-1, false>(g, desc, lut, coef, tab, yuvlut.data(), XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, xcd_order); break; } } });
-        if (rd) launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
-        else launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, (float *)nullptr, 0); });
+        launch(dim3(g.vblk[TM_SCALES], 3, n), dim3(64), [&] { tmk::k_blur_v(g, XYB, XYBT, V); });
+        launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART); });
     } else {
-        std::vector<float> yuvlut((size_t)3 * 2 * 65536);
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
-        launch(dim3(256, 2, 3), dim3(256), [&] { tmk::k_build_yuv_lut(coef, tab, yuvlut.data()); });
-        launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n), 256, [&] { { int kind = desc[0].kind; for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
-          switch (kind) {
-          case TM_KIND_NV12: tmk::k_ingest_tile32<TM_KIND_NV12>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          case TM_KIND_P016: tmk::k_ingest_tile32<TM_KIND_P016>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
-          default: tmk::k_ingest_tile32<-1>(g, desc, lut, coef, tab, yuvlut.data(), XYB, XYBT, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break; } } });
-        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, 2 * n), 256, [&] { tmk::k_ingest_upper(g, lin2.data(), XYB, XYBT, 0); });
+        int kind = desc[0].kind;
+        for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
+        launch_wave_lockstep(dim3((w + 31) / 32, (h + 7) / 8, n), [&] {
+            switch (kind) {
+            case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+            case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+            default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+            } });
+        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
+        launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
+        if (wide_rows) launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });
+        else launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 32, 16>(g, jobs, XYB, V, PART); });
     }
-    const dim3 vgrid(g.vblk[TM_SCALES], 3, n);
-    switch (variant) {
-    case 0: launch(vgrid, dim3(64), [&] { tmk::k_blur_v(g, XYB, XYBT, V); }); break;
-    case 2: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<32, 32>(g, XYB, XYBT, V); }); break;
-    case 3: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<8, 16>(g, XYB, XYBT, V); }); break;
-    case 4: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 16>(g, XYB, XYBT, V); }); break;
-    case 5: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 32, true>(g, XYB, XYBT, V); }, 5); break;
-    case 6: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, true>(g, XYB, XYBT, V); }, 5); break;
-    case 7: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false>(g, XYB, XYBT, V); }, 5); break;
-    case 8: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_split<32, 16, false, true>(g, XYB, XYBT, V); }, 5); break;
-    case 9: launch_wave_lockstep(dim3(jobs.vstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 0, ingest_gen == 4 ? (blocked_v ? 2 : 1) : 0); }, 5); break;
-    case 10: launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V, 1, 0); }, 5); break;
-    default: launch_wave_lockstep(vgrid, [&] { tmk::k_blur_v_lds<16, 32>(g, XYB, XYBT, V); }); break;
-    }
-    if (ingest_gen == 4 && blocked_v) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true, true>(g, jobs, XYB, V, PART, 0); });
-    else if (ingest_gen == 4 && wide_rows) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true, false, 16, 8, 16, 8>(g, jobs, XYB, V, PART, 0); });
-    else if (ingest_gen == 4) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<true, false, 16, 8, 32, 16>(g, jobs, XYB, V, PART, 0); });
-    else if (ingest_gen == 3) launch_wave_lockstep(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), [&] { tmk::k_blur_h_jobs_x<false>(g, jobs, XYB, V, PART, 0); });
-    else if (variant == 10) launch(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 1); });
-    else launch(dim3(jobs.hstart[TM_MAX_JOBS], 1, n), dim3(64), [&] { tmk::k_blur_h_jobs(g, jobs, XYBT, V, PART, 0); });
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });
-    if (blocked_v) { // test convenience: blocked column-pass planes back into plain transposed ones
-        for (int sl = 0; sl < n; ++sl)
-            for (int pl = 0; pl < 5; ++pl)
-                for (int sc = 0; sc < TM_SCALES; ++sc)
-                    for (int c = 0; c < 3; ++c) {
-                        const TmScaleGeom sg = g.s[sc];
-                        float *base = V + (size_t)(sl * 5 + pl) * g.pyr_t + sg.off_t + (size_t)c * sg.plane_t;
-                        std::vector<float> tmp(base, base + sg.plane_t);
-                        const size_t nby = (size_t)sg.pitch_t >> 5, nx = sg.plane_t / sg.pitch_t;
-                        for (size_t x = 0; x < nx; ++x)
-                            for (size_t y = 0; y < (size_t)sg.pitch_t; ++y)
-                                base[x * sg.pitch_t + y] = tmp[((x >> 6) * nby + (y >> 5)) * 2048 + (x & 63) * 32 + (y & 31)];
-                    }
-    }
-    if (ingest_gen == 4) { // test convenience: turn the interleaved pyramid back into two plain ones for the plane checks
+    if (!reference) { // test convenience: turn the interleaved pyramid back into two plain ones for the plane checks
         std::vector<float> tmp((size_t)2 * g.pyr);
         for (int sl = 0; sl < n; ++sl) {
             float *base = XYB + (size_t)sl * 2 * g.pyr;
@@ -358,8 +309,8 @@ void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, fl
         launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n * 6), 256, [&] { tmk::k_ssim_pyramid(sg, QU8, PYR); });
     int nscales = 0;
     for (int s = 0; s < TM_SSIM_SCALES; ++s) if (sg.tiles_x[s] > 0 && sg.tiles_y[s] > 0) nscales = s + 1;
-    if (nscales > 0 && streamed) launch_wave_lockstep(dim3(n * 3, sg.item_off[nscales], 1), [&] { tmk::k_ssim_stream(sg, nscales, QU8, PYR, PART); });
-    else if (nscales > 0) launch_wg_lockstep(dim3(n * 3, sg.tile_off[nscales], 1), 256, [&] { tmk::k_ssim_stats(sg, nscales, QU8, PYR, PART); });
-    launch(dim3(n, 30, 1), dim3(64), [&] { tmk::k_ssim_finish(sg, streamed, PART, SUMS); });
+    (void)streamed;
+    if (nscales > 0) launch_wave_lockstep(dim3(n * 3, sg.item_off[nscales], 1), [&] { tmk::k_ssim_stream(sg, nscales, QU8, PYR, PART); });
+    launch(dim3(n, 30, 1), dim3(64), [&] { tmk::k_ssim_finish(sg, 1, PART, SUMS); });
 }
 }

@@ -46,31 +46,33 @@ def check_against_oracle(em, frames, w, h, have_linear=True, have_xybt=True):
         assert int(em.SSE[slot]) == sse
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
-@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20)])
-def test_nv12_pipeline_matches_oracle(w, h, variant):
+REFERENCE, DEFAULT, WIDE_ROWS = 1, 0, 0x100  # emul_pipeline variants == TM_VARIANT_* of the engine
+
+
+def nv12_frames(w, h, count=2):
     frames = []
-    for n in range(2):
+    for n in range(count):
         (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
         frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=n % 3),
                        dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant)
+    return frames
+
+
+def weight_mask():
+    """(6 scales, 6 kinds, 3 channels) bool: sums that carry a non-zero weight (table layout [channel][scale][kind])"""
+    return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20)])
+def test_reference_pipeline_matches_oracle(w, h):
+    """the straight-line kernels (k_ingest, k_downscale, k_xyb, k_blur_v, k_blur_h_jobs): every plane incl. linear RGB and the
+    transposed XYB copy"""
+    frames = nv12_frames(w, h)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=REFERENCE)
     check_against_oracle(em, frames, w, h)
 
 
-@pytest.mark.parametrize("gen", [1, 2])
-@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (127, 63)])
-def test_fused_ingest_matches_oracle(w, h, gen):
-    frames = []
-    for n in range(2):
-        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
-        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=n % 3),
-                       dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 7 + (gen == 2))
-    check_against_oracle(em, frames, w, h, have_linear=False)
-
-
-@pytest.mark.parametrize("variant", [0, 256 + 7, 512 + 7])
+@pytest.mark.parametrize("variant", [REFERENCE, DEFAULT])
 def test_p016_and_rgb_kinds_match_oracle(variant):
     w, h = 46, 30
     (rs, rp, rch), (ds, dp, dch) = tm.synth.p016_pair(w, h, 3)
@@ -86,11 +88,10 @@ def test_p016_and_rgb_kinds_match_oracle(variant):
         (dict(kind="linear_f32", data=rf), dict(kind="linear_f32", data=df)),
     ]
     em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant)
-    check_against_oracle(em, frames, w, h, have_linear=variant < 256)
+    check_against_oracle(em, frames, w, h, have_linear=variant == REFERENCE, have_xybt=variant == REFERENCE)
 
 
-@pytest.mark.parametrize("gen", [3, 4])
-def test_wave_ingest_p016_launch_and_unaligned_pitch(gen):
+def test_wave_ingest_p016_launch_and_unaligned_pitch():
     """all-P016 launches of the wave ingest (KIND-specialised kernel, pair loads): slot 0 = 10-bit samples in the upper bits,
     slot 1 = full 16-bit content, slot 2 = a BT.601 matrix; NV12 with an odd pitch goes through the unaligned branch of the pair loads"""
     w, h = 46, 30
@@ -101,7 +102,7 @@ def test_wave_ingest_p016_launch_and_unaligned_pitch(gen):
             rs = rs.copy(); ds = ds.copy()
             rs.view(np.uint16)[::7] |= 0x21; ds.view(np.uint16)[::5] |= 0x3F  # 16-bit content
         frames.append((dict(kind="p016", data=rs, pitch=rp, coded_height=rch, matrix=matrix), dict(kind="p016", data=ds, pitch=dp, coded_height=dch, matrix=matrix)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=True)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
     # NV12, pitch not a multiple of 2
     frames = []
@@ -115,7 +116,7 @@ def test_wave_ingest_p016_launch_and_unaligned_pitch(gen):
         newp = w + 1 if (w + 1) % 2 else w + 3
         frames.append((dict(kind="nv12", data=repitch(rs, rp, rows, newp), pitch=newp, coded_height=rch, matrix=1),
                        dict(kind="nv12", data=repitch(ds, dp, rows, newp), pitch=newp, coded_height=dch, matrix=1)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=True)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
 
 
@@ -130,41 +131,32 @@ def test_default_pipeline_on_random_frame_sizes():
             frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=int(rng.integers(0, 3))),
                            dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0)))
             frames[-1][1]["matrix"] = frames[-1][0]["matrix"]
-        em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=4 * 256 + 9, weights=O.weights(), full_sums=True)
+        em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
         check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
 
 
 def test_default_pipeline_on_a_multi_tile_frame():
-    """640x360 through the default pipeline (generation 4): 20 x 45 ingest tiles, 10 column blocks, 6 row blocks at scale 0, every
+    """640x360 through the default pipeline: 20 x 45 ingest tiles, 10 column blocks, 6 row blocks at scale 0, every
     scale with partial tiles somewhere; planes bit-exact, pruned sums and score equal to the full computation"""
     w, h = 640, 360
     (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, 7)
     frames = [(dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=0), dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0))]
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=4 * 256 + 9, weights=O.weights(), full_sums=True)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
-    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=4 * 256 + 9, weights=O.weights(), full_sums=False)
+    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=False)
     m = weight_mask()
     assert np.array_equal(pr.sums(0).reshape(6, 6, 3)[m], em.sums(0).reshape(6, 6, 3)[m])
 
 
-def weight_mask():
-    """(6 scales, 6 kinds, 3 channels) bool: sums that carry a non-zero weight (table layout [channel][scale][kind])"""
-    return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
-
-
+@pytest.mark.parametrize("variant", [REFERENCE, DEFAULT])
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (1, 1), (129, 20), (200, 9)])
-def test_job_driven_blur_passes_full_and_pruned(w, h):
-    """variant 9 = job-table column pass.  full_sums: every plane and all 108 sums equal the oracle.  Pruned (the
-    default of the engine): the sums that carry weight are bit-identical to the full run, the others read 0, and
-    the score is bit-identical."""
-    frames = []
-    for n in range(2):
-        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
-        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=0),
-                       dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0)))
-    full = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 9, weights=O.weights(), full_sums=True)
-    check_against_oracle(full, frames, w, h, have_linear=False)
-    pruned = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 10, weights=O.weights(), full_sums=False)  # 10: slot-major grid
+def test_job_driven_blur_passes_full_and_pruned(w, h, variant):
+    """full_sums: every plane and all 108 sums equal the oracle.  Pruned (the default of the engine): the sums that carry
+    weight are bit-identical to the full run, the others read 0, and the score is bit-identical."""
+    frames = nv12_frames(w, h)
+    full = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant, weights=O.weights(), full_sums=True)
+    check_against_oracle(full, frames, w, h, have_linear=False, have_xybt=variant == REFERENCE)
+    pruned = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant, weights=O.weights(), full_sums=False)
     m = weight_mask()
     assert m.sum() == 52
     for slot in range(2):
@@ -174,18 +166,16 @@ def test_job_driven_blur_passes_full_and_pruned(w, h):
         assert O.score_from_sums(a, w, h) == O.score_from_sums(b, w, h)
 
 
-@pytest.mark.parametrize("streamed", [True, False])
 @pytest.mark.parametrize("w,h", [(200, 180), (64, 40), (11, 11), (33, 12), (70, 300)])
-def test_ssim_kernels_match_oracle(w, h, streamed):
+def test_ssim_kernels_match_oracle(w, h):
     """SSIM / MS-SSIM stage (tm_ssim_kernels.h) on the CPU lane emulator: the u8 planes written by the ingest kernel are
     the oracle's quantised frames bit for bit; the per-scale sums agree to 1e-12; the finishing functions agree exactly."""
-    frames = []
-    for n in range(2):
-        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
-        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=0), dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=0)))
+    frames = nv12_frames(w, h)
+    for f in frames:
+        f[0]["matrix"] = f[1]["matrix"] = 0
     r8, d8 = tm.synth.rgb8_pair(w, h)
     frames.append((dict(kind="rgb8", data=r8), dict(kind="rgb8", data=d8)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=512 + 9, weights=O.weights(), ssim_window=O.ssim_window(), ssim_streamed=streamed)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), ssim_window=O.ssim_window())
     for slot, (fr, fd) in enumerate(frames):
         lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
         for side in range(2):
@@ -201,24 +191,18 @@ def test_ssim_kernels_match_oracle(w, h, streamed):
         assert (a == b) or (np.isnan(a) and np.isnan(b))   # NaN below 176x176
 
 
-# gen: ingest generation + A/B option bits shifted down by 8: 1 << 14 = variant bit 22 (XCD-aware ingest tile order),
-# 1 << 15 = bit 23 (blocked column-pass planes), 1 << 16 = bit 24 (the wide-frame row-pass instantiation)
-@pytest.mark.parametrize("gen", [3, 4, 4 + (1 << 14), 4 + (1 << 15), 4 + (1 << 16)])
+@pytest.mark.parametrize("variant", [DEFAULT, WIDE_ROWS])
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (64, 64), (1, 1), (2, 5), (129, 20), (65, 130), (200, 9), (257, 131)])
-def test_wave_ingest_and_transposing_row_pass_match_oracle(w, h, gen):
-    """ingest generation 3 (no LDS, no transposed XYB copy) + k_blur_h_jobs_x (the row pass transposes ref / dis itself);
-    generation 4: the same with ref and dis interleaved in one plane"""
-    frames = []
-    for n in range(2):
-        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
-        frames.append((dict(kind="nv12", data=rs, pitch=rp, coded_height=rch, matrix=n % 3),
-                       dict(kind="nv12", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))
+def test_default_pipeline_matches_oracle(w, h, variant):
+    """k_ingest_wave + k_ingest_upper_rd (interleaved pyramid, no transposed copy) -> k_blur_v_jobs -> k_blur_h_jobs_x (the row pass
+    transposes ref / dis itself), both row-pass instantiations, NV12 and RGB8 slots in one launch (per-frame dispatch)"""
+    frames = nv12_frames(w, h)
     r8, d8 = tm.synth.rgb8_pair(w, h)
     frames.append((dict(kind="rgb8", data=r8), dict(kind="rgb8", data=d8)))
-    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=True,
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant, weights=O.weights(), full_sums=True,
                     ssim_window=O.ssim_window() if min(w, h) >= 11 else None)
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
-    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=gen * 256 + 9, weights=O.weights(), full_sums=False)
+    pr = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant, weights=O.weights(), full_sums=False)
     m = weight_mask()
     for slot in range(len(frames)):
         assert np.array_equal(em.sums(slot)[m], pr.sums(slot)[m])

@@ -79,21 +79,38 @@ def test_nv12_planes_and_scores_match_oracle(w, h):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 256, 256 + 2, 256 + 6, 256 + 7, 512 + 6, 512 + 7, 512 + 8, 512 + 9, 768 + 9, 1024 + 9, (1 << 20) + 768 + 9, (1 << 20) + 1024 + 9, (1 << 22) + 1024 + 9, (1 << 23) + 1024 + 9, (1 << 23) + (1 << 20) + 1024 + 9, (1 << 24) + 1024 + 9, (1 << 20) + 512 + 9, 2 * 65536 + 512 + 7, 3 * 65536 + 512 + 9])
-def test_kernel_generations_are_bit_identical(variant):
-    # low byte: column-pass generation, bit 8: fused ingest.  Every combination must reproduce the oracle bit for bit.
+@pytest.mark.parametrize("variant", [F.TM_VARIANT_REFERENCE, F.TM_VARIANT_WIDE_ROWS])
+def test_reference_pipeline_and_wide_row_pass_are_bit_identical_with_the_default(variant):
+    """TM_VARIANT_REFERENCE: the straight-line kernels kept as the on-device cross-check (they also keep linear RGB and a
+    transposed XYB copy in HBM); TM_VARIANT_WIDE_ROWS: the row-pass instantiation of frames wider than 2560 pixels.  Both must
+    reproduce the oracle bit for bit, like the default pipeline (test_nv12_planes_and_scores_match_oracle)."""
     w, h = 333, 203
-    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=2, full_sums=True)
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2, full_sums=True)
     eng.set_variant(variant)
     frames = [nv12_frames(w, h, n) for n in range(2)]
     for slot, (fr, fd) in enumerate(frames):
         eng.set_pair(slot, fr, fd)
     eng.compute_async()
     eng.sync()
+    ref = variant == F.TM_VARIANT_REFERENCE
     for slot, (fr, fd) in enumerate(frames):
-        lin, sums = check_planes(eng, slot, fr, fd, w, h, have_linear=variant < 256, have_xybt=(variant >> 8 & 255) < 3)  # generations 0-2 also write a transposed XYB copy
+        lin, sums = check_planes(eng, slot, fr, fd, w, h, have_linear=ref, have_xybt=ref)
         check_scores(eng, slot, lin, sums, w, h)
+    got = [eng.raw_sums(i).copy() for i in range(2)]
+    eng.set_variant(F.TM_VARIANT_DEFAULT)
+    eng.compute_async()
+    eng.sync()
+    for i in range(2):
+        np.testing.assert_allclose(eng.raw_sums(i), got[i], rtol=1e-12, atol=1e-300)
+    with pytest.raises(tm.TmError):
+        eng.set_variant(2)
     eng.close()
+    with pytest.raises(tm.TmError):  # the reference pipeline has no SSIM / MS-SSIM stage
+        e2 = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, ssim=True), batch=1)
+        try:
+            e2.set_variant(F.TM_VARIANT_REFERENCE)
+        finally:
+            e2.close()
 
 
 def test_every_input_kind_matches_oracle():

@@ -102,10 +102,9 @@ struct tm_engine {
     unsigned char *QU8 = nullptr;  // [slot][side][3] planar u8-quantised linear RGB
     float *SPYR = nullptr;         // [slot][side][3] box pyramid, scales 1..4
     double *SPART = nullptr, *SSUMS = nullptr, *h_ssums = nullptr;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_pipe[4] = {};
-    float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr;
-    float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_tile32 -> k_ingest_upper
+    hipStream_t stream = nullptr;
+    float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr; // LIN, XYBT: reference pipeline only (TM_VARIANT_REFERENCE)
+    float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_wave -> k_ingest_upper_rd
     double *PART = nullptr, *SUMS = nullptr;
     unsigned long long *SSE = nullptr;
     TmFrameDesc *d_desc = nullptr, *h_desc = nullptr;
@@ -113,7 +112,6 @@ struct tm_engine {
     unsigned long long *h_sse = nullptr;
     float *d_lut = nullptr, *d_coef = nullptr;
     double *d_powtab = nullptr;
-    float *d_yuvlut = nullptr; // [matrix 3][R|B][C<<8|Y]: memoised 8-bit YUV -> linear R,B (k_build_yuv_lut)
     std::vector<void *> staging;      // [slot*2+side], lazily allocated
     std::vector<size_t> staging_size;
     size_t mem_bytes = 0;
@@ -123,7 +121,7 @@ struct tm_engine {
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
-    int variant = (4 << 8) | 9; // wave ingest into the ref/dis-interleaved pyramid (no transposed copy) + job-driven split column pass + transposing row pass
+    int variant = TM_VARIANT_DEFAULT;
 };
 
 namespace {
@@ -319,13 +317,13 @@ static int placement_search(tm_engine *e)
             // both kernels that touch the arena: the column pass writes it, the row pass reads it, and they do not always agree
             // on a placement (row pass 1.89 ... 1.98 ms per 64 pairs across candidates) -- the sum decides
             hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), dim3(320), 0, e->stream,
-                               e->g, e->jobs, e->XYB, e->V, 1, 1);
+                               e->g, e->jobs, e->XYB, e->V);
             if (e->g.s[0].w > 2560)
-                hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 16, 8, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
-                                   e->g, e->jobs, e->XYB, e->V, e->PART, 1);
+                hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
+                                   e->g, e->jobs, e->XYB, e->V, e->PART);
             else
-                hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
-                                   e->g, e->jobs, e->XYB, e->V, e->PART, 1);
+                hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
+                                   e->g, e->jobs, e->XYB, e->V, e->PART);
             (void)hipEventRecord(e1, e->stream);
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&m, e0, e1) != hipSuccess) { rc = hip_fail(hipGetLastError(), "placement search"); break; }
             if (rep > 0 && m < ms) ms = m;
@@ -375,7 +373,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (metrics_mask & TM_METRIC_SSIMULACRA2) { // PSNR / SSIM / MS-SSIM alone need none of the XYB machinery
         if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->LIN2, B * 2 * 3 * g.s[2].plane, true))) return fail(rc);
-        // XYBT (the transposed copy) is only written by ingest generations 0-2: allocated when such a variant is selected
+        // LIN and XYBT (linear pyramid, transposed XYB copy) belong to the reference pipeline: allocated by tm_engine_set_variant
         if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
@@ -400,9 +398,6 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     for (int m = 0; m < 3; ++m) { yuv_coefficients(m, 8, coef[m][0]); yuv_coefficients(m, 16, coef[m][1]); }
     if ((he = hipMemcpy(e->d_coef, coef, sizeof coef, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(coef)"));
     if ((he = hipMemcpy(e->d_lut, k_lut_bits, sizeof k_lut_bits, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(he, "hipMemcpy(lut)"));
-    if ((rc = dev_alloc(e, &e->d_yuvlut, (size_t)3 * 2 * 65536, false))) return fail(rc);
-    hipLaunchKernelGGL(tmk::k_build_yuv_lut, dim3(256, 2, 3), dim3(256), 0, e->stream, e->d_coef, e->d_powtab, e->d_yuvlut);
-    if ((he = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(hip_fail(he, "k_build_yuv_lut"));
     if (e->V && (rc = placement_search(e))) return fail(rc);
     if ((he = hipHostMalloc((void **)&e->h_desc, B * 2 * sizeof(TmFrameDesc), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     if ((he = hipHostMalloc((void **)&e->h_sums, B * 108 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
@@ -412,9 +407,6 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     e->staging_size.assign(B * 2, 0);
     for (int i = 0; i <= TM_STAGE_COUNT; ++i)
         if ((he = hipEventCreate(&e->ev[i])) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
-    if ((he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
-    for (int i = 0; i < 4; ++i)
-        if ((he = hipEventCreateWithFlags(&e->ev_pipe[i], hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     *out = e;
     return TM_OK;
 }
@@ -425,14 +417,12 @@ void tm_engine_destroy(tm_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
-    if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
-    for (int i = 0; i < 4; ++i) if (e->ev_pipe[i]) (void)hipEventDestroy(e->ev_pipe[i]);
     for (void *p : e->staging) if (p) (void)hipFree(p);
     (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
     (void)hipFree(e->QU8); (void)hipFree(e->SPYR); (void)hipFree(e->SPART); (void)hipFree(e->SSUMS);
     if (e->h_ssums) (void)hipHostFree(e->h_ssums);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
-    (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab); (void)hipFree(e->d_yuvlut);
+    (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab);
     if (e->h_desc) (void)hipHostFree(e->h_desc);
     if (e->h_sums) (void)hipHostFree(e->h_sums);
     if (e->h_sse) (void)hipHostFree(e->h_sse);
@@ -485,22 +475,16 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    // bits 0-7 column-pass generation, 8-15 ingest generation, 16-19 pipeline chunks (0/1 = off), bit 20: slot-minor
-    // dispatch order of the two blur passes (default: slot-major), bit 21: LDS-tiled SSIM statistics kernel (default: streaming)
-    if (!e || variant < 0 || (variant & 255) > 9 || (variant >> 8 & 255) > 4 || (variant >> 25) != 0) return TM_ERR_INVALID_ARG;
-    if ((variant & 255) >= 7 && (variant >> 8 & 255) == 0) return TM_ERR_INVALID_ARG; // no-copy column pass needs the fused ingest
-    if ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 write the u8 planes
-    if (!(e->mask & TM_METRIC_SSIMULACRA2) && (variant >> 8 & 255) < 2) return TM_ERR_INVALID_ARG; // only generations 2, 3 can run without the XYB arenas
-    if (((variant >> 23) & 1) && (variant >> 8 & 255) != 4) return TM_ERR_INVALID_ARG; // blocked V planes exist for the interleaved pipeline only
-    if ((variant >> 8 & 255) >= 3 && (variant & 255) != 9) return TM_ERR_INVALID_ARG; // no transposed XYB copy: needs the job-driven column pass
-    if ((variant >> 8 & 255) < 3 && !e->XYBT && (e->mask & TM_METRIC_SSIMULACRA2)) { // generations 0-2 write a transposed XYB copy
+    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS))) return TM_ERR_INVALID_ARG;
+    const bool ref = (variant & TM_VARIANT_REFERENCE) != 0;
+    // the reference pipeline is SSIMULACRA2 (+ PSNR) only: its ingest kernel neither writes the u8 planes of SSIM / MS-SSIM nor runs without the XYB arenas
+    if (ref && ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) || !(e->mask & TM_METRIC_SSIMULACRA2))) return TM_ERR_INVALID_ARG;
+    if (ref && (variant & TM_VARIANT_WIDE_ROWS)) return TM_ERR_INVALID_ARG;
+    if (ref && (!e->XYBT || !e->LIN)) { // it keeps the linear pyramid and a transposed XYB copy in HBM
         if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
-        int rc = dev_alloc(e, &e->XYBT, (size_t)e->cap * 2 * e->g.pyr_t, true);
-        if (rc) return rc;
-    }
-    if ((variant >> 8 & 255) == 0 && !e->LIN) { // generation-0 ingest keeps the linear pyramid in HBM
-        if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
-        int rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
+        int rc = TM_OK;
+        if (!e->XYBT) rc = dev_alloc(e, &e->XYBT, (size_t)e->cap * 2 * e->g.pyr_t, true);
+        if (rc == TM_OK && !e->LIN) rc = dev_alloc(e, &e->LIN, (size_t)e->cap * 2 * e->g.pyr, true);
         if (rc) return rc;
     }
     e->variant = variant;
@@ -531,47 +515,32 @@ int tm_engine_get_job_modes(const tm_engine *e, int out[18])
     return TM_OK;
 }
 
-// Launch the whole pipeline for slots [slot0, slot0 + n) on stream `st`.  Every arena is slot-major, so a
-// chunk is just the same kernels on offset base pointers.  ev (optional): 5 events bracketing the 4 stages.
-// ev_ingest_done (optional): recorded right after the ingest stage (lets the next chunk's ingest start).
-static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want_sse, hipEvent_t *ev, hipEvent_t ev_ingest_done)
+// Launch the whole pipeline for slots [0, n) on stream `st`.  ev (optional): 5 events bracketing the 4 stages.
+static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEvent_t *ev)
 {
     const TmGeom &g = e->g;
-    const TmFrameDesc *h_desc = e->h_desc + (size_t)slot0 * 2;
-    const TmFrameDesc *d_desc = e->d_desc + (size_t)slot0 * 2;
+    const TmFrameDesc *h_desc = e->h_desc, *d_desc = e->d_desc;
     const bool ssimu2 = (e->mask & TM_METRIC_SSIMULACRA2) != 0;
-    float *XYB = ssimu2 ? e->XYB + (size_t)slot0 * 2 * g.pyr : nullptr, *XYBT = (ssimu2 && e->XYBT) ? e->XYBT + (size_t)slot0 * 2 * g.pyr_t : nullptr;
-    float *V = ssimu2 ? e->V + (size_t)slot0 * 5 * g.pyr_t : nullptr;
-    float *LIN = e->LIN ? e->LIN + (size_t)slot0 * 2 * g.pyr : nullptr;
-    float *LIN2 = ssimu2 ? e->LIN2 + (size_t)slot0 * 2 * 3 * g.s[2].plane : nullptr;
-    double *PART = ssimu2 ? e->PART + (size_t)slot0 * e->jobs.hstart[TM_MAX_JOBS] * 6 : nullptr, *SUMS = ssimu2 ? e->SUMS + (size_t)slot0 * 108 : nullptr;
-    unsigned long long *SSE = e->SSE + (size_t)slot0 * TM_SSE_BINS * 3;
-    unsigned char *QU8 = e->QU8 ? e->QU8 + (size_t)slot0 * 2 * 3 * e->sg.qplane : nullptr;
+    float *XYB = e->XYB, *XYBT = e->XYBT, *V = e->V, *LIN = e->LIN, *LIN2 = e->LIN2;
+    double *PART = e->PART, *SUMS = e->SUMS;
+    unsigned long long *SSE = e->SSE;
+    unsigned char *QU8 = e->QU8;
+    const bool reference = (e->variant & TM_VARIANT_REFERENCE) != 0;
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
-    // ---- stage INGEST: frames -> linear pyramid -> XYB pyramid
-    if ((e->variant >> 8 & 255) == 0) { // generation 0: separate kernels, linear pyramid in HBM (kept as the on-device reference)
+    // ---- stage INGEST: frames -> linear RGB -> XYB pyramid
+    if (reference) { // separate straight-line kernels, linear pyramid in HBM, two plain XYB pyramids [side][scale][channel]
         const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
         dim3 grid((unsigned)((qw + 63) / 64), (unsigned)((qh + 3) / 4), (unsigned)n), block(64, 4, 1);
         hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, LIN, SSE, want_sse);
-        if (e->mask & TM_METRIC_SSIMULACRA2) {
-            for (int s = 1; s < TM_SCALES; ++s)
-                hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, LIN);
-            for (int s = 0; s < TM_SCALES; ++s)
-                hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, LIN, XYB);
-        }
-    } else if ((e->variant >> 8 & 255) == 1) { // generation 1: one kernel, 64x64 tiles, 4x4 pixels per lane
-        dim3 grid((unsigned)((e->w + 63) / 64), (unsigned)((e->h + 63) / 64), (unsigned)n);
-        hipLaunchKernelGGL(tmk::k_ingest_fused, grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, XYB, XYBT, SSE, want_sse);
-    } else if ((e->variant >> 8 & 255) >= 3) {
-        // generation 3: wave-private tiles, no LDS tile, no transposed copy; generation 4: the same with ref and dis
-        // interleaved in one plane (the XYB arena is then read as [slot][scale][channel][y][x][side])
-        const bool rd = (e->variant >> 8 & 255) == 4;
+        for (int s = 1; s < TM_SCALES; ++s)
+            hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, LIN);
+        for (int s = 0; s < TM_SCALES; ++s)
+            hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, LIN, XYB);
+    } else {
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
-        int kind = h_desc[0].kind;
+        int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_W(K) do { const float *ytab = e->d_yuvlut; const int xcd = (e->variant >> 22) & 1; \
-                        if (rd) hipLaunchKernelGGL((tmk::k_ingest_wave<K, true>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], xcd); \
-                        else hipLaunchKernelGGL((tmk::k_ingest_wave<K, false>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, ytab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], xcd); } while (0)
+#define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
@@ -582,57 +551,20 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
         default: TM_LAUNCH_W(-1); break;
         }
 #undef TM_LAUNCH_W
-        // levels 2..5; no transposed copy (the row pass k_blur_h_jobs_x transposes ref / dis itself)
-        if (ssimu2 && rd) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
-        else if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, (float *)nullptr, 0);
-    } else { // generation 2: 32x32 tiles, one quad per lane, LDS-staged stores
-        dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 31) / 32), (unsigned)n);
-        int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
-        for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
-#define TM_LAUNCH_T32(K) hipLaunchKernelGGL((tmk::k_ingest_tile32<K>), grid, dim3(256), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, e->d_yuvlut, XYB, XYBT, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
-        switch (kind) {
-        case TM_KIND_NV12: TM_LAUNCH_T32(TM_KIND_NV12); break;
-        case TM_KIND_P016: TM_LAUNCH_T32(TM_KIND_P016); break;
-        case TM_KIND_RGB8: TM_LAUNCH_T32(TM_KIND_RGB8); break;
-        case TM_KIND_RGB16: TM_LAUNCH_T32(TM_KIND_RGB16); break;
-        case TM_KIND_RGBF32: TM_LAUNCH_T32(TM_KIND_RGBF32); break;
-        case TM_KIND_LINEARF32: TM_LAUNCH_T32(TM_KIND_LINEARF32); break;
-        default: TM_LAUNCH_T32(-1); break;
-        }
-#undef TM_LAUNCH_T32
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)(2 * n)), dim3(256), 0, st, g, LIN2, XYB, XYBT, 0);
+        // levels 2..5
+        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
-    if (ev_ingest_done) HIPCHK(hipEventRecord(ev_ingest_done, st));
-    const int sm = (e->variant >> 20) & 1 ? 0 : 1; // bit 20 set: slot-minor dispatch order (A/B)
-    if (e->mask & TM_METRIC_SSIMULACRA2) {
+    if (ssimu2) {
+        const dim3 vgrid((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), hgrid((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1);
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
-        {
-            const dim3 vgrid((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n);
-            switch (e->variant & 255) { // column-pass generations; all bit-identical (tests/test_gpu_parity.py)
-            case 0: hipLaunchKernelGGL(tmk::k_blur_v, vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
-            case 2: hipLaunchKernelGGL((tmk::k_blur_v_lds<32, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
-            case 3: hipLaunchKernelGGL((tmk::k_blur_v_lds<8, 16>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
-            case 4: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 16>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
-            case 5: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 32, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 6: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 7: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 8: hipLaunchKernelGGL((tmk::k_blur_v_split<32, 16, false, true>), vgrid, dim3(320), 0, st, g, XYB, XYBT, V); break;
-            case 9: hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.vstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(320), 0, st, g, e->jobs, XYB, V, sm, (e->variant >> 8 & 255) == 4 ? ((e->variant >> 23) & 1 ? 2 : 1) : 0); break;
-            default: hipLaunchKernelGGL((tmk::k_blur_v_lds<16, 32>), vgrid, dim3(64), 0, st, g, XYB, XYBT, V); break;
-            }
-        }
+        if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
+        else hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, e->jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
-        if ((e->variant >> 8 & 255) == 4 && ((e->variant >> 23) & 1))
-            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, true>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
-        else if ((e->variant >> 8 & 255) == 4 && (g.s[0].w > 2560 || ((e->variant >> 24) & 1))) // wide frames (bit 24 forces this instantiation, for tests)
-            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 16, 8>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
-        else if ((e->variant >> 8 & 255) == 4)
-            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<true, false, 16, 8, 32, 16>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
-        else if ((e->variant >> 8 & 255) == 3)
-            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<false>), sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYB, V, PART, sm);
-        else hipLaunchKernelGGL(tmk::k_blur_h_jobs, sm ? dim3((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1) : dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART, sm);
+        if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART);
+        else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
+        else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, e->jobs, PART, SUMS);
     } else if (ev) {
@@ -642,15 +574,11 @@ static int launch_chunk(tm_engine *e, hipStream_t st, int slot0, int n, int want
     if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
         const TmSsimGeom &sg = e->sg;
-        float *SPYR = e->SPYR + (size_t)slot0 * 2 * 3 * sg.pyr;
-        double *SPART = e->SPART + (size_t)slot0 * 3 * (sg.tile_off[TM_SSIM_SCALES] > sg.item_off[TM_SSIM_SCALES] ? sg.tile_off[TM_SSIM_SCALES] : sg.item_off[TM_SSIM_SCALES]) * 2, *SSUMS = e->SSUMS + (size_t)slot0 * 30;
         const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
         if (nscales > 1)
-            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 31) / 32), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(256), 0, st, sg, QU8, SPYR);
-        const int streamed = (e->variant >> 21) & 1 ? 0 : 1; // bit 21 set: the LDS-tiled statistics kernel (A/B)
-        if (streamed) hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, QU8, SPYR, SPART);
-        else hipLaunchKernelGGL(tmk::k_ssim_stats, dim3((unsigned)(n * 3), (unsigned)sg.tile_off[nscales], 1), dim3(256), 0, st, sg, nscales, QU8, SPYR, SPART);
-        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, streamed, SPART, SSUMS);
+            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 31) / 32), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(256), 0, st, sg, QU8, e->SPYR);
+        hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, QU8, e->SPYR, e->SPART);
+        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, 1, e->SPART, e->SSUMS);
     }
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
     return TM_OK;
@@ -669,31 +597,13 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     hipStream_t st = e->stream;
     const int n = (int)n_slots;
     const int want_sse = (e->mask & TM_METRIC_PSNR) ? 1 : 0;
-    int chunks = (e->variant >> 16) & 15;
-    if (chunks < 1) chunks = 1;
-    if (chunks > n) chunks = n;
     // everything one batch enqueues: descriptor upload, accumulator reset, the kernels, result download
     auto enqueue_all = [&]() -> int {
         HIPCHK(hipMemcpyAsync(e->d_desc, e->h_desc, (size_t)n * 2 * sizeof(TmFrameDesc), hipMemcpyHostToDevice, st));
         if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * TM_SSE_BINS * 3 * sizeof(unsigned long long), st));
-        if (chunks == 1) {
-            int rc = launch_chunk(e, st, 0, n, want_sse, e->profiling ? e->ev : nullptr, nullptr);
+        {
+            int rc = launch_batch(e, st, n, want_sse, e->profiling ? e->ev : nullptr);
             if (rc) return rc;
-        } else {
-            // Software pipeline over chunks of slots on two streams: chunk i+1's ingest starts as soon as chunk i's
-            // ingest is done and runs beside chunk i's blur passes.  Stage events are not recorded in this mode.
-            HIPCHK(hipEventRecord(e->ev_pipe[0], st)); // descriptors + SSE reset are visible
-            HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_pipe[0], 0));
-            const int per = (n + chunks - 1) / chunks;
-            int i = 0;
-            for (int s0 = 0; s0 < n; s0 += per, ++i) {
-                hipStream_t cs = (i & 1) ? e->stream2 : st;
-                if (i > 0) HIPCHK(hipStreamWaitEvent(cs, e->ev_pipe[1 + ((i - 1) & 1)], 0));
-                int rc = launch_chunk(e, cs, s0, (s0 + per <= n) ? per : n - s0, want_sse, nullptr, e->ev_pipe[1 + (i & 1)]);
-                if (rc) return rc;
-            }
-            HIPCHK(hipEventRecord(e->ev_pipe[3], e->stream2));
-            HIPCHK(hipStreamWaitEvent(st, e->ev_pipe[3], 0));
         }
         if (e->mask & TM_METRIC_SSIMULACRA2)
             HIPCHK(hipMemcpyAsync(e->h_sums, e->SUMS, (size_t)n * 108 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -704,12 +614,12 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     };
     // The sequence is the same from batch to batch (frame pointers travel through h_desc, which the captured copy node
     // re-reads at every replay), so it is captured once into a hipGraph and replayed: one submission instead of ~10.
-    // Key = everything the launch code branches on.  Profiling (events between the stages) and the chunk pipeline launch directly.
+    // Key = everything the launch code branches on.  Profiling (events between the stages) launches directly.
     int kind = e->h_desc[0].kind;
     for (int i = 1; i < 2 * n; ++i) if (e->h_desc[i].kind != kind) kind = -1;
     const long long key = ((long long)n << 40) ^ ((long long)(kind + 2) << 32) ^ ((long long)e->variant << 4) ^ (e->full_sums ? 1 : 0);
     bool launched = false;
-    if (e->use_graph && !e->profiling && chunks == 1) {
+    if (e->use_graph && !e->profiling) {
         if (!e->gexec || e->gkey != key) {
             if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
             hipGraph_t graph = nullptr;
@@ -732,7 +642,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
         if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
-    e->ev_pending = e->profiling && chunks == 1;
+    e->ev_pending = e->profiling;
     e->last_n = n_slots;
     e->in_flight = true;
     e->have_results = false;
@@ -951,34 +861,25 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
     case TM_PLANE_LINEAR:
     case TM_PLANE_XYB:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
-        if (kind == TM_PLANE_XYB && (e->variant >> 8 & 255) == 4) { // ref/dis-interleaved pyramid: de-interleave on the host
+        if (kind == TM_PLANE_XYB && !(e->variant & TM_VARIANT_REFERENCE)) { // ref/dis-interleaved pyramid: de-interleave on the host
             std::vector<float> rows((size_t)sg.h * sg.pitch * 2);
             HIPCHK(hipMemcpy(rows.data(), e->XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + channel * sg.plane), rows.size() * sizeof(float), hipMemcpyDeviceToHost));
             for (int y = 0; y < sg.h; ++y)
                 for (int x = 0; x < sg.w; ++x) out[(size_t)y * sg.w + x] = rows[2 * ((size_t)y * sg.pitch + x) + index];
             return TM_OK;
         }
-        if (kind == TM_PLANE_LINEAR && (!e->LIN || (e->variant >> 8 & 255) != 0)) return TM_ERR_STATE; // only the gen-0 ingest stores it
+        if (kind == TM_PLANE_LINEAR && (!e->LIN || !(e->variant & TM_VARIANT_REFERENCE))) return TM_ERR_STATE; // only the reference pipeline stores it
         src = (kind == TM_PLANE_LINEAR ? e->LIN : e->XYB) + (size_t)(slot * 2 + index) * g.pyr + sg.off + channel * sg.plane;
         pitch = sg.pitch; width = sg.w; rows = sg.h;
         break;
     case TM_PLANE_XYB_T:
         if (index < 0 || index > 1) return TM_ERR_INVALID_ARG;
-        if ((e->variant >> 8 & 255) >= 3 || !e->XYBT) return TM_ERR_STATE; // ingest generations 3, 4 write no transposed copy
+        if (!(e->variant & TM_VARIANT_REFERENCE) || !e->XYBT) return TM_ERR_STATE; // the default pipeline writes no transposed copy
         src = e->XYBT + (size_t)(slot * 2 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
         pitch = sg.pitch_t; width = sg.h; rows = sg.w;
         break;
     case TM_PLANE_PASS1_T:
         if (index < 0 || index > 4) return TM_ERR_INVALID_ARG;
-        if ((e->variant >> 23) & 1) { // blocked planes (64 x 32 tiles): gather on the host
-            std::vector<float> pl((size_t)sg.plane_t);
-            HIPCHK(hipMemcpy(pl.data(), e->V + (size_t)(slot * 5 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t, pl.size() * sizeof(float), hipMemcpyDeviceToHost));
-            const size_t nby = (size_t)sg.pitch_t >> 5;
-            for (int x = 0; x < sg.w; ++x)
-                for (int y = 0; y < sg.h; ++y)
-                    out[(size_t)x * sg.h + y] = pl[(((size_t)x >> 6) * nby + ((size_t)y >> 5)) * 2048 + ((size_t)x & 63) * 32 + ((size_t)y & 31)];
-            return TM_OK;
-        }
         src = e->V + (size_t)(slot * 5 + index) * g.pyr_t + sg.off_t + channel * sg.plane_t;
         pitch = sg.pitch_t; width = sg.h; rows = sg.w;
         break;

@@ -1,18 +1,23 @@
-// tm_kernels.h -- gfx950 kernels of the SSIMULACRA2 / PSNR frame-pair path (generation 0:
-// straight-line, LDS-free kernels whose only job is to be obviously correct; the tuned
-// generation lives next to them and is A/B-checked against these on the device).
+// tm_kernels.h -- gfx950 kernels of the SSIMULACRA2 / PSNR frame-pair path.
 //
-// Launch geometry (all kernels: 64-lane wavefront == 1 workgroup unless noted):
-//   k_ingest     grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/4), slots)   block (64,4)
-//   k_downscale  grid (ceil(dw/64), dh, slots*2*3)                     block 64
-//   k_xyb        grid (ceil(w/64), h, slots*2)                         block 64
-//   k_blur_v     grid (vblk[6], 3, slots)   one lane per image COLUMN, all 6 scales in one launch
-//   k_blur_v_jobs grid (jobs.vstart[n], 1, slots) block 320   the tuned column pass, job table driven
-//   k_blur_h_jobs grid (jobs.hstart[n], 1, slots) block 64    one lane per image ROW, job table driven
-//   k_finish_jobs grid (slots)                                          block 128
-// The default pipeline (engine variant (4 << 8) | 9) is k_ingest_wave<KIND, true> + k_ingest_upper_rd -> k_blur_v_jobs<32, 16>
-// (rd = 1) -> k_blur_h_jobs_x<true> -> k_finish_jobs over the ref/dis-interleaved pyramid, slot-major grids (x = slot);
-// everything else in this file is an older generation kept selectable for A/B runs and as on-device cross-checks.
+// Two pipelines live here:
+//   default    k_ingest_wave<KIND> + k_ingest_upper_rd -> k_blur_v_jobs<32, 16> -> k_blur_h_jobs_x -> k_finish_jobs
+//              over the ref/dis-interleaved XYB pyramid, job-table driven, slot-major grids (x = slot)
+//   reference  k_ingest + k_downscale + k_xyb -> k_blur_v -> k_blur_h_jobs -> k_finish_jobs: straight-line, LDS-free kernels
+//              whose only job is to be obviously correct (engine variant TM_VARIANT_REFERENCE); the GPU tier checks that the
+//              two pipelines produce identical bits on the device, and both against the CPU oracle.
+//
+// Launch geometry (64-lane wavefront == 1 workgroup unless noted):
+//   k_ingest_wave     grid (ceil(w/32), ceil(h/8), slots)            block 64    one 32 x 8 tile, both sides
+//   k_ingest_upper_rd grid (ceil(w2/32), ceil(h2/32), slots)         block 256   pyramid levels 2..5
+//   k_blur_v_jobs     grid (slots, jobs.vstart[n])                   block 320   column pass, five role-waves per 64 columns
+//   k_blur_h_jobs_x   grid (slots, jobs.hstart[n])                   block 64    row pass + error maps + sums, lane = image row
+//   k_finish_jobs     grid (slots)                                   block 128
+//   k_ingest          grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/4), slots)   block (64,4)
+//   k_downscale       grid (ceil(dw/64), dh, slots*2*3)              block 64
+//   k_xyb             grid (ceil(w/64), h, slots*2)                  block 64
+//   k_blur_v          grid (vblk[6], 3, slots)                       block 64    lane = image column, all 6 scales in one launch
+//   k_blur_h_jobs     grid (jobs.hstart[n], 1, slots)                block 64
 //
 // Arithmetic follows the reference kernels operation for operation (cited per function); the
 // file must be compiled with -ffp-contract=off so that only the explicit fmaf calls fuse.
@@ -65,7 +70,6 @@ __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, in
     const float v = p[(size_t)rc * pitch];
     return row < nrows ? v : 0.0f;
 }
-
 // ------------------------------------------------------------------------------------------------
 // ingest: decoded frame -> planar linear RGB (scale 0) for both sides of a slot, + integer SSE of
 // the u8-quantised pair for PSNR.
@@ -76,14 +80,9 @@ __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, in
 //   quantise   sample_conv.rs:6-35 (float2uint_rn(v*255))
 // coef: [matrix 0..2][bits 8|16][5] = y, r, b, g1, g2 coefficients (lib.rs:186-200), host computed.
 // ------------------------------------------------------------------------------------------------
-// R and B of an 8-bit frame depend on two 8-bit samples each ((Y,Cr) and (Y,Cb)): k_build_yuv_lut memoises
-// clamp01(eotf(luma(Y) + coeff*(C-128))) -- evaluated by the very same device functions, so the values are
-// bit-identical -- in two 256x256 f32 tables per matrix (512 KB, L2 resident).  Two gathers replace two
-// pow + two IEEE divisions per pixel; G (three samples) is still evaluated.  rb == nullptr: no table.
 template <typename T, int BITS>
 __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const float *__restrict__ coef,
-                                                const double *__restrict__ tab, int qx, int qy, float (&px)[2][2][3],
-                                                const float *__restrict__ rb = nullptr)
+                                                const double *__restrict__ tab, int qx, int qy, float (&px)[2][2][3])
 {
     const float *k = coef + (d.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
     const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
@@ -105,32 +104,13 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
         for (int ix = 0; ix < 2; ++ix) {
             const unsigned ys = yv[iy][ix];
             const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
+            px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
             px[iy][ix][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
-            if (BITS == 8 && rb != nullptr) {
-                const float *t = rb + (size_t)d.matrix * 2 * 65536;
-                px[iy][ix][0] = t[(ucr << 8) | ys];
-                px[iy][ix][2] = t[65536 + ((ucb << 8) | ys)];
-            } else {
-                px[iy][ix][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
-                px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
-            }
+            px[iy][ix][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
         }
     }
 }
-
-// ingest_yuv_quad in two phases, so that the tile32 kernel can have the next side's samples in flight while it
-// stores the current side (raw: [0..3] luma iy*2+ix, [4] cb, [5] cr)
-template <typename T>
-__device__ __forceinline__ void yuv_quad_load(const TmFrameDesc &d, int qx, int qy, unsigned (&raw)[6])
-{
-    const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
-    const T *yrow0 = (const T *)((const char *)d.p0 + (size_t)(2 * qy) * d.pitch) + 2 * qx;
-    const T *yrow1 = (const T *)((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch) + 2 * qx;
-    raw[4] = uv[0]; raw[5] = uv[1];
-    raw[0] = yrow0[0]; raw[1] = yrow0[1]; raw[2] = yrow1[0]; raw[3] = yrow1[1];
-}
-
-// The same six samples as three pair loads (two luma rows, one CbCr pair): half the load instructions and half the
+// The six samples of a quad as three pair loads (two luma rows, one CbCr pair): half the load instructions and half the
 // registers, which is what lets k_ingest_wave hold BOTH sides' samples from the start.  raw[i] = first | second << bits.
 // Pair loads need the plane pointers and the pitch to be multiples of the pair size; otherwise single loads are packed.
 template <typename T>
@@ -158,7 +138,7 @@ template <int BITS> __device__ __forceinline__ void yuv_quad_unpack(const unsign
 
 template <int BITS>
 __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const unsigned (&raw)[6], const float *__restrict__ coef,
-                                                 const double *__restrict__ tab, float (&px)[2][2][3], const float *__restrict__ rb)
+                                                 const double *__restrict__ tab, float (&px)[2][2][3])
 {
     const float *k = coef + (d.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
     const int neutral = 1 << (BITS - 1);
@@ -169,36 +149,16 @@ __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const uns
     const float r_ = k[1] * cr;
     const float g_ = __builtin_fmaf(k[3], cb, k[4] * cr);
     const float b_ = k[2] * cb;
-    // (a 10-bit table for P016 -- 2 x 4 MB per matrix, chroma-major -- was measured: 2.75 vs 2.3 ms per 16 4K pairs, the gathers
-    // cost more than the eight pow they replace)
+    // (memoising R and B of 8-bit frames in two 256 x 256 tables per matrix, and a 10-bit variant for P016, were measured: the
+    // gathers cost more than the evaluations they replace)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const unsigned ys = raw[q];
         const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
+        px[q >> 1][q & 1][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
         px[q >> 1][q & 1][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
-        if (BITS == 8 && rb != nullptr) {
-            const float *t = rb + (size_t)d.matrix * 2 * 65536;
-            px[q >> 1][q & 1][0] = t[(ucr << 8) | ys];
-            px[q >> 1][q & 1][2] = t[65536 + ((ucb << 8) | ys)];
-        } else {
-            px[q >> 1][q & 1][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
-            px[q >> 1][q & 1][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
-        }
+        px[q >> 1][q & 1][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
     }
-}
-
-// out[matrix][0][Cr<<8|Y] = R, out[matrix][1][Cb<<8|Y] = B of an 8-bit limited-range sample pair (chroma-major: the 256 luma
-// values of one chroma value share 1 KB, and a wave sees few chroma values); grid (256, 2, 3) x 256
-__global__ void __launch_bounds__(256) k_build_yuv_lut(const float *__restrict__ coef, const double *__restrict__ tab,
-                                                       float *__restrict__ out)
-{
-    const int c = threadIdx.x, y = blockIdx.x, which = blockIdx.y, matrix = blockIdx.z;
-    const float *k = coef + (matrix * 2 + 0) * 5;
-    const unsigned ys = (unsigned)y, ymin = 16u;
-    const float luma = (float)((ys > ymin ? ys : ymin) - ymin) * k[0];
-    const float ch = (float)(c - 128);
-    const float add = (which == 0 ? k[1] : k[2]) * ch; // r_ = r_coeff*cr, b_ = b_coeff*cb (biplanar.rs:36-38)
-    out[((size_t)matrix * 2 + which) * 65536 + ((c << 8) | y)] = tmdev::clamp01(tmdev::bt709_eotf(luma + add, tab));
 }
 
 __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__restrict__ desc,
@@ -286,22 +246,6 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused ingest (generation 1): decoded frame pair -> linear RGB -> 6-level pyramid -> XYB, in one kernel.
-// Replaces gen 0's k_ingest + 5 x k_downscale + 6 x k_xyb and the whole linear-RGB arena: linear RGB only
-// ever lives in registers / LDS.  HBM traffic is the algorithmic minimum for this stage: the frame surfaces
-// are read once, the XYB pyramid is written once in the normal orientation (for the column pass) and once
-// transposed (for the row pass' edge terms).
-//
-//   workgroup = one 64x64 tile of scale 0 of one slot, both sides (so the PSNR SSE needs no second pass);
-//               64-aligned tiles keep every 2x2 parent block of every level inside the tile
-//   wave      = one 32x32 quadrant;  lane = one 4x4 pixel block:  in BOTH orientations 8 neighbouring lanes
-//               write 8 x 16 B = one full 128-B line
-//   levels 1,2 come straight from the lane's registers (4x4 -> 2x2 -> 1), levels 3..5 (8x8, 4x4, 2x2 per
-//   tile) go through a few hundred bytes of LDS.
-// Arithmetic per pixel is exactly gen 0's (same helper functions); the downscale clamp
-// min(2o+i, size-1) (downscale.rs:24-25) becomes "take the in-range neighbour of the 2x2 block".
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ds4(float v00, float v01, float v10, float v11, bool okx, bool oky)
 {
     // sum order of downscale.rs:22-30: (iy,ix) = (0,0),(0,1),(1,0),(1,1), starting from 0.0
@@ -313,230 +257,6 @@ __device__ __forceinline__ float ds4(float v00, float v01, float v10, float v11,
     return sum * 0.25f;
 }
 
-__global__ void __launch_bounds__(256) k_ingest_fused(TmGeom g, const TmFrameDesc *__restrict__ desc,
-                                                      const float *__restrict__ lut, const float *__restrict__ coef,
-                                                      const double *__restrict__ gtab, float *__restrict__ XYB,
-                                                      float *__restrict__ XYBT, unsigned long long *__restrict__ SSE,
-                                                      int want_sse)
-{
-    __shared__ double tab[TM_TAB_DOUBLES]; // pow tables: 32 entries x 8 B = one LDS bank row each, conflict-free for any index mix
-    __shared__ float l2s[3][16][17];
-    __shared__ float l3s[3][8][9];
-    __shared__ float l4s[3][4][5];
-    __shared__ unsigned sse_s[256];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int bx = (wave & 1) * 8 + (lane & 7), by = (wave >> 1) * 8 + (lane >> 3); // 4x4-block coords in the tile
-    const int slot = blockIdx.z;
-    const int X0 = blockIdx.x * 64 + bx * 4, Y0 = blockIdx.y * 64 + by * 4;
-    const int w = g.s[0].w, h = g.s[0].h;
-    unsigned qref[12];
-    unsigned sse3[3] = {0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 12; ++i) qref[i] = 0;
-    for (int i = tid; i < TM_TAB_DOUBLES; i += 256) tab[i] = gtab[i];
-    __syncthreads();
-
-#pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-        const TmFrameDesc d = desc[slot * 2 + side];
-        float l0[4][4][3];
-#pragma unroll
-        for (int iy = 0; iy < 4; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < 4; ++ix)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) l0[iy][ix][c] = 0.0f;
-        // ---- level 0: decoded samples -> linear RGB (registers)
-        if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016) {
-#pragma unroll
-            for (int qy = 0; qy < 2; ++qy)
-#pragma unroll
-                for (int qx = 0; qx < 2; ++qx) {
-                    const int gx = X0 / 2 + qx, gy = Y0 / 2 + qy; // quad coordinates in the image
-                    if (2 * gx + 1 < w && 2 * gy + 1 < h) {
-                        float px[2][2][3];
-                        if (d.kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, gx, gy, px);
-                        else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, gx, gy, px);
-#pragma unroll
-                        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                            for (int ix = 0; ix < 2; ++ix)
-#pragma unroll
-                                for (int c = 0; c < 3; ++c) l0[2 * qy + iy][2 * qx + ix][c] = px[iy][ix][c];
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int iy = 0; iy < 4; ++iy)
-#pragma unroll
-                for (int ix = 0; ix < 4; ++ix) {
-                    const int x = X0 + ix, y = Y0 + iy;
-                    if (x < w && y < h) {
-                        const char *row = (const char *)d.p0 + (size_t)y * d.pitch;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            float v;
-                            if (d.kind == TM_KIND_RGB8) v = lut[((const unsigned char *)row)[3 * x + c]];
-                            else if (d.kind == TM_KIND_RGB16)
-                                v = tmdev::srgb_inverse_oetf((float)((const unsigned short *)row)[3 * x + c] / 65535.0f, tab);
-                            else if (d.kind == TM_KIND_RGBF32) v = tmdev::srgb_inverse_oetf(((const float *)row)[3 * x + c], tab);
-                            else v = ((const float *)row)[3 * x + c];
-                            l0[iy][ix][c] = v;
-                        }
-                    }
-                }
-        }
-        if (want_sse) { // sample_conv.rs:6-35 quantisation; out-of-image samples are 0 on both sides
-#pragma unroll
-            for (int iy = 0; iy < 4; ++iy)
-#pragma unroll
-                for (int ix = 0; ix < 4; ++ix)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int k = (iy * 4 + ix) * 3 + c;
-                        const unsigned q = (unsigned)(int)rintf(l0[iy][ix][c] * 255.0f) & 255u;
-                        if (side == 0) qref[k >> 2] |= q << (8 * (k & 3));
-                        else {
-                            const int dlt = (int)((qref[k >> 2] >> (8 * (k & 3))) & 255u) - (int)q;
-                            sse3[c] += (unsigned)(dlt * dlt);
-                        }
-                    }
-        }
-        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
-        float *xybt = XYBT + (size_t)(slot * 2 + side) * g.pyr_t;
-        // ---- level 0 XYB: normal rows (float4 per row) and transposed rows (float4 per column)
-        {
-            const TmScaleGeom sg = g.s[0];
-            float xv[4][4][3];
-#pragma unroll
-            for (int iy = 0; iy < 4; ++iy)
-#pragma unroll
-                for (int ix = 0; ix < 4; ++ix)
-                    tmdev::linear_to_xyb(l0[iy][ix][0], l0[iy][ix][1], l0[iy][ix][2], xv[iy][ix][0], xv[iy][ix][1], xv[iy][ix][2]);
-            if (X0 < w && Y0 < h) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                    for (int iy = 0; iy < 4; ++iy)
-                        if (Y0 + iy < h)
-                            *(float4 *)(xyb + sg.off + c * sg.plane + (size_t)(Y0 + iy) * sg.pitch + X0) =
-                                make_float4(xv[iy][0][c], xv[iy][1][c], xv[iy][2][c], xv[iy][3][c]);
-#pragma unroll
-                    for (int ix = 0; ix < 4; ++ix)
-                        if (X0 + ix < w)
-                            *(float4 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(X0 + ix) * sg.pitch_t + Y0) =
-                                make_float4(xv[0][ix][c], xv[1][ix][c], xv[2][ix][c], xv[3][ix][c]);
-                }
-            }
-        }
-        // ---- level 1 (2x2 per lane)
-        float l1[2][2][3];
-        {
-            const TmScaleGeom sg = g.s[1];
-            const int X1 = X0 / 2, Y1 = Y0 / 2;
-#pragma unroll
-            for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix) {
-                    const bool okx = X0 + 2 * ix + 1 < w, oky = Y0 + 2 * iy + 1 < h;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        l1[iy][ix][c] = ds4(l0[2 * iy][2 * ix][c], l0[2 * iy][2 * ix + 1][c], l0[2 * iy + 1][2 * ix][c],
-                                            l0[2 * iy + 1][2 * ix + 1][c], okx, oky);
-                }
-            if (X1 < sg.w && Y1 < sg.h) {
-                float xv[2][2][3];
-#pragma unroll
-                for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                    for (int ix = 0; ix < 2; ++ix)
-                        tmdev::linear_to_xyb(l1[iy][ix][0], l1[iy][ix][1], l1[iy][ix][2], xv[iy][ix][0], xv[iy][ix][1], xv[iy][ix][2]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                    for (int iy = 0; iy < 2; ++iy)
-                        if (Y1 + iy < sg.h)
-                            *(float2 *)(xyb + sg.off + c * sg.plane + (size_t)(Y1 + iy) * sg.pitch + X1) = make_float2(xv[iy][0][c], xv[iy][1][c]);
-#pragma unroll
-                    for (int ix = 0; ix < 2; ++ix)
-                        if (X1 + ix < sg.w)
-                            *(float2 *)(xybt + sg.off_t + c * sg.plane_t + (size_t)(X1 + ix) * sg.pitch_t + Y1) = make_float2(xv[0][ix][c], xv[1][ix][c]);
-                }
-            }
-        }
-        // ---- level 2 (one pixel per lane) -> LDS for the upper levels
-        {
-            const TmScaleGeom sg = g.s[2];
-            const int X2 = X0 / 4, Y2 = Y0 / 4;
-            const bool okx = X0 / 2 + 1 < g.s[1].w, oky = Y0 / 2 + 1 < g.s[1].h;
-            float l2[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                l2[c] = ds4(l1[0][0][c], l1[0][1][c], l1[1][0][c], l1[1][1][c], okx, oky);
-                l2s[c][by][bx] = l2[c];
-            }
-            if (X2 < sg.w && Y2 < sg.h) {
-                float X, Y, B;
-                tmdev::linear_to_xyb(l2[0], l2[1], l2[2], X, Y, B);
-                const size_t o = sg.off + (size_t)Y2 * sg.pitch + X2, ot = sg.off_t + (size_t)X2 * sg.pitch_t + Y2;
-                xyb[o] = X; xyb[o + sg.plane] = Y; xyb[o + 2 * sg.plane] = B;
-                xybt[ot] = X; xybt[ot + sg.plane_t] = Y; xybt[ot + 2 * sg.plane_t] = B;
-            }
-        }
-        __syncthreads();
-        // ---- levels 3, 4, 5: 8x8, 4x4, 2x2 pixels per tile
-#pragma unroll
-        for (int lv = 3; lv < TM_SCALES; ++lv) {
-            const int n = 64 >> lv; // tile edge at this level
-            if (tid < n * n) {
-                const TmScaleGeom sg = g.s[lv], sp = g.s[lv - 1];
-                const int ox = tid % n, oy = tid / n;
-                const int XL = (int)(blockIdx.x * 64 >> lv) + ox, YL = (int)(blockIdx.y * 64 >> lv) + oy;
-                const bool okx = 2 * XL + 1 < sp.w, oky = 2 * YL + 1 < sp.h;
-                float v[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (lv == 3) v[c] = ds4(l2s[c][2 * oy][2 * ox], l2s[c][2 * oy][2 * ox + 1], l2s[c][2 * oy + 1][2 * ox], l2s[c][2 * oy + 1][2 * ox + 1], okx, oky);
-                    else if (lv == 4) v[c] = ds4(l3s[c][2 * oy][2 * ox], l3s[c][2 * oy][2 * ox + 1], l3s[c][2 * oy + 1][2 * ox], l3s[c][2 * oy + 1][2 * ox + 1], okx, oky);
-                    else v[c] = ds4(l4s[c][2 * oy][2 * ox], l4s[c][2 * oy][2 * ox + 1], l4s[c][2 * oy + 1][2 * ox], l4s[c][2 * oy + 1][2 * ox + 1], okx, oky);
-                    if (lv == 3) l3s[c][oy][ox] = v[c];
-                    if (lv == 4) l4s[c][oy][ox] = v[c];
-                }
-                if (XL < sg.w && YL < sg.h) {
-                    float X, Y, B;
-                    tmdev::linear_to_xyb(v[0], v[1], v[2], X, Y, B);
-                    const size_t o = sg.off + (size_t)YL * sg.pitch + XL, ot = sg.off_t + (size_t)XL * sg.pitch_t + YL;
-                    xyb[o] = X; xyb[o + sg.plane] = Y; xyb[o + 2 * sg.plane] = B;
-                    xybt[ot] = X; xybt[ot + sg.plane_t] = Y; xybt[ot + 2 * sg.plane_t] = B;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (want_sse) {
-        for (int c = 0; c < 3; ++c) {
-            sse_s[tid] = sse3[c];
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long tot = 0;
-                for (int i = 0; i < 256; ++i) tot += sse_s[i];
-                atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS * 3 + c], tot);
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused ingest, generation 2 ("tile32"): same job and same arithmetic as k_ingest_fused, restructured
-// after measuring it: generation 1 keeps a 4x4 pixel block per lane in registers, which unrolls into
-// ~27 000 instructions (~190 KB of code: several times the instruction cache, and 5x more instruction
-// bytes than data bytes per wave) at 238 VGPRs / 2 waves per SIMD.  Here a lane owns ONE 2x2 quad (the
-// unit the reference's NV12 kernel works on), the workgroup a 32x32 tile; XYB goes through a 12 KB LDS
-// tile so that both orientations are stored as float4 with 8 lanes per 128-B line; levels 1..5 of the
-// pyramid (16, 8, 4, 2, 1 pixels per tile edge) go through a few KB of LDS.  ~3 000 instructions, < 100
-// VGPRs, so 5+ workgroups per CU hide each other's load latency, barriers and the thin upper levels.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, const float *__restrict__ lut,
                                               const double *__restrict__ tab, int x, int y, float (&v)[3])
 {
@@ -560,260 +280,42 @@ __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, co
     }
 }
 
-__device__ __forceinline__ void store_xyb_px(float *__restrict__ xyb, float *__restrict__ xybt, const TmScaleGeom &sg,
-                                             int X, int Y, const float (&lin)[3], float *__restrict__ xi = nullptr)
-{
-    if (X < sg.w && Y < sg.h) {
-        float a, b, c;
-        tmdev::linear_to_xyb(lin[0], lin[1], lin[2], a, b, c);
-        const size_t o = sg.off + (size_t)Y * sg.pitch + X, ot = sg.off_t + (size_t)X * sg.pitch_t + Y;
-        if (xyb != nullptr) { xyb[o] = a; xyb[o + sg.plane] = b; xyb[o + 2 * sg.plane] = c; }
-        if (xybt != nullptr) { xybt[ot] = a; xybt[ot + sg.plane_t] = b; xybt[ot + 2 * sg.plane_t] = c; }
-        if (xi != nullptr) { xi[2 * o] = a; xi[2 * (o + sg.plane)] = b; xi[2 * (o + 2 * sg.plane)] = c; } // interleaved pyramid, this side's lane
-    }
-}
-
-// LDS working set of k_ingest_tile32 (one side at a time; double buffering it and finishing the upper levels on a
-// designated wave was measured slower: 42 KB per workgroup cost a workgroup of occupancy)
-struct IngestSideLds {
-    float t0[3][32][33];   // level-0 XYB tile
-    float t1[3][16][17];   // level-1 XYB tile
-    float lin1[3][16][17]; // level-1 linear RGB
-};
-
-// XYB tiles out of LDS: a 32x32 tile of level A (tile origin tx0, ty0) and the 16x16 tile of level A+1 below it, each
-// in both orientations; float4 per lane, so 8 (4) neighbouring lanes complete a 128-B (64-B) run of one row.
-__device__ __forceinline__ void store_tiles_both(const IngestSideLds &L, const TmScaleGeom &sa, const TmScaleGeom &sb,
-                                                 float *__restrict__ xyb, float *__restrict__ xybt, int tx0, int ty0, int tid)
-{
-    {
-        const int r = tid >> 3, q4 = (tid & 7) * 4;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (xyb != nullptr && ty0 + r < sa.h && tx0 + q4 < sa.w)
-                *(float4 *)(xyb + sa.off + c * sa.plane + (size_t)(ty0 + r) * sa.pitch + tx0 + q4) =
-                    make_float4(L.t0[c][r][q4], L.t0[c][r][q4 + 1], L.t0[c][r][q4 + 2], L.t0[c][r][q4 + 3]);
-            if (xybt != nullptr && tx0 + r < sa.w && ty0 + q4 < sa.h)
-                *(float4 *)(xybt + sa.off_t + c * sa.plane_t + (size_t)(tx0 + r) * sa.pitch_t + ty0 + q4) =
-                    make_float4(L.t0[c][q4][r], L.t0[c][q4 + 1][r], L.t0[c][q4 + 2][r], L.t0[c][q4 + 3][r]);
-        }
-    }
-    if (tid < 192) {
-        const int c = tid >> 6, r = (tid & 63) >> 2, q4 = (tid & 3) * 4;
-        const int x1 = tx0 / 2, y1 = ty0 / 2;
-        if (xyb != nullptr && y1 + r < sb.h && x1 + q4 < sb.w)
-            *(float4 *)(xyb + sb.off + c * sb.plane + (size_t)(y1 + r) * sb.pitch + x1 + q4) =
-                make_float4(L.t1[c][r][q4], L.t1[c][r][q4 + 1], L.t1[c][r][q4 + 2], L.t1[c][r][q4 + 3]);
-        if (xybt != nullptr && x1 + r < sb.w && y1 + q4 < sb.h)
-            *(float4 *)(xybt + sb.off_t + c * sb.plane_t + (size_t)(x1 + r) * sb.pitch_t + y1 + q4) =
-                make_float4(L.t1[c][q4][r], L.t1[c][q4 + 1][r], L.t1[c][q4 + 2][r], L.t1[c][q4 + 3][r]);
-    }
-}
-
-#ifndef TM_TILE32_WAVES
-#define TM_TILE32_WAVES 5 // waves per SIMD the register allocation is held to
-#endif
-// KIND >= 0: every frame of the launch has this TM_KIND_* (the normal case; the host checks), so all format
-// branches fold away and the sample loads of a quad are issued back to back; KIND = -1: per-frame dispatch.
-template <int KIND>
-__global__ void __launch_bounds__(256, TM_TILE32_WAVES) k_ingest_tile32(TmGeom g, const TmFrameDesc *__restrict__ desc,
-                                                       const float *__restrict__ lut, const float *__restrict__ coef,
-                                                       const double *__restrict__ gtab, const float *__restrict__ yuvlut,
-                                                       float *__restrict__ XYB, float *__restrict__ XYBT,
-                                                       float *__restrict__ LIN2, unsigned long long *__restrict__ SSE,
-                                                       int want_sse, unsigned char *__restrict__ QU8, unsigned long long qplane,
-                                                       int qpitch)
-{
-    __shared__ double tab[TM_TAB_DOUBLES];
-    __shared__ IngestSideLds L;
-    __shared__ unsigned sse_s[256];
-    __shared__ __attribute__((aligned(16))) unsigned short qt[3][32][16]; // u8 tile, two pixels per entry (SSIM / MS-SSIM only)
-    const int tid = threadIdx.x;
-    const int qx = tid & 15, qy = tid >> 4; // quad inside the tile
-    const int slot = blockIdx.z;
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
-    const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
-    const int w = g.s[0].w, h = g.s[0].h;
-    unsigned qref[3] = {0, 0, 0};
-    unsigned sse3[3] = {0, 0, 0}; // per channel: NPP's C3 quality functions may report per channel
-    // YUV kinds: the quad's six samples are fetched one side ahead -- side 0 before the table barrier, side 1 while
-    // side 0 is being stored -- so that their latency never sits in front of the arithmetic
-    constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016;
-    const bool quad_ok = X0 + 1 < w && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
-    unsigned raw[6] = {0, 0, 0, 0, 0, 0};
-    TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
-    if (YUV && quad_ok) {
-        if (KIND == TM_KIND_NV12) yuv_quad_load<unsigned char>(dd0, X0 / 2, Y0 / 2, raw);
-        else yuv_quad_load<unsigned short>(dd0, X0 / 2, Y0 / 2, raw);
-    }
-    for (int i = tid; i < TM_TAB_DOUBLES; i += 256) tab[i] = gtab[i];
-    TM_LDS_BARRIER();
-
-#pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-        TmFrameDesc d = dd0;
-        if (side) d = dd1;
-        const int kind = KIND >= 0 ? KIND : d.kind;
-        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
-        float *xybt = XYBT + (size_t)(slot * 2 + side) * g.pyr_t;
-        // ---- the lane's quad -> linear RGB
-        float px[2][2][3];
-#pragma unroll
-        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < 2; ++ix)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
-        if (YUV) {
-            if (quad_ok) {
-                if (KIND == TM_KIND_NV12) yuv_quad_convert<8>(d, raw, coef, tab, px, yuvlut);
-                else yuv_quad_convert<16>(d, raw, coef, tab, px, nullptr);
-                if (side == 0) { // next side's samples: in flight during this side's XYB arithmetic and stores
-                    if (KIND == TM_KIND_NV12) yuv_quad_load<unsigned char>(dd1, X0 / 2, Y0 / 2, raw);
-                    else yuv_quad_load<unsigned short>(dd1, X0 / 2, Y0 / 2, raw);
-                }
-            }
-        } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
-            if (quad_ok) {
-                if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px, yuvlut);
-                else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
-            }
-        } else {
-#pragma unroll
-            for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix)
-                    if (X0 + ix < w && Y0 + iy < h) ingest_px_rgb(d, kind, lut, tab, X0 + ix, Y0 + iy, px[iy][ix]);
-        }
-        if (want_sse) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const unsigned q = (unsigned)(int)rintf(px[k / 6][(k / 3) & 1][k % 3] * 255.0f) & 255u;
-                if (side == 0) qref[k >> 2] |= q << (8 * (k & 3));
-                else {
-                    const int dlt = (int)((qref[k >> 2] >> (8 * (k & 3))) & 255u) - (int)q;
-                    sse3[k % 3] += (unsigned)(dlt * dlt);
-                }
-            }
-        }
-        if (QU8 != nullptr) { // u8-quantised pixels (f32_to_8bit, sample_conv.rs:6-35) into the LDS byte tile; stored below
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int iy = 0; iy < 2; ++iy) {
-                    const unsigned q0 = (unsigned)(int)rintf(px[iy][0][c] * 255.0f) & 255u;
-                    const unsigned q1 = (unsigned)(int)rintf(px[iy][1][c] * 255.0f) & 255u;
-                    qt[c][2 * qy + iy][qx] = (unsigned short)(q0 | (q1 << 8));
-                }
-        }
-        // ---- level-0 XYB into the LDS tile, level-1 linear pixel of this quad and its XYB (five pixels = 15 cube
-        // roots, evaluated pairwise).  XYB == nullptr: SSIMULACRA2 is not asked for (PSNR / SSIM only): no pyramid at all.
-        if (XYB != nullptr) {
-            const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
-            float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { lr[k] = px[k >> 1][k & 1][0]; lg[k] = px[k >> 1][k & 1][1]; lb[k] = px[k >> 1][k & 1][2]; }
-            lr[4] = ds4(px[0][0][0], px[0][1][0], px[1][0][0], px[1][1][0], okx, oky);
-            lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
-            lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
-            L.lin1[0][qy][qx] = lr[4]; L.lin1[1][qy][qx] = lg[4]; L.lin1[2][qy][qx] = lb[4];
-            tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                L.t0[0][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xa[k];
-                L.t0[1][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xb[k];
-                L.t0[2][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xc[k];
-            }
-            L.t1[0][qy][qx] = xa[4]; L.t1[1][qy][qx] = xb[4]; L.t1[2][qy][qx] = xc[4];
-        }
-        TM_LDS_BARRIER();
-        // ---- levels 0 and 1 out of their tiles
-        if (XYB != nullptr) store_tiles_both(L, g.s[0], g.s[1], xyb, xybt, tx0, ty0, tid);
-        if (QU8 != nullptr && tid < 192) { // the u8 tile: 16 pixels = one 16-B store per lane, two lanes per row
-            const int c = tid >> 6, r = (tid & 63) >> 1, half = tid & 1;
-            if (ty0 + r < h && tx0 + 16 * half < w)
-                *(uint4 *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(ty0 + r) * qpitch + tx0 + 16 * half) =
-                    *(const uint4 *)&qt[c][r][8 * half];
-        }
-        // ---- level-2 LINEAR pixels of this tile (8x8) go to HBM: levels 2..5 are finished by k_ingest_upper.
-        // (Doing them here cost four more barriers per side with 3/4 .. 255/256 of the workgroup idle.)
-        if (XYB != nullptr && tid < 64) {
-            const TmScaleGeom s1 = g.s[1], s2 = g.s[2];
-            const int ox = tid & 7, oy = tid >> 3;
-            const int XL = (tx0 >> 2) + ox, YL = (ty0 >> 2) + oy;
-            if (XL < s2.w && YL < s2.h) {
-                const bool okx = 2 * XL + 1 < s1.w, oky = 2 * YL + 1 < s1.h;
-                float *l2 = LIN2 + (size_t)(slot * 2 + side) * 3 * s2.plane + (size_t)YL * s2.pitch + XL;
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    l2[c * s2.plane] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox],
-                                           L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
-            }
-        }
-        TM_LDS_BARRIER(); // the tile is reused by the next side
-    }
-    if (want_sse) {
-        // per-wave sum through LDS (wave-synchronous), one 64-bit integer atomic per wave into one of TM_SSE_BINS
-        // x 3 (channel) accumulators of the slot (exact and order-free; a single address per slot serialised 8 000 atomics
-        // at 1080p and doubled the kernel's time); the host adds the bins
-        const unsigned bin = (blockIdx.x * 4 + (tid >> 6) + blockIdx.y * 29) % TM_SSE_BINS;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            sse_s[tid] = sse3[c];
-            __builtin_amdgcn_wave_barrier();
-            if ((tid & 63) == 0) {
-                unsigned long long tot = 0;
-                for (int i = 0; i < 64; ++i) tot += sse_s[tid + i];
-                atomicAdd(&SSE[((size_t)slot * TM_SSE_BINS + bin) * 3 + c], tot);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Ingest, generation 3 ("wave"): no LDS tile, no barrier.  One wave = one 32 x 8 pixel tile (16 x 4 quads, lane = quad),
-// both sides.  Rows are stored straight from registers: a lane's float2 per row and 16 lanes along x make whole 128-B lines
-// in the normal orientation; the level-2 linear pixels (8 x 2 per tile) come from the level-1 pixels of four neighbouring
-// lanes through wave shuffles.  No transposed copy is written: the row pass k_blur_h_jobs_x transposes ref / dis itself.
+// Ingest ("wave"): decoded frame pair -> linear RGB -> XYB of pyramid levels 0 and 1 + the level-2 LINEAR pixels, no LDS
+// tile, no barrier.  One wave = one 32 x 8 pixel tile (16 x 4 quads, lane = quad = the unit the reference's NV12 kernel
+// works on), both sides one after the other (so the PSNR SSE needs no second pass).
+// The XYB pyramid holds ref and dis in ONE plane, interleaved per pixel ([y][x][side], rows of 2 * pitch floats): both blur
+// passes need both sides of a pixel at the same time and fetch them with one load of whole 128-B lines.  Side 0's XYB
+// waits in wave-private LDS; when side 1 is done the lane stores {ref, dis} pairs straight from registers: a float4 per
+// row (two pixels x two sides), 16 lanes along x = 256 contiguous bytes.  The level-2 linear pixels (8 x 2 per tile) come
+// from the level-1 pixels of four neighbouring lanes through wave shuffles and go to LIN2 for k_ingest_upper_rd.
+// KIND >= 0: every frame of the launch has this TM_KIND_* (the normal case; the host checks), so all format branches fold
+// away and the sample loads of both sides are issued back to back; KIND = -1: per-frame dispatch.
 // grid (ceil(w/32), ceil(h/8), slots), block 64.
 // ------------------------------------------------------------------------------------------------
-// RD: ref and dis share one plane, interleaved per pixel ([y][x][side], rows of 2 * pitch floats): the row pass then fetches
-// both inputs of the edge terms with one load of whole 128-B lines.  The wave keeps side 0's XYB in registers and stores
-// {ref, dis} pairs when side 1 is done: float4 per row (two pixels x two sides), 16 lanes = 256 contiguous bytes.
-template <int KIND, bool RD = false>
+template <int KIND>
 __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
-                                                    const float *__restrict__ yuvlut, float *__restrict__ XYB,
-                                                    float *__restrict__ LIN2, unsigned long long *__restrict__ SSE, int want_sse,
-                                                    unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch, int xcd_order)
+                                                    float *__restrict__ XYB, float *__restrict__ LIN2,
+                                                    unsigned long long *__restrict__ SSE, int want_sse,
+                                                    unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch)
 {
     __shared__ double tab[TM_TAB_DOUBLES];
     const int lane = threadIdx.x;
     const int qx = lane & 15, qy = lane >> 4;
     const int slot = blockIdx.z;
-    // xcd_order (A/B option, off: measured 8 % slower at 1080p): workgroups are dealt round-robin to the 8 XCDs (each with its
-    // own L2), and four neighbouring tiles share every 128-B line of an 8-bit luma / chroma row (two tiles for 16-bit samples).
-    // Inside each run of 32 workgroups, XCD r (= workgroup id mod 8) takes tiles 4r .. 4r+3: a line goes to one L2, not four.
-    int bx = blockIdx.x, by = blockIdx.y;
-    {
-        const unsigned ntx = gridDim.x, total = gridDim.x * gridDim.y;
-        const unsigned L = blockIdx.x + blockIdx.y * ntx, base = L & ~31u;
-        if (xcd_order && base + 32 <= total) {
-            const unsigned T = base + 4 * (L & 7) + ((L >> 3) & 3);
-            bx = (int)(T % ntx); by = (int)(T / ntx);
-        }
-    }
-    const int tx0 = bx * 32, ty0 = by * 8;
+    // (an XCD-aware tile order -- the four tiles that share a 128-B line of an NV12 row sent to the same XCD's L2 -- measured
+    // 8 % slower: four L2s fetching the line in parallel beat one fetching it once)
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     const int w = g.s[0].w, h = g.s[0].h;
     unsigned qref[3] = {0, 0, 0};
     unsigned sse3[3] = {0, 0, 0};
     for (int i = lane; i < TM_TAB_DOUBLES; i += 64) tab[i] = gtab[i];
     __builtin_amdgcn_wave_barrier();
-    // RD: side 0's XYB (four level-0 pixels + the level-1 pixel) waits in LDS until side 1 is done ([value][lane]: wave-private,
+    // side 0's XYB (four level-0 pixels + the level-1 pixel) waits in LDS until side 1 is done ([value][lane]: wave-private,
     // conflict-free; holding it in 15 VGPRs cost the fifth wave per SIMD)
-    __shared__ float keep_s[RD ? 15 : 1][64];
+    __shared__ float keep_s[15][64];
     // YUV kinds: the samples of BOTH sides are requested before anything else (three pair loads per side), so that side 1's
     // never sit behind side 0's arithmetic
     constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016;
@@ -840,12 +342,12 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                 const unsigned prs[3] = {side ? pr1[0] : pr0[0], side ? pr1[1] : pr0[1], side ? pr1[2] : pr0[2]};
                 unsigned raw[6];
                 yuv_quad_unpack<KIND == TM_KIND_NV12 ? 8 : 16>(prs, raw);
-                if (KIND == TM_KIND_NV12) yuv_quad_convert<8>(d, raw, coef, tab, px, nullptr); // R, B evaluated: with the table-cubic transfer function 8 more evaluations beat the 8 gathers of the memoised tables (1.42 vs 1.51 ms per 64 pairs)
-                else yuv_quad_convert<16>(d, raw, coef, tab, px, nullptr);
+                if (KIND == TM_KIND_NV12) yuv_quad_convert<8>(d, raw, coef, tab, px);
+                else yuv_quad_convert<16>(d, raw, coef, tab, px);
             }
         } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
             if (quad_ok) {
-                if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px, yuvlut);
+                if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px);
                 else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
             }
         } else {
@@ -878,7 +380,6 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                     }
         }
         if (XYB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
-        float *xyb = XYB + (size_t)(slot * 2 + side) * g.pyr;
         const bool okx = X0 + 1 < w, oky = Y0 + 1 < h;
         float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
 #pragma unroll
@@ -890,18 +391,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
         constexpr bool UNIT = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_RGB8 || KIND == TM_KIND_RGB16;
         tmdev::linear_to_xyb_n<5, UNIT>(lr, lg, lb, xa, xb, xc);
         // ---- level 0: two rows of two pixels; level 1: one pixel
-        if (!RD) {
-            const TmScaleGeom s0 = g.s[0], s1 = g.s[1];
-            const float *xv[3] = {xa, xb, xc};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int iy = 0; iy < 2; ++iy)
-                    if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair stays inside the row
-                        *(float2 *)(xyb + s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0) = make_float2(xv[c][2 * iy], xv[c][2 * iy + 1]);
-                if (X0 / 2 < s1.w && Y0 / 2 < s1.h) xyb[s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2] = xv[c][4];
-            }
-        } else if (side == 0) {
+        if (side == 0) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) { keep_s[k][lane] = xa[k]; keep_s[5 + k][lane] = xb[k]; keep_s[10 + k][lane] = xc[k]; }
         } else {
@@ -915,14 +405,14 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                 for (int k = 0; k < 5; ++k) keep[k] = keep_s[5 * c + k][lane];
 #pragma unroll
                 for (int iy = 0; iy < 2; ++iy)
-                    if (X0 < w && Y0 + iy < h)
+                    if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair of pixels stays inside the row
                         *(float4 *)(xi + 2 * (s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0)) =
                             make_float4(keep[2 * iy], xv[c][2 * iy], keep[2 * iy + 1], xv[c][2 * iy + 1]);
                 if (X0 / 2 < s1.w && Y0 / 2 < s1.h)
                     *(float2 *)(xi + 2 * (s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2)) = make_float2(keep[4], xv[c][4]);
             }
         }
-        // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper)
+        // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper_rd)
         {
             const TmScaleGeom s1 = g.s[1], s2 = g.s[2];
             const int XL = X0 >> 2, YL = Y0 >> 2;
@@ -951,94 +441,12 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     }
 }
 
-// Levels 2..5 of the pyramid from the level-2 linear RGB that k_ingest_tile32 leaves in LIN2 (1/16 of the
-// pixels): XYB of level 2, then 2x2 box downscales (downscale.rs:5-35) and XYB for levels 3, 4, 5.
-// Workgroup = 32x32 tile of level 2 (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad.
-// grid (ceil(w2/32), ceil(h2/32), slots*2), block 256.
-// rd: the XYB arena is the ref/dis-interleaved pyramid of ingest generation 4 (element (x, y, side) at 2 * plain offset + side)
-__global__ void __launch_bounds__(256) k_ingest_upper(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB,
-                                                      float *__restrict__ XYBT, int rd)
-{
-    __shared__ IngestSideLds L; // t0: level-2 XYB tile, t1: level-3 XYB tile, lin1: level-3 linear RGB
-    __shared__ float lin4[3][8][9];
-    const int tid = threadIdx.x, qx = tid & 15, qy = tid >> 4;
-    const int img = blockIdx.z; // slot*2 + side
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32;
-    const TmScaleGeom s2 = g.s[2];
-    float *xyb = rd ? nullptr : XYB + (size_t)img * g.pyr, *xybt = XYBT != nullptr ? XYBT + (size_t)img * g.pyr_t : nullptr;
-    float *xi = rd ? XYB + (size_t)(img >> 1) * 2 * g.pyr + (img & 1) : nullptr; // interleaved pyramid of the slot, this side's lane
-    const float *l2 = LIN2 + (size_t)img * 3 * s2.plane;
-    const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
-    {
-        float lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int x = X0 + (k & 1), y = Y0 + (k >> 1);
-            const bool in = x < s2.w && y < s2.h;
-            const size_t o = (size_t)(in ? y : 0) * s2.pitch + (in ? x : 0);
-            const float a = l2[o], b = l2[s2.plane + o], c = l2[2 * s2.plane + o];
-            lr[k] = in ? a : 0.0f; lg[k] = in ? b : 0.0f; lb[k] = in ? c : 0.0f;
-        }
-        const bool okx = X0 + 1 < s2.w, oky = Y0 + 1 < s2.h;
-        lr[4] = ds4(lr[0], lr[1], lr[2], lr[3], okx, oky);
-        lg[4] = ds4(lg[0], lg[1], lg[2], lg[3], okx, oky);
-        lb[4] = ds4(lb[0], lb[1], lb[2], lb[3], okx, oky);
-        L.lin1[0][qy][qx] = lr[4]; L.lin1[1][qy][qx] = lg[4]; L.lin1[2][qy][qx] = lb[4];
-        tmdev::linear_to_xyb_n<5>(lr, lg, lb, xa, xb, xc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            L.t0[0][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xa[k];
-            L.t0[1][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xb[k];
-            L.t0[2][2 * qy + (k >> 1)][2 * qx + (k & 1)] = xc[k];
-        }
-        L.t1[0][qy][qx] = xa[4]; L.t1[1][qy][qx] = xb[4]; L.t1[2][qy][qx] = xc[4];
-    }
-    TM_LDS_BARRIER();
-    store_tiles_both(L, s2, g.s[3], xyb, xybt, tx0, ty0, tid);
-    if (xi != nullptr) { // levels 2 and 3 are 1/16 and 1/64 of the pixels: plain per-pixel stores at stride 2
-        const TmScaleGeom s3 = g.s[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x = X0 + (k & 1), y = Y0 + (k >> 1);
-                if (x < s2.w && y < s2.h) xi[2 * (s2.off + c * s2.plane + (size_t)y * s2.pitch + x)] = L.t0[c][2 * qy + (k >> 1)][2 * qx + (k & 1)];
-            }
-            if (X0 / 2 < s3.w && Y0 / 2 < s3.h) xi[2 * (s3.off + c * s3.plane + (size_t)(Y0 / 2) * s3.pitch + X0 / 2)] = L.t1[c][qy][qx];
-        }
-    }
-    if (tid < 64) { // level 4: 8x8 per tile
-        const TmScaleGeom s3 = g.s[3];
-        const int ox = tid & 7, oy = tid >> 3;
-        const int XL = (tx0 >> 2) + ox, YL = (ty0 >> 2) + oy;
-        const bool okx = 2 * XL + 1 < s3.w, oky = 2 * YL + 1 < s3.h;
-        float v[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v[c] = ds4(L.lin1[c][2 * oy][2 * ox], L.lin1[c][2 * oy][2 * ox + 1], L.lin1[c][2 * oy + 1][2 * ox], L.lin1[c][2 * oy + 1][2 * ox + 1], okx, oky);
-            lin4[c][oy][ox] = v[c];
-        }
-        store_xyb_px(xyb, xybt, g.s[4], XL, YL, v, xi);
-    }
-    TM_LDS_BARRIER();
-    if (tid < 16) { // level 5: 4x4 per tile
-        const TmScaleGeom s4 = g.s[4];
-        const int ox = tid & 3, oy = tid >> 2;
-        const int XL = (tx0 >> 3) + ox, YL = (ty0 >> 3) + oy;
-        const bool okx = 2 * XL + 1 < s4.w, oky = 2 * YL + 1 < s4.h;
-        float v[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            v[c] = ds4(lin4[c][2 * oy][2 * ox], lin4[c][2 * oy][2 * ox + 1], lin4[c][2 * oy + 1][2 * ox], lin4[c][2 * oy + 1][2 * ox + 1], okx, oky);
-        store_xyb_px(xyb, xybt, g.s[5], XL, YL, v, xi);
-    }
-}
-
-// The same for the ref/dis-interleaved pyramid (ingest generation 4), both sides in one workgroup: side 0's XYB values (five
-// per lane for levels 2 and 3, one each for the lanes that own a level-4 / level-5 pixel) wait in registers and side 1 stores
-// whole {ref, dis} pairs -- a float4 per level-2 row (two pixels x two sides: 16 lanes = 256 contiguous bytes) -- instead of
-// 4-byte stores at stride 8 from two workgroups.  Same arithmetic calls as k_ingest_upper -> same bits.
-// grid (ceil(w2/32), ceil(h2/32), slots), block 256.
+// Levels 2..5 of the pyramid from the level-2 linear RGB that k_ingest_wave leaves in LIN2 (1/16 of the pixels): XYB of
+// level 2, then 2x2 box downscales (downscale.rs:5-35) and XYB for levels 3, 4, 5.  Workgroup = 32x32 tile of level 2
+// (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad, both sides in one workgroup: side 0's XYB
+// values (five per lane for levels 2 and 3, one each for the lanes that own a level-4 / level-5 pixel) wait in registers
+// and side 1 stores whole {ref, dis} pairs -- a float4 per level-2 row (two pixels x two sides: 16 lanes = 256 contiguous
+// bytes).  grid (ceil(w2/32), ceil(h2/32), slots), block 256.
 __global__ void __launch_bounds__(256) k_ingest_upper_rd(TmGeom g, const float *__restrict__ LIN2, float *__restrict__ XYB)
 {
     __shared__ float lin3[3][16][17]; // level-3 linear RGB of this tile
@@ -1251,148 +659,12 @@ __global__ void __launch_bounds__(64) k_blur_v(TmGeom g, const float *__restrict
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Column pass, generation 1: same arithmetic and same per-lane IIR state as k_blur_v, but the
-// transposition goes through LDS so that HBM only ever sees whole 64-B / 128-B segments.
-// gen 0 stores one float4 (4 rows of one column) per lane: 16-B pieces scattered at pitch_t stride,
-// which the memory side has to merge (measured 0.98 TB/s).  Here every lane drops its 7 per-step values
-// (5 blurred planes + the ref/dis copies) into a [plane][row % R][column] LDS tile (row stride S floats,
-// S chosen so that both the row-wise writes and the column-wise read-back are bank-conflict free:
-// S = 65 / 66 / 68 for R = 32 / 16 / 8); every R steps the wave reads the tile back transposed and
-// stores, per column, R contiguous floats (R*4 bytes: one or half a cache line) with R/4 lanes per column.
-// A wave is its own workgroup and only touches its own tile, so no barrier is needed: LDS operations of
-// one wave execute in issue order.
-// W = register window per input (rows t-10 .. t+W-11): the reference's 11-deep ring plus a W-10 row
-// load prefetch.  The body is unrolled max(W, R) steps so that every window slot and flush point is static.
-// ------------------------------------------------------------------------------------------------
 template <int R> struct BlurVTile {
     static constexpr int S = R == 32 ? 65 : (R == 16 ? 66 : 68);
     static constexpr int LPC = R / 4;   // lanes per column in the read-back
     static constexpr int CPI = 64 / LPC; // columns per store instruction
 };
 
-template <int R, int P0, int NP>
-__device__ __forceinline__ void blur_v_flush(const float *__restrict__ tile, float *const (&dst)[7], int x0,
-                                             int pitch_t, int y0)
-{
-    // No predicate on purpose: columns past the right edge land in the plane's padding rows (plane_t is
-    // allocated for round_up(w,64) rows) and rows past the bottom in the pitch padding.  Keeping the stores
-    // unconditional keeps the whole loop body one basic block, so the compiler can give every later load an
-    // exact s_waitcnt vmcnt(N) instead of draining the 20+ stores of a flush with vmcnt(0).
-    using TT = BlurVTile<R>;
-    const int lane = threadIdx.x;
-    const int xl = lane / TT::LPC, yq = lane % TT::LPC;
-#pragma unroll
-    for (int p = P0; p < P0 + NP; ++p) {
-        const float *tp = tile + p * R * TT::S + (4 * yq) * TT::S;
-#pragma unroll
-        for (int i = 0; i < 64 / TT::CPI; ++i) {
-            const int xc = i * TT::CPI + xl;
-            const float4 v = make_float4(tp[xc], tp[TT::S + xc], tp[2 * TT::S + xc], tp[3 * TT::S + xc]);
-            *(float4 *)(dst[p] + (size_t)(x0 + xc) * pitch_t + y0 + 4 * yq) = v;
-        }
-    }
-}
-
-template <int R, int W>
-__global__ void __launch_bounds__(64) k_blur_v_lds(TmGeom g, const float *__restrict__ XYB, float *__restrict__ XYBT,
-                                                   float *__restrict__ V)
-{
-    using TT = BlurVTile<R>;
-    constexpr int P = W - 10;          // prefetch distance in rows
-    constexpr int U = W > R ? W : R;   // unroll (W and R are powers of two, so U is a multiple of both)
-    __shared__ float tile[7 * R * TT::S];
-    int b = blockIdx.x, s = 0;
-#pragma unroll
-    for (int i = 1; i < TM_SCALES; ++i)
-        if (b >= g.vblk[i]) s = i;
-    const TmScaleGeom sg = g.s[s];
-    const int x0 = (b - g.vblk[s]) * 64;
-    const int lane = threadIdx.x;
-    const int x = min(x0 + lane, sg.w - 1); // lanes past the right edge shadow the last column
-    const int c = blockIdx.y, slot = blockIdx.z;
-    const int h = sg.h, pitch = sg.pitch, pitch_t = sg.pitch_t;
-    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane + x;
-    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane + x;
-    const size_t to = sg.off_t + c * sg.plane_t;
-    float *const dst[7] = {V + (size_t)(slot * 5 + 0) * g.pyr_t + to, V + (size_t)(slot * 5 + 1) * g.pyr_t + to,
-                           V + (size_t)(slot * 5 + 2) * g.pyr_t + to, V + (size_t)(slot * 5 + 3) * g.pyr_t + to,
-                           V + (size_t)(slot * 5 + 4) * g.pyr_t + to, XYBT + (size_t)(slot * 2 + 0) * g.pyr_t + to,
-                           XYBT + (size_t)(slot * 2 + 1) * g.pyr_t + to};
-
-    float wr[W], wd[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        wr[j] = j < P ? ld_row(ref, j, h, pitch) : 0.0f;
-        wd[j] = j < P ? ld_row(dis, j, h, pitch) : 0.0f;
-    }
-    tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
-
-    // steps 0..3 have no output row yet (row t-4 < 0): run the recurrences, keep the input copies
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float r = wr[t], d = wd[t];
-        const float rold = wr[(t + P) % W], dold = wd[(t + P) % W];
-        wr[(t + P) % W] = ld_row(ref, t + P, h, pitch);
-        wd[(t + P) % W] = ld_row(dis, t + P, h, pitch);
-        (void)tmdev::iir_step(f0, rold * rold + r * r);
-        (void)tmdev::iir_step(f1, dold * dold + d * d);
-        (void)tmdev::iir_step(f2, rold * dold + r * d);
-        (void)tmdev::iir_step(f3, rold + r);
-        (void)tmdev::iir_step(f4, dold + d);
-        float *ti_ = tile + (t * TT::S) + lane;
-        ti_[5 * R * TT::S] = r;
-        ti_[6 * R * TT::S] = d;
-    }
-    const int T = (h + U - 1) / U * U + 4; // whole U-row groups of outputs; overshoot lands in padding
-    for (int t0 = 4; t0 < T; t0 += U) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int t = t0 + j; // t mod W == (j+4) mod W, (t-4) mod R == j mod R
-            const float r = wr[(j + 4) % W], d = wd[(j + 4) % W];
-            const float rold = wr[(j + 4 + P) % W], dold = wd[(j + 4 + P) % W];
-            wr[(j + 4 + P) % W] = ld_row(ref, t + P, h, pitch);
-            wd[(j + 4 + P) % W] = ld_row(dis, t + P, h, pitch);
-            const float o0 = tmdev::iir_step(f0, rold * rold + r * r);
-            const float o1 = tmdev::iir_step(f1, dold * dold + d * d);
-            const float o2 = tmdev::iir_step(f2, rold * dold + r * d);
-            const float o3 = tmdev::iir_step(f3, rold + r);
-            const float o4 = tmdev::iir_step(f4, dold + d);
-            float *to_ = tile + ((j % R) * TT::S) + lane; // output row y = t-4
-            to_[0 * R * TT::S] = o0;
-            to_[1 * R * TT::S] = o1;
-            to_[2 * R * TT::S] = o2;
-            to_[3 * R * TT::S] = o3;
-            to_[4 * R * TT::S] = o4;
-            float *ti_ = tile + (((j + 4) % R) * TT::S) + lane; // input row t
-            ti_[5 * R * TT::S] = r;
-            ti_[6 * R * TT::S] = d;
-            if (j % R == R - 1) { // output rows y0 .. y0+R-1 complete
-                __builtin_amdgcn_wave_barrier();
-                blur_v_flush<R, 0, 5>(tile, dst, x0, pitch_t, t - 4 - (R - 1));
-                __builtin_amdgcn_wave_barrier();
-            }
-            if ((j + 4) % R == R - 1) { // input rows r0 .. r0+R-1 complete
-                __builtin_amdgcn_wave_barrier();
-                blur_v_flush<R, 5, 2>(tile, dst, x0, pitch_t, t - (R - 1));
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Column pass, generation 2 ("split"): one workgroup = 5 wavefronts = the five blurred planes of one
-// 64-column block; wave `role` runs ONE recurrence (6 state registers) and owns one [32][65] LDS tile
-// (roles mu1/mu2 own a second tile for the transposed ref/dis copy).  Compared with generation 1 this
-//   * flushes R = 32 rows at a time: every store instruction writes whole 128-B lines, which is what the
-//     memory side needs for full write bandwidth (tools/microbench/wrpattern.hip: 64-B runs 3.3 TB/s,
-//     128-B runs 5.4 TB/s, plain fill 5.2 TB/s);
-//   * keeps 10 light waves per CU in flight (2 workgroups x 58 KB LDS) instead of 2-4 heavy ones, each with
-//     its own W-10 row load prefetch;
-//   * re-reads ref/dis from L1/L2 in the waves that share them (3 readers each) -- HBM still sees them once.
-// The five waves never exchange data, so there is no barrier; arithmetic is unchanged (bit-identical).
-// ------------------------------------------------------------------------------------------------
 // row `row` of a plane whose base pointer is wave-uniform: the row address stays in SGPRs and the load uses
 // the scalar-base + per-lane-offset form, so a whole window of in-flight loads costs one VGPR of addressing
 #ifdef TM_EMULATE
@@ -1433,7 +705,7 @@ typedef float tm_g2 __attribute__((ext_vector_type(2)));
 #endif
 __device__ __forceinline__ void ld_row_u2(const float *__restrict__ plane, unsigned xb, int row, int nrows, int pitch, float &a, float &b)
 {
-    // the {ref, dis} pair of the interleaved pyramid (ingest generation 4): one 8-byte load per lane
+    // the {ref, dis} pair of the interleaved pyramid: one 8-byte load per lane
     const int rc = row < nrows ? row : nrows - 1;
     TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(plane + (size_t)rc * pitch);
     const tm_g2 v = *(TM_GLOBAL_AS const tm_g2 *)(rowp + xb);
@@ -1441,54 +713,55 @@ __device__ __forceinline__ void ld_row_u2(const float *__restrict__ plane, unsig
     b = row < nrows ? v.y : 0.0f;
 }
 
-// RDM (ref/dis-interleaved input, ingest generation 4): 0 = plain planes; 1 = "pair lanes": the wave covers 32 columns, lane =
-// (column, side), one coalesced 256-B load per row feeds the ref AND the dis recurrence, and the flush sends the odd tile
-// columns to the next output plane (side_delta floats further); 2 = the product wave: 64 columns, one 8-byte load per lane.
-// BLK: the output planes are stored as 64-column x 32-row tiles of 2048 contiguous floats (element (x, y) of a plane at
-// ((x >> 6) * (pitch_t >> 5) + (y >> 5)) * 2048 + (x & 63) * 32 + (y & 31)): one flush of this wave is ONE contiguous run of
-// 8 KB (4 KB per side for the pair-lane waves) instead of 64 lines 4 KB apart, and the row pass walks a tile front to back.
-// dst then points at the wave's first column inside tile row 0.
-template <int R, int W, bool TWO, bool COPY, bool NT = false, int RDM = 0, bool BLK = false>
-__device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, float *__restrict__ tile_copy,
-                                                  const float *__restrict__ pa, const float *__restrict__ pb, unsigned x,
-                                                  float *__restrict__ dst, float *__restrict__ dst_copy, int h, int pitch,
-                                                  int pitch_t, bool product, unsigned side_delta = 0)
+// ------------------------------------------------------------------------------------------------
+// Column pass ("pass 1"), tuned: blur_plane_pass_fused down the columns of the five planes ref^2, dis^2, ref*dis, ref, dis
+// (ssimulacra2-cuda-kernel/src/blur.rs:34-137; which planes: ssimulacra2-cuda/src/lib.rs:299-335), products formed in
+// registers (a rounded f32 multiply each, exactly what nppiMul stores), output transposed (the reference's nppiTranspose,
+// lib.rs:342-361) as whole 128-B lines.  Exact sequential recurrence per column: step t reads row t and row t-10 and emits
+// row t-4.  One workgroup = 5 wavefronts = the 5 planes of one 64-column block; each wave runs ONE recurrence per lane
+// (6 state registers), keeps a W-row register window of its input (the reference's 11-deep ring + a W-10 row load prefetch;
+// static slot indices via unroll) and owns one [32][65] LDS tile: every 32 steps the wave reads its tile back transposed
+// (row stride 65 -> conflict-free both ways) and stores, per column, 32 contiguous floats, non-temporal.
+// The input is the ref/dis-interleaved pyramid (a pixel = the 8-byte pair {ref, dis}, rows of 2 * pitch floats):
+//   PAIR = false ("pair lanes"): the wave covers 32 columns, lane = (column, side): one coalesced 256-B load per row feeds
+//          the ref AND the dis recurrence, and the flush sends the odd tile columns to the next output plane (side_delta
+//          floats further).  square = true: the input is squared (planes 0, 1), false: plain (planes 3, 4).
+//   PAIR = true: the product wave, 64 columns, one 8-byte {ref, dis} load per lane -> plane 2.
+// Flush stores are unconditional (planes are padded) so the loop body is one basic block and every load gets an exact
+// s_waitcnt vmcnt(N) (gfx950 counts stores in vmcnt, in order).
+// ------------------------------------------------------------------------------------------------
+template <int R, int W, bool PAIR>
+__device__ __forceinline__ void blur_v_role(float *__restrict__ tile, const float *__restrict__ in, unsigned x, float *__restrict__ dst,
+                                            int h, int pitch, int pitch_t, bool square, unsigned side_delta)
 {
-    // pa/pb: wave-uniform input plane bases; x: this lane's column as a BYTE offset; dst/dst_copy: wave-uniform pointers to
-    // transposed row x0 of the output planes
+    // in: wave-uniform base of the interleaved input plane; x: this lane's BYTE offset inside a row; dst: wave-uniform pointer
+    // to transposed row x0 of the (first) output plane
     using TT = BlurVTile<R>;
-    static_assert(RDM == 0 || (!COPY && TT::CPI % 2 == 0 && (RDM == 2) == TWO), "interleaved input: roles");
+    static_assert(TT::CPI % 2 == 0, "pair lanes: two tile columns per image column");
     constexpr int P = W - 10;
     constexpr int U = W > R ? W : R;
-    constexpr int XS = RDM == 1 ? 2 : 1; // tile columns per image column
+    constexpr int XS = PAIR ? 1 : 2; // tile columns per image column
     const int lane = threadIdx.x & 63;
     const int xl = lane / TT::LPC, yq = lane % TT::LPC;
     // per-lane BYTE part of every flush address
-    static_assert(!BLK || (R == 32 && !COPY), "blocked output: 32-row tiles");
-    const int cpitch = BLK ? 32 : pitch_t; // floats between two columns of the output
-    const unsigned voff = RDM == 1 ? (unsigned)((xl >> 1) * cpitch + 4 * yq) * 4u + (unsigned)(xl & 1) * side_delta * 4u
-                                   : (unsigned)(xl * cpitch + 4 * yq) * 4u;
-    float wa[W], wb[TWO ? W : 1];
+    const unsigned voff = PAIR ? (unsigned)(xl * pitch_t + 4 * yq) * 4u
+                               : (unsigned)((xl >> 1) * pitch_t + 4 * yq) * 4u + (unsigned)(xl & 1) * side_delta * 4u;
+    float wa[W], wb[PAIR ? W : 1];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        if (RDM == 2) {
-            if (j < P) ld_row_u2(pa, x, j, h, pitch, wa[j], wb[j]);
+        if (PAIR) {
+            if (j < P) ld_row_u2(in, x, j, h, pitch, wa[j], wb[j]);
             else wa[j] = wb[j] = 0.0f;
-        } else {
-            wa[j] = j < P ? ld_row_u(pa, x, j, h, pitch) : 0.0f;
-            if (TWO) wb[j] = j < P ? ld_row_u(pb, x, j, h, pitch) : 0.0f;
-        }
+        } else wa[j] = j < P ? ld_row_u(in, x, j, h, pitch) : 0.0f;
     }
     tmdev::Iir f = {0, 0, 0, 0, 0, 0};
+    const bool product = PAIR || square;
 #pragma unroll
     for (int t = 0; t < 4; ++t) { // no output row yet
         const float a = wa[t], aold = wa[(t + P) % W];
-        const float b = TWO ? wb[t] : a, bold = TWO ? wb[(t + P) % W] : aold;
-        if (RDM == 2) ld_row_u2(pa, x, t + P, h, pitch, wa[(t + P) % W], wb[(t + P) % W]);
-        else {
-            wa[(t + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
-            if (TWO) wb[(t + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
-        }
+        const float b = PAIR ? wb[t] : a, bold = PAIR ? wb[(t + P) % W] : aold;
+        if (PAIR) ld_row_u2(in, x, t + P, h, pitch, wa[(t + P) % W], wb[(t + P) % W]);
+        else wa[(t + P) % W] = ld_row_u(in, x, t + P, h, pitch);
         (void)tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
     }
     const int T = (h + U - 1) / U * U + 4;
@@ -1502,16 +775,11 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
         for (int j = 0; j < U; ++j) {
             const int t = t0 + j;
             const float a = wa[(j + 4) % W], aold = wa[(j + 4 + P) % W];
-            const float b = TWO ? wb[(j + 4) % W] : a, bold = TWO ? wb[(j + 4 + P) % W] : aold;
-            const float a4 = wa[j % W]; // input row t-4 == output row: its transposed copy rides along
-            if (RDM == 2) ld_row_u2(pa, x, t + P, h, pitch, wa[(j + 4 + P) % W], wb[(j + 4 + P) % W]);
-            else {
-                wa[(j + 4 + P) % W] = ld_row_u(pa, x, t + P, h, pitch);
-                if (TWO) wb[(j + 4 + P) % W] = ld_row_u(pb, x, t + P, h, pitch);
-            }
+            const float b = PAIR ? wb[(j + 4) % W] : a, bold = PAIR ? wb[(j + 4 + P) % W] : aold;
+            if (PAIR) ld_row_u2(in, x, t + P, h, pitch, wa[(j + 4 + P) % W], wb[(j + 4 + P) % W]);
+            else wa[(j + 4 + P) % W] = ld_row_u(in, x, t + P, h, pitch);
             const float o = tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
             tile[(j % R) * TT::S + lane] = o;
-            if (COPY) tile_copy[(j % R) * TT::S + lane] = a4;
             if (j % R == R - 1) {
                 const int y0 = t - 4 - (R - 1);
                 __builtin_amdgcn_wave_barrier();
@@ -1519,15 +787,8 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
                 for (int i = 0; i < 64 / TT::CPI; ++i) {
                     const int xc = i * TT::CPI + xl;
                     const float *tp = tile + (4 * yq) * TT::S + xc;
-                    TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(BLK ? dst + (size_t)(y0 >> 5) * 2048 + (i * TT::CPI / XS) * 32
-                                                                                        : dst + (size_t)(i * TT::CPI / XS) * pitch_t + y0);
-                    if (NT) __builtin_nontemporal_store(tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]), (TM_GLOBAL_AS tm_f4 *)(ub + voff));
-                    else *(TM_GLOBAL_AS tm_f4 *)(ub + voff) = tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]);
-                    if (COPY) {
-                        const float *tc = tile_copy + (4 * yq) * TT::S + xc;
-                        TM_GLOBAL_AS char *uc = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst_copy + (size_t)(i * TT::CPI) * pitch_t + y0);
-                        *(TM_GLOBAL_AS tm_f4 *)(uc + voff) = tm_make_f4(tc[0], tc[TT::S], tc[2 * TT::S], tc[3 * TT::S]);
-                    }
+                    TM_GLOBAL_AS char *ub = (TM_GLOBAL_AS char *)tm_uniform_ptr(dst + (size_t)(i * TT::CPI / XS) * pitch_t + y0);
+                    __builtin_nontemporal_store(tm_make_f4(tp[0], tp[TT::S], tp[2 * TT::S], tp[3 * TT::S]), (TM_GLOBAL_AS tm_f4 *)(ub + voff));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1535,55 +796,12 @@ __device__ __forceinline__ void blur_v_split_role(float *__restrict__ tile, floa
     }
 }
 
-// COPIES = false: the transposed ref/dis copies are already written by k_ingest_fused; 5 tiles (41.6 KB) per
-// workgroup -> 3 workgroups = 15 waves per CU, and the kernel moves exactly the algorithmic 2R + 5W planes.
-template <int R, int W, bool COPIES, bool NT = false>
-__global__ void __launch_bounds__(320, COPIES ? 3 : 4) k_blur_v_split(TmGeom g, const float *__restrict__ XYB,
-                                                                      float *__restrict__ XYBT, float *__restrict__ V)
-{
-    using TT = BlurVTile<R>;
-    __shared__ float tiles[(COPIES ? 7 : 5) * R * TT::S];
-    int b = blockIdx.x, s = 0;
-#pragma unroll
-    for (int i = 1; i < TM_SCALES; ++i)
-        if (b >= g.vblk[i]) s = i;
-    const TmScaleGeom sg = g.s[s];
-    const int x0 = (b - g.vblk[s]) * 64;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
-    const int lane = threadIdx.x & 63;
-    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u; // byte offset; lanes past the right edge shadow the last column
-    const int c = blockIdx.y, slot = blockIdx.z;
-    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
-    const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
-    float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
-    float *tile = tiles + role * R * TT::S;
-    // planes (ssimulacra2-cuda/src/lib.rs:299-335): 0 ref*ref, 1 dis*dis, 2 ref*dis, 3 ref, 4 dis
-    if (role == 2) {
-        blur_v_split_role<R, W, true, false, NT>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
-    } else if (role < 2) {
-        blur_v_split_role<R, W, false, false, NT>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
-                                                  sg.pitch_t, true);
-    } else {
-        const int side = role - 3;
-        if (COPIES) {
-            float *cdst = XYBT + (size_t)(slot * 2 + side) * g.pyr_t + to;
-            blur_v_split_role<R, W, false, true>(tile, tiles + (COPIES ? 5 + side : 0) * R * TT::S, side == 0 ? ref : dis, nullptr, x,
-                                                 vdst, cdst, sg.h, sg.pitch, sg.pitch_t, false);
-        } else {
-            blur_v_split_role<R, W, false, false, NT>(tile, nullptr, side == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch,
-                                                      sg.pitch_t, false);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Column pass, generation 3 ("jobs"): the split kernel driven by the job table (tm_geom.h).  A FULL job's
-// workgroup is the five role-waves of one 64-column block, as above.  An EDGE job (only mu1, mu2 carry weight:
-// scale 0 of the X and B channels, i.e. half of all pixels) runs waves 0..3 as {mu1, mu2} x two neighbouring
-// 64-column blocks and retires wave 4 at once, so it reads 2 and writes 2 planes instead of 2 + 5.
-// grid (jobs.vstart[n], 1, slots), block 320.
-// ------------------------------------------------------------------------------------------------
+// Job-table driven (tm_geom.h).  FULL job: waves 0, 1 = squares of columns 0..31 / 32..63 (-> planes 0 and 1), wave 2 = the
+// product (-> plane 2), waves 3, 4 = plain values (-> planes 3 and 4).  EDGE job (only mu1, mu2 carry weight: scale 0 of the
+// X and B channels, i.e. half of all pixels): waves 0..3 = plain values of four neighbouring 32-column blocks, wave 4 retires
+// at once; it reads 2 and writes 2 planes instead of 2 + 5.  Every row load is a whole run of 256 or 512 bytes.
+// The grid is slot-major (x = slot, y = block): workgroups are dispatched x-fastest, so the long jobs (scale 0) of ALL slots
+// start first and the short scales fill the tail (longest-processing-time order).  grid (slots, jobs.vstart[n]), block 320.
 __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], int b)
 {
     int j = 0; // padding entries hold the total, so they never match
@@ -1593,71 +811,37 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
     return j;
 }
 
-// PROBE: a second instantiation of the same code for the placement search of tm_engine_create, so that profilers list the
-// search's launches (cold caches, zeros) apart from the batch launches
+// PROBE: a second instantiation of the same code for the placement probe of tm_engine_create, so that profilers list its
+// launches (cold caches, zeros) apart from the batch launches
 template <int R, int W, int PROBE = 0>
-__global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V,
-                                                        int slot_major, int rd)
+__global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V)
 {
-    // slot_major: grid (slots, blocks) instead of (blocks, 1, slots) -- workgroups are dispatched x-fastest, so the
-    // long jobs (scale 0) of ALL slots start first and the short scales fill the tail (longest-processing-time order)
     using TT = BlurVTile<R>;
     __shared__ float tiles[5 * R * TT::S];
-    const int b = slot_major ? blockIdx.y : blockIdx.x;
+    const int b = blockIdx.y, slot = blockIdx.x;
     const int j = tm_find_job(jobs.vstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
     const TmScaleGeom sg = g.s[s];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
-    const int slot = slot_major ? blockIdx.x : blockIdx.z;
     const int lane = threadIdx.x & 63;
     float *tile = tiles + wave * R * TT::S;
-    if (rd) {
-        // XYB is the ref/dis-interleaved pyramid (ingest generation 4): a pixel is the 8-byte pair {ref, dis}, rows are
-        // 2 * pitch floats.  FULL: waves 0, 1 = squares of columns 0..31 / 32..63 (lane = (column, side) -> planes 0 and 1),
-        // wave 2 = the product (64 columns, pair loads -> plane 2), waves 3, 4 = plain values -> planes 3 and 4.  EDGE: waves
-        // 0..3 = plain values of four neighbouring 32-column blocks.  Every row load is a whole run of 256 or 512 bytes.
-        const float *in = XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane);
-        int blk = b - jobs.vstart[j], half, role;
-        if (mode == TM_MODE_FULL) { role = wave == 2 ? 2 : (wave < 2 ? 0 : 3); half = wave == 2 ? 0 : (wave < 2 ? wave : wave - 3); }
-        else {
-            if (wave == 4) return; // a retired wave no longer counts at s_barrier
-            role = 3; half = wave & 1; blk = blk * 2 + (wave >> 1);
-            if (blk * 64 >= sg.w) return;
-        }
-        const int x0 = blk * 64;
-        float *vplane = V + (size_t)(slot * 5 + role) * g.pyr_t + sg.off_t + c * sg.plane_t;
-        const unsigned xc = (unsigned)min(x0 + lane, sg.w - 1) * 8u;
-        const unsigned xp = (unsigned)min(x0 + 32 * half + (lane >> 1), sg.w - 1) * 8u + (unsigned)(lane & 1) * 4u;
-        if (rd == 2) { // blocked V planes (rd: 1 = interleaved input, 2 = interleaved input + blocked output)
-            float *vdst = vplane + (size_t)blk * (sg.pitch_t >> 5) * 2048 + (size_t)(32 * half) * 32;
-            if (role == 2) blur_v_split_role<R, W, true, false, true, 2, true>(tile, nullptr, in, nullptr, xc, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, true);
-            else blur_v_split_role<R, W, false, false, true, 1, true>(tile, nullptr, in, nullptr, xp, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, role == 0, (unsigned)g.pyr_t);
-        } else {
-            float *vdst = vplane + (size_t)(x0 + 32 * half) * sg.pitch_t;
-            if (role == 2) blur_v_split_role<R, W, true, false, true, 2>(tile, nullptr, in, nullptr, xc, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, true);
-            else blur_v_split_role<R, W, false, false, true, 1>(tile, nullptr, in, nullptr, xp, vdst, nullptr, sg.h, 2 * sg.pitch, sg.pitch_t, role == 0, (unsigned)g.pyr_t);
-        }
-        return;
-    }
-    int role = wave, blk = b - jobs.vstart[j];
-    if (mode != TM_MODE_FULL) {
+    const float *in = XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane);
+    int blk = b - jobs.vstart[j], half, role;
+    if (mode == TM_MODE_FULL) { role = wave == 2 ? 2 : (wave < 2 ? 0 : 3); half = wave == 2 ? 0 : (wave < 2 ? wave : wave - 3); }
+    else {
         if (wave == 4) return; // a retired wave no longer counts at s_barrier
-        role = 3 + (wave & 1);
-        blk = blk * 2 + (wave >> 1);
+        role = 3; half = wave & 1; blk = blk * 2 + (wave >> 1);
         if (blk * 64 >= sg.w) return;
     }
     const int x0 = blk * 64;
-    const unsigned x = (unsigned)min(x0 + lane, sg.w - 1) * 4u;
-    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
-    const size_t to = sg.off_t + c * sg.plane_t + (size_t)x0 * sg.pitch_t;
-    float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + to;
-    if (role == 2)
-        blur_v_split_role<R, W, true, false, true>(tile, nullptr, ref, dis, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
-    else if (role < 2)
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 0 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, true);
-    else
-        blur_v_split_role<R, W, false, false, true>(tile, nullptr, role == 3 ? ref : dis, nullptr, x, vdst, nullptr, sg.h, sg.pitch, sg.pitch_t, false);
+    float *vdst = V + (size_t)(slot * 5 + role) * g.pyr_t + sg.off_t + c * sg.plane_t + (size_t)(x0 + 32 * half) * sg.pitch_t;
+    if (role == 2) {
+        const unsigned xc = (unsigned)min(x0 + lane, sg.w - 1) * 8u; // lanes past the right edge shadow the last column
+        blur_v_role<R, W, true>(tile, in, xc, vdst, sg.h, 2 * sg.pitch, sg.pitch_t, true, 0u);
+    } else {
+        const unsigned xp = (unsigned)min(x0 + 32 * half + (lane >> 1), sg.w - 1) * 8u + (unsigned)(lane & 1) * 4u;
+        blur_v_role<R, W, false>(tile, in, xp, vdst, sg.h, 2 * sg.pitch, sg.pitch_t, role == 0, (unsigned)g.pyr_t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1741,16 +925,16 @@ __device__ __forceinline__ void blur_h_job(const float *__restrict__ reft, const
 }
 
 __global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYBT,
-                                                    const float *__restrict__ V, double *__restrict__ PART, int slot_major)
+                                                    const float *__restrict__ V, double *__restrict__ PART)
 {
-    const int b = slot_major ? blockIdx.y : blockIdx.x;
+    const int b = blockIdx.x;
     const int j = tm_find_job(jobs.hstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
     const TmScaleGeom sg = g.s[s];
     const int y = (b - jobs.hstart[j]) * 64 + threadIdx.x;
     const bool valid = y < sg.h;
     const int yy = valid ? y : sg.h - 1;
-    const int slot = slot_major ? blockIdx.x : blockIdx.z;
+    const int slot = blockIdx.z;
     const size_t to = sg.off_t + c * sg.plane_t + yy;
     const float *reft = XYBT + (size_t)(slot * 2 + 0) * g.pyr_t + to;
     const float *dist = XYBT + (size_t)(slot * 2 + 1) * g.pyr_t + to;
@@ -1770,34 +954,33 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row pass without a transposed XYB copy ("x" = transposes ref / dis itself).  The blurred planes still come from the
-// transposed V arena (lanes = consecutive y: coalesced); the two edge-term inputs ref(x, y), dis(x, y) are read from the
-// NORMAL planes in blocks of 16 columns: one load fetches 4 rows x 16 columns (64-B runs), 16 loads make a 64 x 16 block,
-// which goes through a double-buffered [64][17] LDS tile per plane and is read back one column per step, one row per lane.
-// Loads run D steps ahead of their LDS write and a whole block ahead of their use: element e = 16 * block + row group is
-// requested at step u = e - 16 - D, written at u = e - 16, consumed during steps 16 * block .. + 15 (u = t - 4 = the column
-// whose maps are evaluated at step t).  Everything stays inside the wave: LDS operations of one wave execute in order.
-// 17.4 KB of LDS per wave -> 9 waves per CU.
+// Row pass, tuned ("x" = transposes ref / dis itself): same arithmetic as blur_h_job, one lane per image row walking x.
+// The five (FULL) or two (EDGE) blurred planes come from the transposed V arena (lanes = consecutive y: coalesced 256-B
+// reads) through WN-slot register windows: rows t-10 .. t+WN-11 are in registers or in flight.  The two edge-term inputs
+// ref(x, y), dis(x, y) exist only in the normal orientation, in the interleaved pyramid: the wave fetches them in blocks of 16
+// columns -- one 8-byte {ref, dis} load per lane = 4 rows x 16 pairs = four whole 128-B lines --, parks each 64 x 16 block in
+// a double-buffered [64][17] LDS tile per side and reads it back one column per step, one row per lane (this replaces the
+// reference's nppiTranspose of ref / dis, lib.rs:383-390).  Loads run D steps ahead of their LDS write and a whole block
+// ahead of their use: element e = 16 * block + row group is requested at step u = e - 16 - D, written at u = e - 16,
+// consumed during steps 16 * block .. + 15 (u = t - 4 = the column whose maps are evaluated at step t).  Everything stays
+// inside the wave: LDS operations of one wave execute in order.  17.4 KB of LDS per wave.
 // ------------------------------------------------------------------------------------------------
-template <bool FULL, int WN, int D, bool RD, bool BLK>
-__device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][17], const float *__restrict__ refn,
-                                             const float *__restrict__ disn, const float *__restrict__ v0,
-                                             const float *__restrict__ v1, const float *__restrict__ v2,
-                                             const float *__restrict__ v3, const float *__restrict__ v4, int y0, int w, int h,
+template <bool FULL, int WN, int D>
+__device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][17], const float *__restrict__ rdn,
+                                             const float *__restrict__ v0, const float *__restrict__ v1,
+                                             const float *__restrict__ v2, const float *__restrict__ v3,
+                                             const float *__restrict__ v4, int y0, int w, int h,
                                              int pitch, int pt, bool valid, double (&acc)[6])
 {
-    // refn, disn: normal planes of this channel (row y at y * pitch); v0..v4: transposed planes + this lane's row
+    // rdn: interleaved plane of this channel ({ref, dis} of row y at 2 * y * pitch); v0..v4: transposed planes + this lane's row
     static_assert(WN % D == 0 && D <= 16, "queue depth");
     constexpr int P = WN - 10; // load distance of the blurred planes, in rows of the transposed arena
     constexpr int NF = FULL ? WN : 1;
     const int lane = threadIdx.x & 63;
     const int lr = lane >> 4, lc = lane & 15;
-    // column x of a blurred plane, this lane's row: transposed planes x * pt floats further, blocked planes (BLK, see
-    // blur_v_split_role) in tile column x >> 6, 32 floats per column inside the tile
-    const size_t tcol = (size_t)(pt >> 5) * 2048;
-    auto ld_row = [&](const float *__restrict__ p, int x, int nx, int) {
+    auto ld_row = [&](const float *__restrict__ p, int x, int nx, int) { // column x of a blurred plane, this lane's row
         const int rc = x < nx ? x : nx - 1;
-        const float v = BLK ? p[(size_t)(rc >> 6) * tcol + (size_t)(rc & 63) * 32] : p[(size_t)rc * pt];
+        const float v = p[(size_t)rc * pt];
         return x < nx ? v : 0.0f;
     };
     float w0[NF], w1[NF], w2[NF], w3[WN], w4[WN];
@@ -1811,19 +994,13 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
             w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
         }
     }
-    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, columns 16 * (e >> 4) + lc.  !RD: two plain planes,
-    // 64-B runs per row (the other half of each 128-B line is fetched again one block later); RD: one interleaved plane,
-    // a lane loads its {ref, dis} pair with one 8-B load and a row of the block is one whole 128-B line.
+    // element e of the ref / dis stream = rows y0 + 4 * (e & 15) + lr, columns 16 * (e >> 4) + lc: a lane loads its
+    // {ref, dis} pair with one 8-B load and a row of the block is one whole 128-B line
     auto fetch2 = [&](int e, float &a, float &b) {
         const int x = 16 * (e >> 4) + lc, y = y0 + 4 * (e & 15) + lr;
         const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
-        if (RD) {
-            const float2 v = *(const float2 *)(refn + 2 * ((size_t)yc * pitch + xc));
-            a = v.x; b = v.y;
-        } else {
-            a = refn[(size_t)yc * pitch + xc];
-            b = disn[(size_t)yc * pitch + xc];
-        }
+        const float2 v = *(const float2 *)(rdn + 2 * ((size_t)yc * pitch + xc));
+        a = v.x; b = v.y;
     };
     auto put = [&](int p, int e, float v) { tile[p][(e >> 4) & 1][4 * (e & 15) + lr][lc] = v; };
     // prologue: block 0 complete in LDS, elements 16 .. 16 + D - 1 in flight
@@ -1886,13 +1063,14 @@ __device__ __forceinline__ void blur_h_job_x(float (*__restrict__ tile)[2][64][1
 // FULL and the EDGE path.  The engine runs <16, 8, 32, 16> up to 2560 pixels wide and <16, 8, 16, 8> above (measured: FULL 12 ->
 // 16 is worth 10 % of this pass at 4K and nothing at 1080p, EDGE 16 -> 32 3.5 % at 1080p and -5 % at 4K); at 217 VGPRs the
 // kernel holds 2 waves per SIMD = 8 per CU, one fewer than its LDS would allow, which by itself measured 3.6 % faster.
-// PROBE: second instantiation for the placement search of tm_engine_create (listed apart by profilers, like k_blur_v_jobs').
-template <bool RD, bool BLK = false, int WNF = 12, int DF = 6, int WNE = 16, int DE = 8, int PROBE = 0>
+// PROBE: second instantiation for the placement probe of tm_engine_create (listed apart by profilers, like k_blur_v_jobs').
+// grid (slots, jobs.hstart[n]) -- slot-major like the column pass --, block 64.  PART[slot][row block over all jobs][6].
+template <int WNF, int DF, int WNE, int DE, int PROBE = 0>
 __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, const float *__restrict__ XYB,
-                                                      const float *__restrict__ V, double *__restrict__ PART, int slot_major)
+                                                      const float *__restrict__ V, double *__restrict__ PART)
 {
     __shared__ float tile[2][2][64][17];
-    const int b = slot_major ? blockIdx.y : blockIdx.x;
+    const int b = blockIdx.y, slot = blockIdx.x;
     const int j = tm_find_job(jobs.hstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
     const TmScaleGeom sg = g.s[s];
@@ -1900,19 +1078,16 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     const int y = y0 + threadIdx.x;
     const bool valid = y < sg.h;
     const int yy = valid ? y : sg.h - 1;
-    const int slot = slot_major ? blockIdx.x : blockIdx.z;
-    const size_t to = sg.off_t + c * sg.plane_t + (BLK ? (size_t)(yy >> 5) * 2048 + (yy & 31) : (size_t)yy);
-    // RD: refn = this channel's interleaved plane ({ref, dis} pairs, rows of 2 * pitch floats); disn unused
-    const float *refn = RD ? XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane) : XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane;
-    const float *disn = RD ? refn : XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane;
+    const size_t to = sg.off_t + c * sg.plane_t + (size_t)yy;
+    const float *rdn = XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane);
     const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to;
     const float *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to;
     const float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
     const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
     const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (mode == TM_MODE_FULL) blur_h_job_x<true, WNF, DF, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
-    else blur_h_job_x<false, WNE, DE, RD, BLK>(tile, refn, disn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    if (mode == TM_MODE_FULL) blur_h_job_x<true, WNF, DF>(tile, rdn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
+    else blur_h_job_x<false, WNE, DE>(tile, rdn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
         __shared__ double redl[6][64];
