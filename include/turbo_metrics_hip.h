@@ -160,6 +160,9 @@ int tm_engine_set_channel_mode(tm_engine *e, int mode);
  * inside the image, K1 = 0.01, K2 = 0.03, L = 255, per channel then averaged; MS-SSIM: five dyadic scales.
  * Raw sums [channel 3][scale 5][sum of ssim, sum of cs] over the (w-10) x (h-10) windows of each scale (SSIM alone fills
  * scale 0 only); the two host functions turn them into the scores that tm_engine_get_scores reports. */
+/* By default the sum of l * cs is only produced where a score reads it (scale 0 for SSIM, scale 4 for MS-SSIM, which uses the
+ * contrast-structure term alone on scales 0..3) and reads 0.0 elsewhere; tm_engine_set_full_sums(e, 1) produces every entry
+ * of the scales that were run. */
 int tm_engine_get_ssim_sums(tm_engine *e, uint32_t slot, double out[30]);
 double tm_ssim_from_sums(const double sums[30], uint32_t width, uint32_t height);
 double tm_msssim_from_sums(const double sums[30], uint32_t width, uint32_t height);

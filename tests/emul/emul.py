@@ -53,7 +53,7 @@ class Geom(C.Structure):
 
 class SsimGeom(C.Structure):
     _fields_ = [("w", C.c_int * 5), ("h", C.c_int * 5), ("pitch", C.c_int * 5), ("off", C.c_ulonglong * 5), ("qplane", C.c_ulonglong),
-                ("pyr", C.c_ulonglong), ("tiles_x", C.c_int * 5), ("tiles_y", C.c_int * 5), ("tile_off", C.c_int * 6), ("strips_x", C.c_int * 5), ("segs_y", C.c_int * 5), ("item_off", C.c_int * 6), ("g", C.c_float * 11)]
+                ("pyr", C.c_ulonglong), ("strips_x", C.c_int * 5), ("segs_y", C.c_int * 5), ("seg_rows", C.c_int * 5), ("item_off", C.c_int * 6), ("g", C.c_float * 11)]
 
 
 class FrameDesc(C.Structure):
@@ -66,7 +66,7 @@ KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 
 class Emulated:
     """Runs the whole generation-0 pipeline for n slots; keeps the arenas for plane inspection."""
 
-    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True, ssim_window=None, ssim_streamed=True):
+    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True, ssim_window=None, ssim_need_l=31):
         """frames: list of (ref, dis) where each is dict(kind=, data=np.ndarray, pitch=, coded_height=, matrix=)."""
         L = C.CDLL(build())
         L.emul_geom_size.restype = C.c_size_t
@@ -114,10 +114,10 @@ class Emulated:
         L.emul_pipeline(w, h, n, desc, vp(lut), vp(coef), vp(powtab), int(want_sse), vp(self.LIN), vp(self.XYB), vp(self.XYBT), vp(self.V),
                         vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant), vp(weights), int(full_sums), qu8, C.c_ulonglong(qplane), int(qpitch))
         if ssim_window is not None:
-            self.SPYR = np.zeros(max(1, n * 2 * 3 * self.sg.pyr), np.float32)
-            self.SPART = np.zeros(max(1, n * 3 * max(self.sg.tile_off[5], self.sg.item_off[5]) * 2), np.float64)
+            self.SPYR = np.zeros(max(1, n * 2 * 3 * self.sg.pyr), np.uint16)
+            self.SPART = np.zeros(max(1, n * 3 * self.sg.item_off[5] * 2), np.float64)
             self.SSUMS = np.zeros(n * 30, np.float64)
-            L.emul_ssim(w, h, n, vp(gw), qu8, vp(self.SPYR), vp(self.SPART), vp(self.SSUMS), int(ssim_streamed))
+            L.emul_ssim(w, h, n, vp(gw), qu8, vp(self.SPYR), vp(self.SPART), vp(self.SSUMS), int(ssim_need_l))
         self.SSE = self.SSE.reshape(n, -1).sum(axis=1)  # TM_SSE_BINS accumulators per slot
         self.w, self.h, self.n = w, h, n
 

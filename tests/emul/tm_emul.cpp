@@ -301,16 +301,15 @@ size_t emul_ssim_geom_size(void) { return sizeof(TmSsimGeom); }
 void emul_ssim_geom(int w, int h, const float *g, TmSsimGeom *out) { tm_make_ssim_geom(out, w, h, g); }
 
 // SSIM / MS-SSIM stage on the planar u8 planes the ingest kernel left in QU8: pyramid, statistics, finisher.
-// PYR: n*2*3*sg.pyr floats, PART: n*3*tile_off[5]*2 doubles, SUMS: n*30 doubles
-void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, float *PYR, double *PART, double *SUMS, int streamed)
+// PYR: n*2*3*sg.pyr u16, PART: n*3*item_off[5]*2 doubles, SUMS: n*30 doubles
+void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, unsigned short *PYR, double *PART, double *SUMS, unsigned need_l)
 {
     TmSsimGeom sg; tm_make_ssim_geom(&sg, w, h, g);
     if (sg.w[1] > 0 && sg.h[1] > 0)
         launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n * 6), 256, [&] { tmk::k_ssim_pyramid(sg, QU8, PYR); });
     int nscales = 0;
-    for (int s = 0; s < TM_SSIM_SCALES; ++s) if (sg.tiles_x[s] > 0 && sg.tiles_y[s] > 0) nscales = s + 1;
-    (void)streamed;
-    if (nscales > 0) launch_wave_lockstep(dim3(n * 3, sg.item_off[nscales], 1), [&] { tmk::k_ssim_stream(sg, nscales, QU8, PYR, PART); });
-    launch(dim3(n, 30, 1), dim3(64), [&] { tmk::k_ssim_finish(sg, 1, PART, SUMS); });
+    for (int s = 0; s < TM_SSIM_SCALES; ++s) if (sg.strips_x[s] > 0 && sg.segs_y[s] > 0) nscales = s + 1;
+    if (nscales > 0) launch_wave_lockstep(dim3(n * 3, sg.item_off[nscales], 1), [&] { tmk::k_ssim_stream(sg, nscales, need_l, QU8, PYR, PART); });
+    launch(dim3(n, 30, 1), dim3(64), [&] { tmk::k_ssim_finish(sg, nscales, PART, SUMS); });
 }
 }

@@ -160,6 +160,18 @@ def test_device_resident_frames_and_slot_independence():
     eng.close(); solo.close()
 
 
+def ssim_sums_used(ssim, msssim):
+    """(3 channels, 5 scales, [sum of l * cs, sum of cs]) bool: the sums a requested score reads -- SSIM the scale-0 mean of
+    l * cs, MS-SSIM the mean of cs on scales 0..3 and of l * cs on scale 4 (Wang et al. 2003)"""
+    m = np.zeros((3, 5, 2), bool)
+    if ssim:
+        m[:, 0, 0] = True
+    if msssim:
+        m[:, :4, 1] = True
+        m[:, 4, 0] = True
+    return m
+
+
 def weight_mask():
     """(6 scales, 6 kinds, 3 channels) bool: sums with a non-zero weight in the reference's table [channel][scale][kind]"""
     return (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
@@ -292,7 +304,8 @@ def test_4k_p016_fused_psnr_msssim_ssimulacra2_against_oracle():
         sse, psnr = O.psnr(a, b)
         assert eng.sse(slot) == sse and got.psnr == psnr
         _, want_ms, ssums = O.ssim_msssim(a, b)
-        np.testing.assert_allclose(eng.ssim_sums(slot), ssums, rtol=1e-12, atol=1e-300)
+        used = ssim_sums_used(ssim=False, msssim=True)
+        np.testing.assert_allclose(eng.ssim_sums(slot)[used], ssums[used], rtol=1e-12, atol=1e-300)
         assert abs(got.msssim - want_ms) <= 1e-6 and 0.0 < got.msssim <= 1.0
         assert got.ssim is None
     assert eng.scores(0).ssimulacra2 != eng.scores(1).ssimulacra2
@@ -366,13 +379,14 @@ def test_ssim_and_msssim_match_oracle(w, h, metrics):
         only.set_pair(slot, fr, fd)
     eng.compute_async(); eng.sync()
     only.compute_async(); only.sync()
+    used = ssim_sums_used(ssim=True, msssim=(metrics == "both"))
     for slot, (fr, fd) in enumerate(frames):
         lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
         want_ssim, want_ms, sums = O.ssim_msssim(lin[0], lin[1])
         got = eng.scores(slot)
         gs = eng.ssim_sums(slot)
-        nsc = 5 if metrics == "both" else 1
-        np.testing.assert_allclose(gs[:, :nsc], sums[:, :nsc], rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(gs[used], sums[used], rtol=1e-12, atol=1e-300)
+        assert np.all(gs[..., 0][~used[..., 0]] == 0.0)  # the luminance term is only evaluated where a score reads it
         assert abs(got.ssim - want_ssim) <= 1e-6 and 0.0 < got.ssim <= 1.0
         if metrics == "both":
             assert abs(got.msssim - want_ms) <= 1e-6 and 0.0 < got.msssim <= 1.0
@@ -381,6 +395,13 @@ def test_ssim_and_msssim_match_oracle(w, h, metrics):
         # the fused pass leaves the other metrics untouched
         assert got.ssimulacra2 == only.scores(slot).ssimulacra2
         assert got.psnr == O.psnr(lin[0], lin[1])[1]
+    # tm_engine_set_full_sums(1): every [channel][scale][sum of l * cs, sum of cs] entry of the scales that were run
+    eng.set_full_sums(True)
+    eng.compute_async(); eng.sync()
+    nsc = 5 if metrics == "both" else 1
+    for slot, (fr, fd) in enumerate(frames):
+        _, _, sums = O.ssim_msssim(oracle_linear(fr, w, h), oracle_linear(fd, w, h))
+        np.testing.assert_allclose(eng.ssim_sums(slot)[:, :nsc], sums[:, :nsc], rtol=1e-12, atol=1e-300)
     eng.close(); only.close()
 
 

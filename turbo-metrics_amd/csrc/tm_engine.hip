@@ -100,7 +100,7 @@ struct tm_engine {
     long long gkey = -1;
     TmSsimGeom sg{};               // SSIM / MS-SSIM (only when the mask asks for them)
     unsigned char *QU8 = nullptr;  // [slot][side][3] planar u8-quantised linear RGB
-    float *SPYR = nullptr;         // [slot][side][3] box pyramid, scales 1..4
+    unsigned short *SPYR = nullptr; // [slot][side][3] box-sum pyramid, scales 1..4
     double *SPART = nullptr, *SSUMS = nullptr, *h_ssums = nullptr;
     hipStream_t stream = nullptr;
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr; // LIN, XYBT: reference pipeline only (TM_VARIANT_REFERENCE)
@@ -385,7 +385,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
         tm_make_ssim_geom(&e->sg, (int)width, (int)height, gw);
         if ((rc = dev_alloc(e, &e->QU8, B * 2 * 3 * e->sg.qplane, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SPYR, B * 2 * 3 * e->sg.pyr, true))) return fail(rc);
-        if ((rc = dev_alloc(e, &e->SPART, B * 3 * (size_t)(e->sg.tile_off[TM_SSIM_SCALES] > e->sg.item_off[TM_SSIM_SCALES] ? e->sg.tile_off[TM_SSIM_SCALES] : e->sg.item_off[TM_SSIM_SCALES]) * 2, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->SPART, B * 3 * (size_t)e->sg.item_off[TM_SSIM_SCALES] * 2, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SSUMS, B * 30, true))) return fail(rc);
         if ((he = hipHostMalloc((void **)&e->h_ssums, B * 30 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     }
@@ -577,8 +577,10 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
         if (nscales > 1)
             hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 31) / 32), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(256), 0, st, sg, QU8, e->SPYR);
-        hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, QU8, e->SPYR, e->SPART);
-        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, 1, e->SPART, e->SSUMS);
+        // the sum of l * cs is needed on scale 0 for SSIM and on the last scale for MS-SSIM (the others use cs alone)
+        const unsigned need_l = e->full_sums ? 31u : ((e->mask & TM_METRIC_SSIM) ? 1u : 0u) | ((e->mask & TM_METRIC_MSSSIM) ? 1u << (TM_SSIM_SCALES - 1) : 0u);
+        hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, need_l, QU8, e->SPYR, e->SPART);
+        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, nscales, e->SPART, e->SSUMS);
     }
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
     return TM_OK;

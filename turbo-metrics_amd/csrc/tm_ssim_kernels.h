@@ -1,42 +1,56 @@
 // tm_ssim_kernels.h -- gfx950 kernels for SSIM and MS-SSIM of the u8-quantised linear-RGB pair: the inputs of the
 // reference's nppiSSIM_8u_C3R_Ctx / nppiWMSSSIM_8u_C3R_Ctx calls (crates/turbo-metrics/src/lib.rs:296-340).
 // NPP is closed source and nothing in the reference pins its results, so the arithmetic here is BUILD-DEFINED (the
-// published algorithms): 11x11 Gaussian window (sigma 1.5) over the windows that fit inside the
-// image, K1 = 0.01, K2 = 0.03, L = 255; five dyadic scales (2x2 box mean) for MS-SSIM.
+// published algorithms; stated operation by operation in oracle/tm_ssim.c): 11x11 Gaussian window
+// (sigma 1.5) over the windows that fit inside the image, K1 = 0.01, K2 = 0.03, L = 255; five dyadic scales (2x2 box mean,
+// odd last row / column dropped) for MS-SSIM.
 //
 //   k_ssim_pyramid  grid (ceil(w/32), ceil(h/32), slots*2*3)  block 256   scales 1..4 of the box pyramid from one 32x32 u8 tile
-//   k_ssim_stats    grid (slots*3, tiles of all scales)       block 256   32x32 windows per workgroup: 42x42 input tile of both
-//                                                                       sides in LDS, row filter of {x, y, x^2, y^2, xy} into
-//                                                                       LDS, column filter + SSIM / cs terms from LDS, f64 sums
-//   k_ssim_finish   grid (slots, 30)                          block 64    fixed-order sum of the tile partials -> 30 sums / slot
-// Filter order (the oracle executes the same): taps ascending, acc = fma(g[k], v, acc) starting from 0.
+//   k_ssim_stream   grid (slots*3, items of all scales)       block 64    one wave = a strip of 118 window columns x a segment
+//                                                                         of window rows, see below
+//   k_ssim_finish   grid (slots, 30)                          block 64    fixed-order sum of the partials -> 30 sums / slot
+//
+// The pyramid is stored as INTEGER box sums (u16): a pixel of scale s is ((a + b) + (c + d)) * 0.25 of scale s-1 in the oracle,
+// and since every value is a multiple of 4^-s below 256 all of those f32 operations are exact -- the pixel equals
+// (sum of its 4^s u8 samples) * 4^-s, and the sum fits 16 bits (<= 255 * 256).  Half the bytes of an f32 pyramid, same bits.
+//
+// This stage is bound by arithmetic, not by HBM: per window and channel the separable 11-tap filter of the five quantities
+// {x, y, x^2, y^2, xy} costs 110 fused multiply-adds, against 2 bytes of input.  So the kernel is built around the VALU:
+//   * lane = TWO adjacent image columns, walking down its segment one input row per step: the products x^2, y^2, xy are
+//     formed once per loaded sample (12 per lane and row for 2 windows), not once per tap;
+//   * everything is said on register pairs so that the filters run as v_pk_fma_f32 (two fused multiply-adds per
+//     instruction): the row filter on {x, y} and {x^2, y^2} pairs of one column, the column filter on the same pairs plus the
+//     {xy(col 0), xy(col 1)} pair, the SSIM terms on {col 0, col 1} pairs;
+//   * neighbours' samples come from a 1-KB wave-private LDS row as five ds_read_b128 per row (no workgroup barrier: LDS
+//     operations of one wave execute in order); the row-filtered values live in an 11-row register window (static slots
+//     through an unroll of 11), the column filter reads registers only;
+//   * need_l: the luminance term l (one of the two IEEE divisions per window) is only evaluated where its sum is used --
+//     MS-SSIM uses the contrast-structure term alone on scales 0..3 (Wang et al. 2003); tm_engine_set_full_sums(e, 1)
+//     evaluates everything.
+// Filter order (the oracle executes the same): rows first, taps ascending, acc = fma(g[k], v, acc) starting from 0.
 #pragma once
 #include "tm_device_math.h"
 #include "tm_geom.h"
 
 #define TM_SSIM_SCALES 5
 #define TM_SSIM_TAPS 11
+#define TM_SSIM_STRIP 118  /* window columns per wave: 64 lanes x 2 columns = 128 input columns, 10 of them halo */
+#define TM_SSIM_SEG 192    /* upper bound of the window rows per wave (each wave re-reads 10 halo rows); segments are balanced */
 
 struct TmSsimGeom {
     int w[TM_SSIM_SCALES], h[TM_SSIM_SCALES];
-    int pitch[TM_SSIM_SCALES];               // elements (bytes at scale 0, floats above)
-    unsigned long long off[TM_SSIM_SCALES];  // float offset of scales 1..4 inside one (slot, side, channel) pyramid; [0] unused
+    int pitch[TM_SSIM_SCALES];               // elements per row: bytes at scale 0 (u8), u16 sums above
+    unsigned long long off[TM_SSIM_SCALES];  // u16 offset of scales 1..4 inside one (slot, side, channel) pyramid; [0] unused
     unsigned long long qplane;               // bytes of one u8 plane (scale 0)
-    unsigned long long pyr;                  // floats of scales 1..4 of one (slot, side, channel)
-    int tiles_x[TM_SSIM_SCALES], tiles_y[TM_SSIM_SCALES];
-    int tile_off[TM_SSIM_SCALES + 1];        // prefix sums of tiles per (slot, channel)
-    // streaming kernel: one wave = one strip of TM_SSIM_STRIP window columns x one segment of TM_SSIM_SEG window rows
-    int strips_x[TM_SSIM_SCALES], segs_y[TM_SSIM_SCALES];
+    unsigned long long pyr;                  // u16 elements of scales 1..4 of one (slot, side, channel)
+    int strips_x[TM_SSIM_SCALES], segs_y[TM_SSIM_SCALES], seg_rows[TM_SSIM_SCALES];
     int item_off[TM_SSIM_SCALES + 1];        // prefix sums of (strip, segment) items per (slot, channel)
     float g[TM_SSIM_TAPS];
 };
-#define TM_SSIM_STRIP 54  /* 64 lanes hold 64 input columns = 54 windows + 10 columns of halo */
-#define TM_SSIM_SEG 128   /* window rows per wave (each wave re-reads 10 halo rows) */
 
 static inline void tm_make_ssim_geom(TmSsimGeom *s, int w, int h, const float g[TM_SSIM_TAPS])
 {
     unsigned long long off = 0;
-    s->tile_off[0] = 0;
     s->item_off[0] = 0;
     for (int i = 0; i < TM_SSIM_SCALES; ++i) {
         s->w[i] = w; s->h[i] = h;
@@ -44,11 +58,9 @@ static inline void tm_make_ssim_geom(TmSsimGeom *s, int w, int h, const float g[
         s->off[i] = off;
         if (i > 0) off += (unsigned long long)(h > 0 ? h : 1) * s->pitch[i];
         const int ow = w - 10, oh = h - 10;
-        s->tiles_x[i] = ow > 0 ? (ow + 31) / 32 : 0;
-        s->tiles_y[i] = oh > 0 ? (oh + 31) / 32 : 0;
-        s->tile_off[i + 1] = s->tile_off[i] + s->tiles_x[i] * s->tiles_y[i];
         s->strips_x[i] = ow > 0 ? (ow + TM_SSIM_STRIP - 1) / TM_SSIM_STRIP : 0;
         s->segs_y[i] = oh > 0 ? (oh + TM_SSIM_SEG - 1) / TM_SSIM_SEG : 0;
+        s->seg_rows[i] = s->segs_y[i] > 0 ? (oh + s->segs_y[i] - 1) / s->segs_y[i] : 0;
         s->item_off[i + 1] = s->item_off[i] + s->strips_x[i] * s->segs_y[i];
         w /= 2; h /= 2;
     }
@@ -59,29 +71,30 @@ static inline void tm_make_ssim_geom(TmSsimGeom *s, int w, int h, const float g[
 
 namespace tmk {
 
-// plane of scale `s` of image (slot*2+side), channel c
-__device__ __forceinline__ const float *ssim_plane_f(const TmSsimGeom &sg, const float *PYR, int img, int c, int s)
+// plane of scale `s` (1..4) of image (slot*2+side), channel c
+__device__ __forceinline__ const unsigned short *ssim_plane_s(const TmSsimGeom &sg, const unsigned short *PYR, int img, int c, int s)
 {
     return PYR + ((size_t)img * 3 + c) * sg.pyr + sg.off[s];
 }
 
-// 2x2 box mean with decimation, four levels at once; an odd last row / column of a level is dropped (level s has
-// floor(w/2^s) x floor(h/2^s) pixels): ((a + b) + (c + d)) * 0.25.  Tiles are 32-aligned, so every parent stays inside.
-__global__ void __launch_bounds__(256) k_ssim_pyramid(TmSsimGeom sg, const unsigned char *__restrict__ Q, float *__restrict__ PYR)
+// Box sums of scales 1..4, four levels at once; an odd last row / column of a level is dropped (level s has
+// floor(w/2^s) x floor(h/2^s) pixels).  Tiles are 32-aligned, so every parent stays inside.
+__global__ void __launch_bounds__(256) k_ssim_pyramid(TmSsimGeom sg, const unsigned char *__restrict__ Q, unsigned short *__restrict__ PYR)
 {
-    __shared__ float l1[16][17], l2[8][9], l3[4][5];
+    __shared__ unsigned l1[16][17], l2[8][9], l3[4][5];
     const int tid = threadIdx.x;
     const int img = blockIdx.z / 3, c = blockIdx.z % 3;
     const int bx = blockIdx.x, by = blockIdx.y;
+    unsigned short *base = PYR + ((size_t)img * 3 + c) * sg.pyr;
     {
         const int tx = tid & 15, ty = tid >> 4;
         const int x = bx * 16 + tx, y = by * 16 + ty;
-        float v = 0.0f;
+        unsigned v = 0;
         if (x < sg.w[1] && y < sg.h[1]) {
             const unsigned char *p = Q + ((size_t)img * 3 + c) * sg.qplane + (size_t)(2 * y) * sg.pitch[0] + 2 * x;
-            const float a = (float)p[0], b = (float)p[1], cc = (float)p[sg.pitch[0]], d = (float)p[sg.pitch[0] + 1];
-            v = ((a + b) + (cc + d)) * 0.25f;
-            const_cast<float *>(ssim_plane_f(sg, PYR, img, c, 1))[(size_t)y * sg.pitch[1] + x] = v;
+            const unsigned a = *(const unsigned short *)p, b = *(const unsigned short *)(p + sg.pitch[0]); // two u8 each (x even, pitch even)
+            v = (a & 255u) + (a >> 8) + (b & 255u) + (b >> 8);
+            base[sg.off[1] + (size_t)y * sg.pitch[1] + x] = (unsigned short)v;
         }
         l1[ty][tx] = v;
     }
@@ -89,170 +102,145 @@ __global__ void __launch_bounds__(256) k_ssim_pyramid(TmSsimGeom sg, const unsig
     if (tid < 64) {
         const int tx = tid & 7, ty = tid >> 3;
         const int x = bx * 8 + tx, y = by * 8 + ty;
-        const float v = ((l1[2 * ty][2 * tx] + l1[2 * ty][2 * tx + 1]) + (l1[2 * ty + 1][2 * tx] + l1[2 * ty + 1][2 * tx + 1])) * 0.25f;
+        const unsigned v = (l1[2 * ty][2 * tx] + l1[2 * ty][2 * tx + 1]) + (l1[2 * ty + 1][2 * tx] + l1[2 * ty + 1][2 * tx + 1]);
         l2[ty][tx] = v;
-        if (x < sg.w[2] && y < sg.h[2]) const_cast<float *>(ssim_plane_f(sg, PYR, img, c, 2))[(size_t)y * sg.pitch[2] + x] = v;
+        if (x < sg.w[2] && y < sg.h[2]) base[sg.off[2] + (size_t)y * sg.pitch[2] + x] = (unsigned short)v;
     }
     __syncthreads();
     if (tid < 16) {
         const int tx = tid & 3, ty = tid >> 2;
         const int x = bx * 4 + tx, y = by * 4 + ty;
-        const float v = ((l2[2 * ty][2 * tx] + l2[2 * ty][2 * tx + 1]) + (l2[2 * ty + 1][2 * tx] + l2[2 * ty + 1][2 * tx + 1])) * 0.25f;
+        const unsigned v = (l2[2 * ty][2 * tx] + l2[2 * ty][2 * tx + 1]) + (l2[2 * ty + 1][2 * tx] + l2[2 * ty + 1][2 * tx + 1]);
         l3[ty][tx] = v;
-        if (x < sg.w[3] && y < sg.h[3]) const_cast<float *>(ssim_plane_f(sg, PYR, img, c, 3))[(size_t)y * sg.pitch[3] + x] = v;
+        if (x < sg.w[3] && y < sg.h[3]) base[sg.off[3] + (size_t)y * sg.pitch[3] + x] = (unsigned short)v;
     }
     __syncthreads();
     if (tid < 4) {
         const int tx = tid & 1, ty = tid >> 1;
         const int x = bx * 2 + tx, y = by * 2 + ty;
-        const float v = ((l3[2 * ty][2 * tx] + l3[2 * ty][2 * tx + 1]) + (l3[2 * ty + 1][2 * tx] + l3[2 * ty + 1][2 * tx + 1])) * 0.25f;
-        if (x < sg.w[4] && y < sg.h[4]) const_cast<float *>(ssim_plane_f(sg, PYR, img, c, 4))[(size_t)y * sg.pitch[4] + x] = v;
+        const unsigned v = (l3[2 * ty][2 * tx] + l3[2 * ty][2 * tx + 1]) + (l3[2 * ty + 1][2 * tx] + l3[2 * ty + 1][2 * tx + 1]);
+        if (x < sg.w[4] && y < sg.h[4]) base[sg.off[4] + (size_t)y * sg.pitch[4] + x] = (unsigned short)v;
     }
 }
 
-__global__ void __launch_bounds__(256) k_ssim_stats(TmSsimGeom sg, int nscales, const unsigned char *__restrict__ Q,
-                                                    const float *__restrict__ PYR, double *__restrict__ PART)
-{
-    __shared__ float in[2][42][44];
-    __shared__ float hz[5][42][33];
-    __shared__ double red[2][4];
-    const int tid = threadIdx.x;
-    const int slot = blockIdx.x / 3, c = blockIdx.x % 3;
-    int s = 0; // scale of this tile: all scales share the launch (grid.y runs over sg.tile_off[nscales] tiles)
-#pragma unroll
-    for (int i = 1; i < TM_SSIM_SCALES; ++i)
-        if (i < nscales && (int)blockIdx.y >= sg.tile_off[i]) s = i;
-    const int tile = (int)blockIdx.y - sg.tile_off[s];
-    const int w = sg.w[s], h = sg.h[s];
-    const int x0 = (tile % sg.tiles_x[s]) * 32, y0 = (tile / sg.tiles_x[s]) * 32;
-    // ---- 42 x 42 input tile of both sides, one row per wave-load (lanes = columns); samples outside the image read
-    // as 0 (no valid window uses them)
-    {
-        // all 21 row loads of a wave are issued before the first LDS write (a load followed by its own write in a loop
-        // waits out the full memory latency 21 times)
-        const int lane = tid & 63, wave = tid >> 6;
-        const int x = x0 + lane;
-        float v[21];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) {
-            const int i = wave + 4 * k, side = i / 42, r = i % 42;
-            const int y = y0 + r;
-            v[k] = 0.0f;
-            if (lane < 42 && x < w && y < h) {
-                if (s == 0) v[k] = (float)Q[((size_t)(slot * 2 + side) * 3 + c) * sg.qplane + (size_t)y * sg.pitch[0] + x];
-                else v[k] = ssim_plane_f(sg, PYR, slot * 2 + side, c, s)[(size_t)y * sg.pitch[s] + x];
-            }
-        }
-        if (lane < 42) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) {
-                const int i = wave + 4 * k;
-                in[i / 42][i % 42][lane] = v[k];
-            }
-        }
-    }
-    if (tid < 2 * 42) { in[tid / 42][tid % 42][42] = 0.0f; in[tid / 42][tid % 42][43] = 0.0f; }
-    __syncthreads();
-    // ---- row filter of x, y, x^2, y^2, xy: 42 rows x 32 columns, four neighbouring columns per lane (14 samples of each
-    // side serve 4 x 11 taps: 7 LDS reads per output instead of 22)
-    for (int i = tid; i < 42 * 8; i += 256) {
-        const int r = i >> 3, c0 = (i & 7) * 4;
-        float rv[14], dv[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) { rv[k] = in[0][r][c0 + k]; dv[k] = in[1][r][c0 + k]; }
-        float rr[14], dd[14], rd[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) { rr[k] = rv[k] * rv[k]; dd[k] = dv[k] * dv[k]; rd[k] = rv[k] * dv[k]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
-#pragma unroll
-            for (int k = 0; k < TM_SSIM_TAPS; ++k) {
-                const float gk = sg.g[k];
-                a0 = __builtin_fmaf(gk, rv[j + k], a0);
-                a1 = __builtin_fmaf(gk, dv[j + k], a1);
-                a2 = __builtin_fmaf(gk, rr[j + k], a2);
-                a3 = __builtin_fmaf(gk, dd[j + k], a3);
-                a4 = __builtin_fmaf(gk, rd[j + k], a4);
-            }
-            hz[0][r][c0 + j] = a0; hz[1][r][c0 + j] = a1; hz[2][r][c0 + j] = a2; hz[3][r][c0 + j] = a3; hz[4][r][c0 + j] = a4;
-        }
-    }
-    __syncthreads();
-    // ---- column filter + the two terms: four vertically neighbouring windows per lane (14 rows serve 4 x 11 taps)
-    const float C1 = 6.5025f, C2 = 58.5225f; // (0.01*255)^2, (0.03*255)^2
-    double s_ssim = 0.0, s_cs = 0.0;
-    const int col = tid & 31, r0 = (tid >> 5) * 4;
-    float acc[4][5];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) acc[j][q] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        float v[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) v[k] = hz[q][r0 + k][col];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < TM_SSIM_TAPS; ++k) acc[j][q] = __builtin_fmaf(sg.g[k], v[j + k], acc[j][q]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a0 = acc[j][0], a1 = acc[j][1], a2 = acc[j][2], a3 = acc[j][3], a4 = acc[j][4];
-        const float mxx = a0 * a0, myy = a1 * a1, mxy = a0 * a1;
-        const float sx = a2 - mxx, sy = a3 - myy, sxy = a4 - mxy;
-        const float cs = __builtin_fmaf(2.0f, sxy, C2) / ((sx + sy) + C2);
-        const float l = __builtin_fmaf(2.0f, mxy, C1) / ((mxx + myy) + C1);
-        if (x0 + col < w - 10 && y0 + r0 + j < h - 10) {
-            s_ssim += (double)(l * cs);
-            s_cs += (double)cs;
-        }
-    }
-    // ---- workgroup sum: 64-lane shuffle tree per wave, then the four wave totals in a fixed order
 #ifdef TM_EMULATE
-    {
-        __shared__ double all[2][256]; // CPU lane emulation (tests/emul): no shuffles, plain in-order sum
-        all[0][tid] = s_ssim; all[1][tid] = s_cs;
-        __syncthreads();
-        if (tid == 0) {
-            double t0 = 0.0, t1 = 0.0;
-            for (int i = 0; i < 256; ++i) { t0 += all[0][i]; t1 += all[1][i]; }
-            double *o = PART + (((size_t)slot * 3 + c) * sg.tile_off[TM_SSIM_SCALES] + blockIdx.y) * 2;
-            o[0] = t0; o[1] = t1;
-        }
-        (void)red;
-    }
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        s_ssim += __shfl_down(s_ssim, off, 64);
-        s_cs += __shfl_down(s_cs, off, 64);
-    }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s_ssim; red[1][tid >> 6] = s_cs; }
-    __syncthreads();
-    if (tid == 0) {
-        double *o = PART + (((size_t)slot * 3 + c) * sg.tile_off[TM_SSIM_SCALES] + blockIdx.y) * 2;
-        o[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        o[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-    }
+static inline tmdev::tm_f2 operator+(tmdev::tm_f2 a, tmdev::tm_f2 b) { return {a.x + b.x, a.y + b.y}; }
 #endif
+
+// One (strip, segment) item.  S0: scale 0 (u8 planes) / pyramid scale (u16 box sums, value = sum * inv); NEED_L: also the
+// luminance term and the sum of l * cs.  acc: [sum of l * cs, sum of cs] of the lane's valid windows.
+template <bool S0, bool NEED_L>
+__device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2], const void *__restrict__ pr, const void *__restrict__ pd,
+                                           int pitch, float inv, int w, int h, int x, int y_base, int y_end, const float (&gw)[TM_SSIM_TAPS],
+                                           double (&acc)[2])
+{
+    using tmdev::tm_f2;
+    using tmdev::f2_fma;
+    using tmdev::f2_make;
+    using tmdev::f2_splat;
+    const int lane = threadIdx.x & 63;
+    const bool in0 = x < w, in1 = x + 1 < w;
+    // the lane's two samples of row y, both sides, as raw integers (rows past the image: 0)
+    auto load = [&](int y, unsigned &a, unsigned &b) {
+        const int yc = y < h ? y : h - 1;
+        unsigned va = 0, vb = 0;
+        if (in0) { // x is even and the pitch a multiple of 64 elements: the pair load stays inside the (padded) row
+            if (S0) { va = *(const unsigned short *)((const unsigned char *)pr + (size_t)yc * pitch + x); vb = *(const unsigned short *)((const unsigned char *)pd + (size_t)yc * pitch + x); }
+            else { va = *(const unsigned *)((const unsigned short *)pr + (size_t)yc * pitch + x); vb = *(const unsigned *)((const unsigned short *)pd + (size_t)yc * pitch + x); }
+        }
+        const bool ok = y < h;
+        a = ok ? va : 0u; b = ok ? vb : 0u;
+    };
+    auto unpack = [&](unsigned raw, float &v0, float &v1) {
+        if (S0) { v0 = (float)(raw & 255u); v1 = (float)((raw >> 8) & 255u); }
+        else { v0 = (float)(raw & 0xFFFFu) * inv; v1 = (float)(raw >> 16) * inv; }
+        if (!in1) v1 = 0.0f;
+    };
+    constexpr int PF = 11; // rows of load prefetch (= the window depth, so that one unroll of 11 makes every slot static)
+    unsigned pa[PF], pb[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load(y_base + k, pa[k], pb[k]);
+    tm_f2 g2[TM_SSIM_TAPS];
+#pragma unroll
+    for (int k = 0; k < TM_SSIM_TAPS; ++k) g2[k] = f2_splat(gw[k]);
+    // the 11-row window of row-filtered values: per column {x, y} and {x^2, y^2} pairs, and the {xy(col 0), xy(col 1)} pair
+    tm_f2 w01[11][2], w23[11][2], w4[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { w01[k][0] = w01[k][1] = w23[k][0] = w23[k][1] = w4[k] = f2_splat(0.0f); }
+    const tm_f2 C1 = f2_splat(6.5025f), C2 = f2_splat(58.5225f), two = f2_splat(2.0f); // (0.01*255)^2, (0.03*255)^2
+    double a_l[2] = {0.0, 0.0}, a_cs[2] = {0.0, 0.0};
+    const int n_rows = (y_end - y_base) + 10; // input rows y_base .. y_end+9
+    for (int t0 = 0; t0 < n_rows; t0 += 11) {
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int t = t0 + j;
+            if (t < n_rows) { // wave-uniform
+                float r0, r1, d0, d1;
+                unpack(pa[j % PF], r0, r1);
+                unpack(pb[j % PF], d0, d1);
+                load(y_base + t + PF, pa[j % PF], pb[j % PF]);
+                __builtin_amdgcn_wave_barrier();
+                rowbuf[lane][0] = f2_make(r0, d0); rowbuf[lane][1] = f2_make(r1, d1);
+                __builtin_amdgcn_wave_barrier();
+                // samples of columns x .. x+11 as {ref, dis} pairs: the own two from registers, ten from the neighbours
+                tm_f2 s[12];
+                s[0] = f2_make(r0, d0); s[1] = f2_make(r1, d1);
+#pragma unroll
+                for (int i = 1; i < 6; ++i) { s[2 * i] = rowbuf[lane + i][0]; s[2 * i + 1] = rowbuf[lane + i][1]; }
+                // row filter of the two windows that start at columns x and x+1: taps ascending, fma from 0
+                tm_f2 a01[2] = {f2_splat(0.0f), f2_splat(0.0f)}, a23[2] = {f2_splat(0.0f), f2_splat(0.0f)};
+                float a4[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const tm_f2 sq = s[i] * s[i];
+                    const float p = s[i].x * s[i].y;
+                    if (i < 11) { a01[0] = f2_fma(g2[i], s[i], a01[0]); a23[0] = f2_fma(g2[i], sq, a23[0]); a4[0] = __builtin_fmaf(gw[i], p, a4[0]); }
+                    if (i > 0) { a01[1] = f2_fma(g2[i - 1], s[i], a01[1]); a23[1] = f2_fma(g2[i - 1], sq, a23[1]); a4[1] = __builtin_fmaf(gw[i - 1], p, a4[1]); }
+                }
+                w01[j % 11][0] = a01[0]; w01[j % 11][1] = a01[1]; w23[j % 11][0] = a23[0]; w23[j % 11][1] = a23[1];
+#ifndef TM_EMULATE
+                // keeps the two xy chains scalar (12 products + 22 fma): left alone, the SLP vectorizer pairs them tap by tap, which
+                // costs four register moves per tap to line up {xy(i), xy(i+1)} -- 66 instead of 34 instructions
+                asm volatile("" : "+v"(a4[0]), "+v"(a4[1]));
+#endif
+                w4[j % 11] = f2_make(a4[0], a4[1]);
+                if (t >= 10) { // window rows t-10 .. t are in slots (j+1)%11 .. j%11
+                    tm_f2 v01[2] = {f2_splat(0.0f), f2_splat(0.0f)}, v23[2] = {f2_splat(0.0f), f2_splat(0.0f)}, v4 = f2_splat(0.0f);
+#pragma unroll
+                    for (int k = 0; k < TM_SSIM_TAPS; ++k) {
+                        const int q = (j + 1 + k) % 11;
+                        v01[0] = f2_fma(g2[k], w01[q][0], v01[0]); v01[1] = f2_fma(g2[k], w01[q][1], v01[1]);
+                        v23[0] = f2_fma(g2[k], w23[q][0], v23[0]); v23[1] = f2_fma(g2[k], w23[q][1], v23[1]);
+                        v4 = f2_fma(g2[k], w4[q], v4);
+                    }
+                    // the two windows side by side: {col 0, col 1} pairs
+                    const tm_f2 mx = f2_make(v01[0].x, v01[1].x), my = f2_make(v01[0].y, v01[1].y);
+                    const tm_f2 mxx = mx * mx, myy = my * my, mxy = mx * my;
+                    const tm_f2 sx = f2_make(v23[0].x, v23[1].x) - mxx, sy = f2_make(v23[0].y, v23[1].y) - myy, sxy = v4 - mxy;
+                    const tm_f2 csn = f2_fma(two, sxy, C2), csd = (sx + sy) + C2;
+                    const float cs0 = csn.x / csd.x, cs1 = csn.y / csd.y;
+                    a_cs[0] += (double)cs0; a_cs[1] += (double)cs1;
+                    if (NEED_L) {
+                        const tm_f2 ln = f2_fma(two, mxy, C1), ld = (mxx + myy) + C1;
+                        const float l0 = ln.x / ld.x, l1 = ln.y / ld.y;
+                        a_l[0] += (double)(l0 * cs0); a_l[1] += (double)(l1 * cs1);
+                    }
+                }
+            }
+        }
+    }
+    // windows that start inside the strip and fit the image; the others (halo lanes, right edge) are dropped here
+    const bool ok0 = 2 * lane < TM_SSIM_STRIP && x < w - 10, ok1 = 2 * lane + 1 < TM_SSIM_STRIP && x + 1 < w - 10;
+    acc[0] = (ok0 ? a_l[0] : 0.0) + (ok1 ? a_l[1] : 0.0);
+    acc[1] = (ok0 ? a_cs[0] : 0.0) + (ok1 ? a_cs[1] : 0.0);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Streaming statistics kernel: one wave walks one strip of 54 window columns down one segment of window rows.
-// Lane L owns input column x_base + L.  Per input row: both samples go through a 2 x 76-float LDS row so that every lane
-// can read its 11 right-hand neighbours (wave-synchronous: no workgroup barrier anywhere), the row filter of
-// {x, y, x^2, y^2, xy} is evaluated for the lane's column and pushed into an 11-row register window; once the window is
-// full every step also evaluates the column filter over it and the two terms of one window.  Same operations in the same
-// order as k_ssim_stats (taps ascending, fma from 0) -> the same per-window values; only the order of the f64 sums differs.
-// grid (slots*3, items of all scales), block 64.  PART[(slot*3+c)][item][2].
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_ssim_stream(TmSsimGeom sg, int nscales, const unsigned char *__restrict__ Q,
-                                                    const float *__restrict__ PYR, double *__restrict__ PART)
+// grid (slots*3, items of the scales [0, nscales)), block 64.  PART[(slot*3+c)][item][2].
+// need_l: bit s set = scale s also needs the sum of l * cs (otherwise PART[..][0] is written as 0).
+__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(2) k_ssim_stream(TmSsimGeom sg, int nscales, unsigned need_l, const unsigned char *__restrict__ Q,
+                                                                         const unsigned short *__restrict__ PYR, double *__restrict__ PART)
 {
-    __shared__ float row[2][80];
+    __shared__ tmdev::tm_f2 rowbuf[72][2]; // [column pair of the strip][col 0 | col 1] = {ref, dis}
     const int lane = threadIdx.x;
     const int slot = blockIdx.x / 3, c = blockIdx.x % 3;
     int s = 0;
@@ -261,76 +249,24 @@ __global__ void __launch_bounds__(64) k_ssim_stream(TmSsimGeom sg, int nscales, 
         if (i < nscales && (int)blockIdx.y >= sg.item_off[i]) s = i;
     const int item = (int)blockIdx.y - sg.item_off[s];
     const int w = sg.w[s], h = sg.h[s];
-    const int x_base = (item % sg.strips_x[s]) * TM_SSIM_STRIP, y_base = (item / sg.strips_x[s]) * TM_SSIM_SEG;
-    const int oh = h - 10;
-    const int y_end = min(y_base + TM_SSIM_SEG, oh); // window rows [y_base, y_end)
-    const int x = x_base + lane;
-    const bool in_x = x < w;
-    const bool out_x = lane < TM_SSIM_STRIP && x < w - 10;
-    const unsigned char *qr = Q + ((size_t)(slot * 2 + 0) * 3 + c) * sg.qplane + (in_x ? x : 0);
-    const unsigned char *qd = Q + ((size_t)(slot * 2 + 1) * 3 + c) * sg.qplane + (in_x ? x : 0);
-    const float *fr = s ? ssim_plane_f(sg, PYR, slot * 2 + 0, c, s) + (in_x ? x : 0) : nullptr;
-    const float *fd = s ? ssim_plane_f(sg, PYR, slot * 2 + 1, c, s) + (in_x ? x : 0) : nullptr;
-    const int pitch = sg.pitch[s];
-    auto load = [&](int y, float &a, float &b) { // row y of both sides at this lane's column (rows past the image: 0)
-        const int yc = y < h ? y : h - 1;
-        float va, vb;
-        if (s == 0) { va = (float)qr[(size_t)yc * pitch]; vb = (float)qd[(size_t)yc * pitch]; }
-        else { va = fr[(size_t)yc * pitch]; vb = fd[(size_t)yc * pitch]; }
-        const bool ok = in_x && y < h;
-        a = ok ? va : 0.0f; b = ok ? vb : 0.0f;
-    };
-    constexpr int PF = 11; // rows of load prefetch (= the window depth, so that one unroll of 11 makes every slot static)
-    float pa[PF], pb[PF];
+    const int x_base = (item % sg.strips_x[s]) * TM_SSIM_STRIP, y_base = (item / sg.strips_x[s]) * sg.seg_rows[s];
+    const int y_end = min(y_base + sg.seg_rows[s], h - 10); // window rows [y_base, y_end)
+    const int x = x_base + 2 * lane;
+    if (lane < 8) { rowbuf[64 + lane][0] = tmdev::f2_splat(0.0f); rowbuf[64 + lane][1] = tmdev::f2_splat(0.0f); } // the halo lanes' right-hand neighbours
+    float gw[TM_SSIM_TAPS];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load(y_base + k, pa[k], pb[k]);
-    if (lane < 16) { row[0][64 + lane] = 0.0f; row[1][64 + lane] = 0.0f; } // the halo lanes' right-hand neighbours
-    float win[11][5];
-#pragma unroll
-    for (int k = 0; k < 11; ++k)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) win[k][q] = 0.0f;
-    const float C1 = 6.5025f, C2 = 58.5225f; // (0.01*255)^2, (0.03*255)^2
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const int n_rows = (y_end - y_base) + 10; // input rows y_base .. y_end+9
-    float g[TM_SSIM_TAPS];
-#pragma unroll
-    for (int k = 0; k < TM_SSIM_TAPS; ++k) g[k] = sg.g[k];
-    for (int t0 = 0; t0 < n_rows; t0 += 11) {
-#pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const int t = t0 + j;
-            if (t < n_rows) { // wave-uniform
-                const float rv = pa[j % PF], dv = pb[j % PF];
-                load(y_base + t + PF, pa[j % PF], pb[j % PF]);
-                __builtin_amdgcn_wave_barrier();
-                row[0][lane] = rv; row[1][lane] = dv;
-                __builtin_amdgcn_wave_barrier();
-                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
-#pragma unroll
-                for (int k = 0; k < TM_SSIM_TAPS; ++k) {
-                    const float r = row[0][lane + k], d = row[1][lane + k], gk = g[k];
-                    a0 = __builtin_fmaf(gk, r, a0);
-                    a1 = __builtin_fmaf(gk, d, a1);
-                    a2 = __builtin_fmaf(gk, r * r, a2);
-                    a3 = __builtin_fmaf(gk, d * d, a3);
-                    a4 = __builtin_fmaf(gk, r * d, a4);
-                }
-                win[j % 11][0] = a0; win[j % 11][1] = a1; win[j % 11][2] = a2; win[j % 11][3] = a3; win[j % 11][4] = a4;
-                if (t >= 10) { // window rows t-10 .. t are in slots (j+1)%11 .. j%11
-                    float v[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int k = 0; k < TM_SSIM_TAPS; ++k)
-#pragma unroll
-                        for (int q = 0; q < 5; ++q) v[q] = __builtin_fmaf(g[k], win[(j + 1 + k) % 11][q], v[q]);
-                    const float mxx = v[0] * v[0], myy = v[1] * v[1], mxy = v[0] * v[1];
-                    const float sx = v[2] - mxx, sy = v[3] - myy, sxy = v[4] - mxy;
-                    const float cs = __builtin_fmaf(2.0f, sxy, C2) / ((sx + sy) + C2);
-                    const float l = __builtin_fmaf(2.0f, mxy, C1) / ((mxx + myy) + C1);
-                    if (out_x) { acc[0] += (double)(l * cs); acc[1] += (double)cs; }
-                }
-            }
-        }
+    for (int k = 0; k < TM_SSIM_TAPS; ++k) gw[k] = sg.g[k];
+    double acc[2] = {0.0, 0.0};
+    const bool nl = (need_l >> s) & 1u;
+    if (s == 0) {
+        const unsigned char *qr = Q + ((size_t)(slot * 2 + 0) * 3 + c) * sg.qplane, *qd = Q + ((size_t)(slot * 2 + 1) * 3 + c) * sg.qplane;
+        if (nl) ssim_strip<true, true>(rowbuf, qr, qd, sg.pitch[0], 1.0f, w, h, x, y_base, y_end, gw, acc);
+        else ssim_strip<true, false>(rowbuf, qr, qd, sg.pitch[0], 1.0f, w, h, x, y_base, y_end, gw, acc);
+    } else {
+        const unsigned short *fr = ssim_plane_s(sg, PYR, slot * 2 + 0, c, s), *fd = ssim_plane_s(sg, PYR, slot * 2 + 1, c, s);
+        const float inv = 1.0f / (float)(1 << (2 * s)); // 4^-s, exact
+        if (nl) ssim_strip<false, true>(rowbuf, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
+        else ssim_strip<false, false>(rowbuf, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
     }
 #ifdef TM_EMULATE
     { // CPU lane emulation runs the 64 lanes as concurrent host threads: sum through memory, not through shuffles
@@ -346,23 +282,24 @@ __global__ void __launch_bounds__(64) k_ssim_stream(TmSsimGeom sg, int nscales, 
         __builtin_amdgcn_wave_barrier();
     }
 #else
-    if (tm_wave_sum6(acc)) {
+    double a6[6] = {acc[0], acc[1], 0, 0, 0, 0};
+    if (tm_wave_sum6(a6)) {
         double *o = PART + (((size_t)slot * 3 + c) * sg.item_off[TM_SSIM_SCALES] + blockIdx.y) * 2;
-        o[0] = acc[0]; o[1] = acc[1];
+        o[0] = a6[0]; o[1] = a6[1];
     }
 #endif
 }
 
-// SUMS[slot][channel 3][scale 5][ssim, cs]: lane l adds tiles l, l+64, ... in order, then the 64 lane totals are added
-// by a fixed tree (deterministic run to run).  grid (slots, 30), block 64.
-__global__ void __launch_bounds__(64) k_ssim_finish(TmSsimGeom sg, int streamed, const double *__restrict__ PART, double *__restrict__ SUMS)
+// SUMS[slot][channel 3][scale 5][ssim, cs]: lane l adds items l, l+64, ... in order, then the 64 lane totals are added
+// by a fixed tree (deterministic run to run); scales that were not run read 0.  grid (slots, 30), block 64.
+__global__ void __launch_bounds__(64) k_ssim_finish(TmSsimGeom sg, int nscales, const double *__restrict__ PART, double *__restrict__ SUMS)
 {
     const int slot = blockIdx.x, i = blockIdx.y;
     const int c = i / 10, s = (i % 10) / 2, which = i & 1;
-    const int *off = streamed ? sg.item_off : sg.tile_off; // partials of k_ssim_stream or of k_ssim_stats
     double a[6] = {0, 0, 0, 0, 0, 0};
-    for (int t = off[s] + (int)threadIdx.x; t < off[s + 1]; t += 64)
-        a[0] += PART[(((size_t)slot * 3 + c) * off[TM_SSIM_SCALES] + t) * 2 + which];
+    if (s < nscales)
+        for (int t = sg.item_off[s] + (int)threadIdx.x; t < sg.item_off[s + 1]; t += 64)
+            a[0] += PART[(((size_t)slot * 3 + c) * sg.item_off[TM_SSIM_SCALES] + t) * 2 + which];
     if (tm_wave_sum6(a)) SUMS[(size_t)slot * 30 + i] = a[0];
 }
 
