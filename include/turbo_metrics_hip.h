@@ -12,7 +12,7 @@
  *   ssimulacra2-cuda/src/lib.rs:48-107 Ssimulacra2::new (buffers)      tm_engine_create
  *   ssimulacra2-cuda/src/lib.rs:110   Ssimulacra2::mem_usage           tm_engine_mem_usage
  *   turbo-metrics/src/color.rs:96-116 convert_frame_to_linearrgb       tm_engine_set_frame_{nv12,p016,
- *     + cuda-colorspace/src/lib.rs:33-170 ColorspaceConversion::*        rgb8,rgb16,rgbf32}
+ *     + cuda-colorspace/src/lib.rs:33-170 ColorspaceConversion::*        rgb8,rgb16,rgbf32} (+ _i420: planar)
  *   ssimulacra2-cuda/src/lib.rs:48-52 (linear f32 C3 inputs of
  *     Ssimulacra2::new / compute)                                      tm_engine_set_frame_linear_f32
  *   turbo-metrics/src/lib.rs:268-345  compute_one (launch part)        tm_engine_compute_async
@@ -115,6 +115,15 @@ int tm_engine_set_frame_nv12(tm_engine *e, uint32_t slot, int side, const void *
  * For TM_MEM_HOST the engine copies `height` luma rows and ceil(height/2) chroma rows. */
 int tm_engine_set_frame_p016(tm_engine *e, uint32_t slot, int side, const void *y, const void *uv,
                              size_t pitch, int matrix, int transfer, int full_range, int mem);
+/* Planar 4:2:0 as files and software decoders deliver it (I420 / yuv420p: bits = 8; yuv420p10le etc.: bits = 9..16, little
+ * endian u16 with the value in the LOW bits): luma plane `y` at pitch_y bytes, chroma planes `u` (Cb) and `v` (Cr) of
+ * ceil(w/2) x ceil(h/2) samples at pitch_uv bytes.  Not a reference format: its decoder only ever hands over NV12 / P016
+ * (cudarse-video/src/dec.rs:299-403), so a host that holds planar pictures would have to repack them first -- this entry point
+ * lets it upload the file bytes as they are.  The arithmetic is the NV12 / P016 conversion of the same samples: a 16-bit
+ * sample v enters as v << (16 - bits), exactly what the repacked P016 surface would hold (dec.rs:398-400); results are
+ * bit-identical to tm_engine_set_frame_{nv12,p016} on the repacked surface (tests/test_gpu_parity.py). */
+int tm_engine_set_frame_i420(tm_engine *e, uint32_t slot, int side, const void *y, const void *u, const void *v,
+                             size_t pitch_y, size_t pitch_uv, int bits, int matrix, int transfer, int full_range, int mem);
 /* packed RGB, 3 samples per pixel (HwFrame::Npp8 / Npp16 / Npp32, turbo-metrics/src/lib.rs:125-130);
  * sRGB transfer: 8-bit through the LUT, 16-bit / f32 through the formula (color.rs:112-114). */
 int tm_engine_set_frame_rgb8(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem);

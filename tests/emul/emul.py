@@ -57,10 +57,11 @@ class SsimGeom(C.Structure):
 
 
 class FrameDesc(C.Structure):
-    _fields_ = [("p0", C.c_void_p), ("p1", C.c_void_p), ("pitch", C.c_ulonglong), ("kind", C.c_int), ("matrix", C.c_int)]
+    _fields_ = [("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p), ("pitch", C.c_ulonglong), ("pitch2", C.c_ulonglong),
+                ("kind", C.c_int), ("matrix", C.c_int), ("shift", C.c_int), ("pad_", C.c_int)]
 
 
-KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 5}
+KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 5, "i420_8": 6, "i420_16": 7}
 
 
 class Emulated:
@@ -84,8 +85,15 @@ class Emulated:
         keep = []
         for i, pair in enumerate(frames):
             for side, f in enumerate(pair):
-                a = np.ascontiguousarray(f["data"]); keep.append(a)
                 d = desc[2 * i + side]
+                if f["kind"] == "i420":  # planar: data = (Y, Cb, Cr), uint8 or uint16 with the value in the low `bits` bits
+                    pl = [np.ascontiguousarray(p) for p in f["data"]]; keep.extend(pl)
+                    d.kind = KIND["i420_8" if f["bits"] == 8 else "i420_16"]; d.matrix = int(f.get("matrix", 0))
+                    d.p0, d.p1, d.p2 = (p.ctypes.data for p in pl)
+                    d.pitch, d.pitch2 = pl[0].strides[0], pl[1].strides[0]
+                    d.shift = 0 if f["bits"] == 8 else 16 - f["bits"]
+                    continue
+                a = np.ascontiguousarray(f["data"]); keep.append(a)
                 d.kind = KIND[f["kind"]]; d.matrix = int(f.get("matrix", 0)); d.p0 = a.ctypes.data
                 if f["kind"] in ("nv12", "p016"):
                     d.pitch = f["pitch"]; d.p1 = a.ctypes.data + f["pitch"] * f["coded_height"]

@@ -49,3 +49,6 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 bool tm_wave_sum6(double (&a)[6]);
 bool tm_wave_sum_u32x3(unsigned (&v)[3]);
 float tm_shfl_xor(float v, int mask); // lockstep wave emulation only
+unsigned tm_shfl_xor_u32(unsigned v, int mask);
+struct alignas(8) uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }

@@ -136,6 +136,17 @@ static void run_fibers(unsigned n, unsigned tid0, void (*body)(void *), void *ar
 
 // wave shuffle for the lockstep emulation (64 host threads = the lanes of one wave): exchange through memory
 static float g_shfl[64];
+unsigned tm_shfl_xor_u32(unsigned v, int mask)
+{
+    static unsigned buf[64];
+    const unsigned l = threadIdx.x & 63;
+    tm_emul_wave_barrier();
+    buf[l] = v;
+    tm_emul_wave_barrier();
+    const unsigned r = buf[l ^ (unsigned)mask];
+    tm_emul_wave_barrier();
+    return r;
+}
 float tm_shfl_xor(float v, int mask)
 {
     const unsigned l = threadIdx.x & 63;
@@ -279,6 +290,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             switch (kind) {
             case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+            case TM_KIND_I420_8: tmk::k_ingest_wave<TM_KIND_I420_8>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+            case TM_KIND_I420_16: tmk::k_ingest_wave<TM_KIND_I420_16>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
@@ -306,7 +319,7 @@ void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, un
 {
     TmSsimGeom sg; tm_make_ssim_geom(&sg, w, h, g);
     if (sg.w[1] > 0 && sg.h[1] > 0)
-        launch_wg_lockstep(dim3((w + 31) / 32, (h + 31) / 32, n * 6), 256, [&] { tmk::k_ssim_pyramid(sg, QU8, PYR); });
+        launch_wave_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n * 6), [&] { tmk::k_ssim_pyramid(sg, QU8, PYR); });
     int nscales = 0;
     for (int s = 0; s < TM_SSIM_SCALES; ++s) if (sg.strips_x[s] > 0 && sg.segs_y[s] > 0) nscales = s + 1;
     if (nscales > 0) launch_wave_lockstep(dim3(n * 3, sg.item_off[nscales], 1), [&] { tmk::k_ssim_stream(sg, nscales, need_l, QU8, PYR, PART); });

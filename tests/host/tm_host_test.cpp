@@ -88,6 +88,12 @@ int main(int argc, char **argv)
                     out.write((const char *)f.data, (std::streamsize)(f.pitch * luma_rows));
                     out.write((const char *)f.uv, (std::streamsize)(f.pitch * crows));
                     std::cout << (f.kind == HwFrame::NvDecNV12 ? "nv12 " : "p016 ") << f.pitch << " " << luma_rows << " " << crows << "\n";
+                } else if (f.kind == HwFrame::Planar420) {
+                    const size_t crows = (hh + 1) / 2;
+                    out.write((const char *)f.data, (std::streamsize)(f.pitch * hh));
+                    out.write((const char *)f.u, (std::streamsize)(f.pitch_uv * crows));
+                    out.write((const char *)f.v, (std::streamsize)(f.pitch_uv * crows));
+                    std::cout << "i420 " << f.bits << " " << f.pitch << " " << f.pitch_uv << " " << hh << " " << crows << "\n";
                 } else {
                     out.write((const char *)f.data, (std::streamsize)(f.pitch * hh));
                     std::cout << (f.kind == HwFrame::Npp8 ? "rgb8 " : f.kind == HwFrame::Npp16 ? "rgb16 " : "rgbf32 ") << f.pitch << " " << w << "\n";

@@ -15,6 +15,9 @@ def coef_table():
 
 def oracle_linear(f, w, h):
     k = f["kind"]
+    if k == "i420":  # planar: the oracle sees the same samples repacked into the reference's biplanar surface
+        surf, pitch, ch = tm.synth.pack_biplanar(tuple(np.asarray(p, np.int64) for p in f["data"]), w, h, f["bits"])
+        return O.yuv420_biplanar_to_linear(surf, pitch, ch, w, h, 8 if f["bits"] == 8 else 16, int(f.get("matrix", 0)))
     if k in ("nv12", "p016"):
         return O.yuv420_biplanar_to_linear(f["data"], f["pitch"], f["coded_height"], w, h, 8 if k == "nv12" else 16, int(f.get("matrix", 0)))
     return {"rgb8": O.rgb8_to_linear, "rgb16": O.rgb16_to_linear, "rgbf32": O.rgbf32_to_linear, "linear_f32": O.linear_packed_to_planar}[k](f["data"])
@@ -212,3 +215,32 @@ def test_default_pipeline_matches_oracle(w, h, variant):
                 q = O.quantize_u8(lin[side])
                 for c in range(3):
                     assert np.array_equal(em.qplane(slot, side, c), q[c])
+
+
+def planar_frames(w, h, bits, count=2):
+    frames = []
+    dt = np.uint8 if bits == 8 else np.uint16
+    for n in range(count):
+        ref, dis = tm.synth.yuv420_pair(w, h, n + 3, bits)
+        frames.append(tuple(dict(kind="i420", data=tuple(p.astype(dt) for p in side), bits=bits, matrix=n % 3) for side in (ref, dis)))
+    return frames
+
+
+@pytest.mark.parametrize("variant", [DEFAULT, REFERENCE])
+@pytest.mark.parametrize("bits", [8, 10])
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (129, 20)])
+def test_planar_i420_equals_the_repacked_biplanar_surface(w, h, bits, variant):
+    """tm_engine_set_frame_i420's kinds: planar 4:2:0 (8-bit; 10-bit values in the low bits of u16) give exactly the planes and
+    sums of the NV12 / P016 surface the same samples would be repacked into"""
+    frames = planar_frames(w, h, bits)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant, weights=O.weights(), full_sums=True)
+    check_against_oracle(em, frames, w, h, have_linear=variant == REFERENCE, have_xybt=variant == REFERENCE)
+
+
+def test_planar_and_biplanar_frames_in_one_launch():
+    """per-frame dispatch (mixed kinds): planar 8-bit, planar 10-bit with stray high bits masked away, NV12"""
+    w, h = 46, 30
+    frames = planar_frames(w, h, 8, 1) + planar_frames(w, h, 10, 1) + nv12_frames(w, h, 1)
+    dirty = tuple(dict(f, data=tuple((p | np.uint16(0xFC00)) for p in f["data"])) for f in frames[1])  # bits above the declared depth
+    em = E.Emulated(w, h, frames[:1] + [dirty] + frames[2:], O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
+    check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)

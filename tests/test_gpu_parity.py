@@ -312,6 +312,52 @@ def test_4k_p016_fused_psnr_msssim_ssimulacra2_against_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("bits,w,h", [(8, 333, 203), (10, 333, 203), (8, 70, 38), (10, 1920, 1080), (12, 129, 20)])
+def test_planar_i420_is_bit_identical_with_the_repacked_biplanar_surface(bits, w, h):
+    """tm_engine_set_frame_i420 (planar 4:2:0 as files deliver it: u8, or the value in the low bits of little-endian u16) against
+    tm_engine_set_frame_{nv12,p016} on the surface the same samples are repacked into -- the reference's only YUV contract --
+    and against the oracle: same raw sums, SSE and scores, from host memory and from device memory."""
+    import torch
+    dt = np.uint8 if bits == 8 else np.uint16
+    frames = []
+    for n in range(2):
+        ref, dis = tm.synth.yuv420_pair(w, h, n + 1, 8 if bits == 8 else 10)
+        if bits == 12:
+            ref, dis = tuple(p * 4 + 1 for p in ref), tuple(p * 4 + 2 for p in dis)
+        frames.append((ref, dis))
+    planar = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2, full_sums=True)
+    packed = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2, full_sums=True)
+    keep = []
+    for slot, (ref, dis) in enumerate(frames):
+        for side, planes in enumerate((ref, dis)):
+            pl = [np.ascontiguousarray(p.astype(dt)) for p in planes]
+            if slot == 1:  # device-resident planes (zero copy), with a pitch wider than the row
+                pl = [torch.from_numpy(np.pad(p, ((0, 0), (0, 6)))).cuda()[:, :p.shape[1]] for p in pl]
+                keep.append(pl)
+            planar.set_frame(slot, side, tm.HwFrame.i420(pl[0], pl[1], pl[2], bits=bits, matrix=tm.ColorMatrix(slot)))
+            surf, pitch, ch = tm.synth.pack_biplanar(planes, w, h, bits)
+            mk = tm.HwFrame.nv12 if bits == 8 else tm.HwFrame.p016
+            packed.set_frame(slot, side, mk(surf, pitch, ch, tm.ColorMatrix(slot)))
+    for e in (planar, packed):
+        e.compute_async(); e.sync()
+    for slot, (ref, dis) in enumerate(frames):
+        assert np.array_equal(planar.raw_sums(slot), packed.raw_sums(slot))
+        assert planar.sse(slot) == packed.sse(slot) and planar.scores(slot) == packed.scores(slot)
+        lin = []
+        for planes in (ref, dis):
+            surf, pitch, ch = tm.synth.pack_biplanar(planes, w, h, bits)
+            lin.append(O.yuv420_biplanar_to_linear(surf, pitch, ch, w, h, 8 if bits == 8 else 16, slot))
+        if w * h <= 640 * 360:
+            want, sums = O.ssimulacra2_from_linear(lin[0], lin[1])
+            np.testing.assert_allclose(planar.raw_sums(slot), sums, rtol=1e-12, atol=1e-300)
+            assert abs(planar.scores(slot).ssimulacra2 - want) <= 1e-9
+        assert planar.sse(slot) == O.psnr(lin[0], lin[1])[0]
+    with pytest.raises(tm.TmError) as ei:  # full range is todo!() in the reference for every YUV kind
+        planar.set_frame(0, 0, tm.HwFrame.i420(*[np.ascontiguousarray(p.astype(dt)) for p in frames[0][0]], bits=bits, full_range=True))
+    assert ei.value.code == F.TM_ERR_UNSUPPORTED
+    planar.close(); packed.close()
+
+
 def test_8k_pair_against_oracle():
     """7680x4320: one slot's arenas pass 2 GB (several kernels carry 32-bit lane offsets inside a plane), two slots so that the
     second one starts beyond 4 GB of the pass-1 arena"""

@@ -211,7 +211,46 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
         d.p0 = s; d.pitch = spitch;
     }
-    d.kind = kind; d.matrix = matrix;
+    d.kind = kind; d.matrix = matrix; d.p2 = nullptr; d.pitch2 = 0; d.shift = 0;
+    return TM_OK;
+}
+
+// planar 4:2:0 (TM_KIND_I420_8 / I420_16): three planes; the staged copy keeps them planar (Y rows, then Cb rows, then Cr rows)
+int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const void *u, const void *v, size_t pitch_y,
+                     size_t pitch_uv, int bits, int matrix, int mem)
+{
+    int rc = check_slot_side(e, slot, side);
+    if (rc) return rc;
+    TM_BIND(e);
+    if (!y || !u || !v || (mem != TM_MEM_HOST && mem != TM_MEM_DEVICE && mem != TM_MEM_HOST_PINNED)) return TM_ERR_INVALID_ARG;
+    if (bits < 8 || bits > 16) return TM_ERR_INVALID_ARG;
+    const size_t bps = bits == 8 ? 1 : 2;
+    const size_t cw = (e->w + 1) / 2, ch = (e->h + 1) / 2;
+    const size_t row_y = (size_t)e->w * bps, row_c = cw * bps;
+    if (pitch_y < row_y || pitch_uv < row_c) return TM_ERR_INVALID_ARG;
+    TmFrameDesc &d = e->h_desc[slot * 2 + side];
+    if (e->in_flight) { // descriptors are read by an async copy; do not race with it
+        rc = tm_engine_sync(e);
+        if (rc) return rc;
+    }
+    if (mem == TM_MEM_DEVICE) {
+        d.p0 = y; d.p1 = u; d.p2 = v; d.pitch = pitch_y; d.pitch2 = pitch_uv;
+    } else {
+        const size_t idx = slot * 2 + side;
+        const size_t sp_y = (row_y + 255) / 256 * 256, sp_c = (row_c + 255) / 256 * 256;
+        rc = ensure_staging(e, idx, sp_y * e->h + 2 * sp_c * ch);
+        if (rc) return rc;
+        char *s = (char *)e->staging[idx];
+        char *su = s + sp_y * e->h, *sv = su + sp_c * ch;
+        if ((rc = stage_rows(e, s, sp_y, y, pitch_y, row_y, e->h))) return rc;
+        if ((rc = stage_rows(e, su, sp_c, u, pitch_uv, row_c, ch))) return rc;
+        if ((rc = stage_rows(e, sv, sp_c, v, pitch_uv, row_c, ch))) return rc;
+        if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+        d.p0 = s; d.p1 = su; d.p2 = sv; d.pitch = sp_y; d.pitch2 = sp_c;
+    }
+    d.kind = bits == 8 ? TM_KIND_I420_8 : TM_KIND_I420_16;
+    d.matrix = matrix;
+    d.shift = bits == 8 ? 0 : 16 - bits;
     return TM_OK;
 }
 
@@ -402,7 +441,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if ((he = hipHostMalloc((void **)&e->h_desc, B * 2 * sizeof(TmFrameDesc), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     if ((he = hipHostMalloc((void **)&e->h_sums, B * 108 * sizeof(double), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
     if ((he = hipHostMalloc((void **)&e->h_sse, B * TM_SSE_BINS * 3 * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return fail(hip_fail(he, "hipHostMalloc"));
-    for (size_t i = 0; i < B * 2; ++i) { e->h_desc[i] = TmFrameDesc{nullptr, nullptr, 0, TM_KIND_NONE, 0}; }
+    for (size_t i = 0; i < B * 2; ++i) { e->h_desc[i] = TmFrameDesc{nullptr, nullptr, nullptr, 0, 0, TM_KIND_NONE, 0, 0, 0}; }
     e->staging.assign(B * 2, nullptr);
     e->staging_size.assign(B * 2, 0);
     for (int i = 0; i <= TM_STAGE_COUNT; ++i)
@@ -447,6 +486,14 @@ int tm_engine_set_frame_p016(tm_engine *e, uint32_t slot, int side, const void *
     int rc = check_yuv_args(matrix, transfer, full_range);
     if (rc) return rc;
     return set_frame_common(e, slot, side, TM_KIND_P016, y, uv, pitch, matrix, mem);
+}
+
+int tm_engine_set_frame_i420(tm_engine *e, uint32_t slot, int side, const void *y, const void *u, const void *v, size_t pitch_y,
+                             size_t pitch_uv, int bits, int matrix, int transfer, int full_range, int mem)
+{
+    int rc = check_yuv_args(matrix, transfer, full_range);
+    if (rc) return rc;
+    return set_frame_planar(e, slot, side, y, u, v, pitch_y, pitch_uv, bits, matrix, mem);
 }
 
 int tm_engine_set_frame_rgb8(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
@@ -544,6 +591,8 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         switch (kind) {
         case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
+        case TM_KIND_I420_8: TM_LAUNCH_W(TM_KIND_I420_8); break;
+        case TM_KIND_I420_16: TM_LAUNCH_W(TM_KIND_I420_16); break;
         case TM_KIND_RGB8: TM_LAUNCH_W(TM_KIND_RGB8); break;
         case TM_KIND_RGB16: TM_LAUNCH_W(TM_KIND_RGB16); break;
         case TM_KIND_RGBF32: TM_LAUNCH_W(TM_KIND_RGBF32); break;
@@ -576,7 +625,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         const TmSsimGeom &sg = e->sg;
         const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
         if (nscales > 1)
-            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 31) / 32), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(256), 0, st, sg, QU8, e->SPYR);
+            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 63) / 64), (unsigned)((sg.h[0] + 63) / 64), (unsigned)(n * 6)), dim3(64), 0, st, sg, QU8, e->SPYR);
         // the sum of l * cs is needed on scale 0 for SSIM and on the last scale for MS-SSIM (the others use cs alone)
         const unsigned need_l = e->full_sums ? 31u : ((e->mask & TM_METRIC_SSIM) ? 1u : 0u) | ((e->mask & TM_METRIC_MSSSIM) ? 1u << (TM_SSIM_SCALES - 1) : 0u);
         hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, need_l, QU8, e->SPYR, e->SPART);

@@ -38,15 +38,22 @@ struct TmGeom {
 };
 
 // frame descriptor consumed by the ingest kernel
+// I420_8 / I420_16: PLANAR 4:2:0 as files and software decoders deliver it (three planes; 16-bit samples little endian with
+// the value in the LOW `16 - shift` bits): converted exactly like NV12 / P016 -- a 16-bit sample enters as v << shift, which is
+// what an NVDEC P016 surface holds (cudarse-video/src/dec.rs:398-400)
 enum { TM_KIND_NONE = -1, TM_KIND_NV12 = 0, TM_KIND_P016 = 1, TM_KIND_RGB8 = 2, TM_KIND_RGB16 = 3,
-       TM_KIND_RGBF32 = 4, TM_KIND_LINEARF32 = 5 };
+       TM_KIND_RGBF32 = 4, TM_KIND_LINEARF32 = 5, TM_KIND_I420_8 = 6, TM_KIND_I420_16 = 7 };
 
 struct TmFrameDesc {
-    const void *p0;           // luma plane or packed RGB
-    const void *p1;           // interleaved CbCr plane (YUV kinds)
-    unsigned long long pitch; // bytes
+    const void *p0;            // luma plane or packed RGB
+    const void *p1;            // interleaved CbCr plane (biplanar kinds) / Cb plane (planar kinds)
+    const void *p2;            // Cr plane (planar kinds)
+    unsigned long long pitch;  // bytes (luma / RGB rows; CbCr rows of the biplanar kinds)
+    unsigned long long pitch2; // bytes, chroma rows of the planar kinds
     int kind;
     int matrix;
+    int shift;                 // I420_16: left shift that brings the sample to the top of 16 bits (6 for 10-bit content)
+    int pad_;
 };
 
 // ---- job table of the two blur passes ---------------------------------------------------------------

@@ -37,6 +37,7 @@ __device__ __forceinline__ bool tm_wave_sum6(double (&a)[6])
     return (threadIdx.x & 63) == 0;
 }
 __device__ __forceinline__ float tm_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ unsigned tm_shfl_xor_u32(unsigned v, int mask) { return (unsigned)__shfl_xor((int)v, mask, 64); }
 __device__ __forceinline__ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 {
 #pragma unroll
@@ -80,19 +81,31 @@ __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, in
 //   quantise   sample_conv.rs:6-35 (float2uint_rn(v*255))
 // coef: [matrix 0..2][bits 8|16][5] = y, r, b, g1, g2 coefficients (lib.rs:186-200), host computed.
 // ------------------------------------------------------------------------------------------------
+//   planar     TM_KIND_I420_8 / I420_16: the same conversion; Cb and Cr come from two planes and a 16-bit sample is first
+//              shifted to the top of its 16 bits (a P016 surface holds exactly that)
 template <typename T, int BITS>
 __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const float *__restrict__ coef,
                                                 const double *__restrict__ tab, int qx, int qy, float (&px)[2][2][3])
 {
     const float *k = coef + (d.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
-    const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
     const int neutral = 1 << (BITS - 1);
     const unsigned ymin = 16u << (BITS - 8);
+    const bool planar = d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16;
+    const int sh = planar && BITS == 16 ? d.shift : 0;
     // all six samples of the quad are fetched before any is used: one exposed latency instead of six
     const T *yrow0 = (const T *)((const char *)d.p0 + (size_t)(2 * qy) * d.pitch) + 2 * qx;
     const T *yrow1 = (const T *)((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch) + 2 * qx;
-    const unsigned ucb = uv[0], ucr = uv[1];
-    const unsigned yv[2][2] = {{yrow0[0], yrow0[1]}, {yrow1[0], yrow1[1]}};
+    unsigned ucb, ucr;
+    if (planar) {
+        ucb = ((const T *)((const char *)d.p1 + (size_t)qy * d.pitch2))[qx];
+        ucr = ((const T *)((const char *)d.p2 + (size_t)qy * d.pitch2))[qx];
+    } else {
+        const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
+        ucb = uv[0]; ucr = uv[1];
+    }
+    ucb = (ucb << sh) & 0xFFFFu; ucr = (ucr << sh) & 0xFFFFu;
+    const unsigned yv[2][2] = {{((unsigned)yrow0[0] << sh) & 0xFFFFu, ((unsigned)yrow0[1] << sh) & 0xFFFFu},
+                               {((unsigned)yrow1[0] << sh) & 0xFFFFu, ((unsigned)yrow1[1] << sh) & 0xFFFFu}};
     const float cb = (float)((int)ucb - neutral);
     const float cr = (float)((int)ucr - neutral);
     const float r_ = k[1] * cr;
@@ -113,21 +126,35 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
 // The six samples of a quad as three pair loads (two luma rows, one CbCr pair): half the load instructions and half the
 // registers, which is what lets k_ingest_wave hold BOTH sides' samples from the start.  raw[i] = first | second << bits.
 // Pair loads need the plane pointers and the pitch to be multiples of the pair size; otherwise single loads are packed.
-template <typename T>
+// PLANAR: Cb and Cr are single loads from their own planes (16 lanes along x = 16 / 32 contiguous bytes of each), and 16-bit
+// samples are shifted to the top of their half (masked first: bits above the declared depth cannot spill into the neighbour).
+template <typename T, bool PLANAR>
 __device__ __forceinline__ void yuv_quad_load_pairs(const TmFrameDesc &d, int qx, int qy, unsigned (&raw)[3])
 {
-    const char *uv = (const char *)d.p1 + (size_t)qy * d.pitch + (size_t)(2 * qx) * sizeof(T);
     const char *y0 = (const char *)d.p0 + (size_t)(2 * qy) * d.pitch + (size_t)(2 * qx) * sizeof(T);
     const char *y1 = y0 + d.pitch;
-    const bool aligned = (((unsigned long long)d.p0 | (unsigned long long)d.p1 | (unsigned long long)d.pitch) & (2 * sizeof(T) - 1)) == 0; // wave-uniform
+    const int sh = 8 * (int)sizeof(T);
+    const bool aligned = (((unsigned long long)d.p0 | (PLANAR ? 0ull : (unsigned long long)d.p1) | (unsigned long long)d.pitch) & (2 * sizeof(T) - 1)) == 0; // wave-uniform
     if (aligned) {
-        if (sizeof(T) == 1) { raw[0] = *(const unsigned short *)y0; raw[1] = *(const unsigned short *)y1; raw[2] = *(const unsigned short *)uv; }
-        else { raw[0] = *(const unsigned *)y0; raw[1] = *(const unsigned *)y1; raw[2] = *(const unsigned *)uv; }
+        if (sizeof(T) == 1) { raw[0] = *(const unsigned short *)y0; raw[1] = *(const unsigned short *)y1; }
+        else { raw[0] = *(const unsigned *)y0; raw[1] = *(const unsigned *)y1; }
     } else {
-        const int sh = 8 * (int)sizeof(T);
         raw[0] = (unsigned)((const T *)y0)[0] | ((unsigned)((const T *)y0)[1] << sh);
         raw[1] = (unsigned)((const T *)y1)[0] | ((unsigned)((const T *)y1)[1] << sh);
-        raw[2] = (unsigned)((const T *)uv)[0] | ((unsigned)((const T *)uv)[1] << sh);
+    }
+    if (PLANAR) {
+        const unsigned cb = ((const T *)((const char *)d.p1 + (size_t)qy * d.pitch2))[qx];
+        const unsigned cr = ((const T *)((const char *)d.p2 + (size_t)qy * d.pitch2))[qx];
+        raw[2] = cb | (cr << sh);
+        if (sizeof(T) == 2) {
+            const unsigned keep = (0xFFFFu >> d.shift) * 0x10001u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) raw[i] = (raw[i] & keep) << d.shift;
+        }
+    } else {
+        const char *uv = (const char *)d.p1 + (size_t)qy * d.pitch + (size_t)(2 * qx) * sizeof(T);
+        if (aligned) raw[2] = sizeof(T) == 1 ? (unsigned)*(const unsigned short *)uv : *(const unsigned *)uv;
+        else raw[2] = (unsigned)((const T *)uv)[0] | ((unsigned)((const T *)uv)[1] << sh);
     }
 }
 template <int BITS> __device__ __forceinline__ void yuv_quad_unpack(const unsigned (&pr)[3], unsigned (&raw)[6])
@@ -183,9 +210,9 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
         if (inside) {
-            if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016) {
+            if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016 || d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16) {
                 if (2 * qx + 1 < w && 2 * qy + 1 < h) {
-                    if (d.kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, qx, qy, px);
+                    if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, qx, qy, px);
                     else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, qx, qy, px);
                 }
             } else {
@@ -318,13 +345,15 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     __shared__ float keep_s[15][64];
     // YUV kinds: the samples of BOTH sides are requested before anything else (three pair loads per side), so that side 1's
     // never sit behind side 0's arithmetic
-    constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016;
+    constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16;
+    constexpr bool PLANAR = KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16;
+    constexpr bool YUV8 = KIND == TM_KIND_NV12 || KIND == TM_KIND_I420_8;
     const TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
     const bool quad_ok = X0 + 1 < w && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
     unsigned pr0[3] = {0, 0, 0}, pr1[3] = {0, 0, 0};
     if (YUV && quad_ok) {
-        if (KIND == TM_KIND_NV12) { yuv_quad_load_pairs<unsigned char>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned char>(dd1, X0 / 2, Y0 / 2, pr1); }
-        else { yuv_quad_load_pairs<unsigned short>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned short>(dd1, X0 / 2, Y0 / 2, pr1); }
+        if (YUV8) { yuv_quad_load_pairs<unsigned char, PLANAR>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned char, PLANAR>(dd1, X0 / 2, Y0 / 2, pr1); }
+        else { yuv_quad_load_pairs<unsigned short, PLANAR>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned short, PLANAR>(dd1, X0 / 2, Y0 / 2, pr1); }
     }
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
@@ -341,13 +370,13 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
             if (quad_ok) {
                 const unsigned prs[3] = {side ? pr1[0] : pr0[0], side ? pr1[1] : pr0[1], side ? pr1[2] : pr0[2]};
                 unsigned raw[6];
-                yuv_quad_unpack<KIND == TM_KIND_NV12 ? 8 : 16>(prs, raw);
-                if (KIND == TM_KIND_NV12) yuv_quad_convert<8>(d, raw, coef, tab, px);
+                yuv_quad_unpack<YUV8 ? 8 : 16>(prs, raw);
+                if (YUV8) yuv_quad_convert<8>(d, raw, coef, tab, px);
                 else yuv_quad_convert<16>(d, raw, coef, tab, px);
             }
-        } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016) {
+        } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16) {
             if (quad_ok) {
-                if (kind == TM_KIND_NV12) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px);
+                if (kind == TM_KIND_NV12 || kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px);
                 else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
             }
         } else {
@@ -388,7 +417,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
         lg[4] = ds4(px[0][0][1], px[0][1][1], px[1][0][1], px[1][1][1], okx, oky);
         lb[4] = ds4(px[0][0][2], px[0][1][2], px[1][0][2], px[1][1][2], okx, oky);
         // 8- and 16-bit kinds give linear RGB in [0, 1] (clamp01 / the sRGB tables): the cube roots need no range test
-        constexpr bool UNIT = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_RGB8 || KIND == TM_KIND_RGB16;
+        constexpr bool UNIT = YUV || KIND == TM_KIND_RGB8 || KIND == TM_KIND_RGB16;
         tmdev::linear_to_xyb_n<5, UNIT>(lr, lg, lb, xa, xb, xc);
         // ---- level 0: two rows of two pixels; level 1: one pixel
         if (side == 0) {

@@ -5,7 +5,7 @@
 // (sigma 1.5) over the windows that fit inside the image, K1 = 0.01, K2 = 0.03, L = 255; five dyadic scales (2x2 box mean,
 // odd last row / column dropped) for MS-SSIM.
 //
-//   k_ssim_pyramid  grid (ceil(w/32), ceil(h/32), slots*2*3)  block 256   scales 1..4 of the box pyramid from one 32x32 u8 tile
+//   k_ssim_pyramid  grid (ceil(w/64), ceil(h/64), slots*2*3)  block 64    scales 1..4 of the box-sum pyramid, lane = 8x8 pixels
 //   k_ssim_stream   grid (slots*3, items of all scales)       block 64    one wave = a strip of 118 window columns x a segment
 //                                                                         of window rows, see below
 //   k_ssim_finish   grid (slots, 30)                          block 64    fixed-order sum of the partials -> 30 sums / slot
@@ -77,55 +77,78 @@ __device__ __forceinline__ const unsigned short *ssim_plane_s(const TmSsimGeom &
     return PYR + ((size_t)img * 3 + c) * sg.pyr + sg.off[s];
 }
 
-// Box sums of scales 1..4, four levels at once; an odd last row / column of a level is dropped (level s has
-// floor(w/2^s) x floor(h/2^s) pixels).  Tiles are 32-aligned, so every parent stays inside.
-__global__ void __launch_bounds__(256) k_ssim_pyramid(TmSsimGeom sg, const unsigned char *__restrict__ Q, unsigned short *__restrict__ PYR)
+// Box sums of scales 1..4 in one pass over the u8 plane; an odd last row / column of a level is dropped (level s has
+// floor(w/2^s) x floor(h/2^s) pixels).  Lane = one 8 x 8 pixel block, read as eight 8-byte rows: scales 1..3 of the block (4 x 4,
+// 2 x 2, 1 sums) are formed in registers with packed 16-bit adds -- two neighbouring sums in one dword, which is also how they
+// are stored --, scale 4 from the 2 x 2 lane group through three shuffles.  The wave covers 64 x 64 pixels (lanes 8 x 8), so a
+// row of the tile is one 64-byte run.  No LDS, no barrier.  grid (ceil(w/64), ceil(h/64), slots*2*3), block 64.
+__global__ void __launch_bounds__(64) k_ssim_pyramid(TmSsimGeom sg, const unsigned char *__restrict__ Q, unsigned short *__restrict__ PYR)
 {
-    __shared__ unsigned l1[16][17], l2[8][9], l3[4][5];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int img = blockIdx.z / 3, c = blockIdx.z % 3;
-    const int bx = blockIdx.x, by = blockIdx.y;
+    const int x0 = blockIdx.x * 64 + 8 * (lane & 7), y0 = blockIdx.y * 64 + 8 * (lane >> 3);
+    const unsigned char *q = Q + ((size_t)img * 3 + c) * sg.qplane + x0; // x0 + 7 < pitch[0]: the pitch is a multiple of 64
     unsigned short *base = PYR + ((size_t)img * 3 + c) * sg.pyr;
-    {
-        const int tx = tid & 15, ty = tid >> 4;
-        const int x = bx * 16 + tx, y = by * 16 + ty;
-        unsigned v = 0;
-        if (x < sg.w[1] && y < sg.h[1]) {
-            const unsigned char *p = Q + ((size_t)img * 3 + c) * sg.qplane + (size_t)(2 * y) * sg.pitch[0] + 2 * x;
-            const unsigned a = *(const unsigned short *)p, b = *(const unsigned short *)(p + sg.pitch[0]); // two u8 each (x even, pitch even)
-            v = (a & 255u) + (a >> 8) + (b & 255u) + (b >> 8);
-            base[sg.off[1] + (size_t)y * sg.pitch[1] + x] = (unsigned short)v;
+    const int h = sg.h[0];
+    // h0[r], h1[r]: the four horizontal pair sums of row r, two per dword (16 bits each)
+    unsigned l1[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned hs[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int y = min(y0 + 2 * j + i, h - 1); // rows past the image only feed sums that are never stored
+            const uint2 u = *(const uint2 *)(q + (size_t)y * sg.pitch[0]);
+            hs[i][0] = (u.x & 0x00FF00FFu) + ((u.x >> 8) & 0x00FF00FFu);
+            hs[i][1] = (u.y & 0x00FF00FFu) + ((u.y >> 8) & 0x00FF00FFu);
         }
-        l1[ty][tx] = v;
+        l1[j][0] = hs[0][0] + hs[1][0]; // scale-1 sums of columns x0/2 + {0, 1} | {2, 3}: <= 1020 each, no carry between the halves
+        l1[j][1] = hs[0][1] + hs[1][1];
     }
-    __syncthreads();
-    if (tid < 64) {
-        const int tx = tid & 7, ty = tid >> 3;
-        const int x = bx * 8 + tx, y = by * 8 + ty;
-        const unsigned v = (l1[2 * ty][2 * tx] + l1[2 * ty][2 * tx + 1]) + (l1[2 * ty + 1][2 * tx] + l1[2 * ty + 1][2 * tx + 1]);
-        l2[ty][tx] = v;
-        if (x < sg.w[2] && y < sg.h[2]) base[sg.off[2] + (size_t)y * sg.pitch[2] + x] = (unsigned short)v;
+    const int x1 = x0 >> 1, y1 = y0 >> 1, x2 = x0 >> 2, y2 = y0 >> 2, x3 = x0 >> 3, y3 = y0 >> 3;
+    if (x1 < sg.w[1]) // x1 is a multiple of 4 and the pitch one of 64: the four sums stay inside the row (columns past w[1] are padding)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (y1 + j < sg.h[1]) *(uint2 *)(base + sg.off[1] + (size_t)(y1 + j) * sg.pitch[1] + x1) = make_uint2(l1[j][0], l1[j][1]);
+    unsigned l2[2]; // rows of scale 2: two sums per dword
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned a = l1[2 * j][0] + l1[2 * j + 1][0], b = l1[2 * j][1] + l1[2 * j + 1][1]; // vertical pairs (<= 2040 per half)
+        l2[j] = ((a & 0xFFFFu) + (a >> 16)) | (((b & 0xFFFFu) + (b >> 16)) << 16);
     }
-    __syncthreads();
-    if (tid < 16) {
-        const int tx = tid & 3, ty = tid >> 2;
-        const int x = bx * 4 + tx, y = by * 4 + ty;
-        const unsigned v = (l2[2 * ty][2 * tx] + l2[2 * ty][2 * tx + 1]) + (l2[2 * ty + 1][2 * tx] + l2[2 * ty + 1][2 * tx + 1]);
-        l3[ty][tx] = v;
-        if (x < sg.w[3] && y < sg.h[3]) base[sg.off[3] + (size_t)y * sg.pitch[3] + x] = (unsigned short)v;
-    }
-    __syncthreads();
-    if (tid < 4) {
-        const int tx = tid & 1, ty = tid >> 1;
-        const int x = bx * 2 + tx, y = by * 2 + ty;
-        const unsigned v = (l3[2 * ty][2 * tx] + l3[2 * ty][2 * tx + 1]) + (l3[2 * ty + 1][2 * tx] + l3[2 * ty + 1][2 * tx + 1]);
-        if (x < sg.w[4] && y < sg.h[4]) base[sg.off[4] + (size_t)y * sg.pitch[4] + x] = (unsigned short)v;
-    }
+    if (x2 < sg.w[2])
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (y2 + j < sg.h[2]) *(unsigned *)(base + sg.off[2] + (size_t)(y2 + j) * sg.pitch[2] + x2) = l2[j];
+    const unsigned t = l2[0] + l2[1];
+    const unsigned l3 = (t & 0xFFFFu) + (t >> 16);
+    if (x3 < sg.w[3] && y3 < sg.h[3]) base[sg.off[3] + (size_t)y3 * sg.pitch[3] + x3] = (unsigned short)l3;
+    // scale 4: the 2 x 2 lane group (lanes are 8 x 8 row-major: right neighbour lane ^ 1, lower one lane ^ 8)
+    const unsigned l4 = (l3 + tm_shfl_xor_u32(l3, 1)) + (tm_shfl_xor_u32(l3, 8) + tm_shfl_xor_u32(l3, 9));
+    if (!(lane & 1) && !(lane & 8) && (x0 >> 4) < sg.w[4] && (y0 >> 4) < sg.h[4])
+        base[sg.off[4] + (size_t)(y0 >> 4) * sg.pitch[4] + (x0 >> 4)] = (unsigned short)l4;
 }
 
 #ifdef TM_EMULATE
 static inline tmdev::tm_f2 operator+(tmdev::tm_f2 a, tmdev::tm_f2 b) { return {a.x + b.x, a.y + b.y}; }
 #endif
+
+// n / d for operands far from the ends of the exponent range (here: |n| <= 2.7e5 or 0, 6.5 <= d <= 2.7e5): the sequence the
+// compiler emits for an IEEE division -- reciprocal, one Newton step on it, quotient, two residual corrections -- without
+// v_div_scale / v_div_fixup, which only act on operands that need rescaling or are special: same operations on the same
+// values, hence the same correctly rounded quotient, 8 instead of 12 instructions.
+__device__ __forceinline__ float ssim_div(float n, float d)
+{
+#ifdef TM_EMULATE
+    return n / d;
+#else
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    const float q0 = n * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+#endif
+}
 
 // One (strip, segment) item.  S0: scale 0 (u8 planes) / pyramid scale (u16 box sums, value = sum * inv); NEED_L: also the
 // luminance term and the sum of l * cs.  acc: [sum of l * cs, sum of cs] of the lane's valid windows.
@@ -156,7 +179,8 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
         else { v0 = (float)(raw & 0xFFFFu) * inv; v1 = (float)(raw >> 16) * inv; }
         if (!in1) v1 = 0.0f;
     };
-    constexpr int PF = 11; // rows of load prefetch (= the window depth, so that one unroll of 11 makes every slot static)
+    constexpr int PF = 3; // rows of load prefetch: a shift register (two moves per row; a ring with static slots would need an
+                          // unroll of 33, or 16 more registers at depth 11 -- which cost the third wave per SIMD)
     unsigned pa[PF], pb[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) load(y_base + k, pa[k], pb[k]);
@@ -176,9 +200,11 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
             const int t = t0 + j;
             if (t < n_rows) { // wave-uniform
                 float r0, r1, d0, d1;
-                unpack(pa[j % PF], r0, r1);
-                unpack(pb[j % PF], d0, d1);
-                load(y_base + t + PF, pa[j % PF], pb[j % PF]);
+                unpack(pa[0], r0, r1);
+                unpack(pb[0], d0, d1);
+#pragma unroll
+                for (int k = 0; k + 1 < PF; ++k) { pa[k] = pa[k + 1]; pb[k] = pb[k + 1]; }
+                load(y_base + t + PF, pa[PF - 1], pb[PF - 1]);
                 __builtin_amdgcn_wave_barrier();
                 rowbuf[lane][0] = f2_make(r0, d0); rowbuf[lane][1] = f2_make(r1, d1);
                 __builtin_amdgcn_wave_barrier();
@@ -218,11 +244,11 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
                     const tm_f2 mxx = mx * mx, myy = my * my, mxy = mx * my;
                     const tm_f2 sx = f2_make(v23[0].x, v23[1].x) - mxx, sy = f2_make(v23[0].y, v23[1].y) - myy, sxy = v4 - mxy;
                     const tm_f2 csn = f2_fma(two, sxy, C2), csd = (sx + sy) + C2;
-                    const float cs0 = csn.x / csd.x, cs1 = csn.y / csd.y;
+                    const float cs0 = ssim_div(csn.x, csd.x), cs1 = ssim_div(csn.y, csd.y);
                     a_cs[0] += (double)cs0; a_cs[1] += (double)cs1;
                     if (NEED_L) {
                         const tm_f2 ln = f2_fma(two, mxy, C1), ld = (mxx + myy) + C1;
-                        const float l0 = ln.x / ld.x, l1 = ln.y / ld.y;
+                        const float l0 = ssim_div(ln.x, ld.x), l1 = ssim_div(ln.y, ld.y);
                         a_l[0] += (double)(l0 * cs0); a_l[1] += (double)(l1 * cs1);
                     }
                 }
@@ -237,7 +263,7 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
 
 // grid (slots*3, items of the scales [0, nscales)), block 64.  PART[(slot*3+c)][item][2].
 // need_l: bit s set = scale s also needs the sum of l * cs (otherwise PART[..][0] is written as 0).
-__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(2) k_ssim_stream(TmSsimGeom sg, int nscales, unsigned need_l, const unsigned char *__restrict__ Q,
+__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(3) k_ssim_stream(TmSsimGeom sg, int nscales, unsigned need_l, const unsigned char *__restrict__ Q,
                                                                          const unsigned short *__restrict__ PYR, double *__restrict__ PART)
 {
     __shared__ tmdev::tm_f2 rowbuf[72][2]; // [column pair of the strip][col 0 | col 1] = {ref, dis}

@@ -92,7 +92,8 @@ class FrameScores:
 
 @dataclass
 class HwFrame:
-    """One decoded frame.  kind: 'nv12' | 'p016' | 'rgb8' | 'rgb16' | 'rgbf32' | 'linear_f32'.
+    """One decoded frame.  kind: 'nv12' | 'p016' | 'i420' | 'rgb8' | 'rgb16' | 'rgbf32' | 'linear_f32'.
+    'i420': planar 4:2:0, `data` = (Y, Cb, Cr) arrays (uint8, or uint16 with the value in the low `bits` bits).
     data: numpy array (host memory) or any object with .data_ptr() (device memory, e.g. a torch
     tensor on the GPU).  For the biplanar kinds `data` is the whole surface (luma rows, then the CbCr
     plane at pitch*coded_height); for RGB kinds it is (h, w, 3)."""
@@ -103,6 +104,11 @@ class HwFrame:
     matrix: ColorMatrix = ColorMatrix.BT709
     full_range: bool = False
     transfer: int = ffi.TM_TRANSFER_BT709
+    bits: int = 8
+
+    @staticmethod
+    def i420(y, u, v, bits=8, matrix=ColorMatrix.BT709, full_range=False):
+        return HwFrame("i420", (y, u, v), 0, 0, matrix, full_range, bits=bits)
 
     @staticmethod
     def nv12(surface, pitch, coded_height, matrix=ColorMatrix.BT709, full_range=False):
@@ -168,6 +174,17 @@ class TurboMetrics:
 
     # -- frames -------------------------------------------------------------------------------
     def set_frame(self, slot: int, side: int, f: HwFrame):
+        if f.kind == "i420":
+            planes = [_ptr_and_mem(p) for p in f.data]
+            self._keep[(slot, side)] = [k for _, _, k in planes]
+            mems = {m for _, m, _ in planes}
+            if len(mems) != 1:
+                raise ValueError("the three planes must live in the same kind of memory")
+            pitch = lambda k: int(k.stride(0) * k.element_size()) if hasattr(k, "data_ptr") else int(k.strides[0])
+            _chk(self._L.tm_engine_set_frame_i420(self._h, slot, side, planes[0][0], planes[1][0], planes[2][0], pitch(planes[0][2]),
+                                                  pitch(planes[1][2]), int(f.bits), int(f.matrix), int(f.transfer),
+                                                  int(bool(f.full_range)), mems.pop()), "tm_engine_set_frame_i420")
+            return
         ptr, mem, keep = _ptr_and_mem(f.data)
         self._keep[(slot, side)] = keep  # device pointers must outlive the compute
         L, h = self._L, self._h

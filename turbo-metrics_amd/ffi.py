@@ -35,6 +35,7 @@ SYMBOLS = {
     "tm_engine_mem_usage": (_sz, [_vp]),
     "tm_engine_set_frame_nv12": (_i, [_vp, _u32, _i, _vp, _vp, _sz, _i, _i, _i, _i]),
     "tm_engine_set_frame_p016": (_i, [_vp, _u32, _i, _vp, _vp, _sz, _i, _i, _i, _i]),
+    "tm_engine_set_frame_i420": (_i, [_vp, _u32, _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _i, _i, _i]),
     "tm_engine_set_frame_rgb8": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
     "tm_engine_set_frame_rgb16": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
     "tm_engine_set_frame_rgbf32": (_i, [_vp, _u32, _i, _vp, _sz, _i]),

@@ -25,8 +25,6 @@ void check_dims(const char *what, uint64_t w, uint64_t h)
 
 uint32_t be32(const unsigned char *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 
-size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
-
 } // namespace
 
 // ---- probing -------------------------------------------------------------------------------------------------------
@@ -268,9 +266,7 @@ YuvStreamSource::YuvStreamSource(FILE *in, bool y4m, uint32_t w, uint32_t h, int
 {
     const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
     planar_bytes_ = ((size_t)w_ * h_ + 2 * cw * ch) * bps;
-    pitch_ = round_up(std::max((size_t)w_, cw * 2) * bps, 256);
-    surface_bytes_ = pitch_ * (round_up(h_, 2) + ch);
-    // a regular file is mapped: pictures are repacked straight out of the page cache
+    // a regular file is mapped: pictures are copied straight out of the page cache into the page-locked ring
     struct stat st;
     const int fd = fileno(in_);
     const long at = ftell(in_);
@@ -374,19 +370,19 @@ void YuvStreamSource::ensure_ring()
     const size_t n = lookahead_ + 1;
     ring_pinned_ = true;
     for (size_t i = 0; i < n; ++i) {
-        unsigned char *p = (unsigned char *)tm_host_alloc(surface_bytes_);
+        unsigned char *p = (unsigned char *)tm_host_alloc(planar_bytes_);
         if (!p) { // fall back to pageable memory for the whole ring (the engine then copies synchronously)
             for (unsigned char *q : ring_) tm_host_free(q);
             ring_.clear();
             ring_pinned_ = false;
             break;
         }
-        memset(p, 0, surface_bytes_);
+        memset(p, 0, planar_bytes_);
         ring_.push_back(p);
     }
     if (!ring_pinned_)
         for (size_t i = 0; i < n; ++i) {
-            unsigned char *p = (unsigned char *)calloc(1, surface_bytes_);
+            unsigned char *p = (unsigned char *)calloc(1, planar_bytes_);
             if (!p) fail("out of memory for the frame ring");
             ring_.push_back(p);
         }
@@ -443,47 +439,35 @@ const unsigned char *YuvStreamSource::acquire_picture()
     return planar_.data();
 }
 
+// next picture -> `surface` (planar_bytes_ bytes: Y, Cb, Cr planes back to back, as in the stream); nullptr: consume it only
 bool YuvStreamSource::read_picture(unsigned char *surface)
 {
-    const bool keep = surface != nullptr;
+    if (!map_ && surface) { // a pipe: read straight into the surface
+        if (y4m_) {
+            unsigned char tag[6];
+            const size_t got = read_bytes(tag, 5);
+            if (got == 0) return false;
+            if (got != 5 || memcmp(tag, "FRAME", 5)) fail("Y4M: expected a FRAME header");
+            unsigned char c;
+            do {
+                if (read_bytes(&c, 1) != 1) fail("Y4M: truncated FRAME header");
+            } while (c != '\n');
+        }
+        const size_t got = read_bytes(surface, planar_bytes_);
+        if (got == 0 && !y4m_) return false;
+        if (got != planar_bytes_) {
+            if (!y4m_) return false; // a trailing partial picture of a raw stream is ignored
+            fail("truncated picture in the YUV stream");
+        }
+        return true;
+    }
     const unsigned char *planar = acquire_picture();
     if (!planar) return false;
-    if (!keep) return true;
-    // planar I420 -> the NVDEC surface contract: luma rows at `pitch`, then interleaved CbCr rows at the same pitch.  The rows are
-    // independent: luma and chroma rows form one index space [0, h + ch) that the workers split.
-    const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
-    unsigned char *luma = surface, *uv = surface + pitch_ * round_up(h_, 2);
-    const int sh = 16 - bits_; // P016: the value sits in the high bits (cudarse-video/src/dec.rs:398-400)
-    const size_t bps = bits_ == 8 ? 1 : 2;
-    const unsigned char *y = planar, *u = y + (size_t)w_ * h_ * bps, *v = u + cw * ch * bps;
-    // 16-bit samples sit wherever the stream's headers left them (a file mapping: any byte offset): read them through memcpy
-    // (one unaligned 16-bit load each once compiled), little endian like the Y4M / raw formats
-    auto ld16 = [](const unsigned char *p) { uint16_t t; memcpy(&t, p, 2); return t; };
-    const std::function<void(size_t, size_t)> rows = [&](size_t first, size_t last) {
-        for (size_t r = first; r < last; ++r) {
-            if (r < h_) { // a luma row
-                if (bps == 1) memcpy(luma + r * pitch_, y + r * w_, w_);
-                else {
-                    uint16_t *o = (uint16_t *)(luma + r * pitch_);
-                    const unsigned char *srow = y + r * w_ * 2;
-                    for (uint32_t x = 0; x < w_; ++x) o[x] = (uint16_t)(ld16(srow + 2 * x) << sh);
-                }
-            } else { // a chroma row: Cb, Cr interleaved
-                const size_t cr = r - h_;
-                if (bps == 1) {
-                    unsigned char *o = uv + cr * pitch_;
-                    const unsigned char *ur = u + cr * cw, *vr = v + cr * cw;
-                    for (size_t x = 0; x < cw; ++x) { o[2 * x] = ur[x]; o[2 * x + 1] = vr[x]; }
-                } else {
-                    uint16_t *o = (uint16_t *)(uv + cr * pitch_);
-                    const unsigned char *ur = u + cr * cw * 2, *vr = v + cr * cw * 2;
-                    for (size_t x = 0; x < cw; ++x) { o[2 * x] = (uint16_t)(ld16(ur + 2 * x) << sh); o[2 * x + 1] = (uint16_t)(ld16(vr + 2 * x) << sh); }
-                }
-            }
-        }
-    };
-    if (workers_) workers_->run((size_t)h_ + ch, rows);
-    else rows(0, (size_t)h_ + ch);
+    if (!surface) return true;
+    // out of the file mapping (page cache) into the page-locked surface: the workers split the bytes
+    const std::function<void(size_t, size_t)> piece = [&](size_t first, size_t last) { memcpy(surface + first, planar + first, last - first); };
+    if (workers_) workers_->run(planar_bytes_, piece);
+    else piece(0, planar_bytes_);
     return true;
 }
 
@@ -499,11 +483,15 @@ bool YuvStreamSource::next_frame(HwFrame &out)
     unsigned char *surface = ring_[ring_pos_];
     if (!read_picture(surface)) return false;
     ring_pos_ = (ring_pos_ + 1) % ring_.size();
+    const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
     out = HwFrame{};
-    out.kind = bits_ == 8 ? HwFrame::NvDecNV12 : HwFrame::NvDecP016;
+    out.kind = HwFrame::Planar420;
     out.data = surface;
-    out.uv = surface + pitch_ * round_up(h_, 2);
-    out.pitch = pitch_;
+    out.u = surface + (size_t)w_ * h_ * bps;
+    out.v = surface + ((size_t)w_ * h_ + cw * ch) * bps;
+    out.pitch = (size_t)w_ * bps;
+    out.pitch_uv = cw * bps;
+    out.bits = bits_;
     out.pinned = ring_pinned_;
     return true;
 }

@@ -1,12 +1,13 @@
 // frame_sources.hpp -- CPU frame sources for the CLI: counterparts of the reference's FrameSource implementations
 // (turbo-metrics/src/input_image.rs:91-229 for still images; its video sources are NVDEC demux/decode, which has no
-// place on this hardware, so decoded video enters as Y4M / raw planar YUV and is repacked to the NV12 / P016 surface
-// contract of cudarse-video/src/dec.rs:299-403 that the ingest kernel consumes).
+// place on this hardware, so decoded video enters as Y4M / raw planar YUV and is handed to the engine as it is: planar 4:2:0
+// through tm_engine_set_frame_i420, which converts it exactly like the NV12 / P016 surface of cudarse-video/src/dec.rs:299-403
+// that the same samples would be repacked into).
 //
 //   ImageFrameSource   PNG (8/16-bit RGB, also Adam7), PPM P6 (8/16-bit), PFM "PF" (f32 RGB): like the reference,
 //                      only RGB sample layouts are accepted (img.rs:17-37 is todo!() for anything else)
-//   Y4mFrameSource     YUV4MPEG2, C420* 8-bit -> NV12, C420p10 / p12 / p16 -> P016 (value MSB aligned in 16 bits)
-//   RawYuvFrameSource  headerless planar I420 / I420p10 with the size given on the command line
+//   YuvStreamSource    YUV4MPEG2 (C420* 8-bit, C420p10 / p12 / p16) and headerless planar I420 / I420p10 with the size given on
+//                      the command line -> HwFrame::Planar420
 #pragma once
 #include <condition_variable>
 #include <cstdio>
@@ -60,8 +61,8 @@ private:
     uint32_t width_ = 0, height_ = 0;
 };
 
-// planar 4:2:0 stream -> biplanar surfaces
-// A few persistent workers that split the rows of one picture: repacking planar 4:2:0 into the biplanar surface is a pure
+// planar 4:2:0 stream -> page-locked planar pictures
+// A few persistent workers that split one picture: bringing it from the page cache into a page-locked surface is a pure
 // memory copy (3 MB at 1080p, 25 MB at 4K 10-bit) and one thread per stream was what bounded the CLI end to end.
 class RowWorkers {
 public:
@@ -97,6 +98,7 @@ public:
     size_t frame_count() const override { return frame_count_; }
     void skip_frames(uint32_t n) override;
     bool next_frame(HwFrame &out) override;
+    bool skip_one() override { return read_picture(nullptr); }
     void set_lookahead(size_t frames) override;
     // bytes that were read from the stream before this source took it over (the format probe of a pipe)
     void set_prefix(std::vector<unsigned char> bytes);
@@ -115,7 +117,7 @@ private:
     ColorRange cr_;
     size_t frame_count_;
     std::string codec_;
-    size_t pitch_ = 0, surface_bytes_ = 0, planar_bytes_ = 0;
+    size_t planar_bytes_ = 0;
     std::vector<unsigned char> planar_;         // pipes: one picture read with fread
     const unsigned char *map_ = nullptr;        // regular files: the whole file mapped
     size_t map_size_ = 0, map_pos_ = 0;

@@ -167,6 +167,12 @@ void TurboMetrics::set_frame(tm_engine *e, uint32_t slot, int side, const HwFram
             chk(tm_engine_set_frame_p016(e, slot, side, f.data, f.uv, f.pitch, matrix, transfer, full, mem), "tm_engine_set_frame_p016");
         break;
     }
+    case HwFrame::Planar420: {
+        const int matrix = get_color_matrix(c.first), transfer = get_transfer(c.first);
+        const int full = c.second == ColorRange::Full ? 1 : 0;
+        chk(tm_engine_set_frame_i420(e, slot, side, f.data, f.u, f.v, f.pitch, f.pitch_uv, f.bits, matrix, transfer, full, mem), "tm_engine_set_frame_i420");
+        break;
+    }
     case HwFrame::Npp8: chk(tm_engine_set_frame_rgb8(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgb8"); break;
     case HwFrame::Npp16: chk(tm_engine_set_frame_rgb16(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgb16"); break;
     case HwFrame::Npp32: chk(tm_engine_set_frame_rgbf32(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgbf32"); break;
@@ -245,7 +251,7 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     struct Fetch {
         std::mutex m;
         std::condition_variable cv;
-        bool want = false, done = false, quit = false, ok = false;
+        bool want = false, done = false, quit = false, ok = false, keep = true;
         std::exception_ptr err;
     } fx;
     std::thread helper([&] {
@@ -254,10 +260,11 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
             fx.cv.wait(lk, [&] { return fx.want || fx.quit; });
             if (fx.quit) return;
             fx.want = false;
+            const bool keep = fx.keep;
             lk.unlock();
             bool ok = false;
             std::exception_ptr err;
-            try { ok = frames_ref.next_frame(fref); } catch (...) { err = std::current_exception(); }
+            try { ok = keep ? frames_ref.next_frame(fref) : frames_ref.skip_one(); } catch (...) { err = std::current_exception(); }
             lk.lock();
             fx.ok = ok; fx.err = err; fx.done = true;
             fx.cv.notify_all();
@@ -267,20 +274,25 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
         Fetch &f; std::thread &t;
         ~Joiner() { { std::lock_guard<std::mutex> g(f.m); f.quit = true; } f.cv.notify_all(); if (t.joinable()) t.join(); }
     } joiner{fx, helper};
-    auto next_pair = [&]() {
-        { std::lock_guard<std::mutex> g(fx.m); fx.want = true; fx.done = false; }
+    // keep = false: the pair is consumed but not handed out (dropped by `every`): no upload preparation, and the sources' rings of
+    // page-locked surfaces do not advance -- a surface is only reused after `lookahead` KEPT frames, which is what the engines'
+    // asynchronous DMA relies on
+    auto next_pair = [&](bool keep) {
+        { std::lock_guard<std::mutex> g(fx.m); fx.want = true; fx.done = false; fx.keep = keep; }
         fx.cv.notify_all();
         bool ok_dis = false;
         std::exception_ptr err_dis;
-        try { ok_dis = frames_dis.next_frame(fdis); } catch (...) { err_dis = std::current_exception(); }
+        try { ok_dis = keep ? frames_dis.next_frame(fdis) : frames_dis.skip_one(); } catch (...) { err_dis = std::current_exception(); }
         std::unique_lock<std::mutex> lk(fx.m);
         fx.cv.wait(lk, [&] { return fx.done; });
         if (fx.err) std::rethrow_exception(fx.err);
         if (err_dis) std::rethrow_exception(err_dis);
         return fx.ok && ok_dis;
     };
-    while (next_pair()) {
-        if (opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0) { // lib.rs:391-394
+    for (;;) {
+        const bool dropped = opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0; // lib.rs:391-394
+        if (!next_pair(!dropped)) break;
+        if (dropped) {
             ++decode_count;
             continue;
         }

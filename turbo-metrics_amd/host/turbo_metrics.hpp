@@ -106,10 +106,15 @@ const char *to_string(ColorRange v);
 // One decoded frame handed to the engine (== HwFrame, lib.rs:125-130).  NvDecNV12 / NvDecP016 carry the surface
 // contract of an NVDEC mapping (cudarse-video/src/dec.rs:299-403): luma rows at `pitch`, interleaved CbCr at `uv`.
 struct HwFrame {
-    enum Kind { NvDecNV12, NvDecP016, Npp8, Npp16, Npp32 } kind = Npp8;
+    // Planar420: planar 4:2:0 as files deliver it (not a reference kind: its decoder only yields NV12 / P016) -- data = Y, u, v =
+    // the chroma planes at pitch_uv, `bits` = 8, or 9..16 for little-endian u16 samples with the value in the low bits
+    enum Kind { NvDecNV12, NvDecP016, Npp8, Npp16, Npp32, Planar420 } kind = Npp8;
     const void *data = nullptr; // luma plane or packed RGB
     const void *uv = nullptr;   // CbCr plane (NvDec kinds)
+    const void *u = nullptr, *v = nullptr; // Cb, Cr planes (Planar420)
     size_t pitch = 0;           // bytes
+    size_t pitch_uv = 0;        // bytes, chroma rows of Planar420
+    int bits = 8;               // Planar420
     bool device = false;        // the pointers are device memory (zero copy) rather than host memory
     bool pinned = false;        // host memory from tm_host_alloc that stays untouched until the engine has synced: async DMA
 };
@@ -132,6 +137,9 @@ public:
     virtual size_t frame_count() const = 0; // 0 when unknown
     virtual void skip_frames(uint32_t n) = 0;
     virtual bool next_frame(HwFrame &out) = 0;
+    // consume one frame that nobody will look at (`--every N` drops N-1 of N decoded frames, lib.rs:391-394): sources that
+    // prepare a frame for upload override this to skip that work and to leave their ring of page-locked surfaces alone
+    virtual bool skip_one() { HwFrame f; return next_frame(f); }
     // How many further next_frame calls a returned frame must survive (the engine reads a pinned frame asynchronously until
     // its batch has synced).  Sources that hand out pinned memory size their ring from this; call before the first frame.
     virtual void set_lookahead(size_t frames) {}
