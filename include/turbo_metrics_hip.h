@@ -86,6 +86,8 @@ typedef struct tm_frame_scores {
 /* Bind the calling process to `device` (hipSetDevice) and make sure a gfx950 device is there.
  * Fails loudly (TM_ERR_HIP / TM_ERR_UNSUPPORTED) when no usable GPU exists: there is no CPU path. */
 int tm_init(int device);
+/* number of visible devices (0 when the runtime finds none); does not bind the process to any */
+int tm_device_count(void);
 
 /* page-locked host memory for frame staging (hipHostMalloc / hipHostFree); NULL when out of memory */
 void *tm_host_alloc(size_t bytes);
@@ -210,6 +212,10 @@ enum {
 };
 int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale, int index, int channel,
                                float *out, size_t out_count);
+
+/* measurement hook: move the start of the pass-1 arena by `bytes` (multiple of 16, <= 4 MiB) inside its allocation -- how the
+ * column pass reacts to the arena's alignment can then be measured on ONE allocation (tools/v_offset_probe.py) */
+int tm_engine_debug_set_v_offset(tm_engine *e, size_t bytes);
 
 const char *tm_strerror(int code);
 /* text of the last HIP error seen by this thread's calls ("" if none) */

@@ -311,8 +311,8 @@ def test_corrupt_headers_end_in_errors_not_allocations(helper, tmp_path):
 
 
 # ---- the command line on the device ------------------------------------------------------------------------------------
-def cli(*args, stdin=None):
-    r = subprocess.run([CLI] + [str(a) for a in args], input=stdin, capture_output=True, check=False)
+def cli(*args, stdin=None, env=None):
+    r = subprocess.run([CLI] + [str(a) for a in args], input=stdin, capture_output=True, check=False, env=None if env is None else dict(os.environ, **env))
     return r.returncode, r.stdout.decode(), r.stderr.decode()
 
 
@@ -385,6 +385,34 @@ def test_cli_y4m_stream_frame_selection_batching_and_pipeline(tmp_path, bits):
     # explicit BT.709 metadata overrides the fallback
     rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--output", "json", "--color-primaries", 1, "--matrix-coefficients", 1, "--transfer-characteristics", 1)
     assert rc == 0 and "mc=BT709" in err and json.loads(out)["ssimulacra2"]["scores"] != base
+
+
+@pytest.mark.gpu
+def test_cli_shards_the_stream_over_devices_with_identical_output(tmp_path):
+    """--devices N: contiguous shards of the decode indices, one host thread + engines per shard, scores concatenated in shard
+    order -- stdout is byte-identical to the single-device run for every format and frame selection.  On the 1-GPU test box the
+    shards share the device (TM_SHARE_DEVICE=1)."""
+    w, h, n, bits = 96, 64, 23, 8
+    pairs = [tm.synth.yuv420_pair(w, h, i, bits) for i in range(n)]
+    pr, pd = str(tmp_path / "r.y4m"), str(tmp_path / "d.y4m")
+    write_y4m(pr, [p[0] for p in pairs], w, h, bits)
+    write_y4m(pd, [p[1] for p in pairs], w, h, bits)
+    share = {"TM_SHARE_DEVICE": "1"}
+    for extra in ((), ("--every", 4), ("--skip", 3, "--frames", 11), ("--skip-ref", 2, "--every", 3, "--frames", 17), ("-m", "psnr", "--batch", 2)):
+        for fmt in ("json", "json-lines", "csv", "default"):
+            one = cli(pr, pd, "-m", "ssimulacra2", "--output", fmt, "--batch", 4, *extra)
+            assert one[0] == 0, one[2]
+            for ndev in (2, 3, 5):
+                many = cli(pr, pd, "-m", "ssimulacra2", "--output", fmt, "--batch", 4, "--devices", ndev, *extra, env=share)
+                assert many[0] == 0, many[2]
+                assert many[1] == one[1], (extra, fmt, ndev)
+                assert "on %d devices" % ndev in many[2] or n < ndev
+    import torch
+    rc, _, err = cli(pr, pd, "-m", "ssimulacra2", "--devices", torch.cuda.device_count() + 1)
+    assert rc == 1 and "GPU(s) visible" in err
+    # a pipe has no length: one device, with a warning
+    rc, out, err = cli("-", pd, "-m", "ssimulacra2", "--output", "csv", "--devices", 2, stdin=open(pr, "rb").read(), env=share)
+    assert rc == 0 and "running on one device" in err and out == cli(pr, pd, "-m", "ssimulacra2", "--output", "csv")[1]
 
 
 @pytest.mark.gpu

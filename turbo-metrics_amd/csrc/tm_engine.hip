@@ -104,6 +104,7 @@ struct tm_engine {
     double *SPART = nullptr, *SSUMS = nullptr, *h_ssums = nullptr;
     hipStream_t stream = nullptr;
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr; // LIN, XYBT: reference pipeline only (TM_VARIANT_REFERENCE)
+    float *V_alloc = nullptr; // the allocation behind V (V = V_alloc + an offset inside TM_V_SLACK, see tm_engine_debug_set_v_offset)
     float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_wave -> k_ingest_upper_rd
     double *PART = nullptr, *SUMS = nullptr;
     unsigned long long *SSE = nullptr;
@@ -309,6 +310,13 @@ void tm_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
+int tm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 int tm_init(int device)
 {
     int n = 0;
@@ -324,6 +332,7 @@ int tm_init(int device)
     return TM_OK;
 }
 
+#define TM_V_SLACK ((size_t)4 << 20) /* bytes allocated beyond the pass-1 arena so that its start can be moved */
 static int g_placement_candidates = -1; // -1: not set -> environment or default
 
 void tm_set_placement_candidates(int n) { g_placement_candidates = n < 1 ? 1 : n; }
@@ -333,7 +342,7 @@ static int placement_search(tm_engine *e)
 {
     int want = g_placement_candidates;
     if (want < 0) { const char *s = getenv("TM_PLACEMENT_CANDIDATES"); want = s ? atoi(s) : 6; }
-    const size_t count = (size_t)e->cap * 5 * e->g.pyr_t, bytes = count * sizeof(float);
+    const size_t count = (size_t)e->cap * 5 * e->g.pyr_t + TM_V_SLACK / sizeof(float), bytes = count * sizeof(float);
     if (want <= 1 || bytes < ((size_t)1 << 30)) return TM_OK;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventCreate");
@@ -345,9 +354,10 @@ static int placement_search(tm_engine *e)
         if (t > 0) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes) break;
-            cand.push_back(e->V);
-            e->V = nullptr;
-            if (dev_alloc(e, &e->V, count, true) != TM_OK) { e->V = cand.back(); cand.pop_back(); (void)hipGetLastError(); break; }
+            cand.push_back(e->V_alloc);
+            e->V_alloc = nullptr;
+            if (dev_alloc(e, &e->V_alloc, count, true) != TM_OK) { e->V_alloc = cand.back(); cand.pop_back(); (void)hipGetLastError(); break; }
+            e->V = e->V_alloc;
         }
         float ms = 1e30f;
         for (int rep = 0; rep < 3; ++rep) { // the first run warms the instruction cache; the faster of the other two counts
@@ -368,12 +378,13 @@ static int placement_search(tm_engine *e)
             if (rep > 0 && m < ms) ms = m;
         }
         if (rc) break;
-        if (!best || ms < best_ms) { best = e->V; best_ms = ms; }
+        if (!best || ms < best_ms) { best = e->V_alloc; best_ms = ms; }
     }
-    cand.push_back(e->V);
+    cand.push_back(e->V_alloc);
     for (float *p : cand)
         if (p != best && p) { (void)hipFree(p); e->mem_bytes -= bytes; }
-    e->V = best ? best : cand.back();
+    e->V_alloc = best ? best : cand.back();
+    e->V = e->V_alloc;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc == TM_OK && hipMemsetAsync(e->V, 0, bytes, e->stream) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipMemset");
     if (rc == TM_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = hip_fail(hipGetLastError(), "placement search");
@@ -413,7 +424,8 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
         if ((rc = dev_alloc(e, &e->XYB, B * 2 * g.pyr, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->LIN2, B * 2 * 3 * g.s[2].plane, true))) return fail(rc);
         // LIN and XYBT (linear pyramid, transposed XYB copy) belong to the reference pipeline: allocated by tm_engine_set_variant
-        if ((rc = dev_alloc(e, &e->V, B * 5 * g.pyr_t, true))) return fail(rc);
+        if ((rc = dev_alloc(e, &e->V_alloc, B * 5 * g.pyr_t + TM_V_SLACK / sizeof(float), true))) return fail(rc);
+        e->V = e->V_alloc;
         if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
     }
@@ -457,7 +469,7 @@ void tm_engine_destroy(tm_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     for (void *p : e->staging) if (p) (void)hipFree(p);
-    (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V);
+    (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V_alloc);
     (void)hipFree(e->QU8); (void)hipFree(e->SPYR); (void)hipFree(e->SPART); (void)hipFree(e->SSUMS);
     if (e->h_ssums) (void)hipHostFree(e->h_ssums);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
@@ -893,6 +905,15 @@ int tm_engine_get_scores_batch(tm_engine *e, uint32_t first_slot, uint32_t n, tm
         const int rc = tm_engine_get_scores(e, first_slot + i, out + i);
         if (rc) return rc;
     }
+    return TM_OK;
+}
+
+int tm_engine_debug_set_v_offset(tm_engine *e, size_t bytes)
+{
+    if (!e || !e->V_alloc || bytes > TM_V_SLACK || (bytes & 15)) return TM_ERR_INVALID_ARG;
+    if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+    e->V = e->V_alloc + bytes / sizeof(float);
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old pointer
     return TM_OK;
 }
 

@@ -27,6 +27,7 @@ class FrameScoresC(C.Structure):
 _vp, _u32, _i, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
 SYMBOLS = {
     "tm_init": (_i, [_i]),
+    "tm_device_count": (_i, []),
     "tm_host_alloc": (_vp, [_sz]),
     "tm_host_free": (None, [_vp]),
     "tm_set_placement_candidates": (None, [_i]),
@@ -62,6 +63,7 @@ SYMBOLS = {
     "tm_engine_get_stage_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), _i]),
     "tm_engine_set_graph": (_i, [_vp, _i]),
     "tm_engine_set_variant": (_i, [_vp, _i]),
+    "tm_engine_debug_set_v_offset": (_i, [_vp, _sz]),
     "tm_engine_debug_read_plane": (_i, [_vp, _u32, _i, _i, _i, _i, C.POINTER(C.c_float), _sz]),
     "tm_strerror": (C.c_char_p, [_i]),
     "tm_last_hip_error": (C.c_char_p, []),

@@ -108,7 +108,6 @@ private:
     std::vector<unsigned char> prefix_;
     size_t prefix_pos_ = 0;
     bool read_picture(unsigned char *surface);
-    const unsigned char *acquire_picture();
     FILE *in_;
     bool y4m_;
     uint32_t w_, h_;
@@ -118,9 +117,9 @@ private:
     size_t frame_count_;
     std::string codec_;
     size_t planar_bytes_ = 0;
-    std::vector<unsigned char> planar_;         // pipes: one picture read with fread
-    const unsigned char *map_ = nullptr;        // regular files: the whole file mapped
-    size_t map_size_ = 0, map_pos_ = 0;
+    std::vector<unsigned char> planar_;         // pipes: scratch for a picture that is consumed but not handed out
+    int fd_ = -1;                               // regular files: positioned reads (pread), split over the workers
+    size_t file_size_ = 0, file_pos_ = 0;
     // ring of page-locked surfaces (tm_host_alloc): a frame stays valid for `lookahead` further next_frame calls, which
     // lets the engine pull it by asynchronous DMA; plain memory when page-locking fails
     std::vector<unsigned char *> ring_;

@@ -1,7 +1,7 @@
 // main.cpp -- `turbo-metrics`: the command line of the reference (crates/turbo-metrics-cli/src/main.rs:31-356) over the
 // MI355X engine.  Same positional arguments, same flags (-m/--metrics, --every, --skip, --skip-ref, --skip-dis, --frames,
 // --output), same stdout formats (output.cpp), status on stderr, ExitCode::FAILURE on the same conditions.
-// Additions (no counterpart in the reference, all optional): --batch, --device, --no-pipeline, --full-sums, and the
+// Additions (no counterpart in the reference, all optional): --batch, --device, --devices, --no-pipeline, --full-sums, and the
 // description of headerless YUV input (--width, --height, --bits, --color-primaries, --matrix-coefficients,
 // --transfer-characteristics, --full-range).
 #include <algorithm>
@@ -10,6 +10,7 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "frame_sources.hpp"
@@ -49,6 +50,7 @@ void usage(std::ostream &os)
           "      --output <OUTPUT>      stdout format [possible values: default, json, json-lines, csv]\n"
           "      --batch <N>            frame pairs per GPU launch [default: 8]\n"
           "      --device <N>           GPU ordinal [default: 0]\n"
+          "      --devices <N>          shard the frame pairs of two regular files over N GPUs (0 = all visible) [default: 1]\n"
           "      --no-pipeline          do not overlap reading/upload of the next batch with the current one\n"
           "      --full-sums            compute all 108 SSIMULACRA2 sums, also the zero-weighted ones\n"
           "      --width <W> --height <H> [--bits 8|10|12|16]   headerless planar 4:2:0 input\n"
@@ -102,7 +104,7 @@ int main(int argc, char **argv)
     Options opts;
     Output output = Output::Default;
     SourceHints hints;
-    uint32_t batch = 8, device = 0;
+    uint32_t batch = 8, device = 0, devices = 1;
     bool pipeline = true, full_sums = false;
 
     auto bad = [&](const std::string &m) {
@@ -149,6 +151,7 @@ int main(int argc, char **argv)
             if (!value(s) || !parse_output(s, output)) return bad("invalid value '" + s + "' for '--output <OUTPUT>'\n  [possible values: default, json, json-lines, csv]");
         } else if (a == "--batch") { if (!u32(batch) || batch == 0) return bad("invalid value for '--batch <N>'"); }
         else if (a == "--device") { if (!u32(device)) return bad("invalid value for '--device <N>'"); }
+        else if (a == "--devices") { if (!u32(devices)) return bad("invalid value for '--devices <N>'"); }
         else if (a == "--no-pipeline") pipeline = false;
         else if (a == "--full-sums") full_sums = true;
         else if (a == "--width") { if (!u32(hints.width)) return bad("invalid value for '--width <W>'"); }
@@ -195,6 +198,87 @@ int main(int argc, char **argv)
         // the reference logs this and carries on into undefined territory (main.rs:156-158); here it is fatal
         log_line(L_ERROR, kTarget, "Reference and distorted are not the same size");
         return EXIT_FAILURE;
+    }
+
+    // ---- frame-pair sharding over several GPUs (the reference is single-GPU: device 0 hard-coded, lib.rs:442).
+    // One host thread per device, each with its own sources (opened on the same files) and its own engines; decode indices
+    // [0, L) are cut into contiguous blocks, every thread runs the reference's selection loop on its block, and the per-frame
+    // scores are concatenated in block order: the output is byte-identical to the single-device run.  (bench.py measures the
+    // one-process-per-GPU arrangement with the RCCL reduce; inside one process the "reduce" is this concatenation.)
+    {
+        int visible = tm_device_count();
+        if (visible < 1) visible = 1;
+        // TM_SHARE_DEVICE=1 (tests on a 1-GPU box): the shards share the visible devices round-robin
+        const bool share = getenv("TM_SHARE_DEVICE") && atoi(getenv("TM_SHARE_DEVICE")) != 0;
+        uint32_t want = devices == 0 ? (uint32_t)visible : devices;
+        if (want > 1 && !share && want > (uint32_t)visible) {
+            log_line(L_ERROR, kTarget, "--devices " + std::to_string(want) + " but only " + std::to_string(visible) + " GPU(s) visible");
+            return EXIT_FAILURE;
+        }
+        const size_t known = std::min(source_ref->frame_count(), source_dis->frame_count());
+        const uint32_t lead = opts.skip + std::max(opts.skip_ref, opts.skip_dis);
+        if (want > 1 && (ref_is_stdin || dis_is_stdin || known == 0 || known <= lead)) {
+            log_line(L_WARN, kTarget, "--devices needs two regular files of known length: running on one device");
+            want = 1;
+        }
+        if (want > 1) {
+            if (metrics.mask() == 0) { log_line(L_ERROR, kTarget, "Could not initialize engine : no metric selected (-m psnr|ssim|msssim|ssimulacra2)"); return EXIT_FAILURE; }
+            uint32_t total = (uint32_t)(known - lead); // decode indices available
+            if (opts.frames > 0) total = std::min(total, opts.frames);
+            want = std::min(want, std::max(1u, total));
+            const uint32_t per = (total + want - 1) / want;
+            log_source("reference", *source_ref);
+            log_source("distorted", *source_dis);
+            const uint32_t w = source_ref->width(), h = source_ref->height();
+            source_ref.reset(); source_dis.reset(); // every shard opens its own
+            struct Shard { std::vector<FrameScores> scores; uint32_t decoded = 0; std::string err; };
+            std::vector<Shard> shards(want);
+            const auto start = std::chrono::steady_clock::now();
+            std::vector<std::thread> th;
+            for (uint32_t r = 0; r < want; ++r)
+                th.emplace_back([&, r] {
+                    Shard &sh = shards[r];
+                    try {
+                        const uint32_t lo = std::min(total, r * per), hi = std::min(total, lo + per);
+                        if (lo >= hi) return;
+                        init_hip((int)((device + r) % (uint32_t)std::max(1, visible)));
+                        auto sr = create_source(pos[0], hints), sd = create_source(pos[1], hints);
+                        uint32_t b = std::min(batch, hi - lo);
+                        TurboMetrics tmx(w, h, metrics, b, pipeline && hi - lo > b);
+                        if (full_sums) tmx.set_full_sums(true);
+                        Options o = opts;
+                        o.decode_start = lo;
+                        o.frames = hi; // absolute decode index at which this shard stops (lib.rs:396-398)
+                        uint32_t dc = 0;
+                        tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { sh.scores.push_back(fs); }, &dc);
+                        sh.decoded = dc - lo;
+                    } catch (const std::exception &e) { sh.err = e.what(); }
+                });
+            for (auto &t : th) t.join();
+            for (const Shard &sh : shards)
+                if (!sh.err.empty()) { log_line(L_ERROR, kTarget, "Computation failed : " + sh.err); return EXIT_FAILURE; }
+            output_prepare(output, metrics, std::cout);
+            std::vector<FrameScores> all;
+            uint32_t decoded = 0;
+            for (const Shard &sh : shards) {
+                for (const FrameScores &fs : sh.scores) { output_single_score(output, fs, std::cout); all.push_back(fs); }
+                decoded += sh.decoded;
+            }
+            MetricsResults results;
+            try { results = aggregate_scores(all, metrics); }
+            catch (const std::exception &e) { std::cout.flush(); log_line(L_ERROR, kTarget, std::string("Computation failed : ") + e.what()); return EXIT_FAILURE; }
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start);
+            const long long dms = ms.count() > 0 ? ms.count() : 1;
+            const unsigned long long fps = (unsigned long long)results.frame_count * 1000ull / (unsigned long long)dms;
+            char perf_s[64];
+            snprintf(perf_s, sizeof perf_s, "%.3f", (double)w * (double)h * (double)results.frame_count / (double)dms / 1000.0);
+            log_line(L_INFO, kTarget, "Processed: " + std::to_string(results.frame_count) + " (decoded: ~" + std::to_string(decoded + opts.skip) +
+                                          ") frame pairs in " + format_duration(ms) + " (" + std::to_string(fps) + " fps) (Mpx/s: " + perf_s + ") on " +
+                                          std::to_string(want) + " devices");
+            output_results(output, results, std::cout);
+            std::cout.flush();
+            return EXIT_SUCCESS;
+        }
     }
 
     std::unique_ptr<TurboMetrics> turbo;

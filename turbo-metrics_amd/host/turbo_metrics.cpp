@@ -200,6 +200,30 @@ FrameScores TurboMetrics::compute_one(const HwFrame &fref, const ColorInfo &cref
     return scores_of(eng_[0], 0);
 }
 
+MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Metrics &metrics)
+{
+    std::optional<std::vector<double>> a, b, c, d;
+    if (metrics.psnr) a.emplace();
+    if (metrics.ssim) b.emplace();
+    if (metrics.msssim) c.emplace();
+    if (metrics.ssimulacra2) d.emplace();
+    for (const FrameScores &r : frames) {
+        if (a && r.psnr) a->push_back(*r.psnr);
+        if (b && r.ssim) b->push_back(*r.ssim);
+        if (c && r.msssim) c->push_back(*r.msssim);
+        if (d && r.ssimulacra2) d->push_back(*r.ssimulacra2);
+    }
+    MetricsResults res;
+    res.frame_count = frames.size();
+    if (frames.empty() && (a || b || c || d))
+        throw std::out_of_range("no frame pair was processed (the reference panics in Stats::compute: index out of bounds)");
+    if (a) res.psnr = MetricAggregate::from(std::move(*a));
+    if (b) res.ssim = MetricAggregate::from(std::move(*b));
+    if (c) res.msssim = MetricAggregate::from(std::move(*c));
+    if (d) res.ssimulacra2 = MetricAggregate::from(std::move(*d));
+    return res;
+}
+
 MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts,
                                          const std::function<void(const FrameScores &)> &on_frame, uint32_t *decode_count_out)
 {
@@ -213,13 +237,13 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     if (metrics_.msssim) s_msssim.emplace();
     if (metrics_.ssimulacra2) s_ssimu.emplace();
 
-    uint32_t decode_count = 0;
+    uint32_t decode_count = opts.decode_start;
     size_t compute_count = 0;
     // a pinned frame is read by DMA until its batch has synced: with two engines that is up to 2 * batch frames later
     frames_ref.set_lookahead((size_t)batch_ * (eng_[1] ? 2 : 1) + 1);
     frames_dis.set_lookahead((size_t)batch_ * (eng_[1] ? 2 : 1) + 1);
-    frames_ref.skip_frames(opts.skip_ref + opts.skip);
-    frames_dis.skip_frames(opts.skip_dis + opts.skip);
+    frames_ref.skip_frames(opts.skip_ref + opts.skip + opts.decode_start);
+    frames_dis.skip_frames(opts.skip_dis + opts.skip + opts.decode_start);
 
     // A batch in flight on engine `cur` while the next one is being read and uploaded into the other engine.
     uint32_t filled[2] = {0, 0};

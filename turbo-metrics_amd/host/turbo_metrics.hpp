@@ -38,6 +38,10 @@ struct Metrics {
 
 struct Options {
     uint32_t every = 0, skip = 0, skip_ref = 0, skip_dis = 0, frames = 0;
+    // Not a reference field -- frame-pair sharding across devices: this call is one shard of a longer stream and
+    // starts at decode index `decode_start` (that many further pairs are skipped first, and the `every` / `frames` arithmetic
+    // of lib.rs:391-398 continues from there, so that the shards together select exactly the frames one call would).
+    uint32_t decode_start = 0;
 };
 
 struct MetricAggregate {
@@ -103,6 +107,9 @@ const char *to_string(TransferCharacteristic v);
 const char *to_string(ColorRange v);
 
 // ---- frames ----------------------------------------------------------------------------------------------------
+// the aggregate of per-frame scores in stream order (what compute_all returns; also how the shards of several devices are merged)
+MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Metrics &metrics);
+
 // One decoded frame handed to the engine (== HwFrame, lib.rs:125-130).  NvDecNV12 / NvDecP016 carry the surface
 // contract of an NVDEC mapping (cudarse-video/src/dec.rs:299-403): luma rows at `pitch`, interleaved CbCr at `uv`.
 struct HwFrame {
