@@ -93,13 +93,15 @@ int tm_device_count(void);
 void *tm_host_alloc(size_t bytes);
 void tm_host_free(void *p);
 
-/* Placement search at engine creation (process-wide setting, default 6, 1 = off; also TM_PLACEMENT_CANDIDATES in the environment).
- * The column pass stores transposed 128-B lines over the whole pass-1 arena, and how fast that goes depends on where the
- * arena lands physically: the same kernel on the same box takes 1.04 ... 1.24 ms per 32 1080p pairs from one allocation to the
- * next.  For arenas of 1 GiB and more tm_engine_create therefore allocates up to `n` candidates, times
- * the column pass and the row pass on each (neither has a data-dependent branch) and keeps the fastest; the others are freed before it
- * returns.  Costs ~10 ms per candidate and, while it runs, n times the arena's memory (it stops early when less than twice the
- * arena is free). */
+/* Placement search at engine creation (process-wide setting, default 4, 1 = off; also TM_PLACEMENT_CANDIDATES in the environment).
+ * The column pass stores transposed 128-B lines over the whole pass-1 arena, and how fast that goes depends on the PHYSICAL
+ * backing of the allocation: the same kernel takes 2.14 ... 2.47 ms per 64 1080p pairs from one allocation to the next, while
+ * moving the arena's start inside one allocation changes nothing (profiles/r02d_v_offset_probe.json) -- so there is no
+ * alignment rule to apply instead.  For arenas of 1 GiB and more tm_engine_create therefore allocates up to `n` candidates,
+ * times the column pass and the row pass on each (neither has a data-dependent branch) and keeps the fastest; the others are
+ * freed before it returns.  Costs ~10 ms per candidate and, WHILE IT RUNS, up to n times the arena's memory (not reflected by
+ * tm_engine_mem_usage afterwards): it stops early when the candidates would hold more than a quarter of the device's memory or
+ * when less than twice the arena is free. */
 void tm_set_placement_candidates(int n);
 
 int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t metrics_mask,

@@ -172,6 +172,8 @@ __device__ __forceinline__ float div_const(float x, float c, float rc)
 __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ tab)
 {
     const float THRESHOLD = 0.08124285829863521110029445797874f;
+    // (a branchless form -- both branches evaluated, one selected, so that the table reads of a quad's twelve evaluations are
+    // not fenced by divergent regions -- was measured: 1.44 vs 1.44 ms per 64 1080p pairs, no difference)
     if (v >= THRESHOLD) {
         if (v >= 1.0f) return 1.0f;
         const float *__restrict__ et = (const float *)(tab + 96);

@@ -10,6 +10,7 @@
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -103,9 +104,6 @@ struct tm_engine {
     unsigned short *SPYR = nullptr; // [slot][side][3] box-sum pyramid, scales 1..4
     double *SPART = nullptr, *SSUMS = nullptr, *h_ssums = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // SSIM / MS-SSIM stage beside the blur passes (ssim_overlap)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool ssim_overlap = false;
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr; // LIN, XYBT: reference pipeline only (TM_VARIANT_REFERENCE)
     float *V_alloc = nullptr; // the allocation behind V (V = V_alloc + an offset inside TM_V_SLACK, see tm_engine_debug_set_v_offset)
     float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_wave -> k_ingest_upper_rd
@@ -336,15 +334,15 @@ int tm_init(int device)
 }
 
 #define TM_V_SLACK ((size_t)4 << 20) /* bytes allocated beyond the pass-1 arena so that its start can be moved */
-static int g_placement_candidates = -1; // -1: not set -> environment or default
+static std::atomic<int> g_placement_candidates{-1}; // -1: not set -> environment or default
 
-void tm_set_placement_candidates(int n) { g_placement_candidates = n < 1 ? 1 : n; }
+void tm_set_placement_candidates(int n) { g_placement_candidates.store(n < 1 ? 1 : n); }
 
 // see include/turbo_metrics_hip.h (tm_set_placement_candidates): keep the fastest of a few allocations of the pass-1 arena
 static int placement_search(tm_engine *e)
 {
-    int want = g_placement_candidates;
-    if (want < 0) { const char *s = getenv("TM_PLACEMENT_CANDIDATES"); want = s ? atoi(s) : 6; }
+    int want = g_placement_candidates.load();
+    if (want < 0) { const char *s = getenv("TM_PLACEMENT_CANDIDATES"); want = s ? atoi(s) : 4; }
     const size_t count = (size_t)e->cap * 5 * e->g.pyr_t + TM_V_SLACK / sizeof(float), bytes = count * sizeof(float);
     if (want <= 1 || bytes < ((size_t)1 << 30)) return TM_OK;
     hipEvent_t e0, e1;
@@ -356,7 +354,9 @@ static int placement_search(tm_engine *e)
     for (int t = 0; t < want; ++t) {
         if (t > 0) {
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes) break;
+            // memory budget: the candidates alive at once (every one stays allocated so that the next lands elsewhere) never hold
+            // more than a quarter of the device's memory, and at least twice the arena must still be free for the next one
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes || (size_t)(t + 1) * bytes > total_b / 4) break;
             cand.push_back(e->V_alloc);
             e->V_alloc = nullptr;
             if (dev_alloc(e, &e->V_alloc, count, true) != TM_OK) { e->V_alloc = cand.back(); cand.pop_back(); (void)hipGetLastError(); break; }
@@ -461,13 +461,6 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     e->staging_size.assign(B * 2, 0);
     for (int i = 0; i <= TM_STAGE_COUNT; ++i)
         if ((he = hipEventCreate(&e->ev[i])) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
-    if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
-        if ((he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
-        if ((he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
-        if ((he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
-        const char *ov = getenv("TM_SSIM_OVERLAP");
-        e->ssim_overlap = ov && atoi(ov) != 0;
-    }
     *out = e;
     return TM_OK;
 }
@@ -478,9 +471,6 @@ void tm_engine_destroy(tm_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
-    if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (void *p : e->staging) if (p) (void)hipFree(p);
     (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V_alloc);
     (void)hipFree(e->QU8); (void)hipFree(e->SPYR); (void)hipFree(e->SPART); (void)hipFree(e->SSUMS);
@@ -629,15 +619,8 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
-    // The SSIM stage only needs the u8 planes of the ingest kernel and is bound by arithmetic, the blur passes by HBM: with
-    // ssim_overlap it runs on a second stream beside them (fork after ingest, join at the end)
-    hipStream_t main_st = st, ssim_st = st;
-    const bool fork = e->ssim_overlap && ssimu2 && (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) && e->stream2;
-    if (fork) {
-        HIPCHK(hipEventRecord(e->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-        ssim_st = e->stream2;
-    }
+    // (the SSIM stage only needs the u8 planes of the ingest kernel and is bound by arithmetic while the blur passes are bound by
+    // HBM -- but running it on a second stream beside them was measured: 7.63 k vs 7.77 k pairs/s)
     if (ssimu2) {
         const dim3 vgrid((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), hgrid((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1);
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
@@ -656,7 +639,6 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
     }
     if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
-        st = ssim_st;
         const TmSsimGeom &sg = e->sg;
         const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
         if (nscales > 1)
@@ -666,11 +648,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, need_l, QU8, e->SPYR, e->SPART);
         hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, nscales, e->SPART, e->SSUMS);
     }
-    if (fork) {
-        HIPCHK(hipEventRecord(e->ev_join, e->stream2));
-        HIPCHK(hipStreamWaitEvent(main_st, e->ev_join, 0));
-    }
-    if (ev) HIPCHK(hipEventRecord(ev[4], main_st));
+    if (ev) HIPCHK(hipEventRecord(ev[4], st));
     return TM_OK;
 }
 
