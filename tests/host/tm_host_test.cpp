@@ -8,6 +8,7 @@
 #include <sstream>
 
 #include "../../turbo-metrics_amd/host/frame_sources.hpp"
+#include "../../turbo-metrics_amd/host/video_input.hpp"
 #include "../../turbo-metrics_amd/host/output.hpp"
 #include "../../turbo-metrics_amd/host/rust_fmt.hpp"
 
@@ -99,6 +100,36 @@ int main(int argc, char **argv)
                     std::cout << (f.kind == HwFrame::Npp8 ? "rgb8 " : f.kind == HwFrame::Npp16 ? "rgb16 " : "rgbf32 ") << f.pitch << " " << w << "\n";
                 }
             }
+        } else if (cmd == "demux") { // demux PATH OUT: container codec frame_count, then OUT = [u32 len][bytes] of init() and of every demux() piece
+            FILE *f = fopen(argv[2], "rb");
+            if (!f) throw std::runtime_error("open");
+            std::string why;
+            auto dm = probe_video(f, why);
+            if (!dm) { fclose(f); std::cout << "NONE " << why << "\n"; return 0; }
+            std::ofstream out(argv[3], std::ios::binary);
+            std::vector<uint8_t> pkt;
+            auto put = [&](const std::vector<uint8_t> &v) { const uint32_t n = (uint32_t)v.size(); out.write((const char *)&n, 4); out.write((const char *)v.data(), n); };
+            dm->init(pkt);
+            put(pkt);
+            size_t n = 0;
+            auto parse_all = [&](const std::vector<uint8_t> &v) { // every header parser sees every piece (the fuzzer's way into them)
+                if (v.empty()) return;
+                (void)av1_parse_sequence_header(v.data(), v.size());
+                (void)mpeg2_parse_sequence(v.data(), v.size());
+                for (size_t i = 0; i + 4 < v.size(); ++i)
+                    if (v[i] == 0 && v[i + 1] == 0 && v[i + 2] == 1) (void)h264_parse_sps(v.data() + i + 3, v.size() - i - 3);
+            };
+            parse_all(pkt);
+            while (dm->demux(pkt)) { put(pkt); parse_all(pkt); ++n; }
+            std::cout << to_string(dm->container()) << " " << to_string(dm->codec()) << " " << dm->frame_count() << " " << n << "\n";
+        } else if (cmd == "seqhdr") { // seqhdr h264|av1|mpeg2 HEX
+            std::vector<uint8_t> b;
+            const std::string hex = argv[3];
+            for (size_t i = 0; i + 1 < hex.size(); i += 2) b.push_back((uint8_t)std::stoul(hex.substr(i, 2), nullptr, 16));
+            const std::string k = argv[2];
+            const StreamFormat f = k == "h264" ? h264_parse_sps(b.data(), b.size()) : (k == "av1" ? av1_parse_sequence_header(b.data(), b.size()) : mpeg2_parse_sequence(b.data(), b.size()));
+            std::cout << (f.valid ? 1 : 0) << " " << f.width << " " << f.height << " " << f.bit_depth << " " << f.chroma_format << " " << f.cp << " " << f.mc << " "
+                      << f.tc << " " << (f.full_range ? 1 : 0) << "\n";
         } else if (cmd == "colors") { // colors CP MC TC HEIGHT -> resolved characteristics + engine codes (or the error)
             const ColorCharacteristics c = ColorCharacteristics::from_codes(atoi(argv[2]), atoi(argv[3]), atoi(argv[4])).or_(color_characteristics_fallback(atoi(argv[5])));
             std::cout << to_string(c.cp) << " " << to_string(c.mc) << " " << to_string(c.tc) << " ";

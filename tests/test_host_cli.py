@@ -25,7 +25,7 @@ CLI = os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")
 
 @pytest.fixture(scope="module")
 def helper():
-    srcs = [os.path.join(ROOT, "tests", "host", "tm_host_test.cpp")] + [os.path.join(HOST, f) for f in ("frame_sources.cpp", "output.cpp", "turbo_metrics.cpp")]
+    srcs = [os.path.join(ROOT, "tests", "host", "tm_host_test.cpp")] + [os.path.join(HOST, f) for f in ("frame_sources.cpp", "video_input.cpp", "output.cpp", "turbo_metrics.cpp")]
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
     if not os.path.exists(HELPER) or any(os.path.getmtime(d) > os.path.getmtime(HELPER) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17"] + (["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"] if SANITIZE else [])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mutation fuzz of the host-side frame sources (PNG incl. 16-bit / Adam7, PPM, PFM, Y4M 8/10-bit) through the sanitised test
+"""Mutation fuzz of the host-side frame sources (PNG incl. 16-bit / Adam7, PPM, PFM, Y4M 8/10-bit, Matroska / IVF demuxing) through the sanitised test
 helper: TM_HOST_SANITIZE=1 python -m pytest tests/test_host_cli.py -m "not gpu" builds tests/host/tm_host_test_san
 (AddressSanitizer + UBSan, abort on report).  Every mutated file must end in exit code 0 (decoded) or 1 (clean error):
 anything else -- a sanitizer report, a signal -- is printed and counted.  usage: tools/fuzz_sources.py [iterations per seed file]"""
@@ -37,6 +37,16 @@ seeds = {
     "g.y4m": b"YUV4MPEG2 W70 H38 F30:1 Ip A1:1 C420jpeg\n" + b"".join(b"FRAME\n" + nrng.integers(0, 256, 70 * 38 + 2 * 35 * 19, dtype=np.uint8).tobytes() for _ in range(2)),
     "h.y4m": b"YUV4MPEG2 W46 H30 C420p10 XCOLORRANGE=FULL\n" + b"".join(b"FRAME\n" + nrng.integers(0, 1024, 46 * 30 + 2 * 23 * 15, dtype=np.uint16).tobytes() for _ in range(2)),
 }
+# compressed-video containers (video_input.cpp): demuxed and their sequence headers parsed; the files are built by the test writers
+sys.path.insert(0, ROOT)
+from tests import test_video_input as V  # noqa: E402
+_sps, _pps = V.h264_sps(640, 360, vui=(0, 1, 1, 1)), bytes([0x68, 0xCE, 0x3C, 0x80])
+_nal = [bytes([0x65, 1, 2, 3, i]) + bytes(range(20)) for i in range(6)]
+_seq = V.av1_sequence_header_obu(320, 240, color=(1, 1, 1))
+seeds["i.mkv"] = V.mkv_file(b"V_MPEG4/ISO/AVC", V.avcc(_sps, _pps), [(2, struct.pack(">I", len(n)) + n) for n in _nal], 640, 360)
+seeds["j.mkv"] = V.mkv_file(b"V_AV1", bytes([0x81, 8, 12, 0]) + _seq, [(2, bytes([6 << 3 | 2, 2, i, i])) for i in range(6)], 320, 240, unknown_cluster_size=True)
+seeds["k.ivf"] = V.ivf_file(b"AV01", 320, 240, [bytes([(2 << 3) | 2, 0]) + _seq + bytes([6 << 3 | 2, 1, 7])] + [bytes([6 << 3 | 2, 2, i, i]) for i in range(4)])
+seeds["l.mkv"] = V.mkv_file(b"V_MPEG2", V.mpeg2_sequence(720, 480, color=(6, 6, 6)), [(2, [b"\0\0\1\0ab", b"\0\0\1\0cd"]), (2, b"\0\0\1\0zz")], 720, 480, lacing="fixed")
 bad = 0
 runs = 0
 with tempfile.TemporaryDirectory() as d:
@@ -56,7 +66,8 @@ with tempfile.TemporaryDirectory() as d:
             open(p, "wb").write(bytes(b))
             runs += 1
             try:
-                r = subprocess.run([HELPER, "source", p, os.path.join(d, "out.bin")], capture_output=True, text=True, errors="replace", timeout=20,
+                # video containers: the demuxer + sequence-header parsers (`demux` writes the whole elementary stream); everything else: `source`
+                r = subprocess.run([HELPER, "demux" if name.endswith((".mkv", ".ivf")) else "source", p, os.path.join(d, "out.bin")], capture_output=True, text=True, errors="replace", timeout=20,
                                    env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
             except subprocess.TimeoutExpired:
                 bad += 1

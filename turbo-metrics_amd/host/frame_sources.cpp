@@ -1,5 +1,6 @@
 // frame_sources.cpp -- see frame_sources.hpp
 #include "frame_sources.hpp"
+#include "video_input.hpp"
 #include <cerrno>
 #include <fcntl.h>
 #include <unistd.h>
@@ -530,50 +531,19 @@ std::unique_ptr<FrameSource> create_source(const std::string &path, const Source
     }
 
     if (!hints.force_raw && got >= 10 && !memcmp(probe, "YUV4MPEG2 ", 10)) {
-        // the stream header ends at the first '\n'; it may be longer than the probe
-        std::string header((const char *)probe, got);
-        size_t nl = header.find('\n');
-        while (nl == std::string::npos) {
-            const int c = fgetc(f);
-            if (c == EOF) { close(); fail("Y4M: truncated stream header"); }
-            header.push_back((char)c);
-            if (c == '\n') nl = header.size() - 1;
-            if (header.size() > 4096) { close(); fail("Y4M: stream header too long"); }
+        try {
+            return open_y4m_stream(f, std::string((const char *)probe, got), !is_stdin, hints, "'" + path + "'");
+        } catch (...) { close(); throw; }
+    }
+
+    // compressed video: IVF / Matroska, demuxed here, decoded by an external decoder process (video_input.hpp)
+    std::string why_not_video = "UnknownContainer";
+    if (!hints.force_raw && !is_stdin && !(hints.width && hints.height)) {
+        if (fseek(f, 0, SEEK_SET) == 0) {
+            std::unique_ptr<Demuxer> dm;
+            try { dm = probe_video(f, why_not_video); } catch (...) { close(); throw; }
+            if (dm) return std::make_unique<VideoFrameSource>(std::move(dm), hints); // the demuxer owns the stream now
         }
-        const std::string rest = header.substr(nl + 1); // bytes of the first FRAME that the probe already consumed
-        std::istringstream ss(header.substr(10, nl - 10));
-        uint32_t w = 0, h = 0;
-        int bits = 8;
-        std::string cs = "420";
-        bool full = hints.full_range;
-        std::string tok;
-        while (ss >> tok) {
-            if (tok[0] == 'W') w = (uint32_t)std::stoul(tok.substr(1));
-            else if (tok[0] == 'H') h = (uint32_t)std::stoul(tok.substr(1));
-            else if (tok[0] == 'C') cs = tok.substr(1);
-            else if (tok == "XCOLORRANGE=FULL") full = true;
-            else if (tok == "XCOLORRANGE=LIMITED") full = false;
-        }
-        if (w == 0 || h == 0) { close(); fail("Y4M: missing W/H"); }
-        if (w > MAX_DIM || h > MAX_DIM) { close(); check_dims("Y4M", w, h); }
-        if (cs.rfind("420", 0) != 0) { close(); fail("not implemented: Y4M colourspace C" + cs + " (only 4:2:0 reaches the NV12 / P016 surfaces of the reference)"); }
-        const size_t pp = cs.find('p', 3);
-        if (pp != std::string::npos && pp + 1 < cs.size() && isdigit((unsigned char)cs[pp + 1])) bits = std::stoi(cs.substr(pp + 1));
-        if (bits != 8 && bits != 10 && bits != 12 && bits != 14 && bits != 16) { close(); fail("Y4M: unsupported bit depth in C" + cs); }
-        // the probe may have swallowed the beginning of the first FRAME: a seekable file is rewound, a pipe gets the
-        // over-read bytes handed to the source as a prefix that it consumes before touching the stream again
-        std::vector<unsigned char> prefix;
-        FILE *in = f;
-        if (!rest.empty() && (is_stdin || fseek(f, (long)(nl + 1), SEEK_SET) != 0)) prefix.assign(rest.begin(), rest.end());
-        const size_t bps = bits > 8 ? 2 : 1, cw = (w + 1) / 2, ch = (h + 1) / 2;
-        const size_t pic = ((size_t)w * h + 2 * cw * ch) * bps + 6;
-        const long total = !is_stdin ? file_size_or_zero(f) : 0;
-        const size_t count = total > (long)(nl + 1) ? ((size_t)total - (nl + 1)) / pic : 0;
-        const ColorCharacteristics cc = ColorCharacteristics::from_codes(hints.cp, hints.mc, hints.tc).or_(color_characteristics_fallback(h));
-        auto src = std::make_unique<YuvStreamSource>(in, true, w, h, bits, cc, full ? ColorRange::Full : ColorRange::Limited, count,
-                                                     "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
-        src->set_prefix(std::move(prefix));
-        return src;
     }
 
     if (hints.width && hints.height) { // headerless planar 4:2:0
@@ -591,8 +561,63 @@ std::unique_ptr<FrameSource> create_source(const std::string &path, const Source
         return src;
     }
     close();
-    fail("'" + path + "': not a PNG / PPM / PFM image nor a Y4M stream (for headerless planar YUV give --width/--height); "
-         "MKV / IVF demuxing and hardware decode of the reference are NVDEC-specific and have no counterpart here");
+    fail("'" + path + "': not a PNG / PPM / PFM image, a Y4M stream, nor an IVF / Matroska video (" + why_not_video +
+         "); for headerless planar YUV give --width/--height");
+}
+
+// The YUV4MPEG2 stream whose first bytes are `head` (everything read from `in` so far; the stream header may be longer).
+std::unique_ptr<FrameSource> open_y4m_stream(FILE *f, std::string header, bool seekable_file, const SourceHints &hints, const std::string &what)
+{
+    if (header.size() < 10) {
+        char buf[10];
+        const size_t need = 10 - header.size(), got = fread(buf, 1, need, f);
+        header.append(buf, got);
+    }
+    if (header.size() < 10 || memcmp(header.data(), "YUV4MPEG2 ", 10)) fail(what + ": not a YUV4MPEG2 stream");
+    // the stream header ends at the first '\n'; it may be longer than what was read so far
+    size_t nl = header.find('\n');
+    while (nl == std::string::npos) {
+        const int c = fgetc(f);
+        if (c == EOF) fail("Y4M: truncated stream header");
+        header.push_back((char)c);
+        if (c == '\n') nl = header.size() - 1;
+        if (header.size() > 4096) fail("Y4M: stream header too long");
+    }
+    const std::string rest = header.substr(nl + 1); // bytes of the first FRAME that were already consumed
+    std::istringstream ss(header.substr(10, nl - 10));
+    uint32_t w = 0, h = 0;
+    int bits = 8;
+    std::string cs = "420";
+    bool full = hints.full_range;
+    std::string tok;
+    while (ss >> tok) {
+        try {
+            if (tok[0] == 'W') w = (uint32_t)std::stoul(tok.substr(1));
+            else if (tok[0] == 'H') h = (uint32_t)std::stoul(tok.substr(1));
+            else if (tok[0] == 'C') cs = tok.substr(1);
+            else if (tok == "XCOLORRANGE=FULL") full = true;
+            else if (tok == "XCOLORRANGE=LIMITED") full = false;
+        } catch (const std::logic_error &) { fail("Y4M: malformed stream header"); }
+    }
+    if (w == 0 || h == 0) fail("Y4M: missing W/H");
+    if (w > MAX_DIM || h > MAX_DIM) check_dims("Y4M", w, h);
+    if (cs.rfind("420", 0) != 0) fail("not implemented: Y4M colourspace C" + cs + " (only 4:2:0 reaches the NV12 / P016 surfaces of the reference)");
+    const size_t pp = cs.find('p', 3);
+    if (pp != std::string::npos && pp + 1 < cs.size() && isdigit((unsigned char)cs[pp + 1])) bits = std::stoi(cs.substr(pp + 1));
+    if (bits != 8 && bits != 10 && bits != 12 && bits != 14 && bits != 16) fail("Y4M: unsupported bit depth in C" + cs);
+    // more than the stream header may have been read: a seekable file is rewound to the first FRAME, a pipe gets the over-read
+    // bytes handed to the source as a prefix that it consumes before touching the stream again
+    std::vector<unsigned char> prefix;
+    if (!rest.empty() && (!seekable_file || fseek(f, (long)(nl + 1), SEEK_SET) != 0)) prefix.assign(rest.begin(), rest.end());
+    const size_t bps = bits > 8 ? 2 : 1, cw = (w + 1) / 2, ch = (h + 1) / 2;
+    const size_t pic = ((size_t)w * h + 2 * cw * ch) * bps + 6;
+    const long total = seekable_file ? file_size_or_zero(f) : 0;
+    const size_t count = total > (long)(nl + 1) ? ((size_t)total - (nl + 1)) / pic : 0;
+    const ColorCharacteristics cc = ColorCharacteristics::from_codes(hints.cp, hints.mc, hints.tc).or_(color_characteristics_fallback(h));
+    auto src = std::make_unique<YuvStreamSource>(f, true, w, h, bits, cc, full ? ColorRange::Full : ColorRange::Limited, count,
+                                                 "I420" + (bits > 8 ? "p" + std::to_string(bits) : std::string()));
+    src->set_prefix(std::move(prefix));
+    return src;
 }
 
 } // namespace tm_host

@@ -99,6 +99,7 @@ public:
     void skip_frames(uint32_t n) override;
     bool next_frame(HwFrame &out) override;
     bool skip_one() override { return read_picture(nullptr); }
+    bool shardable() const override { return fd_ >= 0; }
     void set_lookahead(size_t frames) override;
     // bytes that were read from the stream before this source took it over (the format probe of a pipe)
     void set_prefix(std::vector<unsigned char> bytes);

@@ -38,7 +38,7 @@ void usage(std::ostream &os)
     os << "Turbo metrics compares two images or videos using quality metrics\n\n"
           "Usage: turbo-metrics [OPTIONS] <REFERENCE> <DISTORTED>\n\n"
           "Arguments:\n"
-          "  <REFERENCE>  Reference media. Use `-` to read from stdin\n"
+          "  <REFERENCE>  Reference media (PNG / PPM / PFM image, Y4M or raw planar YUV, IVF / Matroska video through TM_DECODER). Use `-` to read from stdin\n"
           "  <DISTORTED>  Distorted media. Use `-` to read from stdin\n\n"
           "Options:\n"
           "  -m, --metrics <METRICS>    Select the metrics to compute [possible values: psnr, ssim, msssim, ssimulacra2]\n"
@@ -173,14 +173,9 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
 
-    // Frame sources might need the device (main.rs:138-139)
-    try {
-        init_hip((int)device);
-    } catch (const std::exception &e) {
-        log_line(L_ERROR, kTarget, std::string("Could not initialize the GPU : ") + e.what());
-        return EXIT_FAILURE;
-    }
-
+    // The reference initialises the device first because its frame sources decode on it (main.rs:138-139).  Here the sources
+    // come first: a compressed-video source starts its decoder as a child process, and that must happen before this process
+    // has touched the GPU runtime (a source only page-locks memory when its first frame is asked for, after init_hip).
     std::unique_ptr<FrameSource> source_ref, source_dis;
     try {
         source_ref = create_source(pos[0], hints);
@@ -197,6 +192,12 @@ int main(int argc, char **argv)
     if (source_ref->width() != source_dis->width() || source_ref->height() != source_dis->height()) {
         // the reference logs this and carries on into undefined territory (main.rs:156-158); here it is fatal
         log_line(L_ERROR, kTarget, "Reference and distorted are not the same size");
+        return EXIT_FAILURE;
+    }
+    try {
+        init_hip((int)device);
+    } catch (const std::exception &e) {
+        log_line(L_ERROR, kTarget, std::string("Could not initialize the GPU : ") + e.what());
         return EXIT_FAILURE;
     }
 
@@ -217,8 +218,8 @@ int main(int argc, char **argv)
         }
         const size_t known = std::min(source_ref->frame_count(), source_dis->frame_count());
         const uint32_t lead = opts.skip + std::max(opts.skip_ref, opts.skip_dis);
-        if (want > 1 && (ref_is_stdin || dis_is_stdin || known == 0 || known <= lead)) {
-            log_line(L_WARN, kTarget, "--devices needs two regular files of known length: running on one device");
+        if (want > 1 && (ref_is_stdin || dis_is_stdin || known == 0 || known <= lead || !source_ref->shardable() || !source_dis->shardable())) {
+            log_line(L_WARN, kTarget, "--devices needs two regular planar-YUV files of known length: running on one device");
             want = 1;
         }
         if (want > 1) {

@@ -147,6 +147,9 @@ public:
     // consume one frame that nobody will look at (`--every N` drops N-1 of N decoded frames, lib.rs:391-394): sources that
     // prepare a frame for upload override this to skip that work and to leave their ring of page-locked surfaces alone
     virtual bool skip_one() { HwFrame f; return next_frame(f); }
+    // can a second source opened on the same path jump to an arbitrary frame cheaply?  (regular planar files: yes; images, pipes and
+    // decoded video: no) -- what `--devices N` needs to give every device its own shard of the stream
+    virtual bool shardable() const { return false; }
     // How many further next_frame calls a returned frame must survive (the engine reads a pinned frame asynchronously until
     // its batch has synced).  Sources that hand out pinned memory size their ring from this; call before the first frame.
     virtual void set_lookahead(size_t frames) {}
