@@ -344,3 +344,36 @@ def test_video_source_feeds_the_decoder_and_takes_colour_from_the_sequence_heade
     env["TM_DECODER"] = dec
     r = subprocess.run([helper, "source", p, out], capture_output=True, text=True, env=env)
     assert r.stdout.startswith("ERROR") and "sequence header says" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_scores_a_matroska_pair_through_the_decoder_pipe(tmp_path):
+    """the whole CLI on two MKV files: demuxed here, "decoded" by the stand-in decoder (started before the GPU is initialised), scored
+    on the GPU -- the scores equal the Y4M run of the same pictures, the log names container / codec / decoder like the reference"""
+    import json
+    from tests.test_host_cli import cli
+    w, h, n = 96, 64, 5
+    pairs = [tm.synth.yuv420_pair(w, h, i, 8) for i in range(n)]
+    dec = str(tmp_path / "fakedec")
+    open(dec, "w").write(FAKE_DECODER.replace('open(os.environ["TM_FAKE_Y4M"], "rb")', 'open(os.environ["TM_FAKE_Y4M_" + ("REF" if data.find(b"REFSIDE") >= 0 else "DIS")], "rb")'))
+    os.chmod(dec, os.stat(dec).st_mode | stat.S_IXUSR)
+    sps, pps = h264_sps(w, h, vui=(0, 6, 6, 6)), bytes([0x68, 0xCE, 0x3C, 0x80])
+    files = {}
+    for side, tag in ((0, b"REFSIDE"), (1, b"DISSIDE")):
+        y4m = str(tmp_path / f"{side}.y4m")
+        write_y4m(y4m, [pr[side] for pr in pairs], w, h, 8)
+        nals = [bytes([0x65]) + tag] + [bytes([0x41, i]) for i in range(n - 1)]
+        mkv = str(tmp_path / f"{side}.mkv")
+        open(mkv, "wb").write(mkv_file(b"V_MPEG4/ISO/AVC", avcc(sps, pps), [(2, struct.pack(">I", len(x)) + x) for x in nals], w, h))
+        files[side] = (y4m, mkv)
+    env = {"TM_DECODER": dec, "TM_FAKE_ES": str(tmp_path / "es"), "TM_FAKE_Y4M_REF": files[0][0], "TM_FAKE_Y4M_DIS": files[1][0]}
+    rc, out, err = cli(files[0][1], files[1][1], "-m", "ssimulacra2", "-m", "psnr", "--output", "json", "--batch", 2, env=env)
+    assert rc == 0, err
+    assert "codec=Mkv/H264/fakedec" in err and "mc=BT601_525" in err and "cp=BT601_525" in err
+    rc2, out2, err2 = cli(files[0][0], files[1][0], "-m", "ssimulacra2", "-m", "psnr", "--output", "json", "--batch", 2,
+                          "--color-primaries", 6, "--matrix-coefficients", 6, "--transfer-characteristics", 6)
+    assert rc2 == 0, err2
+    assert json.loads(out) == json.loads(out2) and json.loads(out)["frame_count"] == n
+    # no decoder installed: a clear failure, exit code 1
+    rc, _, err = cli(files[0][1], files[1][1], "-m", "ssimulacra2", env={"TM_DECODER": str(tmp_path / "missing")})
+    assert rc == 1 and "Could not read reference" in err and "could not be started" in err
