@@ -180,7 +180,15 @@ __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ 
         const float s = v * 128.0f;
         const int k = (int)s;
         const float t = s - (float)k;
-        const float c0 = et[4 * k], c1 = et[4 * k + 1], c2 = et[4 * k + 2], c3 = et[4 * k + 3], c0lo = et[512 + k];
+        // byte offsets of c0lo[k] and of the cubic {c0hi, c1, c2, c3}[k]: two shifts -- left to itself the compiler derives one
+        // address from the other with a v_mul_lo_u32 by -12 (a quarter-rate instruction per evaluation)
+        unsigned kb = (unsigned)k << 2;
+#ifndef TM_EMULATE
+        asm("" : "+v"(kb));
+#endif
+        const float c0lo = *(const float *)((const char *)(et + 512) + kb);
+        const float *cub = (const float *)((const char *)et + (kb << 2));
+        const float c0 = cub[0], c1 = cub[1], c2 = cub[2], c3 = cub[3];
         float q = __builtin_fmaf(c3, t, c2);
         q = __builtin_fmaf(q, t, c1);
         return __builtin_fmaf(q, t, c0lo) + c0;

@@ -185,6 +185,8 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
     const size_t bps = kind == TM_KIND_NV12 || kind == TM_KIND_RGB8 ? 1 : (kind == TM_KIND_P016 || kind == TM_KIND_RGB16 ? 2 : 4);
     const size_t row_bytes = yuv ? (size_t)e->w * bps : (size_t)e->w * 3 * bps;
     if (pitch < row_bytes) return TM_ERR_INVALID_ARG;
+    // the ingest kernel addresses a surface with 32-bit lane offsets (row * pitch through a 24-bit multiply)
+    if (pitch >= ((size_t)1 << 24) || pitch * ((size_t)e->h + (e->h + 1) / 2) >= ((size_t)1 << 32)) return TM_ERR_INVALID_ARG;
     TmFrameDesc &d = e->h_desc[slot * 2 + side];
     if (e->in_flight) { // descriptors are read by an async copy; do not race with it
         rc = tm_engine_sync(e);
@@ -230,6 +232,7 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
     const size_t cw = (e->w + 1) / 2, ch = (e->h + 1) / 2;
     const size_t row_y = (size_t)e->w * bps, row_c = cw * bps;
     if (pitch_y < row_y || pitch_uv < row_c) return TM_ERR_INVALID_ARG;
+    if (pitch_y >= ((size_t)1 << 24) || pitch_y * (size_t)e->h >= ((size_t)1 << 32) || pitch_uv >= ((size_t)1 << 24)) return TM_ERR_INVALID_ARG;
     TmFrameDesc &d = e->h_desc[slot * 2 + side];
     if (e->in_flight) { // descriptors are read by an async copy; do not race with it
         rc = tm_engine_sync(e);

@@ -65,6 +65,18 @@ __device__ __forceinline__ bool tm_wave_sum_u32x3(unsigned (&v)[3])
 
 namespace tmk {
 
+// lane-dependent row * pitch products of the ingest kernel: v_mul_u32_u24 (full rate) instead of the 64-bit / 32-bit integer
+// multiplies (quarter rate) that size_t arithmetic compiles to.  Both factors are below 2^24 and the product below 2^32: rows
+// <= 16 384, pitches of the engine's own planes <= 2^16 floats, and tm_engine_set_frame_* refuses surfaces of 4 GB and more.
+__device__ __forceinline__ unsigned tm_mul24(unsigned a, unsigned b)
+{
+#ifdef TM_EMULATE
+    return a * b;
+#else
+    return __umul24(a, b);
+#endif
+}
+
 __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, int nrows, int pitch)
 {
     const int rc = row < nrows ? row : nrows - 1;
@@ -131,7 +143,7 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
 template <typename T, bool PLANAR>
 __device__ __forceinline__ void yuv_quad_load_pairs(const TmFrameDesc &d, int qx, int qy, unsigned (&raw)[3])
 {
-    const char *y0 = (const char *)d.p0 + (size_t)(2 * qy) * d.pitch + (size_t)(2 * qx) * sizeof(T);
+    const char *y0 = (const char *)d.p0 + tm_mul24((unsigned)(2 * qy), (unsigned)d.pitch) + (unsigned)(2 * qx) * (unsigned)sizeof(T);
     const char *y1 = y0 + d.pitch;
     const int sh = 8 * (int)sizeof(T);
     const bool aligned = (((unsigned long long)d.p0 | (PLANAR ? 0ull : (unsigned long long)d.p1) | (unsigned long long)d.pitch) & (2 * sizeof(T) - 1)) == 0; // wave-uniform
@@ -143,8 +155,9 @@ __device__ __forceinline__ void yuv_quad_load_pairs(const TmFrameDesc &d, int qx
         raw[1] = (unsigned)((const T *)y1)[0] | ((unsigned)((const T *)y1)[1] << sh);
     }
     if (PLANAR) {
-        const unsigned cb = ((const T *)((const char *)d.p1 + (size_t)qy * d.pitch2))[qx];
-        const unsigned cr = ((const T *)((const char *)d.p2 + (size_t)qy * d.pitch2))[qx];
+        const unsigned coff = tm_mul24((unsigned)qy, (unsigned)d.pitch2) + (unsigned)qx * (unsigned)sizeof(T);
+        const unsigned cb = *(const T *)((const char *)d.p1 + coff);
+        const unsigned cr = *(const T *)((const char *)d.p2 + coff);
         raw[2] = cb | (cr << sh);
         if (sizeof(T) == 2) {
             const unsigned keep = (0xFFFFu >> d.shift) * 0x10001u;
@@ -152,7 +165,7 @@ __device__ __forceinline__ void yuv_quad_load_pairs(const TmFrameDesc &d, int qx
             for (int i = 0; i < 3; ++i) raw[i] = (raw[i] & keep) << d.shift;
         }
     } else {
-        const char *uv = (const char *)d.p1 + (size_t)qy * d.pitch + (size_t)(2 * qx) * sizeof(T);
+        const char *uv = (const char *)d.p1 + tm_mul24((unsigned)qy, (unsigned)d.pitch) + (unsigned)(2 * qx) * (unsigned)sizeof(T);
         if (aligned) raw[2] = sizeof(T) == 1 ? (unsigned)*(const unsigned short *)uv : *(const unsigned *)uv;
         else raw[2] = (unsigned)((const T *)uv)[0] | ((unsigned)((const T *)uv)[1] << sh);
     }
@@ -405,7 +418,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                     if (Y0 + iy < h) {
                         const unsigned q0 = (unsigned)(int)rintf(px[iy][0][c] * 255.0f) & 255u;
                         const unsigned q1 = (unsigned)(int)rintf(px[iy][1][c] * 255.0f) & 255u;
-                        *(unsigned short *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (size_t)(Y0 + iy) * qpitch + X0) = (unsigned short)(q0 | (q1 << 8));
+                        *(unsigned short *)(QU8 + ((size_t)(slot * 2 + side) * 3 + c) * qplane + (tm_mul24((unsigned)(Y0 + iy), (unsigned)qpitch) + (unsigned)X0)) = (unsigned short)(q0 | (q1 << 8));
                     }
         }
         if (XYB == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
@@ -435,10 +448,10 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
 #pragma unroll
                 for (int iy = 0; iy < 2; ++iy)
                     if (X0 < w && Y0 + iy < h) // X0 is even and the pitch a multiple of 64 floats: the pair of pixels stays inside the row
-                        *(float4 *)(xi + 2 * (s0.off + c * s0.plane + (size_t)(Y0 + iy) * s0.pitch + X0)) =
+                        *(float4 *)(xi + 2 * (s0.off + c * s0.plane) + 2u * (tm_mul24((unsigned)(Y0 + iy), (unsigned)s0.pitch) + (unsigned)X0)) =
                             make_float4(keep[2 * iy], xv[c][2 * iy], keep[2 * iy + 1], xv[c][2 * iy + 1]);
                 if (X0 / 2 < s1.w && Y0 / 2 < s1.h)
-                    *(float2 *)(xi + 2 * (s1.off + c * s1.plane + (size_t)(Y0 / 2) * s1.pitch + X0 / 2)) = make_float2(keep[4], xv[c][4]);
+                    *(float2 *)(xi + 2 * (s1.off + c * s1.plane) + 2u * (tm_mul24((unsigned)(Y0 / 2), (unsigned)s1.pitch) + (unsigned)(X0 / 2))) = make_float2(keep[4], xv[c][4]);
             }
         }
         // ---- level-2 linear pixel of the 2 x 2 lane group (levels 2..5 are finished by k_ingest_upper_rd)
@@ -455,7 +468,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                 v[c] = ds4(l1[c], v01, v10, v11, ok2x, ok2y);
             }
             if (!(qx & 1) && !(qy & 1) && XL < s2.w && YL < s2.h) {
-                float *l2 = LIN2 + (size_t)(slot * 2 + side) * 3 * s2.plane + (size_t)YL * s2.pitch + XL;
+                float *l2 = LIN2 + (size_t)(slot * 2 + side) * 3 * s2.plane + (tm_mul24((unsigned)YL, (unsigned)s2.pitch) + (unsigned)XL);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) l2[c * s2.plane] = v[c];
             }
