@@ -168,8 +168,14 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
         const int yc = y < h ? y : h - 1;
         unsigned va = 0, vb = 0;
         if (in0) { // x is even and the pitch a multiple of 64 elements: the pair load stays inside the (padded) row
-            if (S0) { va = *(const unsigned short *)((const unsigned char *)pr + (size_t)yc * pitch + x); vb = *(const unsigned short *)((const unsigned char *)pd + (size_t)yc * pitch + x); }
-            else { va = *(const unsigned *)((const unsigned short *)pr + (size_t)yc * pitch + x); vb = *(const unsigned *)((const unsigned short *)pd + (size_t)yc * pitch + x); }
+            // the row's address is wave-uniform: pinned into SGPRs (scalar multiply) so that the lane part is a 32-bit offset -- left
+            // to the compiler it is a 64-bit vector multiply-add (quarter rate) per load
+            const size_t ro = (size_t)yc * (size_t)pitch * (S0 ? 1 : 2);
+            TM_GLOBAL_AS const char *ra = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)pr + ro);
+            TM_GLOBAL_AS const char *rb = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)pd + ro);
+            const unsigned xo = (unsigned)x * (S0 ? 1u : 2u);
+            if (S0) { va = *(TM_GLOBAL_AS const unsigned short *)(ra + xo); vb = *(TM_GLOBAL_AS const unsigned short *)(rb + xo); }
+            else { va = *(TM_GLOBAL_AS const unsigned *)(ra + xo); vb = *(TM_GLOBAL_AS const unsigned *)(rb + xo); }
         }
         const bool ok = y < h;
         a = ok ? va : 0u; b = ok ? vb : 0u;
