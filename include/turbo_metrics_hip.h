@@ -105,8 +105,9 @@ void tm_host_free(void *p);
  * backing of the allocation: the same kernel takes 2.14 ... 2.47 ms per 64 1080p pairs from one allocation to the next, while
  * moving the arena's start inside one allocation changes nothing (profiles/r02d_v_offset_probe.json) -- so there is no
  * alignment rule to apply instead.  For arenas of 1 GiB and more tm_engine_create therefore allocates up to `n` candidates,
- * times the column pass and the row pass on each (neither has a data-dependent branch) and keeps the fastest; the others are
- * freed before it returns.  Costs ~10 ms per candidate and, WHILE IT RUNS, up to n times the arena's memory (not reflected by
+ * brings the device to its steady clock (~120 ms of the two kernels: a cold device runs 10-15 % slower, more than the placements
+ * differ), times the column pass and the row pass on every candidate in turns (neither has a data-dependent branch) and keeps
+ * the fastest; the others are freed before it returns.  Costs ~0.2 s and, WHILE IT RUNS, up to n times the arena's memory (not reflected by
  * tm_engine_mem_usage afterwards): it stops early when the candidates would hold more than a quarter of the device's memory or
  * when less than twice the arena is free. */
 void tm_set_placement_candidates(int n);
