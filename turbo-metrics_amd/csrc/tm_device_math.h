@@ -55,14 +55,8 @@ __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 //   operations, 27 operations -- missed the correctly rounded value for 2 arguments per three octaves.)
 __device__ __forceinline__ tm_f2 cbrt_core2(tm_f2 a)
 {
-#ifdef TM_CBRT_SEED_F64
-    // floor(u / 3) exactly through f64 (u + 0.5 is exact, the product's error < 1e-6 against a distance of 1/6 to the next integer):
-    // three f64-rate instructions instead of the quarter-rate v_mul_hi_u32 of the integer division
-    const uint32_t qx = (uint32_t)(((double)f2u(a.x) + 0.5) * (1.0 / 3.0)), qy = (uint32_t)(((double)f2u(a.y) + 0.5) * (1.0 / 3.0));
-    tm_f2 r = f2_make(u2f(0x54a23400u - qx), u2f(0x54a23400u - qy));
-#else
+    // (floor(u / 3) through f64 -- three f64-rate instructions instead of v_mul_hi_u32 -- was measured: ingest 1.49 vs 1.44 ms, slower)
     tm_f2 r = f2_make(u2f(0x54a23400u - f2u(a.x) / 3u), u2f(0x54a23400u - f2u(a.y) / 3u));
-#endif
     const tm_f2 one = f2_splat(1.0f), c13 = f2_splat(0x1.555556p-2f);
     {
         tm_f2 t = r * r;
