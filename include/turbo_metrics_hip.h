@@ -119,7 +119,10 @@ void tm_engine_destroy(tm_engine *e);
 /* bytes of device memory held by the engine */
 size_t tm_engine_mem_usage(const tm_engine *e);
 
-/* NV12: 8-bit luma plane `y` (rows at `pitch` bytes) + interleaved CbCr plane `uv` (same pitch);
+/* Frame surfaces: `pitch` (bytes between rows) must be at least one row, below 2^24, and pitch * rows below 4 GB -- the ingest
+ * kernel addresses a surface with 32-bit lane offsets; anything else is TM_ERR_INVALID_ARG.
+ *
+ * NV12: 8-bit luma plane `y` (rows at `pitch` bytes) + interleaved CbCr plane `uv` (same pitch);
  * layout of an NVDEC mapping, cudarse-video/src/dec.rs:299-346.  Visible window starts at the origin. */
 int tm_engine_set_frame_nv12(tm_engine *e, uint32_t slot, int side, const void *y, const void *uv,
                              size_t pitch, int matrix, int transfer, int full_range, int mem);
