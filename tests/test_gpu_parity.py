@@ -394,6 +394,9 @@ def test_reference_mirror_types_and_errors():
     with pytest.raises(tm.TmError) as ei:
         eng.set_frame(0, 0, bad)
     assert ei.value.code == F.TM_ERR_UNSUPPORTED
+    with pytest.raises(tm.TmError) as ei:  # a pitch the 32-bit lane offsets of the ingest kernel cannot address (checked before any byte is read)
+        eng.set_frame(0, 0, tm.HwFrame.nv12(fr.data, 1 << 24, fr.coded_height))
+    assert ei.value.code == F.TM_ERR_INVALID_ARG
     with pytest.raises(tm.TmError) as ei:  # compute before both sides of every slot are set
         eng.compute_async(2)
     assert ei.value.code == F.TM_ERR_STATE
