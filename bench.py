@@ -362,7 +362,7 @@ def run_host_fed(ctx, args, name, B, steps, warmup):
     distinct = max(1, min(args.distinct if w * h <= 1920 * 1080 else 2, B))
     tm.set_placement_candidates(1)
     engs = [tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B) for _ in range(2)]
-    tm.set_placement_candidates(4)
+    tm.set_placement_candidates(8)
     busy = [False, False]
     n_scores = 0
 

@@ -100,7 +100,7 @@ int tm_device_count(void);
 void *tm_host_alloc(size_t bytes);
 void tm_host_free(void *p);
 
-/* Placement search at engine creation (process-wide setting, default 4, 1 = off; also TM_PLACEMENT_CANDIDATES in the environment).
+/* Placement search at engine creation (process-wide setting, default 8, 1 = off; also TM_PLACEMENT_CANDIDATES in the environment).
  * The column pass stores transposed 128-B lines over the whole pass-1 arena, and how fast that goes depends on the PHYSICAL
  * backing of the allocation: the same kernel takes 2.14 ... 2.47 ms per 64 1080p pairs from one allocation to the next, while
  * moving the arena's start inside one allocation changes nothing (profiles/r02d_v_offset_probe.json) -- so there is no
@@ -108,8 +108,8 @@ void tm_host_free(void *p);
  * brings the device to its steady clock (~120 ms of the two kernels: a cold device runs 10-15 % slower, more than the placements
  * differ), times the column pass and the row pass on every candidate in turns (neither has a data-dependent branch) and keeps
  * the fastest; the others are freed before it returns.  Costs ~0.2 s and, WHILE IT RUNS, up to n times the arena's memory (not reflected by
- * tm_engine_mem_usage afterwards): it stops early when the candidates would hold more than a quarter of the device's memory or
- * when less than twice the arena is free. */
+ * tm_engine_mem_usage afterwards): it stops early when the candidates would hold more than a third of the device's memory or
+ * when allocating the next one would leave less than a quarter of the device free. */
 void tm_set_placement_candidates(int n);
 
 int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t metrics_mask,

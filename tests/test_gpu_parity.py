@@ -512,7 +512,7 @@ def test_placement_search_changes_nothing_but_the_address():
             out.append((eng.mem_usage(), [eng.scores(s).ssimulacra2 for s in range(B)], [eng.raw_sums(s).tobytes() for s in range(B)]))
             eng.close()
     finally:
-        tm.set_placement_candidates(4)
+        tm.set_placement_candidates(8)
     assert out[0] == out[1]
 
 

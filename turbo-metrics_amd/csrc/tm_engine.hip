@@ -345,7 +345,7 @@ void tm_set_placement_candidates(int n) { g_placement_candidates.store(n < 1 ? 1
 static int placement_search(tm_engine *e)
 {
     int want = g_placement_candidates.load();
-    if (want < 0) { const char *s = getenv("TM_PLACEMENT_CANDIDATES"); want = s ? atoi(s) : 4; }
+    if (want < 0) { const char *s = getenv("TM_PLACEMENT_CANDIDATES"); want = s ? atoi(s) : 8; }
     const size_t count = (size_t)e->cap * 5 * e->g.pyr_t + TM_V_SLACK / sizeof(float), bytes = count * sizeof(float);
     if (want <= 1 || bytes < ((size_t)1 << 30)) return TM_OK;
     hipEvent_t e0, e1;
@@ -354,9 +354,9 @@ static int placement_search(tm_engine *e)
     std::vector<float *> cand{e->V_alloc};
     for (int t = 1; t < want; ++t) {
         size_t free_b = 0, total_b = 0;
-        // memory budget: the candidates alive at once never hold more than a quarter of the device's memory, and at least twice
-        // the arena must still be free for the next one
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes || (size_t)(t + 1) * bytes > total_b / 4) break;
+        // memory budget: the candidates alive at once never hold more than a third of the device's memory, and with the next one
+        // allocated a quarter of the device must still be free (other tenants of the GPU are not pushed out of memory)
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + total_b / 4 || (size_t)(t + 1) * bytes > total_b / 3) break;
         float *p = nullptr;
         e->V_alloc = nullptr;
         if (dev_alloc(e, &e->V_alloc, count, true) != TM_OK) { (void)hipGetLastError(); break; }
