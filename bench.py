@@ -461,7 +461,8 @@ def run_rank(args):
             for drop in ("unit",):
                 r.pop(drop, None)
             workloads[wl + ("_fused" if m == FUSED else "")] = r
-        host_fed = {wl: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, ks, kw) for wl in ("1080p_nv12", "4k_p016")}
+        if ctx.world == 1:  # a per-GPU PCIe figure: measured on one GPU only
+            host_fed = {wl: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, ks, kw) for wl in ("1080p_nv12", "4k_p016")}
     if ctx.rank == 0:
         out = {
             "metric": "ssimulacra2_frame_pairs_per_sec" if "ssimulacra2" in mets else "frame_pairs_per_sec",

@@ -65,7 +65,7 @@ KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 
 
 
 class Emulated:
-    """Runs the whole generation-0 pipeline for n slots; keeps the arenas for plane inspection."""
+    """Runs one of the two pipelines (variant 0 = default, 1 = reference, 0x100 = default with the wide-frame row pass) for n slots; keeps the arenas for plane inspection."""
 
     def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True, ssim_window=None, ssim_need_l=31):
         """frames: list of (ref, dis) where each is dict(kind=, data=np.ndarray, pitch=, coded_height=, matrix=)."""
@@ -106,7 +106,7 @@ class Emulated:
             weights = np.ones(108)
         weights = np.ascontiguousarray(weights, np.float64).ravel()
         assert weights.size == 108
-        # SSIM / MS-SSIM (only with the tile32 ingest, which writes the quantised u8 planes): ssim_window = the 11 taps
+        # SSIM / MS-SSIM (default pipeline only: its ingest kernel writes the quantised u8 planes): ssim_window = the 11 taps
         self.sg = None
         qu8, qplane, qpitch = None, 0, 0
         if ssim_window is not None:

@@ -38,7 +38,7 @@ def check_planes(eng, slot, fr, fd, w, h, scales=range(6), have_linear=False, ha
     sums, pyr = O.ssimulacra2_sums(lin[0], lin[1], want_xyb=True)
     for side in range(2):
         for c in range(3):
-            if have_linear:  # only the generation-0 ingest keeps linear RGB in HBM
+            if have_linear:  # only the reference pipeline keeps linear RGB in HBM
                 assert np.array_equal(eng.read_plane(slot, F.TM_PLANE_LINEAR, 0, side, c), lin[side][c]), ("linear", side, c)
     for s in scales:
         for side in range(2):
