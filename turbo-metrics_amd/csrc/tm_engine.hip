@@ -398,6 +398,8 @@ static int placement_search(tm_engine *e)
     size_t win = 0;
     for (size_t i = 1; i < cand.size(); ++i)
         if (best_of[i] < best_of[win]) win = i;
+    if (getenv("TM_PLACEMENT_DEBUG")) // tools/pmc_placement.sh: which candidate is which in the counters
+        for (size_t i = 0; i < cand.size(); ++i) fprintf(stderr, "[tm] candidate %zu at %p: %.3f ms%s\n", i, (void *)cand[i], best_of[i], i == win ? " <- kept" : "");
     for (size_t i = 0; i < cand.size(); ++i)
         if (i != win) { (void)hipFree(cand[i]); e->mem_bytes -= bytes; }
     e->V_alloc = cand[win];
