@@ -271,7 +271,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         per_kernel["k_blur_h_jobs_x"] = roof(stage_ms[F.TM_STAGE_BLUR_H], job_bytes * B)
     if has_ssim:
         per_kernel["k_ssim_stage"] = roof(stage_ms[F.TM_STAGE_SSIM], ssim_bytes * B)
-        per_kernel["k_ssim_stage"]["bound"] = "valu (11x11 separable window of 5 quantities: ~100 f32 operations per sample; HBM fraction is informative only)"
+        per_kernel["k_ssim_stage"]["bound"] = "valu (11x11 separable window of 4 quantities: 88 fused multiply-adds per window and channel; HBM fraction is informative only)"
     for kn in per_kernel:
         per_kernel[kn]["traffic"] = traffic.get(kn)
     dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else "k_ingest_wave"

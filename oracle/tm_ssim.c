@@ -32,6 +32,8 @@ void tmo_ssim_window(float g[TMO_SSIM_TAPS])
 }
 
 /* sums over the (w-10) x (h-10) windows of one plane pair: out[0] = sum ssim, out[1] = sum cs
+ * Four window means per pair: E[x], E[y], E[x^2 + y^2], E[xy] -- the two variances only ever appear as their sum
+ * (sigma_x^2 + sigma_y^2 = E[x^2 + y^2] - mu_x^2 - mu_y^2), so they are filtered as one quantity, s = fma(x, x, y * y) per sample.
  * Filtering order: rows first (taps ascending, acc = fma(g[k], v, acc) from 0), then columns the same way. */
 void tmo_ssim_plane_sums(const float *ref, const float *dis, int w, int h, double out[2])
 {
@@ -40,31 +42,30 @@ void tmo_ssim_plane_sums(const float *ref, const float *dis, int w, int h, doubl
     float g[TMO_SSIM_TAPS];
     tmo_ssim_window(g);
     const int ow = w - 10, oh = h - 10;
-    float *hx = malloc(sizeof(float) * 5 * (size_t)ow * h);
+    float *hx = malloc(sizeof(float) * 4 * (size_t)ow * h);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < ow; ++x) {
-            float a[5] = {0, 0, 0, 0, 0};
+            float a[4] = {0, 0, 0, 0};
             for (int k = 0; k < TMO_SSIM_TAPS; ++k) {
                 const float r = ref[(size_t)y * w + x + k], d = dis[(size_t)y * w + x + k];
                 a[0] = fmaf(g[k], r, a[0]);
                 a[1] = fmaf(g[k], d, a[1]);
-                a[2] = fmaf(g[k], r * r, a[2]);
-                a[3] = fmaf(g[k], d * d, a[3]);
-                a[4] = fmaf(g[k], r * d, a[4]);
+                a[2] = fmaf(g[k], fmaf(r, r, d * d), a[2]);
+                a[3] = fmaf(g[k], r * d, a[3]);
             }
-            for (int q = 0; q < 5; ++q) hx[((size_t)q * h + y) * ow + x] = a[q];
+            for (int q = 0; q < 4; ++q) hx[((size_t)q * h + y) * ow + x] = a[q];
         }
     const float C1 = 6.5025f, C2 = 58.5225f; /* (0.01*255)^2, (0.03*255)^2 */
     for (int y = 0; y < oh; ++y)
         for (int x = 0; x < ow; ++x) {
-            float a[5] = {0, 0, 0, 0, 0};
+            float a[4] = {0, 0, 0, 0};
             for (int k = 0; k < TMO_SSIM_TAPS; ++k)
-                for (int q = 0; q < 5; ++q) a[q] = fmaf(g[k], hx[((size_t)q * h + y + k) * ow + x], a[q]);
+                for (int q = 0; q < 4; ++q) a[q] = fmaf(g[k], hx[((size_t)q * h + y + k) * ow + x], a[q]);
             const float mx = a[0], my = a[1];
-            const float mxx = mx * mx, myy = my * my, mxy = mx * my;
-            const float sx = a[2] - mxx, sy = a[3] - myy, sxy = a[4] - mxy;
-            const float cs = fmaf(2.0f, sxy, C2) / ((sx + sy) + C2);
-            const float l = fmaf(2.0f, mxy, C1) / ((mxx + myy) + C1);
+            const float mxx = mx * mx, myy = my * my, mxy = mx * my, mm = mxx + myy;
+            const float sv = a[2] - mm, sxy = a[3] - mxy; /* sigma_x^2 + sigma_y^2, sigma_xy */
+            const float cs = fmaf(2.0f, sxy, C2) / (sv + C2);
+            const float l = fmaf(2.0f, mxy, C1) / (mm + C1);
             out[0] += (double)(l * cs);
             out[1] += (double)cs;
         }

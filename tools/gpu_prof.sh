@@ -8,7 +8,7 @@ mkdir -p $R/gpurun_out
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-compare --no-extras "$@" > $R/gpurun_out/${TAG}_prof.log 2>&1
 cd $R
-tail -1 gpurun_out/${TAG}_prof.log | python3 -c "
+grep '^{"metric"' gpurun_out/${TAG}_prof.log | tail -1 | python3 -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read()); print('value', round(d['value'],1), 'ms/step', round(d['ms_per_step'],3))

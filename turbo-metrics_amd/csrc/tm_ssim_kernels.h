@@ -14,16 +14,20 @@
 // and since every value is a multiple of 4^-s below 256 all of those f32 operations are exact -- the pixel equals
 // (sum of its 4^s u8 samples) * 4^-s, and the sum fits 16 bits (<= 255 * 256).  Half the bytes of an f32 pyramid, same bits.
 //
-// This stage is bound by arithmetic, not by HBM: per window and channel the separable 11-tap filter of the five quantities
-// {x, y, x^2, y^2, xy} costs 110 fused multiply-adds, against 2 bytes of input.  So the kernel is built around the VALU:
-//   * lane = TWO adjacent image columns, walking down its segment one input row per step: the products x^2, y^2, xy are
-//     formed once per loaded sample (12 per lane and row for 2 windows), not once per tap;
+// This stage is bound by arithmetic, not by HBM.  SSIM needs four window means per channel -- E[x], E[y], E[xy] and
+// E[x^2 + y^2]: the variances only ever appear as their sum, sigma_x^2 + sigma_y^2 = E[x^2 + y^2] - mu_x^2 - mu_y^2 -- so the
+// separable 11-tap filter costs 88 fused multiply-adds per window and channel, against 2 bytes of input.  The kernel is built
+// around the VALU:
+//   * lane = TWO adjacent image columns, walking down its segment one input row per step: the per-sample quantities
+//     s = fma(x, x, y * y) and p = x * y are formed ONCE per sample by the lane that loaded it and travel to the five
+//     neighbour lanes that need them with the sample itself: {x, y, s, p} is one 16-byte LDS element per column;
 //   * everything is said on register pairs so that the filters run as v_pk_fma_f32 (two fused multiply-adds per
-//     instruction): the row filter on {x, y} and {x^2, y^2} pairs of one column, the column filter on the same pairs plus the
-//     {xy(col 0), xy(col 1)} pair, the SSIM terms on {col 0, col 1} pairs;
-//   * neighbours' samples come from a 1-KB wave-private LDS row as five ds_read_b128 per row (no workgroup barrier: LDS
-//     operations of one wave execute in order); the row-filtered values live in an 11-row register window (static slots
-//     through an unroll of 11), the column filter reads registers only;
+//     instruction): row filter and column filter on the {x, y} and {s, p} pairs of one column, the SSIM terms on
+//     {col 0, col 1} pairs;
+//   * neighbours' columns come from a 2.3-KB wave-private LDS row as ten conflict-free ds_read_b128 per row (even and odd
+//     columns in separate arrays: lane stride 16 bytes; no workgroup barrier: LDS operations of one wave execute in order);
+//     the row-filtered values live in an 11-row register window (static slots through an unroll of 11), the column filter
+//     reads registers only;
 //   * need_l: the luminance term l (one of the two IEEE divisions per window) is only evaluated where its sum is used --
 //     MS-SSIM uses the contrast-structure term alone on scales 0..3 (Wang et al. 2003); tm_engine_set_full_sums(e, 1)
 //     evaluates everything.
@@ -150,10 +154,13 @@ __device__ __forceinline__ float ssim_div(float n, float d)
 #endif
 }
 
+// one image column of one row on its way through LDS: the sample pair and its two per-sample quantities
+struct __attribute__((aligned(16))) TmSsimCol { tmdev::tm_f2 rd, sp; }; // {ref, dis}, {ref^2 + dis^2, ref * dis}
+
 // One (strip, segment) item.  S0: scale 0 (u8 planes) / pyramid scale (u16 box sums, value = sum * inv); NEED_L: also the
 // luminance term and the sum of l * cs.  acc: [sum of l * cs, sum of cs] of the lane's valid windows.
 template <bool S0, bool NEED_L>
-__device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2], const void *__restrict__ pr, const void *__restrict__ pd,
+__device__ __forceinline__ void ssim_strip(TmSsimCol *__restrict__ bufE, TmSsimCol *__restrict__ bufO, const void *__restrict__ pr, const void *__restrict__ pd,
                                            int pitch, float inv, int w, int h, int x, int y_base, int y_end, const float (&gw)[TM_SSIM_TAPS],
                                            double (&acc)[2])
 {
@@ -186,17 +193,17 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
         if (!in1) v1 = 0.0f;
     };
     constexpr int PF = 3; // rows of load prefetch: a shift register (two moves per row; a ring with static slots would need an
-                          // unroll of 33, or 16 more registers at depth 11 -- which cost the third wave per SIMD)
+                          // unroll of 33, or 16 more registers at depth 11)
     unsigned pa[PF], pb[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) load(y_base + k, pa[k], pb[k]);
     tm_f2 g2[TM_SSIM_TAPS];
 #pragma unroll
     for (int k = 0; k < TM_SSIM_TAPS; ++k) g2[k] = f2_splat(gw[k]);
-    // the 11-row window of row-filtered values: per column {x, y} and {x^2, y^2} pairs, and the {xy(col 0), xy(col 1)} pair
-    tm_f2 w01[11][2], w23[11][2], w4[11];
+    // the 11-row window of row-filtered values: per column the {x, y} and the {x^2 + y^2, xy} pair
+    tm_f2 w01[11][2], w23[11][2];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) { w01[k][0] = w01[k][1] = w23[k][0] = w23[k][1] = w4[k] = f2_splat(0.0f); }
+    for (int k = 0; k < 11; ++k) { w01[k][0] = w01[k][1] = w23[k][0] = w23[k][1] = f2_splat(0.0f); }
     const tm_f2 C1 = f2_splat(6.5025f), C2 = f2_splat(58.5225f), two = f2_splat(2.0f); // (0.01*255)^2, (0.03*255)^2
     double a_l[2] = {0.0, 0.0}, a_cs[2] = {0.0, 0.0};
     const int n_rows = (y_end - y_base) + 10; // input rows y_base .. y_end+9
@@ -211,49 +218,40 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
 #pragma unroll
                 for (int k = 0; k + 1 < PF; ++k) { pa[k] = pa[k + 1]; pb[k] = pb[k + 1]; }
                 load(y_base + t + PF, pa[PF - 1], pb[PF - 1]);
+                // columns x .. x+11 as {ref, dis} and {ref^2 + dis^2, ref * dis} pairs: the own two computed here, ten from the neighbours
+                TmSsimCol c[12];
+                c[0].rd = f2_make(r0, d0); c[0].sp = f2_make(__builtin_fmaf(r0, r0, d0 * d0), r0 * d0);
+                c[1].rd = f2_make(r1, d1); c[1].sp = f2_make(__builtin_fmaf(r1, r1, d1 * d1), r1 * d1);
                 __builtin_amdgcn_wave_barrier();
-                rowbuf[lane][0] = f2_make(r0, d0); rowbuf[lane][1] = f2_make(r1, d1);
+                bufE[lane] = c[0]; bufO[lane] = c[1];
                 __builtin_amdgcn_wave_barrier();
-                // samples of columns x .. x+11 as {ref, dis} pairs: the own two from registers, ten from the neighbours
-                tm_f2 s[12];
-                s[0] = f2_make(r0, d0); s[1] = f2_make(r1, d1);
 #pragma unroll
-                for (int i = 1; i < 6; ++i) { s[2 * i] = rowbuf[lane + i][0]; s[2 * i + 1] = rowbuf[lane + i][1]; }
+                for (int i = 1; i < 6; ++i) { c[2 * i] = bufE[lane + i]; c[2 * i + 1] = bufO[lane + i]; }
                 // row filter of the two windows that start at columns x and x+1: taps ascending, fma from 0
                 tm_f2 a01[2] = {f2_splat(0.0f), f2_splat(0.0f)}, a23[2] = {f2_splat(0.0f), f2_splat(0.0f)};
-                float a4[2] = {0.0f, 0.0f};
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    const tm_f2 sq = s[i] * s[i];
-                    const float p = s[i].x * s[i].y;
-                    if (i < 11) { a01[0] = f2_fma(g2[i], s[i], a01[0]); a23[0] = f2_fma(g2[i], sq, a23[0]); a4[0] = __builtin_fmaf(gw[i], p, a4[0]); }
-                    if (i > 0) { a01[1] = f2_fma(g2[i - 1], s[i], a01[1]); a23[1] = f2_fma(g2[i - 1], sq, a23[1]); a4[1] = __builtin_fmaf(gw[i - 1], p, a4[1]); }
+                    if (i < 11) { a01[0] = f2_fma(g2[i], c[i].rd, a01[0]); a23[0] = f2_fma(g2[i], c[i].sp, a23[0]); }
+                    if (i > 0) { a01[1] = f2_fma(g2[i - 1], c[i].rd, a01[1]); a23[1] = f2_fma(g2[i - 1], c[i].sp, a23[1]); }
                 }
                 w01[j % 11][0] = a01[0]; w01[j % 11][1] = a01[1]; w23[j % 11][0] = a23[0]; w23[j % 11][1] = a23[1];
-#ifndef TM_EMULATE
-                // keeps the two xy chains scalar (12 products + 22 fma): left alone, the SLP vectorizer pairs them tap by tap, which
-                // costs four register moves per tap to line up {xy(i), xy(i+1)} -- 66 instead of 34 instructions
-                asm volatile("" : "+v"(a4[0]), "+v"(a4[1]));
-#endif
-                w4[j % 11] = f2_make(a4[0], a4[1]);
                 if (t >= 10) { // window rows t-10 .. t are in slots (j+1)%11 .. j%11
-                    tm_f2 v01[2] = {f2_splat(0.0f), f2_splat(0.0f)}, v23[2] = {f2_splat(0.0f), f2_splat(0.0f)}, v4 = f2_splat(0.0f);
+                    tm_f2 v01[2] = {f2_splat(0.0f), f2_splat(0.0f)}, v23[2] = {f2_splat(0.0f), f2_splat(0.0f)};
 #pragma unroll
                     for (int k = 0; k < TM_SSIM_TAPS; ++k) {
                         const int q = (j + 1 + k) % 11;
                         v01[0] = f2_fma(g2[k], w01[q][0], v01[0]); v01[1] = f2_fma(g2[k], w01[q][1], v01[1]);
                         v23[0] = f2_fma(g2[k], w23[q][0], v23[0]); v23[1] = f2_fma(g2[k], w23[q][1], v23[1]);
-                        v4 = f2_fma(g2[k], w4[q], v4);
                     }
                     // the two windows side by side: {col 0, col 1} pairs
                     const tm_f2 mx = f2_make(v01[0].x, v01[1].x), my = f2_make(v01[0].y, v01[1].y);
-                    const tm_f2 mxx = mx * mx, myy = my * my, mxy = mx * my;
-                    const tm_f2 sx = f2_make(v23[0].x, v23[1].x) - mxx, sy = f2_make(v23[0].y, v23[1].y) - myy, sxy = v4 - mxy;
-                    const tm_f2 csn = f2_fma(two, sxy, C2), csd = (sx + sy) + C2;
+                    const tm_f2 mxx = mx * mx, myy = my * my, mxy = mx * my, mm = mxx + myy;
+                    const tm_f2 sv = f2_make(v23[0].x, v23[1].x) - mm, sxy = f2_make(v23[0].y, v23[1].y) - mxy; // sigma_x^2 + sigma_y^2, sigma_xy
+                    const tm_f2 csn = f2_fma(two, sxy, C2), csd = sv + C2;
                     const float cs0 = ssim_div(csn.x, csd.x), cs1 = ssim_div(csn.y, csd.y);
                     a_cs[0] += (double)cs0; a_cs[1] += (double)cs1;
                     if (NEED_L) {
-                        const tm_f2 ln = f2_fma(two, mxy, C1), ld = (mxx + myy) + C1;
+                        const tm_f2 ln = f2_fma(two, mxy, C1), ld = mm + C1;
                         const float l0 = ssim_div(ln.x, ld.x), l1 = ssim_div(ln.y, ld.y);
                         a_l[0] += (double)(l0 * cs0); a_l[1] += (double)(l1 * cs1);
                     }
@@ -269,10 +267,13 @@ __device__ __forceinline__ void ssim_strip(tmdev::tm_f2 (*__restrict__ rowbuf)[2
 
 // grid (slots*3, items of the scales [0, nscales)), block 64.  PART[(slot*3+c)][item][2].
 // need_l: bit s set = scale s also needs the sum of l * cs (otherwise PART[..][0] is written as 0).
-__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(3) k_ssim_stream(TmSsimGeom sg, int nscales, unsigned need_l, const unsigned char *__restrict__ Q,
+#ifndef TM_SSIM_WAVES
+#define TM_SSIM_WAVES 3
+#endif
+__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(TM_SSIM_WAVES) k_ssim_stream(TmSsimGeom sg, int nscales, unsigned need_l, const unsigned char *__restrict__ Q,
                                                                          const unsigned short *__restrict__ PYR, double *__restrict__ PART)
 {
-    __shared__ tmdev::tm_f2 rowbuf[72][2]; // [column pair of the strip][col 0 | col 1] = {ref, dis}
+    __shared__ TmSsimCol bufE[72], bufO[72]; // [lane (+ 8 to the right)]: the even / the odd column of the lane's pair
     const int lane = threadIdx.x;
     const int slot = blockIdx.x / 3, c = blockIdx.x % 3;
     int s = 0;
@@ -284,7 +285,10 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(3) k_ssim_stream(TmSsimG
     const int x_base = (item % sg.strips_x[s]) * TM_SSIM_STRIP, y_base = (item / sg.strips_x[s]) * sg.seg_rows[s];
     const int y_end = min(y_base + sg.seg_rows[s], h - 10); // window rows [y_base, y_end)
     const int x = x_base + 2 * lane;
-    if (lane < 8) { rowbuf[64 + lane][0] = tmdev::f2_splat(0.0f); rowbuf[64 + lane][1] = tmdev::f2_splat(0.0f); } // the halo lanes' right-hand neighbours
+    if (lane < 8) { // the halo lanes' right-hand neighbours
+        TmSsimCol z; z.rd = z.sp = tmdev::f2_splat(0.0f);
+        bufE[64 + lane] = z; bufO[64 + lane] = z;
+    }
     float gw[TM_SSIM_TAPS];
 #pragma unroll
     for (int k = 0; k < TM_SSIM_TAPS; ++k) gw[k] = sg.g[k];
@@ -292,13 +296,13 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(3) k_ssim_stream(TmSsimG
     const bool nl = (need_l >> s) & 1u;
     if (s == 0) {
         const unsigned char *qr = Q + ((size_t)(slot * 2 + 0) * 3 + c) * sg.qplane, *qd = Q + ((size_t)(slot * 2 + 1) * 3 + c) * sg.qplane;
-        if (nl) ssim_strip<true, true>(rowbuf, qr, qd, sg.pitch[0], 1.0f, w, h, x, y_base, y_end, gw, acc);
-        else ssim_strip<true, false>(rowbuf, qr, qd, sg.pitch[0], 1.0f, w, h, x, y_base, y_end, gw, acc);
+        if (nl) ssim_strip<true, true>(bufE, bufO, qr, qd, sg.pitch[0], 1.0f, w, h, x, y_base, y_end, gw, acc);
+        else ssim_strip<true, false>(bufE, bufO, qr, qd, sg.pitch[0], 1.0f, w, h, x, y_base, y_end, gw, acc);
     } else {
         const unsigned short *fr = ssim_plane_s(sg, PYR, slot * 2 + 0, c, s), *fd = ssim_plane_s(sg, PYR, slot * 2 + 1, c, s);
         const float inv = 1.0f / (float)(1 << (2 * s)); // 4^-s, exact
-        if (nl) ssim_strip<false, true>(rowbuf, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
-        else ssim_strip<false, false>(rowbuf, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
+        if (nl) ssim_strip<false, true>(bufE, bufO, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
+        else ssim_strip<false, false>(bufE, bufO, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
     }
 #ifdef TM_EMULATE
     { // CPU lane emulation runs the 64 lanes as concurrent host threads: sum through memory, not through shuffles
