@@ -606,3 +606,67 @@ def test_extreme_samples_match_oracle():
         if slot < 4:
             assert eng.sse(slot) == O.psnr(lin[0], lin[1])[0]
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_sweep_of_sizes_kinds_and_metric_masks(seed):
+    """seeded random cases over what a caller can vary at once: frame size (incl. sizes around the tile / strip / segment borders
+    of the kernels), input kind, colour matrix, metric mask, pruned or full sums, batch with different content per slot"""
+    rng = np.random.default_rng(1000 + seed)
+    edges = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 117, 118, 119, 127, 128, 129, 191, 192, 193, 202, 203, 255, 256, 257, 383, 384, 385]
+    w = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 420))
+    h = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 420))
+    kind = str(rng.choice(["nv12", "p016", "rgb8", "rgb16", "rgbf32"]))
+    matrix = tm.ColorMatrix(int(rng.integers(0, 3)))
+    want_ms = w >= 176 and h >= 176 and rng.random() < 0.7
+    want_ssim = w >= 11 and h >= 11 and rng.random() < 0.7
+    m = tm.Metrics(ssimulacra2=True, psnr=bool(rng.random() < 0.7), ssim=want_ssim, msssim=want_ms)
+    full = bool(rng.random() < 0.4)
+    B = int(rng.integers(1, 4))
+    frames = []
+    for slot in range(B):
+        n = int(rng.integers(0, 50))
+        if kind == "nv12":
+            frames.append(nv12_frames(w, h, n, matrix))
+        elif kind == "p016":
+            frames.append(p016_frames(w, h, n))
+        else:
+            r8 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            d8 = np.clip(r8.astype(np.int32) + rng.integers(-9, 10, r8.shape), 0, 255).astype(np.uint8)
+            if kind == "rgb8":
+                frames.append((tm.HwFrame.rgb(r8), tm.HwFrame.rgb(d8)))
+            elif kind == "rgb16":
+                frames.append((tm.HwFrame.rgb(r8.astype(np.uint16) * 257), tm.HwFrame.rgb((d8.astype(np.uint16) * 257 + rng.integers(0, 99, d8.shape)).astype(np.uint16))))
+            else:
+                frames.append((tm.HwFrame.rgb(r8.astype(np.float32) / 255), tm.HwFrame.rgb(d8.astype(np.float32) / 255)))
+    eng = tm.TurboMetrics(w, h, m, batch=B, full_sums=full)
+    for slot, (fr, fd) in enumerate(frames):
+        eng.set_pair(slot, fr, fd)
+    eng.compute_async()
+    eng.sync()
+    used = ssim_sums_used(ssim=want_ssim, msssim=want_ms) if (want_ssim or want_ms) else None
+    for slot, (fr, fd) in enumerate(frames):
+        lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+        sums = O.ssimulacra2_sums(lin[0], lin[1])
+        got = eng.raw_sums(slot)
+        if full:
+            np.testing.assert_allclose(got, sums, rtol=1e-12, atol=1e-300)
+        else:  # the pruned default leaves the sums that carry no weight at 0
+            nz = got != 0
+            np.testing.assert_allclose(got[nz], np.asarray(sums)[nz], rtol=1e-12, atol=1e-300)
+        s = eng.scores(slot)
+        assert abs(s.ssimulacra2 - O.score_from_sums(sums, w, h)) <= 1e-9, (w, h, kind, slot)
+        if m.psnr:
+            sse, psnr = O.psnr(lin[0], lin[1])
+            assert eng.sse(slot) == sse and s.psnr == psnr
+        if used is not None:
+            ws, wm, ssums = O.ssim_msssim(lin[0], lin[1])
+            gs = eng.ssim_sums(slot)
+            u = np.ones_like(used) if full else used
+            nsc = 5 if want_ms else 1
+            np.testing.assert_allclose(gs[:, :nsc][u[:, :nsc]], ssums[:, :nsc][u[:, :nsc]], rtol=1e-12, atol=1e-300)
+            if want_ssim:
+                assert abs(s.ssim - ws) <= 1e-6
+            if want_ms:
+                assert abs(s.msssim - wm) <= 1e-6
+    eng.close()

@@ -754,7 +754,7 @@ VideoFrameSource::VideoFrameSource(std::unique_ptr<Demuxer> demuxer, const Sourc
         close(wfd);
     });
     FILE *out = fdopen(from_child[0], "rb");
-    if (!out) vfail("fdopen failed");
+    if (!out) { close(from_child[0]); shutdown(); vfail("fdopen failed"); }
     try {
         inner_ = open_y4m_stream(out, "", false, hints, "the decoder's output");
     } catch (const std::exception &e) {
