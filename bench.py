@@ -324,6 +324,8 @@ def run_fixed_stream(ctx, eng, name, B, distinct, total):
     tm, np, torch = ctx.tm, ctx.np, ctx.torch
     lo, hi = tm.shard.shard_range(total, ctx.rank, ctx.world)
     first_mod = None
+    if ctx.dist is not None:  # setup: the first reduce of a process group builds its channels (tens of ms over RCCL) -- not the stream's work
+        tm.shard.reduce_scores(np.zeros(hi - lo, np.float64), lo, total, 1, ctx.dist, ctx.cdev)
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
