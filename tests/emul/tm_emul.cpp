@@ -319,7 +319,7 @@ void emul_ssim(int w, int h, int n, const float *g, const unsigned char *QU8, un
 {
     TmSsimGeom sg; tm_make_ssim_geom(&sg, w, h, g);
     if (sg.w[1] > 0 && sg.h[1] > 0)
-        launch_wave_lockstep(dim3((w + 63) / 64, (h + 63) / 64, n * 6), [&] { tmk::k_ssim_pyramid(sg, QU8, PYR); });
+        launch_wave_lockstep(dim3((w + 127) / 128, (h + 31) / 32, n * 6), [&] { tmk::k_ssim_pyramid(sg, QU8, PYR); });
     int nscales = 0;
     for (int s = 0; s < TM_SSIM_SCALES; ++s) if (sg.strips_x[s] > 0 && sg.segs_y[s] > 0) nscales = s + 1;
     if (nscales > 0) launch_wave_lockstep(dim3(n * 3, sg.item_off[nscales], 1), [&] { tmk::k_ssim_stream(sg, nscales, need_l, QU8, PYR, PART); });

@@ -658,7 +658,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         const TmSsimGeom &sg = e->sg;
         const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
         if (nscales > 1)
-            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 63) / 64), (unsigned)((sg.h[0] + 63) / 64), (unsigned)(n * 6)), dim3(64), 0, st, sg, QU8, e->SPYR);
+            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 127) / 128), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(64), 0, st, sg, QU8, e->SPYR);
         // the sum of l * cs is needed on scale 0 for SSIM and on the last scale for MS-SSIM (the others use cs alone)
         const unsigned need_l = e->full_sums ? 31u : ((e->mask & TM_METRIC_SSIM) ? 1u : 0u) | ((e->mask & TM_METRIC_MSSSIM) ? 1u << (TM_SSIM_SCALES - 1) : 0u);
         hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, need_l, QU8, e->SPYR, e->SPART);

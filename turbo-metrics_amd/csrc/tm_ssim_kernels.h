@@ -5,7 +5,7 @@
 // (sigma 1.5) over the windows that fit inside the image, K1 = 0.01, K2 = 0.03, L = 255; five dyadic scales (2x2 box mean,
 // odd last row / column dropped) for MS-SSIM.
 //
-//   k_ssim_pyramid  grid (ceil(w/64), ceil(h/64), slots*2*3)  block 64    scales 1..4 of the box-sum pyramid, lane = 8x8 pixels
+//   k_ssim_pyramid  grid (ceil(w/128), ceil(h/32), slots*2*3) block 64    scales 1..4 of the box-sum pyramid, lane = 8x8 pixels
 //   k_ssim_stream   grid (slots*3, items of all scales)       block 64    one wave = a strip of 118 window columns x a segment
 //                                                                         of window rows, see below
 //   k_ssim_finish   grid (slots, 30)                          block 64    fixed-order sum of the partials -> 30 sums / slot
@@ -84,14 +84,16 @@ __device__ __forceinline__ const unsigned short *ssim_plane_s(const TmSsimGeom &
 // Box sums of scales 1..4 in one pass over the u8 plane; an odd last row / column of a level is dropped (level s has
 // floor(w/2^s) x floor(h/2^s) pixels).  Lane = one 8 x 8 pixel block, read as eight 8-byte rows: scales 1..3 of the block (4 x 4,
 // 2 x 2, 1 sums) are formed in registers with packed 16-bit adds -- two neighbouring sums in one dword, which is also how they
-// are stored --, scale 4 from the 2 x 2 lane group through three shuffles.  The wave covers 64 x 64 pixels (lanes 8 x 8), so a
-// row of the tile is one 64-byte run.  No LDS, no barrier.  grid (ceil(w/64), ceil(h/64), slots*2*3), block 64.
+// are stored --, scale 4 from the 2 x 2 lane group through three shuffles.  The wave covers 128 x 32 pixels (lanes 16 x 4), so a
+// row of the tile is one whole 128-byte line (read) and the scale-1 sums of a row are one 128-byte line too (written).
+// No LDS, no barrier.  grid (ceil(w/128), ceil(h/32), slots*2*3), block 64.
 __global__ void __launch_bounds__(64) k_ssim_pyramid(TmSsimGeom sg, const unsigned char *__restrict__ Q, unsigned short *__restrict__ PYR)
 {
     const int lane = threadIdx.x;
     const int img = blockIdx.z / 3, c = blockIdx.z % 3;
-    const int x0 = blockIdx.x * 64 + 8 * (lane & 7), y0 = blockIdx.y * 64 + 8 * (lane >> 3);
-    const unsigned char *q = Q + ((size_t)img * 3 + c) * sg.qplane + x0; // x0 + 7 < pitch[0]: the pitch is a multiple of 64
+    const int x0 = blockIdx.x * 128 + 8 * (lane & 15), y0 = blockIdx.y * 32 + 8 * (lane >> 4);
+    const bool live = x0 < sg.pitch[0]; // the pitch is a multiple of 64: a live lane's 8 bytes stay inside the (padded) row
+    const unsigned char *q = Q + ((size_t)img * 3 + c) * sg.qplane + x0;
     unsigned short *base = PYR + ((size_t)img * 3 + c) * sg.pyr;
     const int h = sg.h[0];
     // h0[r], h1[r]: the four horizontal pair sums of row r, two per dword (16 bits each)
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(64) k_ssim_pyramid(TmSsimGeom sg, const unsign
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int y = min(y0 + 2 * j + i, h - 1); // rows past the image only feed sums that are never stored
-            const uint2 u = *(const uint2 *)(q + (size_t)y * sg.pitch[0]);
+            const uint2 u = live ? *(const uint2 *)(q + (size_t)y * sg.pitch[0]) : make_uint2(0u, 0u);
             hs[i][0] = (u.x & 0x00FF00FFu) + ((u.x >> 8) & 0x00FF00FFu);
             hs[i][1] = (u.y & 0x00FF00FFu) + ((u.y >> 8) & 0x00FF00FFu);
         }
@@ -127,9 +129,9 @@ __global__ void __launch_bounds__(64) k_ssim_pyramid(TmSsimGeom sg, const unsign
     const unsigned t = l2[0] + l2[1];
     const unsigned l3 = (t & 0xFFFFu) + (t >> 16);
     if (x3 < sg.w[3] && y3 < sg.h[3]) base[sg.off[3] + (size_t)y3 * sg.pitch[3] + x3] = (unsigned short)l3;
-    // scale 4: the 2 x 2 lane group (lanes are 8 x 8 row-major: right neighbour lane ^ 1, lower one lane ^ 8)
-    const unsigned l4 = (l3 + tm_shfl_xor_u32(l3, 1)) + (tm_shfl_xor_u32(l3, 8) + tm_shfl_xor_u32(l3, 9));
-    if (!(lane & 1) && !(lane & 8) && (x0 >> 4) < sg.w[4] && (y0 >> 4) < sg.h[4])
+    // scale 4: the 2 x 2 lane group (lanes are 16 x 4 row-major: right neighbour lane ^ 1, lower one lane ^ 16)
+    const unsigned l4 = (l3 + tm_shfl_xor_u32(l3, 1)) + (tm_shfl_xor_u32(l3, 16) + tm_shfl_xor_u32(l3, 17));
+    if (!(lane & 1) && !(lane & 16) && (x0 >> 4) < sg.w[4] && (y0 >> 4) < sg.h[4])
         base[sg.off[4] + (size_t)(y0 >> 4) * sg.pitch[4] + (x0 >> 4)] = (unsigned short)l4;
 }
 
