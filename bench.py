@@ -112,7 +112,9 @@ class Ctx:
         self.cdev = "cuda" if self.backend == "nccl" else "cpu"
         torch.cuda.set_device(self.local_rank)
         self.dist = None
-        if self.world > 1:
+        # TM_BENCH_FORCE_DIST=1 (testing only): a process group of ONE rank under torchrun-style variables -- every collective of
+        # the path (barrier, all_reduce(MAX), reduce(SUM)) then really goes through RCCL on a 1-GPU box
+        if self.world > 1 or os.environ.get("TM_BENCH_FORCE_DIST") == "1":
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.backend == "nccl":

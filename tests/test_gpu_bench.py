@@ -47,3 +47,18 @@ def test_asking_for_more_gpus_than_exist_fails_loudly():
     assert r.returncode != 0
     assert "device(s) visible" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_one_rank_process_group_runs_every_collective_through_rccl():
+    """the RCCL branch on hardware: a process group of one rank (torchrun-style variables, backend nccl = RCCL): init with
+    device_id, barrier, all_reduce(MAX) of the timing, reduce(SUM) of the scores on device tensors, destroy -- and the same
+    numbers as without a process group"""
+    from tm_pkg import tm
+    free_port = tm.launch.free_port
+    plain = _bench(["--gpus", "1"])
+    env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+           "TM_BENCH_FORCE_DIST": "1", "TM_BENCH_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    grp = _bench(["--gpus", "1"], env)
+    assert grp["n_gpus"] == 1 and grp["ranks_seen"] == 1 and "RCCL" in grp["config"]["parallelism"]
+    assert grp["fixed_stream"]["scores_sha256_16"] == plain["fixed_stream"]["scores_sha256_16"]
+    assert grp["score_mean"] == plain["score_mean"]
