@@ -1,0 +1,18 @@
+#!/bin/bash
+# here (after gpurun merged gpurun_out/): copy the files of tools/gpu_final.sh <TAG> that are to be judged into profiles/
+set -eu
+T=${1:?tag}
+latest() { ls -t "$1"/runc/*_kernel_stats.csv | head -1; }
+cp gpurun_out/${T}_pmc_traffic_1080p_nv12.json profiles/pmc_traffic_1080p_nv12_b64.json
+cp gpurun_out/${T}_pmc_traffic_1080p_nv12_full.json profiles/pmc_traffic_1080p_nv12_b64_full.json
+cp gpurun_out/${T}_pmc_traffic_4k_p016.json profiles/pmc_traffic_4k_p016_b24.json
+cp "$(latest gpurun_out/${T}_prof)" profiles/${T}_kernel_stats_1080p_b64.csv
+cp "$(latest gpurun_out/${T}_fused_prof)" profiles/${T}_kernel_stats_1080p_b64_fused.csv
+cp "$(latest gpurun_out/${T}_4k_prof)" profiles/${T}_kernel_stats_4k_b24.csv
+cp "$(latest gpurun_out/${T}_fused4k_prof)" profiles/${T}_kernel_stats_4k_b24_fused.csv
+grep -h '^{"metric"' gpurun_out/${T}_prof_bench.log | tail -1 > profiles/${T}_prof_bench_1080p.json
+grep -h '^{"metric"' gpurun_out/${T}_bench_2ranks_gloo.json | tail -1 > profiles/${T}_bench_2ranks_gloo_one_device.json
+cp gpurun_out/${T}_bench.json gpurun_out/${T}_pytest_gpu.log gpurun_out/${T}_smoke.log gpurun_out/${T}_env.log profiles/
+cp gpurun_out/${T}_sq_summary.txt profiles/${T}_sq_counters_1080p_b64.txt
+cp gpurun_out/${T}_fused_sq_summary.txt profiles/${T}_sq_counters_1080p_b64_fused.txt
+ls profiles | grep ${T}

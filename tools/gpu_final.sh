@@ -1,14 +1,21 @@
 #!/bin/bash
-# GPU box: the round's evidence in one call -- GPU tests, smoke, the default bench line (headline + workloads + fixed stream +
-# host-fed + cpu baseline), the 2-rank bench over gloo, rocprofv3 kernel stats (SSIMULACRA2 alone and fused, 1080p and 4K),
-# PMC traffic passes.  Outputs -> gpurun_out/<TAG>_*; copy what is to be judged into profiles/.
+# GPU box: the round's evidence in one call.  Order matters: the PMC traffic passes come first and are copied over the
+# profiles/pmc_traffic_*.json of the snapshot, so that the default bench line that follows finds a traffic profile stamped with
+# the kernel sources it runs (bench.py refuses another version's).  Then GPU tests, smoke, the default bench line (headline +
+# workloads + fixed stream + host-fed + cpu baseline), the 2-rank bench over gloo, rocprofv3 kernel stats (SSIMULACRA2 alone
+# and fused, 1080p and 4K), SQ counters.  Outputs -> gpurun_out/<TAG>_*; tools/collect_profiles.sh copies what is judged.
 set -u
 TAG=${1:-r02z}
+bash tools/pmc_traffic.sh $TAG 1080p_nv12 > /dev/null
+bash tools/pmc_traffic.sh $TAG 1080p_nv12 --full-sums > /dev/null
+bash tools/pmc_traffic.sh $TAG 4k_p016 > /dev/null
+cp gpurun_out/${TAG}_pmc_traffic_1080p_nv12.json profiles/pmc_traffic_1080p_nv12_b64.json
+cp gpurun_out/${TAG}_pmc_traffic_1080p_nv12_full.json profiles/pmc_traffic_1080p_nv12_b64_full.json
+cp gpurun_out/${TAG}_pmc_traffic_4k_p016.json profiles/pmc_traffic_4k_p016_b24.json
 bash tools/gpu_check.sh $TAG
 bash tools/gpu_prof.sh ${TAG}_fused --metrics psnr,msssim,ssimulacra2
 bash tools/gpu_prof.sh ${TAG}_4k --workload 4k_p016
 bash tools/gpu_prof.sh ${TAG}_fused4k --workload 4k_p016 --metrics psnr,msssim,ssimulacra2
-bash tools/pmc_traffic.sh $TAG 1080p_nv12 > /dev/null
-bash tools/pmc_traffic.sh $TAG 1080p_nv12 --full-sums > /dev/null
-bash tools/pmc_traffic.sh $TAG 4k_p016 > /dev/null
-ls gpurun_out | grep $TAG | head -40
+bash tools/pmc_sq.sh $TAG > /dev/null 2>&1
+bash tools/pmc_sq.sh ${TAG}_fused --metrics psnr,msssim,ssimulacra2 > /dev/null 2>&1
+ls gpurun_out | grep $TAG | head -60
