@@ -198,18 +198,28 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         const size_t idx = slot * 2 + side;
         const size_t spitch = (row_bytes + 255) / 256 * 256;
         const size_t chroma_rows = (e->h + 1) / 2;
-        const size_t need = yuv ? spitch * (e->h + chroma_rows) : spitch * e->h;
+        const size_t need = yuv ? spitch * (e->h + 64 + chroma_rows) : spitch * e->h; // room for a surface's padding rows (below)
         rc = ensure_staging(e, idx, need);
         if (rc) return rc;
         char *s = (char *)e->staging[idx];
-        rc = stage_rows(e, s, spitch, p0, pitch, row_bytes, e->h);
-        if (rc) return rc;
-        if (yuv) {
-            const size_t uv_bytes = (size_t)((e->w + 1) / 2) * 2 * bps;
-            rc = stage_rows(e, s + spitch * e->h, spitch, p1, pitch, uv_bytes <= pitch ? uv_bytes : pitch, chroma_rows);
+        const size_t uv_bytes = yuv ? (size_t)((e->w + 1) / 2) * 2 * bps : 0, uv_row = uv_bytes <= pitch ? uv_bytes : pitch;
+        // a decoder's surface: the CbCr rows follow the luma rows at the same pitch (after a few padding rows) -> ONE 2-D copy of
+        // all rows instead of two (the per-copy cost is what limits small frames: DESIGN.md section 5, host-fed)
+        const size_t gap = yuv && (const char *)p1 >= (const char *)p0 ? (size_t)((const char *)p1 - (const char *)p0) : 0;
+        const size_t luma_rows = yuv && gap % pitch == 0 ? gap / pitch : 0;
+        if (luma_rows >= e->h && luma_rows <= (size_t)e->h + 64) {
+            rc = stage_rows(e, s, spitch, p0, pitch, row_bytes > uv_row ? row_bytes : uv_row, luma_rows + chroma_rows);
             if (rc) return rc;
-            d.p1 = s + spitch * e->h;
-        } else d.p1 = nullptr;
+            d.p1 = s + spitch * luma_rows;
+        } else {
+            rc = stage_rows(e, s, spitch, p0, pitch, row_bytes, e->h);
+            if (rc) return rc;
+            if (yuv) {
+                rc = stage_rows(e, s + spitch * e->h, spitch, p1, pitch, uv_row, chroma_rows);
+                if (rc) return rc;
+                d.p1 = s + spitch * e->h;
+            } else d.p1 = nullptr;
+        }
         // pageable source: make sure the bytes have left the caller's buffer before returning (a pinned source is
         // the caller's to keep alive until tm_engine_sync, so its DMA stays asynchronous)
         if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
@@ -248,8 +258,12 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
         char *s = (char *)e->staging[idx];
         char *su = s + sp_y * e->h, *sv = su + sp_c * ch;
         if ((rc = stage_rows(e, s, sp_y, y, pitch_y, row_y, e->h))) return rc;
-        if ((rc = stage_rows(e, su, sp_c, u, pitch_uv, row_c, ch))) return rc;
-        if ((rc = stage_rows(e, sv, sp_c, v, pitch_uv, row_c, ch))) return rc;
+        if ((const char *)v == (const char *)u + pitch_uv * ch) { // Cr follows Cb (a picture of a planar file): one copy for both
+            if ((rc = stage_rows(e, su, sp_c, u, pitch_uv, row_c, 2 * ch))) return rc;
+        } else {
+            if ((rc = stage_rows(e, su, sp_c, u, pitch_uv, row_c, ch))) return rc;
+            if ((rc = stage_rows(e, sv, sp_c, v, pitch_uv, row_c, ch))) return rc;
+        }
         if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
         d.p0 = s; d.p1 = su; d.p2 = sv; d.pitch = sp_y; d.pitch2 = sp_c;
     }
