@@ -56,7 +56,7 @@ def parse_args():
                     "reaches its steady clock (the first ~100 ms after idle run 10-15 %% slower); never timed, reported in config")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="run only this workload (default: 1080p_nv12 headline + the extras)")
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled over the batch)")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs generated (cycled over the batch; SURVEY 8d config 2: 32)")
     ap.add_argument("--metrics", default="ssimulacra2", help="comma list: ssimulacra2,psnr,ssim,msssim")
     ap.add_argument("--full-sums", action="store_true", help="compute all 108 per-scale sums like the reference (default: only the 52 with a non-zero weight; same score)")
     ap.add_argument("--no-compare", action="store_true", help="skip the short extra run with the other full_sums setting")
@@ -145,7 +145,9 @@ class Ctx:
             gen = self.tm.synth.nv12_pair if kind == "nv12" else self.tm.synth.p016_pair
             host = self._surfaces.get((name, distinct, "host"))
             if host is None:
-                host = self._surfaces[(name, distinct, "host")] = [gen(w, h, n) for n in range(distinct)]
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(min(8, distinct)) as ex:  # numpy releases the GIL in the heavy parts
+                    host = self._surfaces[(name, distinct, "host")] = list(ex.map(lambda n: gen(w, h, n), range(distinct)))
             put = (lambda a: self.torch.from_numpy(a).pin_memory()) if pinned else (lambda a: self.torch.from_numpy(a).cuda())
             self._surfaces[key] = [((put(rs), rp, rch), (put(ds), dp, dch)) for (rs, rp, rch), (ds, dp, dch) in host]
             self.torch.cuda.synchronize()
