@@ -37,7 +37,7 @@ def lib():
         L.tmo_math_powf.restype = C.c_float; L.tmo_math_powf.argtypes = [C.c_float, C.c_float]
         L.tmo_srgb_inverse_oetf.restype = C.c_float; L.tmo_srgb_inverse_oetf.argtypes = [C.c_float]
         L.tmo_bt709_eotf.restype = C.c_float; L.tmo_bt709_eotf.argtypes = [C.c_float]
-        L.tmo_bt709_eotf_max_ulp.restype = C.c_double; L.tmo_bt709_eotf_max_ulp.argtypes = [C.POINTER(C.c_float)]
+        L.tmo_bt709_eotf_max_ulp2.restype = C.c_double; L.tmo_bt709_eotf_max_ulp2.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_long)]
         L.tmo_psnr_from_sse.restype = C.c_double; L.tmo_psnr_from_sse.argtypes = [C.c_uint64, C.c_size_t]
         L.tmo_sse_u8.restype = C.c_uint64; L.tmo_sse_u8.argtypes = [vp, vp, C.c_size_t]
         L.tmo_score_from_sums.restype = C.c_double; L.tmo_score_from_sums.argtypes = [dp, C.c_int, C.c_int]
@@ -115,9 +115,10 @@ def cbrtf_scan(lo, hi):
 
 
 def bt709_eotf_max_ulp():
-    """(largest error in ulps of the exact result over every float of the power branch, the argument where it occurs)"""
-    w = C.c_float()
-    return float(lib().tmo_bt709_eotf_max_ulp(C.byref(w))), float(w.value)
+    """(largest error in ulps of the reference's expression -- its f32 base, exact pow -- over every float of the power branch,
+    the argument where it occurs, the number of arguments whose result is not the correctly rounded value)"""
+    w, n = C.c_float(), C.c_long()
+    return float(lib().tmo_bt709_eotf_max_ulp2(C.byref(w), C.byref(n))), float(w.value), int(n.value)
 
 
 def kr_kb(matrix):

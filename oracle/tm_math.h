@@ -101,17 +101,24 @@ static inline float tmo_powf(float xf, double y)
     return (float)tmo_u2d(tmo_d2u(res) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
 
-/* BT.709 transfer function, power branch: ((v + a) / A)^(1/0.45) for v in [0.0812, 1) as one of 128 cubics in t = 128 v - k,
- * k = floor(128 v) -- both exact in f32 --, coefficients from tools/gen_math_tables.py, c0 = hi + lo so that the last addition
- * is the only rounding that matters.  8 f32 operations instead of a division and the ~45 of tmo_powf; the product runs the
- * same sequence (tm_device_math.h bt709_eotf).  Error against the exact function: tmo_bt709_eotf_max_ulp() scans every
- * float of the interval (tests/test_oracle_pins.py).  v >= 1: the exact value is >= 1 and every caller clamps to 1. */
+/* BT.709 transfer function, power branch (cuda-colorspace-kernel/src/lib.rs:228): powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45).
+ * The base x is formed exactly as the reference forms it -- one f32 addition, one IEEE f32 division -- and x^(1/0.45f) on
+ * [21/128, 1) is one of 128 cubics in t = 128 x - k, k = floor(128 x) (both exact in f32), coefficients from
+ * tools/gen_math_tables.py, c0 = hi + lo so that the last addition is the only rounding that matters.  So the one deviation
+ * from the reference's expression evaluated with a correctly rounded pow is that last rounding (tmo_bt709_eotf_max_ulp scans
+ * every float of the interval, tests/test_oracle_pins.py); the rounding of the base, which the power amplifies, is the
+ * reference's.  The product runs the same sequence (tm_device_math.h bt709_eotf; its 4-operation constant division returns the
+ * IEEE quotient, tools/check_div_const.c).  x >= 1 (v >= 1, or a sum that rounds up to ALPHA): the exact value is >= 1 and
+ * every caller clamps to 1. */
 static const float tmo_eotf_c[512] = {TM_EOTF_C};
 static const float tmo_eotf_c0lo[128] = {TM_EOTF_C0LO};
 static inline float tmo_bt709_power(float v)
 {
-    if (v >= 1.0f) return 1.0f;
-    const float s = v * 128.0f;
+    const float BETA = 0.018053968510807f;
+    const float ALPHA = 1.0f + 5.5f * BETA;
+    const float x = (v + (ALPHA - 1.0f)) / ALPHA;
+    const float s = x * 128.0f;
+    if (s >= 128.0f) return 1.0f;
     const int k = (int)s;
     const float t = s - (float)k;
     const float *c = tmo_eotf_c + 4 * k;

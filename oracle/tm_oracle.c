@@ -20,7 +20,8 @@
  * in the repository): "parity unpinned" for the final score.
  * The two libdevice routines of the path are closed NVIDIA code (__nv_cbrtf, ~1 ulp; __nv_fast_powf, ~8 ulp): tm_math.h
  * restates them as fixed IEEE sequences that are CLOSER to the exact functions than the originals (cube root <= 0.5003 ulp,
- * BT.709 transfer function <= 0.68 ulp, sRGB pow <= 0.50001 ulp; each scanned exhaustively by tests/test_oracle_pins.py).
+ * BT.709 transfer function: the reference's f32 base, then <= 0.69 ulp of its exact power; sRGB pow <= 0.50001 ulp; each scanned
+ * exhaustively by tests/test_oracle_pins.py).
  * The score reacts to such last-bit differences at the 1e-3 .. 2e-2 level (tools/score_sensitivity.py), the reference's own
  * GPU-vs-CPU check allows +-0.25.
  *
@@ -191,17 +192,19 @@ static inline float bt709_eotf(float v)
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
     const float THRESHOLD = 0.08124285829863521110029445797874f;
-    /* the reference: powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (fast_powf = exp2(y log2 x), ~8 ulp); here the piecewise
-     * cubic of tm_math.h (< 1 ulp from the exact value of that expression) */
-    (void)ALPHA;
+    /* the reference: powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (fast_powf = exp2(y log2 x), ~8 ulp); here the same f32
+     * base, then the piecewise cubic of tm_math.h (< 1 ulp from the exact power of that base) */
+    (void)ALPHA; (void)BETA;
     if (v >= THRESHOLD) return tmo_bt709_power(v);
     return v / 4.5f;
 }
 float tmo_bt709_eotf(float v) { return bt709_eotf(v); }
 
-/* largest error of the power branch, in ulps of the exact result, over EVERY float v in [threshold, 1); exact = powl in long
- * double of the reference's expression with its f32 constants.  worst_v receives the argument of the maximum. */
-double tmo_bt709_eotf_max_ulp(float *worst_v)
+/* largest error of the power branch, in ulps of the exact result, over EVERY float v in [threshold, 1).  exact = the
+ * reference's expression as written: the base x = (v + (ALPHA - 1)) / ALPHA rounded to f32 by its two f32 operations, then
+ * powl(x, 1 / 0.45f) in long double.  worst_v receives the argument of the maximum; *not_nearest (optional) the number of
+ * arguments whose result is not the correctly rounded value of that expression. */
+double tmo_bt709_eotf_max_ulp2(float *worst_v, long *not_nearest)
 {
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
@@ -209,15 +212,23 @@ double tmo_bt709_eotf_max_ulp(float *worst_v)
     const float EXPO = 1.0f / 0.45f;
     const float THRESHOLD = 0.08124285829863521110029445797874f;
     double worst = 0.0;
+    long off = 0;
     for (float v = THRESHOLD; v < 1.0f; v = nextafterf(v, 2.0f)) {
-        const long double exact = powl(((long double)v + (long double)AM1) / (long double)ALPHA, (long double)EXPO);
+        volatile float sum = v + AM1;
+        volatile float x = sum / ALPHA;
+        if (x >= 1.0f) { if (bt709_eotf(v) != 1.0f) { worst = 1e9; if (worst_v) *worst_v = v; } continue; }
+        const long double exact = powl((long double)x, (long double)EXPO);
         int e;
         (void)frexpl(exact, &e); /* exact = m 2^e, m in [0.5, 1): ulp = 2^(e - 24) */
-        const double err = (double)(fabsl((long double)bt709_eotf(v) - exact) / ldexpl(1.0L, e - 24));
+        const float got = bt709_eotf(v);
+        const double err = (double)(fabsl((long double)got - exact) / ldexpl(1.0L, e - 24));
+        off += got != (float)exact;
         if (err > worst) { worst = err; if (worst_v) *worst_v = v; }
     }
+    if (not_nearest) *not_nearest = off;
     return worst;
 }
+double tmo_bt709_eotf_max_ulp(float *worst_v) { return tmo_bt709_eotf_max_ulp2(worst_v, 0); }
 
 static inline float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 

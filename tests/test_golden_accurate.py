@@ -1,11 +1,15 @@
 """FROZEN goldens (tests/golden/scores_accurate_frozen.json, tools/gen_golden_accurate.py): SSIMULACRA2 scores of the seeded
 synthetic pairs from the most accurate evaluation of the reference's expressions (numpy twin, correctly rounded cbrt and pow).
-They are never regenerated when the product's arithmetic changes; oracle and HIP path must stay within BAND of them.
+`accurate` is never regenerated when the product's arithmetic changes; oracle and HIP path must stay within each case's own
+`bound` = max(2 x the committed |build - accurate|, 1e-3) of it (round 2: one flat band of 5e-2).
 
-What the band means: the reference calls closed libdevice code (__nv_fast_powf ~ exp2f(y log2f x), __nv_cbrtf 1 ulp); the file
-also holds the score of a fast_powf-SHAPED evaluation of the same inputs, which lands 3e-4 ... 1.1e-2 away from `accurate` --
-the same order as this build's own distance (2e-5 ... 2.2e-2).  North_star's 1e-4 is held between HIP and oracle (bit-identical
-planes); against upstream's bits the honest statement is this band (the reference's own GPU-vs-CPU check allows 0.25)."""
+What the figures mean: the reference calls closed libdevice code (__nv_fast_powf ~ exp2f(y log2f x), __nv_cbrtf 1 ulp); the file
+also holds the score of a fast_powf-SHAPED evaluation of the same inputs, which lands 3e-4 ... 1.1e-2 away from `accurate`.
+Since round 3 the transfer function is evaluated on the reference's own f32 base (linear planes <= 1 ulp from the exact
+evaluation, 0.8 % of the samples differ): 5e-4 ... 3.2e-3 on the small cases.  The 1080p NV12 case stays at 1.8e-2, and that
+is the case's conditioning, not the stand-in's quality: moving a random 0.8 % of its linear samples by one ulp moves the score
+by 7e-3 ... 4e-2 (tools/score_conditioning.py; f32 cancellation in sigma - mu^2 against C2 at scales 2-4, where the distortion
+has averaged out).  North_star's 1e-4 is held between HIP and oracle (bit-identical planes)."""
 import json
 import os
 import sys
@@ -19,17 +23,23 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_golden_accurate as GA  # noqa: E402
 
 DOC = json.load(open(os.path.join(ROOT, "tests", "golden", "scores_accurate_frozen.json")))
-CASES, BAND = DOC["cases"], DOC["band"]
+CASES = DOC["cases"]
 ID = lambda c: f'{c["kind"]}_{c["width"]}x{c["height"]}'  # noqa: E731
 
 
 def test_file_is_frozen_and_the_committed_deviation_figures_hold():
-    assert DOC["frozen"] is True and BAND == 5e-2 and len(CASES) == 7
+    assert DOC["frozen"] is True and DOC["floor"] == 1e-3 and len(CASES) == 7
     for c in CASES:
-        assert abs(c["oracle_minus_accurate"]) <= BAND
-        if "fast_powf_shape" in c:  # what libdevice's fast path alone would move the score by: same order as this build's distance
-            assert 1e-4 < abs(c["fast_powf_shape_minus_accurate"]) <= BAND
-    assert max(abs(c["oracle_minus_accurate"]) for c in CASES) > 1e-2  # ... which is why 1e-4 against upstream is not claimed
+        assert c["build_round"] == GA.BUILD_ROUND
+        assert c["bound"] == max(2.0 * abs(c["build_minus_accurate"]), 1e-3)
+        if "fast_powf_shape" in c:  # what libdevice's fast path alone would move the score by
+            assert 1e-4 < abs(c["fast_powf_shape_minus_accurate"]) <= 5e-2
+    small = [c for c in CASES if c["width"] * c["height"] <= 640 * 360]
+    assert max(abs(c["build_minus_accurate"]) for c in small) <= 5e-3  # the level a 0.5003-ulp cube root alone costs at 1080p
+    # round 3 moved every YUV case towards `accurate` (the RGB8 cases do not use the transfer function)
+    for c in CASES:
+        if c["kind"] != "rgb8":
+            assert abs(c["build_minus_accurate"]) < abs(c["build_history"]["r02"])
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["width"] <= 333], ids=ID)
@@ -41,14 +51,14 @@ def test_twin_reproduces_the_frozen_scores(case):
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["width"] * c["height"] <= 640 * 360], ids=ID)
-def test_oracle_stays_within_the_band_of_the_frozen_scores(case):
+def test_oracle_stays_within_its_bound_of_the_frozen_scores(case):
     got = GA.oracle_score(case["kind"], case["width"], case["height"], case["pair"], case["matrix"])
-    assert abs(got - case["accurate"]) <= BAND
+    assert abs(got - case["accurate"]) <= case["bound"]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=ID)
-def test_hip_stays_within_the_band_of_the_frozen_scores(case):
+def test_hip_stays_within_its_bound_of_the_frozen_scores(case):
     tm.init_hip(0)
     w, h, kind = case["width"], case["height"], case["kind"]
     if kind == "rgb8":
@@ -61,4 +71,4 @@ def test_hip_stays_within_the_band_of_the_frozen_scores(case):
     eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)
     s = eng.compute_one(fr, fd)
     eng.close()
-    assert abs(s.ssimulacra2 - case["accurate"]) <= BAND
+    assert abs(s.ssimulacra2 - case["accurate"]) <= case["bound"]

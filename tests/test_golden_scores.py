@@ -1,4 +1,4 @@
-"""Regression fixtures (tests/golden/scores_r01.json, written by tools/gen_golden_scores.py): the oracle must keep
+"""Regression fixtures (tests/golden/scores_regression.json, written by tools/gen_golden_scores.py): the oracle must keep
 producing them (CPU tier), and the HIP path must reproduce them through the C ABI (GPU tier), both at the north-star
 tolerance of 1e-4 for SSIMULACRA2 and exactly for the integer SSE / PSNR.  The reference ships no golden vector for this path
 (SURVEY 8c); these pin THIS build's arithmetic so that it cannot drift on both sides of the parity tests at once."""
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_golden_scores as G  # noqa: E402  (input generation only: seeds -> frames)
 
-CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "scores_r01.json")))["cases"]
+CASES = json.load(open(os.path.join(ROOT, "tests", "golden", "scores_regression.json")))["cases"]
 SMALL = [c for c in CASES if c["width"] * c["height"] <= 640 * 360]
 
 

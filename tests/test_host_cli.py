@@ -447,7 +447,7 @@ def test_cli_baseline_config_1_full_hd_png_pair(tmp_path):
     """BASELINE.json configs[0]: one 1080p PNG pair.  The CLI's score equals the committed golden (oracle, GPU arithmetic) to
     1e-4 and lies within the reference's own 0.25 band of its CPU path (examples/cpu.rs restated, examples/compare.rs:72)."""
     from PIL import Image
-    case = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "scores_r01.json")))["cases"]
+    case = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "scores_regression.json")))["cases"]
             if c["kind"] == "rgb8" and c["width"] == 1920][0]
     r8, d8 = tm.synth.rgb8_pair(1920, 1080)
     pr, pd = str(tmp_path / "r.png"), str(tmp_path / "d.png")

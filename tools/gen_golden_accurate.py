@@ -7,9 +7,12 @@ Generator = the numpy twin (oracle/twin_numpy.py, written from the reference's f
 replaced by correctly rounded ones: cbrtf -> float64 cbrt rounded once, __nv_fast_powf -> float64 pow of the reference's
 f32-rounded base, rounded once.  Beside each accurate score the file records, for the same inputs,
   fast_powf_shape   the twin with the transfer function evaluated like libdevice's fast path, exp2f(y * log2f(x)) in f32
-  oracle_at_freeze  the C oracle (= the HIP kernels, bit for bit) at the time of freezing
-so that the distance between this build and the reference's own arithmetic is a committed number, not prose:
-tests/test_golden_accurate.py asserts that oracle and HIP path stay within BAND of `accurate`.
+  build             the C oracle (= the HIP kernels, bit for bit) with the arithmetic of round `build_round`; `build_history`
+                    keeps the figures of earlier rounds (r02: transfer function fitted in v; r03: the reference's f32 base)
+  bound             max(2 x |build - accurate|, 1e-3): what tests/test_golden_accurate.py allows oracle and HIP path
+so that the distance between this build and the reference's own arithmetic is a committed number, not prose.
+`accurate` and `fast_powf_shape` are frozen; `--refresh-build` recomputes only the build's own columns (after a deliberate
+change of the product's arithmetic, in the same commit as that change).
 The inputs are regenerated from their seeds (turbo-metrics_amd/synth.py); only numbers are stored."""
 import json
 import os
@@ -25,7 +28,8 @@ from tm_pkg import tm  # noqa: E402
 
 CASES = [("nv12", 160, 96, 1, 0), ("nv12", 333, 203, 4, 1), ("nv12", 640, 360, 7, 0), ("p016", 320, 200, 2, 0), ("rgb8", 256, 192, 0, 0),
          ("nv12", 1920, 1080, 2, 0), ("rgb8", 1920, 1080, 0, 0)]
-BAND = 5e-2  # |this build - accurate|; the reference's own GPU-vs-CPU check allows 0.25 (ssimulacra2-cuda/examples/compare.rs:70-90)
+BUILD_ROUND = "r03"
+FLOOR = 1e-3  # smallest per-case bound
 OUT = os.path.join(ROOT, "tests", "golden", "scores_accurate_frozen.json")
 
 
@@ -47,6 +51,7 @@ def twin_linear_pair(kind, w, h, n, matrix, eotf):
 
 
 def oracle_score(kind, w, h, n, matrix):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_golden_scores as G
     lr, ld = G.linear_pair(kind, w, h, n, matrix)
     return O.ssimulacra2_from_linear(lr, ld)[0]
@@ -62,20 +67,47 @@ def compute_case(kind, w, h, n, matrix, with_fast=True):
     return out
 
 
+def bound_of(dev):
+    return max(2.0 * abs(dev), FLOOR)
+
+
+def refresh_build():
+    doc = json.load(open(OUT))
+    for c in doc["cases"]:
+        hist = c.setdefault("build_history", {})
+        if "oracle_at_freeze" in c:  # round-2 layout
+            hist["r02"] = c.pop("oracle_at_freeze") - c["accurate"]
+            c.pop("oracle_minus_accurate", None)
+        elif c.get("build_round") not in (None, BUILD_ROUND):
+            hist[c["build_round"]] = c["build_minus_accurate"]
+        c["build"] = oracle_score(c["kind"], c["width"], c["height"], c["pair"], c["matrix"])
+        c["build_round"] = BUILD_ROUND
+        c["build_minus_accurate"] = c["build"] - c["accurate"]
+        c["bound"] = bound_of(c["build_minus_accurate"])
+        print(c, flush=True)
+    doc.pop("band", None)
+    doc["floor"] = FLOOR
+    json.dump(doc, open(OUT, "w"), indent=1)
+
+
 def main():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if "--refresh-build" in sys.argv:
+        return refresh_build()
     if os.path.exists(OUT) and "--force" not in sys.argv:
         raise SystemExit(f"{OUT} exists and is FROZEN; pass --force only to add cases, never because the product's arithmetic changed")
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
     cases = []
     for kind, w, h, n, matrix in CASES:
         c = compute_case(kind, w, h, n, matrix)
-        c["oracle_at_freeze"] = oracle_score(kind, w, h, n, matrix)
-        c["oracle_minus_accurate"] = c["oracle_at_freeze"] - c["accurate"]
+        c["build"] = oracle_score(kind, w, h, n, matrix)
+        c["build_round"] = BUILD_ROUND
+        c["build_minus_accurate"] = c["build"] - c["accurate"]
+        c["bound"] = bound_of(c["build_minus_accurate"])
         if "fast_powf_shape" in c:
             c["fast_powf_shape_minus_accurate"] = c["fast_powf_shape"] - c["accurate"]
         print(c, flush=True)
         cases.append(c)
-    json.dump({"generator": "tools/gen_golden_accurate.py", "frozen": True, "band": BAND, "cases": cases}, open(OUT, "w"), indent=1)
+    json.dump({"generator": "tools/gen_golden_accurate.py", "frozen": True, "floor": FLOOR, "cases": cases}, open(OUT, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/scores_r01.json: scores of seeded synthetic frame pairs computed by the CPU oracle
+"""Writes tests/golden/scores_regression.json: scores of seeded synthetic frame pairs computed by the CPU oracle
 (oracle/tm_oracle.c, oracle/tm_ssim.c, oracle/tm_cpu_path.c).  The inputs are regenerated from their seeds by the tests
 (turbo-metrics_amd/synth.py); only the expected numbers are stored.  These are regression fixtures of THIS build's
 oracle -- the reference ships no golden vector for this path -- checked at the north-star tolerance (1e-4),
@@ -41,8 +41,8 @@ def main():
                     "ssim": ssim, "msssim": None if np.isnan(msssim) else msssim, "cpu_path_ssimulacra2": O.cpu_path_score_linear(lr, ld),
                     "sum_of_raw_sums": float(np.sum(sums))})
         print(out[-1])
-    with open(os.path.join(ROOT, "tests", "golden", "scores_r01.json"), "w") as f:
-        json.dump({"generator": "tools/gen_golden_scores.py", "cases": out}, f, indent=1)
+    with open(os.path.join(ROOT, "tests", "golden", "scores_regression.json"), "w") as f:
+        json.dump({"generator": "tools/gen_golden_scores.py", "arithmetic": "r03 (BT.709 transfer function on the reference's f32 base)", "cases": out}, f, indent=1)
 
 
 if __name__ == "__main__":

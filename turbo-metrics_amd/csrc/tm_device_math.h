@@ -6,7 +6,8 @@
 // Here they are fixed sequences of IEEE-754 operations, deterministic and reproducible on any IEEE machine -- which is what
 // lets the parity tests demand bit equality for every plane:
 //   cbrt              f32 mul / sub / fma only, 20 operations, evaluated on pairs (v_pk_*_f32); <= 0.5003 ulp
-//   BT.709 transfer   the power branch is a table of 128 cubics, 8 f32 operations; <= 0.68 ulp (the reference's fast_powf: ~8 ulp)
+//   BT.709 transfer   the reference's f32 base (v + a) / A, then a table of 128 cubics in it: 10 f32 operations; <= 0.69 ulp of the
+//                     reference's expression with an exact pow (the reference's fast_powf: ~8 ulp)
 //   pow (sRGB path of 16-bit / f32 RGB frames)  ~20 f64 operations, three 32-entry tables, one rounding to f32; <= 0.50001 ulp
 // Cost matters: the ingest kernel is bound by its arithmetic, so none of the routines divides.
 //
@@ -164,23 +165,47 @@ __device__ __forceinline__ float div_const(float x, float c, float rc)
 // transfer-function table: 128 x {c0hi, c1, c2, c3}, then 128 x c0lo (tools/gen_math_tables.py -> tm_math_tables.inc)
 #define TM_TAB_DOUBLES 416
 
+// x / c for x > 0 (no sign handling): the three-operation core of div_const
+__device__ __forceinline__ float div_const_pos(float x, float c, float rc)
+{
+    const float q1 = x * rc;
+    const float r = __builtin_fmaf(-q1, c, x);
+    return __builtin_fmaf(r, rc, q1);
+}
+
+// s - floor(s) for s >= 0 (exact): v_fract_f32
+__device__ __forceinline__ float fract_pos(float s)
+{
+#ifdef TM_EMULATE
+    return s - floorf(s);
+#else
+    return __builtin_amdgcn_fractf(s);
+#endif
+}
+
 // BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs).  Power branch: the reference
-// evaluates powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (exp2(y log2 x), ~8 ulp); here ((v + a) / A)^(1/0.45) on [0.0812, 1) is
-// one of 128 cubics in t = 128 v - k, k = floor(128 v) -- both exact in f32 --, c0 = hi + lo so that the last addition is the only
-// rounding that matters: 8 f32 operations instead of a division and the ~45 of pow_pos, at most 0.68 ulp from the exact value
-// of that expression over every float of the interval (scanned exhaustively by the CPU test tier, tests/test_oracle_pins.py).
-// v >= 1: the exact value is >= 1 and every caller clamps to 1.
+// evaluates powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (exp2(y log2 x), ~8 ulp).  Here the base x is formed with the
+// reference's own two f32 operations -- the addition, then the IEEE quotient (div_const_pos by ALPHA / 128, which returns
+// s = 128 x exactly: a power-of-two scaling of divisor and reciprocal scales every intermediate exactly) -- and x^(1/0.45f) on
+// [21/128, 1) is one of 128 cubics in t = s - k, k = floor(s) (both exact in f32), c0 = hi + lo so that the last addition is the
+// only rounding that matters: 10 f32 operations instead of a division and the ~45 of pow_pos.  The only deviation from the
+// reference's expression evaluated with a correctly rounded pow is that last rounding: <= 0.69 ulp over every float v of
+// [THRESHOLD, 1), 3 % of them not the nearest float (scanned exhaustively by the CPU test tier, tests/test_oracle_pins.py).
+// (Round 2 fitted the real function of v: 8 operations, but up to 5 ulp from the expression as written because the rounding
+// of the base, which the power amplifies, was not the reference's.)  x >= 1: the exact value is >= 1 and every caller clamps.
 __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ tab)
 {
     const float THRESHOLD = 0.08124285829863521110029445797874f;
+    const float BETA = 0.018053968510807f;
+    const float ALPHA = 1.0f + 5.5f * BETA;
     // (a branchless form -- both branches evaluated, one selected, so that the table reads of a quad's twelve evaluations are
     // not fenced by divergent regions -- was measured: 1.44 vs 1.44 ms per 64 1080p pairs, no difference)
     if (v >= THRESHOLD) {
-        if (v >= 1.0f) return 1.0f;
+        const float s = div_const_pos(v + (ALPHA - 1.0f), ALPHA * 0.0078125f, 128.0f / ALPHA);
+        if (s >= 128.0f) return 1.0f;
         const float *__restrict__ et = (const float *)(tab + 96);
-        const float s = v * 128.0f;
         const int k = (int)s;
-        const float t = s - (float)k;
+        const float t = fract_pos(s);
         // byte offsets of c0lo[k] and of the cubic {c0hi, c1, c2, c3}[k]: two shifts -- left to itself the compiler derives one
         // address from the other with a v_mul_lo_u32 by -12 (a quarter-rate instruction per evaluation)
         unsigned kb = (unsigned)k << 2;
