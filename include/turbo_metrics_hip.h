@@ -217,7 +217,7 @@ int tm_engine_set_graph(tm_engine *e, int on);
  * XYB copy in HBM, allocated on first selection) -- the two produce identical bits (tests/test_gpu_parity.py).
  * TM_VARIANT_WIDE_ROWS (test hook, default pipeline only): the row-pass instantiation that frames wider than 2560 pixels get,
  * forced on any size.  TM_ERR_INVALID_ARG for any other value. */
-enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100 };
+enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100, TM_VARIANT_TILE_INGEST = 0x200 };
 int tm_engine_set_variant(tm_engine *e, int variant);
 
 /* ---- test hooks: read back intermediate planes of one slot (blocking) ------------------ */
@@ -233,6 +233,9 @@ int tm_engine_debug_read_plane(tm_engine *e, uint32_t slot, int kind, int scale,
 /* measurement hook: move the start of the pass-1 arena by `bytes` (multiple of 16, <= 4 MiB) inside its allocation -- how the
  * column pass reacts to the arena's alignment can then be measured on ONE allocation (tools/v_offset_probe.py) */
 int tm_engine_debug_set_v_offset(tm_engine *e, size_t bytes);
+/* measurement hook: quad rows one wave of the 4:2:0 ingest kernel (k_ingest_rows) walks; even, 2..128; 0 = chosen per launch
+ * (the default; the environment variable TM_INGEST_ROWS sets it at creation) -- results do not depend on it (tools/ingest_ab.py) */
+int tm_engine_debug_set_ingest_rows(tm_engine *e, int rows);
 
 const char *tm_strerror(int code);
 /* text of the last HIP error seen by this thread's calls ("" if none) */

@@ -110,8 +110,8 @@ static inline float tmo_powf(float xf, double y)
  * reference's.  The product runs the same sequence (tm_device_math.h bt709_eotf; its 4-operation constant division returns the
  * IEEE quotient, tools/check_div_const.c).  x >= 1 (v >= 1, or a sum that rounds up to ALPHA): the exact value is >= 1 and
  * every caller clamps to 1. */
-static const float tmo_eotf_c[512] = {TM_EOTF_C};
-static const float tmo_eotf_c0lo[128] = {TM_EOTF_C0LO};
+static const float tmo_eotf_c[516] = {TM_EOTF_C};
+static const float tmo_eotf_c0lo[129] = {TM_EOTF_C0LO};
 static inline float tmo_bt709_power(float v)
 {
     const float BETA = 0.018053968510807f;

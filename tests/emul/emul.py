@@ -28,17 +28,17 @@ def build():
 
 
 def product_pow_tables():
-    """the math table buffer of turbo-metrics_amd/csrc/tm_math_tables.inc as the kernels expect it (TM_TAB_DOUBLES = 416 doubles):
-    96 doubles (rcp, nlog, exp2 of pow_pos), then the BT.709 transfer-function cubics as 512 + 128 floats"""
+    """the math table buffer of turbo-metrics_amd/csrc/tm_math_tables.inc as the kernels expect it (TM_TAB_DOUBLES = 419 doubles):
+    96 doubles (rcp, nlog, exp2 of pow_pos), then the BT.709 transfer-function cubics as 516 + 129 floats (+ one of padding)"""
     import re
     txt = open(os.path.join(_ROOT, "turbo-metrics_amd", "csrc", "tm_math_tables.inc")).read()
     lits = re.findall(r"(-?0x[0-9a-f.]+p[-+]?[0-9]+)(f?)", txt)
     dbl = [float.fromhex(v) for v, f in lits if not f]
     flt = [float.fromhex(v) for v, f in lits if f]
-    assert len(dbl) == 96 and len(flt) == 640, (len(dbl), len(flt))
-    buf = np.zeros(416, np.float64)
+    assert len(dbl) == 96 and len(flt) == 645, (len(dbl), len(flt))
+    buf = np.zeros(419, np.float64)
     buf[:96] = dbl
-    buf[96:].view(np.float32)[:] = np.array(flt, np.float32)
+    buf[96:].view(np.float32)[:645] = np.array(flt, np.float32)
     return buf
 
 
@@ -67,7 +67,7 @@ KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 
 class Emulated:
     """Runs one of the two pipelines (variant 0 = default, 1 = reference, 0x100 = default with the wide-frame row pass) for n slots; keeps the arenas for plane inspection."""
 
-    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True, ssim_window=None, ssim_need_l=31):
+    def __init__(self, w, h, frames, lut, coef, want_sse=True, variant=0, powtab=None, weights=None, full_sums=True, ssim_window=None, ssim_need_l=31, ingest_rows=4):
         """frames: list of (ref, dis) where each is dict(kind=, data=np.ndarray, pitch=, coded_height=, matrix=)."""
         L = C.CDLL(build())
         L.emul_geom_size.restype = C.c_size_t
@@ -118,6 +118,7 @@ class Emulated:
             qplane, qpitch = self.sg.qplane, self.sg.pitch[0]
             self.QU8 = np.zeros(n * 2 * 3 * qplane, np.uint8)
             qu8 = vp(self.QU8)
+        L.emul_set_ingest_rows(int(ingest_rows))
         L.emul_pipeline.argtypes = None
         L.emul_pipeline(w, h, n, desc, vp(lut), vp(coef), vp(powtab), int(want_sse), vp(self.LIN), vp(self.XYB), vp(self.XYBT), vp(self.V),
                         vp(self.PART), vp(self.SUMS), vp(self.SSE), int(variant), vp(weights), int(full_sums), qu8, C.c_ulonglong(qplane), int(qpitch))

@@ -265,7 +265,11 @@ void emul_sizes(int w, int h, int n, unsigned long long out[7])
     out[4] = (unsigned long long)n * 3 * g.hblk[TM_SCALES] * 6; out[5] = (unsigned long long)n * 108; out[6] = (unsigned long long)n * TM_SSE_BINS * 3;
 }
 
-// variant: 0 = the default pipeline, 1 = the reference pipeline (TM_VARIANT_REFERENCE), 0x100 = default with the wide-frame row pass
+static int g_ingest_rows = 4; // quad rows per wave of k_ingest_rows (even)
+void emul_set_ingest_rows(int r) { g_ingest_rows = r < 2 ? 2 : (r & ~1); }
+
+// variant: 0 = the default pipeline, 1 = the reference pipeline (TM_VARIANT_REFERENCE), 0x100 = default with the wide-frame row pass,
+// 0x200 = default with the tile ingest kernel for the 4:2:0 kinds too (TM_VARIANT_TILE_INGEST)
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
                    int variant, const double *weights, int full_sums, unsigned char *QU8, unsigned long long qplane, int qpitch)
@@ -286,6 +290,17 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
         int kind = desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
+        const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16;
+        if (yuv && !(variant & 0x200)) { // the engine's choice for the 4:2:0 kinds: the side-packed row-walking kernel
+            const int rpw = g_ingest_rows;
+            launch_wave_lockstep(dim3((qw + 63) / 64, (qh + rpw - 1) / rpw, n), [&] {
+                switch (kind) {
+                case TM_KIND_NV12: tmk::k_ingest_rows<TM_KIND_NV12, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                case TM_KIND_P016: tmk::k_ingest_rows<TM_KIND_P016, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                case TM_KIND_I420_8: tmk::k_ingest_rows<TM_KIND_I420_8, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                default: tmk::k_ingest_rows<TM_KIND_I420_16, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                } });
+        } else
         launch_wave_lockstep(dim3((w + 31) / 32, (h + 7) / 8, n), [&] {
             switch (kind) {
             case TM_KIND_NV12: tmk::k_ingest_wave<TM_KIND_NV12>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;

@@ -49,7 +49,7 @@ def check_against_oracle(em, frames, w, h, have_linear=True, have_xybt=True):
         assert int(em.SSE[slot]) == sse
 
 
-REFERENCE, DEFAULT, WIDE_ROWS = 1, 0, 0x100  # emul_pipeline variants == TM_VARIANT_* of the engine
+REFERENCE, DEFAULT, WIDE_ROWS, TILE_INGEST = 1, 0, 0x100, 0x200  # emul_pipeline variants == TM_VARIANT_* of the engine
 
 
 def nv12_frames(w, h, count=2):
@@ -215,6 +215,32 @@ def test_default_pipeline_matches_oracle(w, h, variant):
                 q = O.quantize_u8(lin[side])
                 for c in range(3):
                     assert np.array_equal(em.qplane(slot, side, c), q[c])
+
+
+def p016_frames(w, h, count=2):
+    frames = []
+    for n in range(count):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.p016_pair(w, h, n + 1)
+        frames.append((dict(kind="p016", data=rs, pitch=rp, coded_height=rch, matrix=(n + 1) % 3),
+                       dict(kind="p016", data=ds, pitch=dp, coded_height=dch, matrix=n % 3)))  # ref and dis with different matrices
+    return frames
+
+
+@pytest.mark.parametrize("rows", [2, 6, 16])
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (1, 1), (2, 5), (129, 20), (257, 131), (130, 7)])
+def test_row_walking_ingest_matches_oracle_and_the_tile_kernel(w, h, rows):
+    """k_ingest_rows (what a launch of one 4:2:0 kind gets: a lane = one quad of BOTH frames, a wave = 64 quads x `rows` quad rows,
+    level-2 pixels paired across iterations and across lane ^ 1): every XYB plane, the u8 planes, the integer SSE and the sums
+    against the oracle; bit-identical arenas with k_ingest_wave (TM_VARIANT_TILE_INGEST) for NV12 and P016"""
+    for frames in (nv12_frames(w, h), p016_frames(w, h)):
+        ssimw = O.ssim_window() if min(w, h) >= 11 else None
+        em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True, ssim_window=ssimw, ingest_rows=rows)
+        check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
+        old = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=TILE_INGEST, weights=O.weights(), full_sums=True, ssim_window=ssimw)
+        assert np.array_equal(em.XYB.view(np.uint32), old.XYB.view(np.uint32)) and np.array_equal(em.SSE, old.SSE)
+        assert np.array_equal(em.SUMS, old.SUMS)
+        if ssimw is not None:
+            assert np.array_equal(em.QU8, old.QU8)
 
 
 def planar_frames(w, h, bits, count=2):

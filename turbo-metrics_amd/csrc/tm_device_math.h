@@ -33,6 +33,7 @@ __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as
 struct tm_f2 { float x, y; };
 static inline tm_f2 operator*(tm_f2 a, tm_f2 b) { return {a.x * b.x, a.y * b.y}; }
 static inline tm_f2 operator-(tm_f2 a, tm_f2 b) { return {a.x - b.x, a.y - b.y}; }
+static inline tm_f2 operator+(tm_f2 a, tm_f2 b) { return {a.x + b.x, a.y + b.y}; }
 static inline tm_f2 operator-(tm_f2 a) { return {-a.x, -a.y}; }
 static inline tm_f2 f2_fma(tm_f2 a, tm_f2 b, tm_f2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 #else
@@ -162,8 +163,12 @@ __device__ __forceinline__ float div_const(float x, float c, float rc)
 }
 
 // Layout of the math table buffer every ingest kernel stages in LDS: 96 doubles of pow_pos, then (as floats) the BT.709
-// transfer-function table: 128 x {c0hi, c1, c2, c3}, then 128 x c0lo (tools/gen_math_tables.py -> tm_math_tables.inc)
-#define TM_TAB_DOUBLES 416
+// transfer-function table: TM_EOTF_SEGS x {c0hi, c1, c2, c3}, then TM_EOTF_SEGS x c0lo (tools/gen_math_tables.py ->
+// tm_math_tables.inc; segment 128 is the constant 1 for bases >= 1), one float of padding
+#define TM_EOTF_SEGS 129
+#define TM_TAB_DOUBLES 419
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
 // x / c for x > 0 (no sign handling): the three-operation core of div_const
 __device__ __forceinline__ float div_const_pos(float x, float c, float rc)
@@ -212,7 +217,7 @@ __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ 
 #ifndef TM_EMULATE
         asm("" : "+v"(kb));
 #endif
-        const float c0lo = *(const float *)((const char *)(et + 512) + kb);
+        const float c0lo = *(const float *)((const char *)(et + 4 * TM_EOTF_SEGS) + kb);
         const float *cub = (const float *)((const char *)et + (kb << 2));
         const float c0 = cub[0], c1 = cub[1], c2 = cub[2], c3 = cub[3];
         float q = __builtin_fmaf(c3, t, c2);
@@ -222,6 +227,70 @@ __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ 
     return div_const(v, 4.5f, 1.0f / 4.5f);
 }
 
+// "does any lane of the wave ..." -- a wave-uniform branch (the emulator runs its lanes one after the other: always true there,
+// which is why every use below computes the same bits on either side of the branch)
+#ifdef TM_EMULATE
+#define TM_WAVE_ANY(c) true
+#define TM_NO_IF_CONVERSION() ((void)0)
+#define TM_KEEP_SCALAR(x) ((void)0)
+#else
+#define TM_KEEP_SCALAR(x) asm("" : "+v"(x))
+#define TM_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#define TM_NO_IF_CONVERSION() asm volatile("; rare path") /* keeps the compiler from turning the uniform branch into selects */
+#endif
+
+// The power branch of bt709_eotf for TWO values at once (the ref and the dis sample of one pixel-channel: the side-packed ingest
+// kernel), without a test: same operations as bt709_eotf on each component.  The base, its constant division (-> s = 128 x)
+// run on the pair; s is clamped into [21, 128] so that the table index is always valid -- a base >= 1 lands on segment 128, the
+// constant 1, an argument below THRESHOLD on some segment whose value the caller replaces (bt709_eotf_linear_fix) --; the two
+// cubics run as scalar-lane fma chains straight out of their ds_read_b128 (pairing them would cost six moves to line the
+// coefficients of two different segments up in register pairs, and a packed operation retires at half the rate anyway).
+// Returns the UNCLAMPED values; et16: the table as 16-byte records {c0hi, c1, c2, c3}[129], then {c0lo, -, -, -}[129].
+struct alignas(16) tm_eotf_rec { float c0, c1, c2, c3; };
+#define TM_EOTF_LDS_FLOATS (8 * TM_EOTF_SEGS)
+__device__ __forceinline__ tm_f2 bt709_power2(tm_f2 v, const tm_eotf_rec *__restrict__ et16)
+{
+    const float BETA = 0.018053968510807f;
+    const float ALPHA = 1.0f + 5.5f * BETA;
+    const float C = ALPHA * 0.0078125f, RC = 128.0f / ALPHA;
+    const tm_f2 a = v + f2_splat(ALPHA - 1.0f);
+    const tm_f2 q1 = a * f2_splat(RC);
+    const tm_f2 rem = f2_fma(-q1, f2_splat(C), a);
+    const tm_f2 s = f2_fma(rem, f2_splat(RC), q1); // 128 * RN((v + a) / A)
+    const float s0 = fminf(fmaxf(s.x, 21.0f), 128.0f), s1 = fminf(fmaxf(s.y, 21.0f), 128.0f);
+    const int k0 = (int)s0, k1 = (int)s1;
+    const float t0 = fract_pos(s0), t1 = fract_pos(s1);
+    const tm_eotf_rec ra = et16[k0], rb = et16[k1];
+    const float la = et16[TM_EOTF_SEGS + k0].c0, lb = et16[TM_EOTF_SEGS + k1].c0;
+    float qa = __builtin_fmaf(ra.c3, t0, ra.c2);
+    TM_KEEP_SCALAR(qa); // the SLP vectorizer would pair the two chains again (v_pk_fma_f32 + six moves per pair)
+    float qb = __builtin_fmaf(rb.c3, t1, rb.c2);
+    qa = __builtin_fmaf(qa, t0, ra.c1);
+    TM_KEEP_SCALAR(qa);
+    qb = __builtin_fmaf(qb, t1, rb.c1);
+    qa = __builtin_fmaf(qa, t0, la);
+    TM_KEEP_SCALAR(qa);
+    qb = __builtin_fmaf(qb, t1, lb);
+    qa = qa + ra.c0;
+    TM_KEEP_SCALAR(qa);
+    qb = qb + rb.c0;
+    return f2_make(qa, qb);
+}
+// the linear branch v / 4.5 for the components below THRESHOLD (negative arguments: the reference's quotient is negative and
+// clamps to 0; so does the sign-free three-operation quotient used here -- its magnitude does not matter below 0)
+__device__ __forceinline__ tm_f2 bt709_eotf_linear_fix(tm_f2 v, tm_f2 p)
+{
+    const float THRESHOLD = 0.08124285829863521110029445797874f;
+    const float c = 4.5f, rc = 1.0f / 4.5f;
+    const tm_f2 d1 = v * f2_splat(rc);
+    const tm_f2 dr = f2_fma(-d1, f2_splat(c), v);
+    const tm_f2 lin = f2_fma(dr, f2_splat(rc), d1);
+    p.x = v.x >= THRESHOLD ? p.x : lin.x;
+    p.y = v.y >= THRESHOLD ? p.y : lin.y;
+    return p;
+}
+__device__ __forceinline__ tm_f2 clamp01_2(tm_f2 p) { return f2_make(clamp01(p.x), clamp01(p.y)); }
+
 // srgb_inverse_oetf, cuda-colorspace-kernel/src/srgb.rs:40-48
 __device__ __forceinline__ float srgb_inverse_oetf(float x, const double *__restrict__ tab)
 {
@@ -230,8 +299,6 @@ __device__ __forceinline__ float srgb_inverse_oetf(float x, const double *__rest
     if (x < 12.92f * SRGB_BETA) return x / 12.92f;
     return pow_pos((x + (SRGB_ALPHA - 1.0f)) / SRGB_ALPHA, (double)2.4f, tab);
 }
-
-__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
 // px_linear_rgb_to_positive_xyb, ssimulacra2-cuda-kernel/src/xyb.rs:42-79, for N pixels at once (the 3N cube roots
 // are evaluated pairwise)
@@ -260,6 +327,32 @@ __device__ __forceinline__ void linear_to_xyb_n(const float (&r)[N], const float
         X[i] = __builtin_fmaf(x, 14.0f, 0.42f);
         Y[i] = y + 0.01f;
         B[i] = bb - y + 0.55f;
+    }
+}
+
+// the same for N pixels of BOTH sides at once (component x = ref, y = dis), linear RGB known to be inside [0, 1]: every cube root
+// argument is >= K_B0 > 0, so the reference's max(mixed, 0) (xyb.rs:44) changes nothing and is not evaluated, and the pairs go
+// through cbrt_core2 without a range test.  Same operations per component as linear_to_xyb_n -> same bits.
+template <int N>
+__device__ __forceinline__ void linear_to_xyb_sides(const tm_f2 (&r)[N], const tm_f2 (&g)[N], const tm_f2 (&b)[N], tm_f2 (&X)[N],
+                                                    tm_f2 (&Y)[N], tm_f2 (&B)[N])
+{
+    const float K_M02 = 0.078f, K_M00 = 0.30f, K_M01 = 1.0f - K_M02 - K_M00;
+    const float K_M12 = 0.078f, K_M10 = 0.23f, K_M11 = 1.0f - K_M12 - K_M10;
+    const float K_M20 = 0.24342269f, K_M21 = 0.20476745f, K_M22 = 1.0f - K_M20 - K_M21;
+    const float K_B0 = 0.0037930734f;
+    const float K_B0_ROOT = 0.1559542025327239180319220163705f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const tm_f2 m0 = f2_fma(f2_splat(K_M00), r[i], f2_fma(f2_splat(K_M01), g[i], f2_fma(f2_splat(K_M02), b[i], f2_splat(K_B0))));
+        const tm_f2 m1 = f2_fma(f2_splat(K_M10), r[i], f2_fma(f2_splat(K_M11), g[i], f2_fma(f2_splat(K_M12), b[i], f2_splat(K_B0))));
+        const tm_f2 m2 = f2_fma(f2_splat(K_M20), r[i], f2_fma(f2_splat(K_M21), g[i], f2_fma(f2_splat(K_M22), b[i], f2_splat(K_B0))));
+        const tm_f2 rg = cbrt_core2(m0) - f2_splat(K_B0_ROOT), gr = cbrt_core2(m1) - f2_splat(K_B0_ROOT), bb = cbrt_core2(m2) - f2_splat(K_B0_ROOT);
+        const tm_f2 x = f2_splat(0.5f) * (rg - gr);
+        const tm_f2 y = f2_splat(0.5f) * (rg + gr);
+        X[i] = f2_fma(x, f2_splat(14.0f), f2_splat(0.42f));
+        Y[i] = y + f2_splat(0.01f);
+        B[i] = (bb - y) + f2_splat(0.55f);
     }
 }
 

@@ -45,8 +45,9 @@ const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
 // the math table buffer of tm_device_math.h (TM_TAB_DOUBLES): pow_pos tables, then the transfer-function cubics as floats
 struct TmMathTab {
     double pow[96];
-    float eotf_c[512];
-    float eotf_c0lo[128];
+    float eotf_c[4 * TM_EOTF_SEGS];
+    float eotf_c0lo[TM_EOTF_SEGS];
+    float pad_;
 };
 static_assert(sizeof(TmMathTab) == TM_TAB_DOUBLES * sizeof(double), "math table layout");
 const TmMathTab k_powtab = {{TM_POW_RCP, TM_POW_NLOG, TM_POW_EXP2}, {TM_EOTF_C}, {TM_EOTF_C0LO}};
@@ -124,6 +125,7 @@ struct tm_engine {
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
     int variant = TM_VARIANT_DEFAULT;
+    int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (TM_INGEST_ROWS overrides: tuning)
 };
 
 namespace {
@@ -446,6 +448,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     auto fail = [&](int code) { tm_engine_destroy(e); return code; };
     if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
+    if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
     tm_make_jobs(&e->jobs, &e->g, k_weights, 0);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -567,7 +570,7 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS))) return TM_ERR_INVALID_ARG;
+    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST))) return TM_ERR_INVALID_ARG;
     const bool ref = (variant & TM_VARIANT_REFERENCE) != 0;
     // the reference pipeline is SSIMULACRA2 (+ PSNR) only: its ingest kernel neither writes the u8 planes of SSIM / MS-SSIM nor runs without the XYB arenas
     if (ref && ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) || !(e->mask & TM_METRIC_SSIMULACRA2))) return TM_ERR_INVALID_ARG;
@@ -633,17 +636,32 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
         for (int i = 1; i < 2 * n; ++i) if (h_desc[i].kind != kind) kind = -1;
 #define TM_LAUNCH_W(K) hipLaunchKernelGGL((tmk::k_ingest_wave<K>), grid, dim3(64), 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0])
+        // the 4:2:0 kinds: side-packed row-walking kernel, one wave = 64 quads x rows_per_wave quad rows (e->ingest_rows; even)
+        const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
+        int rpw = e->ingest_rows;
+        if (rpw <= 0) { // enough waves to fill the chip several times over, as few table stagings as that allows (8 vs 16 rows per
+            // wave, 64 1080p pairs: 1.115 vs 1.14 ms; 4: 1.34; 2: 1.38 -- tools/ingest_ab.py)
+            rpw = 8;
+            while (rpw > 2 && (long long)((qw + 63) / 64) * ((qh + rpw - 1) / rpw) * n < 16384) rpw /= 2;
+        }
+        dim3 rgrid((unsigned)((qw + 63) / 64), (unsigned)((qh + rpw - 1) / rpw), (unsigned)n);
+        const tmk::TmIngestGeom ig = tmk::tm_ingest_geom(g);
+        const bool quant = want_sse || QU8 != nullptr;
+#define TM_LAUNCH_R(K) do { if (quant) hipLaunchKernelGGL((tmk::k_ingest_rows<K, true>), rgrid, dim3(64), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); \
+                        else hipLaunchKernelGGL((tmk::k_ingest_rows<K, false>), rgrid, dim3(64), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); } while (0)
+        const bool rows = !(e->variant & TM_VARIANT_TILE_INGEST);
         switch (kind) {
-        case TM_KIND_NV12: TM_LAUNCH_W(TM_KIND_NV12); break;
-        case TM_KIND_P016: TM_LAUNCH_W(TM_KIND_P016); break;
-        case TM_KIND_I420_8: TM_LAUNCH_W(TM_KIND_I420_8); break;
-        case TM_KIND_I420_16: TM_LAUNCH_W(TM_KIND_I420_16); break;
+        case TM_KIND_NV12: if (rows) TM_LAUNCH_R(TM_KIND_NV12); else TM_LAUNCH_W(TM_KIND_NV12); break;
+        case TM_KIND_P016: if (rows) TM_LAUNCH_R(TM_KIND_P016); else TM_LAUNCH_W(TM_KIND_P016); break;
+        case TM_KIND_I420_8: if (rows) TM_LAUNCH_R(TM_KIND_I420_8); else TM_LAUNCH_W(TM_KIND_I420_8); break;
+        case TM_KIND_I420_16: if (rows) TM_LAUNCH_R(TM_KIND_I420_16); else TM_LAUNCH_W(TM_KIND_I420_16); break;
         case TM_KIND_RGB8: TM_LAUNCH_W(TM_KIND_RGB8); break;
         case TM_KIND_RGB16: TM_LAUNCH_W(TM_KIND_RGB16); break;
         case TM_KIND_RGBF32: TM_LAUNCH_W(TM_KIND_RGBF32); break;
         case TM_KIND_LINEARF32: TM_LAUNCH_W(TM_KIND_LINEARF32); break;
         default: TM_LAUNCH_W(-1); break;
         }
+#undef TM_LAUNCH_R
 #undef TM_LAUNCH_W
         // levels 2..5
         if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
@@ -949,6 +967,15 @@ int tm_engine_debug_set_v_offset(tm_engine *e, size_t bytes)
     if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
     e->V = e->V_alloc + bytes / sizeof(float);
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old pointer
+    return TM_OK;
+}
+
+int tm_engine_debug_set_ingest_rows(tm_engine *e, int rows)
+{
+    if (!e || rows < 0 || rows > 128 || (rows & 1)) return TM_ERR_INVALID_ARG;
+    if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+    e->ingest_rows = rows;
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; }
     return TM_OK;
 }
 

@@ -24,6 +24,7 @@
 #pragma once
 #include "tm_device_math.h"
 #include "tm_geom.h"
+#include <type_traits>
 
 #ifndef TM_EMULATE
 // wave-level sum helpers; return true on the lane that ends up holding the total
@@ -77,6 +78,34 @@ __device__ __forceinline__ unsigned tm_mul24(unsigned a, unsigned b)
 #endif
 }
 
+// row `row` of a plane whose base pointer is wave-uniform: the row address stays in SGPRs and the load uses
+// the scalar-base + per-lane-offset form, so a whole window of in-flight loads costs one VGPR of addressing
+#ifdef TM_EMULATE
+#define TM_GLOBAL_AS
+struct alignas(16) tm_f4 { float x, y, z, w; };
+#else
+#define TM_GLOBAL_AS __attribute__((address_space(1)))
+typedef float tm_f4 __attribute__((ext_vector_type(4))); // plain vector: assignable through address_space(1)
+#endif
+__device__ __forceinline__ tm_f4 tm_make_f4(float a, float b, float c, float d) { tm_f4 v = {a, b, c, d}; return v; }
+template <typename T> __device__ __forceinline__ TM_GLOBAL_AS T *tm_uniform_ptr(T *p)
+{
+    // Pin a wave-uniform pointer into an SGPR pair (and keep it in the global address space).  The empty asm
+    // is opaque to LLVM, which otherwise re-associates base + row*pitch + lane into a per-lane 64-bit address
+    // for every load of the window (2 VGPRs and a v_lshl_add_u64 each) instead of selecting the
+    // scalar-base + 32-bit-lane-offset form of global_load / global_store.
+    unsigned long long v = (unsigned long long)p;
+#ifndef TM_EMULATE
+    asm("" : "+s"(v));
+#endif
+    return (TM_GLOBAL_AS T *)v;
+}
+
+#ifdef TM_EMULATE
+struct alignas(8) tm_g2 { float x, y; };
+#else
+typedef float tm_g2 __attribute__((ext_vector_type(2)));
+#endif
 __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, int nrows, int pitch)
 {
     const int rc = row < nrows ? row : nrows - 1;
@@ -483,6 +512,240 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ingest ("rows"), the YUV kinds: same results as k_ingest_wave<KIND>, bit for bit, for a launch whose frames are all of one
+// 4:2:0 kind.  Written for issue slots, not for arithmetic: on gfx950 one wave issues at most one VALU instruction per four
+// cycles while the SIMD retires a 64-lane f32 instruction in two (a packed one in four), so a kernel of dependent scalar-lane
+// chains with branches around every transfer-function evaluation (k_ingest_wave: 1 395 VALU + ~700 scalar / branch / wait
+// instructions per tile, 0.22 VALU instructions per SIMD-cycle of the 0.5 the SIMD retires) is bound by what its five waves
+// can issue.  Here
+//   * a lane owns one 2 x 2 quad of BOTH frames and everything is said on {ref, dis} pairs (tm_f2): the conversion, the
+//     transfer function, the box filter, the colour mix, the cube roots and the XYB affine steps are v_pk_*_f32 -- half the
+//     instructions for the same arithmetic -- and a row of the interleaved pyramid leaves as one float4 per lane straight
+//     from the registers the arithmetic produced (no LDS parking, no second pass over side 0's values);
+//   * a wave covers 64 quads along x = 128 pixels: one whole 128-B line of an NV12 luma row and of its CbCr row per load
+//     (k_ingest_wave's 32-pixel tiles made four workgroups, on different XCDs, fetch every line: 1.59 GB read per 64 1080p
+//     pairs for 0.40 GB of frames), 1-KB runs of the pyramid per store;
+//   * it walks down `rows_per_wave` quad rows: the samples of the next row are requested before the arithmetic of this one
+//     (a wave hides its own load latency), the 3.3 KB of tables are staged once per wave instead of once per 768 input
+//     bytes, row addresses advance in SGPRs, and the level-2 linear pixel (2 x 2 level-1 pixels) takes its upper pair from
+//     the previous iteration's registers and its right-hand column from lane ^ 1 (one DPP move);
+//   * no divergent branch: the transfer function is evaluated branch-free (tm_device_math.h bt709_eotf2_clamped).
+// Edge rules as k_ingest_wave: an incomplete quad (odd last column / row) is not converted and reads as linear 0
+// (cuda-colorspace/src/kernel.rs:64-65); downscale clamps (downscale.rs:22-30) become "take the in-range neighbour".
+// grid (ceil(ceil(w/2) / 64), ceil(ceil(h/2) / rows_per_wave), slots), block 64; rows_per_wave even, <= 128.
+// ------------------------------------------------------------------------------------------------
+#ifdef TM_EMULATE
+__device__ __forceinline__ float tm_swap1(float v) { return tm_shfl_xor(v, 1); }
+#else
+__device__ __forceinline__ float tm_swap1(float v)
+{
+    // lane ^ 1 through DPP quad_perm [1, 0, 3, 2]: one full-rate VALU move, no LDS crossbar
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xF, 0xF, true));
+}
+#endif
+__device__ __forceinline__ tmdev::tm_f2 tm_swap1(tmdev::tm_f2 v) { return tmdev::f2_make(tm_swap1(v.x), tm_swap1(v.y)); }
+
+// ds4 on {ref, dis} pairs with wave-uniform-per-lane flags (level 2 only; level 1 never clamps: an incomplete quad is all zeros)
+__device__ __forceinline__ tmdev::tm_f2 ds4_sides(tmdev::tm_f2 v00, tmdev::tm_f2 v01, tmdev::tm_f2 v10, tmdev::tm_f2 v11, bool okx, bool oky)
+{
+    using namespace tmdev;
+    const tm_f2 b = okx ? v01 : v00;
+    const tm_f2 c = oky ? v10 : v00;
+    const tm_f2 d = okx ? (oky ? v11 : v01) : (oky ? v10 : v00);
+    tm_f2 sum = f2_splat(0.0f) + v00;
+    sum = sum + b; sum = sum + c; sum = sum + d;
+    return sum * f2_splat(0.25f);
+}
+
+// the part of TmGeom this kernel reads (levels 0, 1, 2): a small kernarg keeps the scalar registers for the loop
+struct TmIngestGeom {
+    int w, h, w1, h1, w2, h2;
+    int pitch0, pitch1, pitch2;
+    unsigned long long plane0, plane1, plane2, off1, pyr;
+};
+__host__ __device__ inline TmIngestGeom tm_ingest_geom(const TmGeom &g)
+{
+    return TmIngestGeom{g.s[0].w, g.s[0].h, g.s[1].w, g.s[1].h, g.s[2].w, g.s[2].h, g.s[0].pitch, g.s[1].pitch, g.s[2].pitch,
+                        g.s[0].plane, g.s[1].plane, g.s[2].plane, g.s[1].off, g.pyr};
+}
+
+// QUANT: the launch wants the integer SSE (PSNR) and / or the u8 planes (SSIM, MS-SSIM); the SSIMULACRA2-only instantiation carries
+// none of that code
+// level-0 rows of the pyramid leave non-temporal: nothing reads them before the next kernel, and 4.2 GB per 64 1080p pairs only
+// pass through the caches (measured on one engine, 1080p: ingest stage 1.19 -> 1.12 ms, the column pass that reads them
+// unchanged; 4K: no difference)
+#define TM_ROWS_STORE(v, p) __builtin_nontemporal_store(v, p)
+template <int KIND, bool QUANT>
+__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmIngestGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ coef,
+                                                    const double *__restrict__ gtab, float *__restrict__ XYB, float *__restrict__ LIN2,
+                                                    unsigned long long *__restrict__ SSE, int want_sse, unsigned char *__restrict__ QU8,
+                                                    unsigned long long qplane, int qpitch, int rows_per_wave)
+{
+    using namespace tmdev;
+    static_assert(KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16, "4:2:0 kinds only");
+    constexpr bool PLANAR = KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16;
+    constexpr bool YUV8 = KIND == TM_KIND_NV12 || KIND == TM_KIND_I420_8;
+    constexpr int BITS = YUV8 ? 8 : 16;
+    using T = typename std::conditional<YUV8, unsigned char, unsigned short>::type;
+    __shared__ tm_eotf_rec et16[2 * TM_EOTF_SEGS]; // the transfer-function table as 16-byte records (tm_device_math.h bt709_power2)
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.z;
+    const int w = g.w, h = g.h;
+    const int qx = blockIdx.x * 64 + lane, X0 = 2 * qx;
+    const int qy_begin = blockIdx.y * rows_per_wave;
+    const int qy_end = min(qy_begin + rows_per_wave, g.h1); // h1 == ceil(h / 2): quad rows, the incomplete last one included
+    {
+        const float *gt = (const float *)(gtab + 96); // {c0hi, c1, c2, c3}[129], then c0lo[129]
+        for (int i = lane; i < TM_EOTF_SEGS; i += 64) {
+            et16[i] = tm_eotf_rec{gt[4 * i], gt[4 * i + 1], gt[4 * i + 2], gt[4 * i + 3]};
+            et16[TM_EOTF_SEGS + i] = tm_eotf_rec{gt[4 * TM_EOTF_SEGS + i], 0.0f, 0.0f, 0.0f};
+        }
+    }
+    const TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
+    const float *kr = coef + (dd0.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5, *kd = coef + (dd1.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
+    const tm_f2 k0 = f2_make(kr[0], kd[0]), k1 = f2_make(kr[1], kd[1]), k2 = f2_make(kr[2], kd[2]), k3 = f2_make(kr[3], kd[3]), k4 = f2_make(kr[4], kd[4]);
+    const float neutral = (float)(1 << (BITS - 1)), ymin = (float)(16u << (BITS - 8));
+    const bool colq = X0 + 1 < w; // this lane's quads are complete along x
+    unsigned prn0[3] = {0, 0, 0}, prn1[3] = {0, 0, 0};
+    if (colq && 2 * qy_begin + 1 < h) { yuv_quad_load_pairs<T, PLANAR>(dd0, qx, qy_begin, prn0); yuv_quad_load_pairs<T, PLANAR>(dd1, qx, qy_begin, prn1); }
+    __builtin_amdgcn_wave_barrier();
+    float *xi = XYB ? XYB + (size_t)slot * 2 * g.pyr : nullptr; // the slot's interleaved pyramid
+    unsigned sse3[3] = {0, 0, 0};
+    tm_f2 up[3] = {f2_splat(0.0f), f2_splat(0.0f), f2_splat(0.0f)}; // level-1 linear pixel of the quad row above (even rows wait here)
+    const unsigned lane_b0 = (unsigned)X0 * 8u, lane_b1 = (unsigned)qx * 8u; // byte offsets of this lane's {ref, dis} pairs in a level-0 / level-1 row
+#pragma unroll 1
+    for (int qy = qy_begin; qy < qy_end; ++qy) {
+        const int Y0 = 2 * qy;
+        const bool quad_ok = colq && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
+        unsigned pr0[3] = {prn0[0], prn0[1], prn0[2]}, pr1[3] = {prn1[0], prn1[1], prn1[2]};
+        if (qy + 1 < qy_end && colq && Y0 + 3 < h) { // the next row's samples, requested before this row's arithmetic
+            yuv_quad_load_pairs<T, PLANAR>(dd0, qx, qy + 1, prn0); yuv_quad_load_pairs<T, PLANAR>(dd1, qx, qy + 1, prn1);
+        }
+        // ---- biplanar.rs:8-70 on {ref, dis} pairs
+        tm_f2 pr[4], pg[4], pb[4];
+        {
+            unsigned ra[6], rb[6];
+            yuv_quad_unpack<BITS>(pr0, ra);
+            yuv_quad_unpack<BITS>(pr1, rb);
+            const tm_f2 cb = f2_make((float)ra[4], (float)rb[4]) - f2_splat(neutral), cr = f2_make((float)ra[5], (float)rb[5]) - f2_splat(neutral);
+            const tm_f2 r_ = k1 * cr;
+            const tm_f2 g_ = f2_fma(k3, cb, k4 * cr);
+            const tm_f2 b_ = k2 * cb;
+            tm_f2 vr[4], vg[4], vb[4];
+            float vmin = 1.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const tm_f2 luma = (f2_make(fmaxf((float)ra[q], ymin), fmaxf((float)rb[q], ymin)) - f2_splat(ymin)) * k0;
+                vr[q] = luma + r_; vg[q] = luma + g_; vb[q] = luma + b_;
+                vmin = fminf(fminf(vmin, fminf(vr[q].x, vr[q].y)), fminf(fminf(vg[q].x, vg[q].y), fminf(vb[q].x, vb[q].y)));
+                pr[q] = bt709_power2(vr[q], et16);
+                pg[q] = bt709_power2(vg[q], et16);
+                pb[q] = bt709_power2(vb[q], et16);
+            }
+            // the linear branch (v < 0.0812: luma codes below ~35) is rare in pictures: a wave evaluates it only when one of
+            // its 24 x 64 arguments needs it (same bits either way)
+            if (TM_WAVE_ANY(!(vmin >= 0.08124285829863521110029445797874f))) {
+                TM_NO_IF_CONVERSION();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pr[q] = bt709_eotf_linear_fix(vr[q], pr[q]);
+                    pg[q] = bt709_eotf_linear_fix(vg[q], pg[q]);
+                    pb[q] = bt709_eotf_linear_fix(vb[q], pb[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pr[q] = clamp01_2(pr[q]); pg[q] = clamp01_2(pg[q]); pb[q] = clamp01_2(pb[q]); }
+            if (TM_WAVE_ANY(!quad_ok)) { // only the waves on the right / bottom edge of an odd-sized frame
+                TM_NO_IF_CONVERSION();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pr[q] = quad_ok ? pr[q] : f2_splat(0.0f); pg[q] = quad_ok ? pg[q] : f2_splat(0.0f); pb[q] = quad_ok ? pb[q] : f2_splat(0.0f);
+                }
+            }
+        }
+        if (QUANT) { // sample_conv.rs:6-35 quantisation; out-of-image samples are 0 on both sides
+            const tm_f2 *pc[3] = {pr, pg, pb};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float ssum = 0.0f; // <= 4 * 255^2: exact in f32
+                unsigned qa[4], qb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const tm_f2 v = pc[c][q] * f2_splat(255.0f);
+                    const float fa = rintf(v.x), fb = rintf(v.y), dlt = fa - fb;
+                    ssum += dlt * dlt;
+                    qa[q] = (unsigned)(int)fa; qb[q] = (unsigned)(int)fb;
+                }
+                sse3[c] += (unsigned)(int)ssum;
+                if (QU8 != nullptr && X0 < w) { // u8-quantised planes for SSIM / MS-SSIM: two pixels = one 16-bit store per row
+#pragma unroll
+                    for (int iy = 0; iy < 2; ++iy)
+                        if (Y0 + iy < h) {
+                            const size_t o = tm_mul24((unsigned)(Y0 + iy), (unsigned)qpitch) + (unsigned)X0;
+                            *(unsigned short *)(QU8 + ((size_t)(slot * 2 + 0) * 3 + c) * qplane + o) = (unsigned short)(qa[2 * iy] | (qa[2 * iy + 1] << 8));
+                            *(unsigned short *)(QU8 + ((size_t)(slot * 2 + 1) * 3 + c) * qplane + o) = (unsigned short)(qb[2 * iy] | (qb[2 * iy + 1] << 8));
+                        }
+                }
+            }
+        }
+        if (xi == nullptr) continue; // PSNR / SSIM only: no pyramid (wave-uniform)
+        // ---- level 1: downscale.rs:22-30 (never clamps here: a quad is complete or all zeros), then xyb.rs:42-79 for the 4 + 1 pixels
+        tm_f2 lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lr[q] = pr[q]; lg[q] = pg[q]; lb[q] = pb[q]; }
+        lr[4] = (((f2_splat(0.0f) + pr[0]) + pr[1]) + pr[2] + pr[3]) * f2_splat(0.25f);
+        lg[4] = (((f2_splat(0.0f) + pg[0]) + pg[1]) + pg[2] + pg[3]) * f2_splat(0.25f);
+        lb[4] = (((f2_splat(0.0f) + pb[0]) + pb[1]) + pb[2] + pb[3]) * f2_splat(0.25f);
+        linear_to_xyb_sides<5>(lr, lg, lb, xa, xb, xc);
+        {
+            const tm_f2 *xv[3] = {xa, xb, xc};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+                    if (X0 < w && Y0 + iy < h) { // X0 is even and the pitch a multiple of 64 floats: the pair of pixels stays inside the row
+                        TM_GLOBAL_AS char *rowp = (TM_GLOBAL_AS char *)tm_uniform_ptr(xi + 2 * (c * g.plane0) + 2 * (size_t)(Y0 + iy) * g.pitch0);
+                        TM_ROWS_STORE(tm_make_f4(xv[c][2 * iy].x, xv[c][2 * iy].y, xv[c][2 * iy + 1].x, xv[c][2 * iy + 1].y), (TM_GLOBAL_AS tm_f4 *)(rowp + lane_b0));
+                    }
+                if (qx < g.w1) { // qy < h1 by the loop bound
+                    TM_GLOBAL_AS char *rowp = (TM_GLOBAL_AS char *)tm_uniform_ptr(xi + 2 * (g.off1 + c * g.plane1) + 2 * (size_t)qy * g.pitch1);
+                    *(TM_GLOBAL_AS tm_g2 *)(rowp + lane_b1) = tm_g2{xv[c][4].x, xv[c][4].y};
+                }
+            }
+        }
+        // ---- level-2 LINEAR pixel of each 2 x 2 group of level-1 pixels (levels 2..5 are finished by k_ingest_upper_rd): rows pair
+        // up across two iterations -- qy_begin is even --, columns across lane ^ 1
+        const tm_f2 l1[3] = {lr[4], lg[4], lb[4]};
+        const bool lower = (qy & 1) != 0, last_alone = !lower && qy + 1 == g.h1; // a last even row has no partner: oky = false
+        if (lower || last_alone) {
+            const int XL = qx >> 1, YL = qy >> 1;
+            const bool ok2x = 2 * XL + 1 < g.w1, ok2y = lower;
+            const bool st = !(lane & 1) && XL < g.w2; // YL < h2: row 2 YL exists
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const tm_f2 v00 = lower ? up[c] : l1[c], v10 = l1[c];
+                const tm_f2 v = ds4_sides(v00, tm_swap1(v00), v10, tm_swap1(v10), ok2x, ok2y);
+                if (st) {
+                    const size_t o = (size_t)c * g.plane2 + tm_mul24((unsigned)YL, (unsigned)g.pitch2) + (unsigned)XL;
+                    LIN2[(size_t)(slot * 2 + 0) * 3 * g.plane2 + o] = v.x;
+                    LIN2[(size_t)(slot * 2 + 1) * 3 * g.plane2 + o] = v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) up[c] = l1[c];
+        }
+    }
+    if (QUANT && want_sse) {
+        if (tm_wave_sum_u32x3(sse3)) {
+            const unsigned bin = (blockIdx.x + blockIdx.y * 29) % TM_SSE_BINS;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&SSE[((size_t)slot * TM_SSE_BINS + bin) * 3 + c], (unsigned long long)sse3[c]);
+        }
+    }
+}
+
 // Levels 2..5 of the pyramid from the level-2 linear RGB that k_ingest_wave leaves in LIN2 (1/16 of the pixels): XYB of
 // level 2, then 2x2 box downscales (downscale.rs:5-35) and XYB for levels 3, 4, 5.  Workgroup = 32x32 tile of level 2
 // (= 128x128 px of level 0, so every parent stays in the tile), lane = 2x2 quad, both sides in one workgroup: side 0's XYB
@@ -707,29 +970,6 @@ template <int R> struct BlurVTile {
     static constexpr int CPI = 64 / LPC; // columns per store instruction
 };
 
-// row `row` of a plane whose base pointer is wave-uniform: the row address stays in SGPRs and the load uses
-// the scalar-base + per-lane-offset form, so a whole window of in-flight loads costs one VGPR of addressing
-#ifdef TM_EMULATE
-#define TM_GLOBAL_AS
-struct alignas(16) tm_f4 { float x, y, z, w; };
-#else
-#define TM_GLOBAL_AS __attribute__((address_space(1)))
-typedef float tm_f4 __attribute__((ext_vector_type(4))); // plain vector: assignable through address_space(1)
-#endif
-__device__ __forceinline__ tm_f4 tm_make_f4(float a, float b, float c, float d) { tm_f4 v = {a, b, c, d}; return v; }
-template <typename T> __device__ __forceinline__ TM_GLOBAL_AS T *tm_uniform_ptr(T *p)
-{
-    // Pin a wave-uniform pointer into an SGPR pair (and keep it in the global address space).  The empty asm
-    // is opaque to LLVM, which otherwise re-associates base + row*pitch + lane into a per-lane 64-bit address
-    // for every load of the window (2 VGPRs and a v_lshl_add_u64 each) instead of selecting the
-    // scalar-base + 32-bit-lane-offset form of global_load / global_store.
-    unsigned long long v = (unsigned long long)p;
-#ifndef TM_EMULATE
-    asm("" : "+s"(v));
-#endif
-    return (TM_GLOBAL_AS T *)v;
-}
-
 __device__ __forceinline__ float ld_row_u(const float *__restrict__ plane, unsigned xb, int row, int nrows, int pitch)
 {
     // xb = this lane's BYTE offset inside the row (a zero-extended 32-bit VGPR offset is what the
@@ -740,11 +980,6 @@ __device__ __forceinline__ float ld_row_u(const float *__restrict__ plane, unsig
     return row < nrows ? v : 0.0f;
 }
 
-#ifdef TM_EMULATE
-struct alignas(8) tm_g2 { float x, y; };
-#else
-typedef float tm_g2 __attribute__((ext_vector_type(2)));
-#endif
 __device__ __forceinline__ void ld_row_u2(const float *__restrict__ plane, unsigned xb, int row, int nrows, int pitch, float &a, float &b)
 {
     // the {ref, dis} pair of the interleaved pyramid: one 8-byte load per lane

@@ -135,10 +135,6 @@ __global__ void __launch_bounds__(64) k_ssim_pyramid(TmSsimGeom sg, const unsign
         base[sg.off[4] + (size_t)(y0 >> 4) * sg.pitch[4] + (x0 >> 4)] = (unsigned short)l4;
 }
 
-#ifdef TM_EMULATE
-static inline tmdev::tm_f2 operator+(tmdev::tm_f2 a, tmdev::tm_f2 b) { return {a.x + b.x, a.y + b.y}; }
-#endif
-
 // n / d for operands far from the ends of the exponent range (here: |n| <= 2.7e5 or 0, 6.5 <= d <= 2.7e5): the sequence the
 // compiler emits for an IEEE division -- reciprocal, one Newton step on it, quotient, two residual corrections -- without
 // v_div_scale / v_div_fixup, which only act on operands that need rescaling or are special: same operations on the same

@@ -15,7 +15,7 @@ TM_CHANNELS_POOLED, TM_CHANNELS_FIRST = 0, 1
 TM_MEM_HOST, TM_MEM_DEVICE, TM_MEM_HOST_PINNED = 0, 1, 2
 TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_SSIM, TM_STAGE_COUNT = 0, 1, 2, 3, 4
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
-TM_VARIANT_DEFAULT, TM_VARIANT_REFERENCE, TM_VARIANT_WIDE_ROWS = 0, 1, 0x100
+TM_VARIANT_DEFAULT, TM_VARIANT_REFERENCE, TM_VARIANT_WIDE_ROWS, TM_VARIANT_TILE_INGEST = 0, 1, 0x100, 0x200
 
 
 class FrameScoresC(C.Structure):
@@ -64,6 +64,7 @@ SYMBOLS = {
     "tm_engine_set_graph": (_i, [_vp, _i]),
     "tm_engine_set_variant": (_i, [_vp, _i]),
     "tm_engine_debug_set_v_offset": (_i, [_vp, _sz]),
+    "tm_engine_debug_set_ingest_rows": (_i, [_vp, _i]),
     "tm_engine_debug_read_plane": (_i, [_vp, _u32, _i, _i, _i, _i, C.POINTER(C.c_float), _sz]),
     "tm_strerror": (C.c_char_p, [_i]),
     "tm_last_hip_error": (C.c_char_p, []),
