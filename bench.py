@@ -19,9 +19,14 @@ Objects on the line (besides the contract fields, which describe the headline wo
                 4K P016 (configs[2]) and the fused PSNR + MS-SSIM + SSIMULACRA2 pass at 1080p and 4K (configs[4]);
                 shorter runs of the same code (min(K, 10) steps).  Skipped with --no-extras or an explicit --workload.
   fixed_stream  BASELINE configs[3] / SURVEY 8d config 4: a stream of 2048 1080p pairs (fixed total = strong scaling),
-                contiguous shards, wall clock from the first submit to rank 0 holding all 2048 scores (one reduce).
+                contiguous shards, wall clock from the first submit to rank 0 holding all 2048 scores (one reduce);
+                `long` inside it: the same with 16 384 pairs, so that every rank still has >= 0.15 s of kernels at 8 GPUs.
   host_fed      SURVEY 8d config 2 (ii): the same pairs uploaded from page-locked host memory for every step
                 (two engines ping-pong: the upload of batch k+1 overlaps the kernels of batch k).  Never `value`.
+  batch_curve   the headline workload at 1, 2, 4, 8, 16, 32, 64 pairs per launch (the reference's compute_one is ONE pair per
+                call): pairs/s, ms per step, engine memory.  N = 1 only.
+  cli_end_to_end  the C++ `turbo-metrics` binary on Y4M clips in tmpfs (1080p 8-bit, 4K 10-bit): file -> pinned ring -> upload
+                -> SSIMULACRA2 -> JSON lines, its own "Processed ... fps" figure.  N = 1 only.  Never `value`.
   cpu_baseline  the restated reference CPU path timed on this host on a bounded sample (rank 0, N=1).
 """
 import argparse
@@ -45,6 +50,8 @@ FUSED = "psnr,msssim,ssimulacra2"  # BASELINE configs[4]
 EXTRAS = [("4k_p016", "ssimulacra2"), ("1080p_nv12", FUSED), ("4k_p016", FUSED)]
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec; 6.29 TB/s measured copy ceiling)
 STREAM_PAIRS = 2048
+STREAM_PAIRS_LONG = 16384  # the strong leg's longer companion: 2048 pairs per rank at 8 GPUs (~0.17 s of kernels)
+BATCH_CURVE = (1, 2, 4, 8, 16, 32, 64)
 
 
 def parse_args():
@@ -61,7 +68,9 @@ def parse_args():
     ap.add_argument("--full-sums", action="store_true", help="compute all 108 per-scale sums like the reference (default: only the 52 with a non-zero weight; same score)")
     ap.add_argument("--no-compare", action="store_true", help="skip the short extra run with the other full_sums setting")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (no `workloads`, `fixed_stream`, `host_fed` objects)")
-    ap.add_argument("--stream-pairs", type=int, default=STREAM_PAIRS, help="pairs of the fixed-size stream (strong scaling leg)")
+    ap.add_argument("--stream-pairs", type=int, default=None, help=f"pairs of the fixed-size stream (strong scaling leg; default {STREAM_PAIRS} "
+                    f"plus a second leg of {STREAM_PAIRS_LONG}); given explicitly the leg also runs under --no-extras")
+    ap.add_argument("--no-cli", action="store_true", help="skip the cli_end_to_end leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed for cpu_baseline (0 = auto, ~15 s)")
     return ap.parse_args()
@@ -269,7 +278,8 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     # without SSIMULACRA2 the ingest kernel writes no pyramid (only the u8 planes when SSIM / MS-SSIM ask for them) and the
     # blur kernels are not launched at all
     ingest_bytes = (in_bytes + (24 * spx if has_s2 else 0) + (6 * w * h if has_ssim else 0)) * B
-    per_kernel = {"k_ingest_wave": roof(stage_ms[F.TM_STAGE_INGEST], ingest_bytes)}
+    ingest_name = "k_ingest_rows" if kind in ("nv12", "p016") else "k_ingest_wave"  # stage time: + k_ingest_upper_rd (levels 2-5, ~0.1 ms)
+    per_kernel = {ingest_name: roof(stage_ms[F.TM_STAGE_INGEST], ingest_bytes)}
     if has_s2:
         per_kernel["k_blur_v_jobs"] = roof(stage_ms[F.TM_STAGE_BLUR_V], job_bytes * B)
         per_kernel["k_blur_h_jobs_x"] = roof(stage_ms[F.TM_STAGE_BLUR_H], job_bytes * B)
@@ -278,7 +288,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         per_kernel["k_ssim_stage"]["bound"] = "valu (11x11 separable window of 4 quantities: 88 fused multiply-adds per window and channel; HBM fraction is informative only)"
     for kn in per_kernel:
         per_kernel[kn]["traffic"] = traffic.get(kn)
-    dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else "k_ingest_wave"
+    dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else ingest_name
     ms_v = per_kernel["k_blur_v_jobs"]["avg_launch_ms"] if has_s2 else 0.0
     ms_h = per_kernel["k_blur_h_jobs_x"]["avg_launch_ms"] if has_s2 else 0.0
     stage_ach = 2 * job_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
@@ -289,7 +299,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         "steps": steps,
         "config": {"workload": name, "baseline_config": cfg_name if mets == {"ssimulacra2"} else "configs[4] on this many GPUs: PSNR + MSSSIM + SSIMULACRA2 fused pass" if mets == set(FUSED.split(",")) else cfg_name + " + " + ",".join(sorted(mets)),
                    "width": w, "height": h, "input": kind, "pairs_per_step_per_gpu": B, "metrics": sorted(mets),
-                   "inputs_resident_in_hbm": True, "settle_ms_before_warmup": settle_ms, "full_sums": bool(args.full_sums),
+                   "inputs_resident_in_hbm": True, "distinct_pairs_cycled": distinct, "settle_ms_before_warmup": settle_ms, "full_sums": bool(args.full_sums),
                    "engine_mem_GB": round(eng.mem_usage() / 1e9, 2),
                    "parallelism": f"frame-pair sharding x{ctx.world}, one {'RCCL' if ctx.backend == 'nccl' else ctx.backend} reduce of scores"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
@@ -406,6 +416,84 @@ def run_host_fed(ctx, args, name, B, steps, warmup):
             "h2d_GBs_per_gpu": B * steps * in_bytes / dt / 1e9, "note": "PCIe-inclusive; includes the Python loop's 2 x B set_frame calls per step"}
 
 
+def run_batch_curve(ctx, args, name, head_B, head_res):
+    """the headline workload at the reference's own call granularity and up: compute_one is ONE pair per call
+    (crates/turbo-metrics/src/lib.rs:268-360).  Per batch size: a fresh engine, ~60 ms of settling, ~0.25 s timed."""
+    tm, torch = ctx.tm, ctx.torch
+    w, h, kind, _, _ = WORKLOADS[name]
+    out = []
+    for B in BATCH_CURVE:
+        if B == head_B:
+            out.append({"batch": B, "value": head_res["value"], "ms_per_step": head_res["ms_per_step"], "engine_mem_GB": head_res["config"]["engine_mem_GB"], "from": "headline run"})
+            continue
+        eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B)
+        ctx.fill_slots(eng, name, max(1, min(args.distinct, B)), 0, B)
+        t0 = time.perf_counter()
+        n0 = 0
+        while time.perf_counter() - t0 < 0.06:
+            eng.compute_async(B); eng.sync(); n0 += 1
+        k = max(10, int(0.25 / ((time.perf_counter() - t0) / n0)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            eng.compute_async(B)
+            eng.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out.append({"batch": B, "value": B * k / dt, "ms_per_step": dt / k * 1e3, "steps": k, "engine_mem_GB": round(eng.mem_usage() / 1e9, 2)})
+        eng.close()
+    return {"workload": name, "note": "one compute_async + sync per step, inputs resident in HBM; batch 1 = the reference's compute_one granularity",
+            "points": out}
+
+
+def run_cli_end_to_end(ctx):
+    """the C++ CLI (turbo-metrics_amd/bin/turbo-metrics) end to end on planar Y4M clips in tmpfs: file -> page-locked ring ->
+    upload -> SSIMULACRA2 -> JSON lines on stdout; the figure is the CLI's own "Processed ... (N fps)" line (engine creation
+    excluded, everything per frame included).  A child process; clips are written and removed here."""
+    import re
+    import subprocess
+    np, tm = ctx.np, ctx.tm
+    cli = os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")
+    if not os.path.exists(cli):
+        return {"error": "turbo-metrics binary not built"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    out = {}
+    for tag, w, h, bits, frames in (("1080p_yuv420p", 1920, 1080, 8, 768), ("4k_yuv420p10", 3840, 2160, 10, 96)):
+        frame_bytes = w * h * 3 // 2 * (1 if bits == 8 else 2)
+        paths = []
+        try:
+            st = os.statvfs(base)
+            if st.f_bavail * st.f_frsize < 2 * frames * frame_bytes + (2 << 30):
+                out[tag] = {"error": f"not enough room in {base}"}
+                continue
+            paths = [os.path.join(base, f"tm_bench_{os.getpid()}_{tag}_{s}.y4m") for s in ("ref", "dis")]
+            pairs = [tm.synth.yuv420_pair(w, h, n, bits) for n in range(2)]
+            for side, pth in enumerate(paths):
+                with open(pth, "wb") as f:
+                    f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip A1:1 C420{'jpeg' if bits == 8 else 'p10'}\n".encode())
+                    blobs = [b"FRAME\n" + b"".join(pl.astype(np.uint8 if bits == 8 else "<u2").tobytes() for pl in pr[side]) for pr in pairs]
+                    for i in range(frames):
+                        f.write(blobs[i % len(blobs)])
+            res = {"pairs": frames, "clip_GB_each": round(os.path.getsize(paths[0]) / 1e9, 2), "clips_in": base}
+            for label, extra in (("default", []), ("batch32", ["--batch", "32"])):
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, timeout=300)
+                wall = time.perf_counter() - t0
+                m = re.search(r"Processed: (\d+) .*?\((\d+) fps\)", r.stderr)
+                lines = sum(1 for l in r.stdout.splitlines() if l.startswith("{"))
+                res[label] = {"rc": r.returncode, "pairs_per_s": int(m.group(2)) if m else None, "process_wall_s": round(wall, 2), "score_lines": lines,
+                              "args": " ".join(extra) or "(CLI defaults)"}
+            out[tag] = res
+        except Exception as ex:  # the leg is informative: never take the headline down with it
+            out[tag] = {"error": repr(ex)[:200]}
+        finally:
+            for pth in paths:
+                if os.path.exists(pth):
+                    os.remove(pth)
+    out["note"] = "host-fed through the CLI (PCIe + file reads inclusive): reported beside `value`, never as `value`"
+    return out
+
+
 def cpu_baseline(tm, w, h, kind, n_pairs):
     """CPU baselines on this host, bounded to 10-15 s in total (reported, never the target):
     the restated reference CPU path (oracle/tm_cpu_path.c == examples/cpu.rs, single-threaded like the original)
@@ -433,8 +521,15 @@ def cpu_baseline(tm, w, h, kind, n_pairs):
     for i in range(max(1, n_pairs // 2)):
         one(i, lambda a, b: O.ssimulacra2_from_linear(a, b)[0])
     dt_gpu_arith = (time.perf_counter() - t0) / max(1, n_pairs // 2)
-    threads = min(os.cpu_count() or 1, 64)
-    n_par = threads * 2
+    # every host core, bounded by memory: a 1080p pair of the restated CPU path holds ~0.6 GB while it runs
+    threads = os.cpu_count() or 1
+    try:
+        import psutil
+        per = 0.6e9 * (w * h) / (1920 * 1080)
+        threads = max(1, min(threads, int(psutil.virtual_memory().available * 0.5 / per)))
+    except Exception:
+        threads = min(threads, 64)
+    n_par = threads
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL: real frame-level parallelism
         list(ex.map(lambda i: one(i, O.cpu_path_score_linear), range(n_par)))
@@ -442,7 +537,7 @@ def cpu_baseline(tm, w, h, kind, n_pairs):
     return {"value": n_pairs / dt1, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": f"{n_pairs} {w}x{h} {kind} pairs, YUV->linear + restated reference CPU path (oracle/tm_cpu_path.c == examples/cpu.rs), 1 thread",
             "seconds": dt1, "host_cpus": os.cpu_count(),
-            "all_cores": {"value": n_par / dtp, "cores": threads, "sample": f"{n_par} pairs, one pair per worker thread", "seconds": dtp},
+            "all_cores": {"value": n_par / dtp, "cores": threads, "sample": f"{n_par} pairs, one pair per worker thread, one thread per host CPU (bounded by free memory)", "seconds": dtp},
             "gpu_arithmetic_oracle_1thread_pairs_per_s": 1.0 / dt_gpu_arith}
 
 
@@ -455,9 +550,13 @@ def run_rank(args):
     res, eng, distinct = run_workload(ctx, args, head_name, mets, B, args.steps, args.warmup, args.settle_ms,
                                       compare=not args.no_compare, keep_engine=True)
     fixed = None
-    if "ssimulacra2" in mets and not args.no_extras:
+    if "ssimulacra2" in mets and (not args.no_extras or args.stream_pairs is not None):
         eng.set_full_sums(args.full_sums)
-        fixed = run_fixed_stream(ctx, eng, head_name, B, distinct, args.stream_pairs)
+        fixed = run_fixed_stream(ctx, eng, head_name, B, distinct, args.stream_pairs or STREAM_PAIRS)
+        if args.stream_pairs is None:  # the default line: a second, longer stream (>= 0.15 s of kernels per rank at 8 GPUs)
+            longer = run_fixed_stream(ctx, eng, head_name, B, distinct, STREAM_PAIRS_LONG)
+            if fixed is not None and longer is not None:
+                fixed["long"] = {k: longer[k] for k in ("total_pairs", "seconds_first_submit_to_scores_on_rank0", "value", "pairs_per_rank", "scores_periodic_bit_identical", "scores_sha256_16")}
     eng.close()
     workloads, host_fed = {}, None
     if extras:
@@ -467,8 +566,13 @@ def run_rank(args):
             for drop in ("unit",):
                 r.pop(drop, None)
             workloads[wl + ("_fused" if m == FUSED else "")] = r
-        if ctx.world == 1:  # a per-GPU PCIe figure: measured on one GPU only
-            host_fed = {wl: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, ks, kw) for wl in ("1080p_nv12", "4k_p016")}
+        if ctx.world == 1:  # a per-GPU PCIe figure: measured on one GPU only (>= 40 steps: 8 pairs x 10 steps was too short to be stable)
+            host_fed = {wl: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, max(ks, 40), kw) for wl in ("1080p_nv12", "4k_p016")}
+    batch_curve = cli = None
+    if extras and ctx.world == 1 and head_name == "1080p_nv12":
+        batch_curve = run_batch_curve(ctx, args, head_name, B, res)
+        if not args.no_cli:
+            cli = run_cli_end_to_end(ctx)
     if ctx.rank == 0:
         out = {
             "metric": "ssimulacra2_frame_pairs_per_sec" if "ssimulacra2" in mets else "frame_pairs_per_sec",
@@ -494,6 +598,10 @@ def run_rank(args):
             out["fixed_stream"] = fixed
         if host_fed:
             out["host_fed"] = host_fed
+        if batch_curve:
+            out["batch_curve"] = batch_curve
+        if cli:
+            out["cli_end_to_end"] = cli
         if ctx.world == 1 and not args.no_cpu_baseline:
             w, h, kind = WORKLOADS[head_name][:3]
             out["cpu_baseline"] = cpu_baseline(ctx.tm, w, h, kind, args.cpu_pairs)

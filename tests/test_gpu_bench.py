@@ -39,6 +39,34 @@ def test_two_ranks_are_really_started_and_reproduce_the_one_rank_scores():
         assert k in two
 
 
+def test_eight_ranks_rendezvous_shard_and_reduce_like_one_rank():
+    """the driver's widest run, without eight GPUs: 8 rank processes on one device (gloo carries the one collective), a fixed
+    stream of 2 048 pairs = 256 per rank in 128 launches of 2, one reduce to rank 0 -- the same 2 048 scores as one rank, bit
+    for bit; the whole thing well inside two minutes"""
+    import time
+    args = ["--workload", "1080p_nv12", "--steps", "2", "--warmup", "1", "--settle-ms", "0", "--no-cpu-baseline", "--no-compare",
+            "--batch", "2", "--stream-pairs", "2048", "--no-extras"]
+
+    def run(extra, env_extra=None):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+        env.update(env_extra or {})
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + args, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0]), time.time() - t0
+
+    one, _ = run(["--gpus", "1"])
+    eight, wall = run(["--gpus", "8"], {"TM_BENCH_BACKEND": "gloo"})
+    assert eight["n_gpus"] == 8 and eight["ranks_seen"] == 8 and eight["fixed_stream"]["ranks_seen"] == 8
+    assert eight["fixed_stream"]["total_pairs"] == 2048 and eight["fixed_stream"]["pairs_per_rank"] == 256
+    assert eight["fixed_stream"]["scores_periodic_bit_identical"]
+    assert eight["fixed_stream"]["scores_sha256_16"] == one["fixed_stream"]["scores_sha256_16"]
+    assert "workloads" not in eight and "batch_curve" not in eight  # --no-extras
+    assert wall < 120.0, wall
+
+
 def test_asking_for_more_gpus_than_exist_fails_loudly():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TM_BENCH_BACKEND")}
     import torch
