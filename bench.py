@@ -458,7 +458,7 @@ def run_cli_end_to_end(ctx):
         return {"error": "turbo-metrics binary not built"}
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
     out = {}
-    for tag, w, h, bits, frames in (("1080p_yuv420p", 1920, 1080, 8, 768), ("4k_yuv420p10", 3840, 2160, 10, 96)):
+    for tag, w, h, bits, frames in (("1080p_yuv420p", 1920, 1080, 8, 1536), ("4k_yuv420p10", 3840, 2160, 10, 192)):  # 4.8 GB per clip
         frame_bytes = w * h * 3 // 2 * (1 if bits == 8 else 2)
         paths = []
         try:
@@ -475,7 +475,7 @@ def run_cli_end_to_end(ctx):
                     for i in range(frames):
                         f.write(blobs[i % len(blobs)])
             res = {"pairs": frames, "clip_GB_each": round(os.path.getsize(paths[0]) / 1e9, 2), "clips_in": base}
-            for label, extra in (("default", []), ("batch32", ["--batch", "32"])):
+            for label, extra in (("default", []), ("batch16", ["--batch", "16"])):
                 t0 = time.perf_counter()
                 r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, timeout=300)
                 wall = time.perf_counter() - t0

@@ -127,7 +127,12 @@ size_t tm_engine_mem_usage(const tm_engine *e);
  * kernel addresses a surface with 32-bit lane offsets; anything else is TM_ERR_INVALID_ARG.
  *
  * NV12: 8-bit luma plane `y` (rows at `pitch` bytes) + interleaved CbCr plane `uv` (same pitch);
- * layout of an NVDEC mapping, cudarse-video/src/dec.rs:299-346.  Visible window starts at the origin. */
+ * layout of an NVDEC mapping, cudarse-video/src/dec.rs:299-346.  Visible window starts at the origin.
+ * Host surfaces (TM_MEM_HOST, TM_MEM_HOST_PINNED): when `uv` lies a whole number of rows R behind `y`, height <= R <= height + 64,
+ * the two planes are taken as ONE allocation -- the reference's decoded-surface contract (one allocation, luma rows of the coded
+ * height, then the CbCr rows) -- and go up in one 2-D copy that also reads the R - height padding rows in between.  Planes that
+ * live in separate allocations must therefore not sit at such a distance from each other by accident; any other distance gets
+ * one copy per plane. */
 int tm_engine_set_frame_nv12(tm_engine *e, uint32_t slot, int side, const void *y, const void *uv,
                              size_t pitch, int matrix, int transfer, int full_range, int mem);
 /* P016: 16-bit samples, 10-bit values MSB aligned (dec.rs:348-403). `pitch` in bytes.
@@ -217,7 +222,7 @@ int tm_engine_set_graph(tm_engine *e, int on);
  * XYB copy in HBM, allocated on first selection) -- the two produce identical bits (tests/test_gpu_parity.py).
  * TM_VARIANT_WIDE_ROWS (test hook, default pipeline only): the row-pass instantiation that frames wider than 2560 pixels get,
  * forced on any size.  TM_ERR_INVALID_ARG for any other value. */
-enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100, TM_VARIANT_TILE_INGEST = 0x200 };
+enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100, TM_VARIANT_TILE_INGEST = 0x200, TM_VARIANT_DEEP_ROWS = 0x400 };
 int tm_engine_set_variant(tm_engine *e, int variant);
 
 /* ---- test hooks: read back intermediate planes of one slot (blocking) ------------------ */

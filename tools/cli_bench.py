@@ -23,7 +23,7 @@ for side, p in enumerate(paths):
         for i in range(a.frames):
             f.write(blobs[i % distinct])
 print("files:", [round(os.path.getsize(p) / 1e6) for p in paths], "MB", flush=True)
-for extra in (["--batch", "1", "--no-pipeline"], ["--batch", "8", "--no-pipeline"], ["--batch", "8"], ["--batch", "32"], ["--batch", "32", "-m", "psnr", "-m", "msssim"]):
+for extra in (["--batch", "1", "--no-pipeline"], ["--batch", "8"], ["--batch", "16"], ["--batch", "32"], ["--batch", "64"], ["--batch", "32", "-m", "psnr", "-m", "msssim"]):
     t0 = time.time()
     r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True)
     dt = time.time() - t0

@@ -209,6 +209,8 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         // all rows instead of two (the per-copy cost is what limits small frames: DESIGN.md section 5, host-fed)
         const size_t gap = yuv && (const char *)p1 >= (const char *)p0 ? (size_t)((const char *)p1 - (const char *)p0) : 0;
         const size_t luma_rows = yuv && gap % pitch == 0 ? gap / pitch : 0;
+        // (documented in the header: a CbCr pointer that sits a whole number of rows, h .. h + 64, behind the luma pointer declares
+        // ONE allocation -- the reference's decoded-surface contract, cudarse-video/src/dec.rs:299-393 -- whose padding rows may be read)
         if (luma_rows >= e->h && luma_rows <= (size_t)e->h + 64) {
             rc = stage_rows(e, s, spitch, p0, pitch, row_bytes > uv_row ? row_bytes : uv_row, luma_rows + chroma_rows);
             if (rc) return rc;
@@ -244,7 +246,8 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
     const size_t cw = (e->w + 1) / 2, ch = (e->h + 1) / 2;
     const size_t row_y = (size_t)e->w * bps, row_c = cw * bps;
     if (pitch_y < row_y || pitch_uv < row_c) return TM_ERR_INVALID_ARG;
-    if (pitch_y >= ((size_t)1 << 24) || pitch_y * (size_t)e->h >= ((size_t)1 << 32) || pitch_uv >= ((size_t)1 << 24)) return TM_ERR_INVALID_ARG;
+    // the kernels address a plane with 32-bit lane offsets (row * pitch through a 24-bit multiply), chroma planes included
+    if (pitch_y >= ((size_t)1 << 24) || pitch_y * (size_t)e->h >= ((size_t)1 << 32) || pitch_uv >= ((size_t)1 << 24) || pitch_uv * ch >= ((size_t)1 << 32)) return TM_ERR_INVALID_ARG;
     TmFrameDesc &d = e->h_desc[slot * 2 + side];
     if (e->in_flight) { // descriptors are read by an async copy; do not race with it
         rc = tm_engine_sync(e);
@@ -570,7 +573,7 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST))) return TM_ERR_INVALID_ARG;
+    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST | TM_VARIANT_DEEP_ROWS))) return TM_ERR_INVALID_ARG;
     const bool ref = (variant & TM_VARIANT_REFERENCE) != 0;
     // the reference pipeline is SSIMULACRA2 (+ PSNR) only: its ingest kernel neither writes the u8 planes of SSIM / MS-SSIM nor runs without the XYB arenas
     if (ref && ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) || !(e->mask & TM_METRIC_SSIMULACRA2))) return TM_ERR_INVALID_ARG;
@@ -677,6 +680,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART);
+        else if (e->variant & TM_VARIANT_DEEP_ROWS) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<32, 16, 32, 16>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));

@@ -311,9 +311,13 @@ void RowWorkers::loop(unsigned idx)
             fn = fn_; total = total_;
         }
         const size_t parts = th_.size() + 1, lo = total * (idx + 1) / parts, hi = total * (idx + 2) / parts;
-        if (hi > lo) (*fn)(lo, hi);
+        std::exception_ptr ex;
+        try {
+            if (hi > lo) (*fn)(lo, hi);
+        } catch (...) { ex = std::current_exception(); } // a short read / EIO in a piece: reported by run(), never std::terminate
         {
             std::lock_guard<std::mutex> lk(m_);
+            if (ex && !err_) err_ = ex;
             if (--pending_ == 0) done_cv_.notify_one();
         }
     }
@@ -323,13 +327,21 @@ void RowWorkers::run(size_t total, const std::function<void(size_t, size_t)> &fn
 {
     {
         std::lock_guard<std::mutex> lk(m_);
-        fn_ = &fn; total_ = total; pending_ = (unsigned)th_.size(); ++gen_;
+        fn_ = &fn; total_ = total; pending_ = (unsigned)th_.size(); ++gen_; err_ = nullptr;
     }
     cv_.notify_all();
     const size_t hi = total / (th_.size() + 1);
-    if (hi > 0) fn(0, hi);
+    std::exception_ptr mine;
+    try {
+        if (hi > 0) fn(0, hi);
+    } catch (...) { mine = std::current_exception(); }
+    // always wait: the workers hold a pointer to `fn` and write into the caller's buffer until their pieces are done
     std::unique_lock<std::mutex> lk(m_);
     done_cv_.wait(lk, [&] { return pending_ == 0; });
+    std::exception_ptr first = mine ? mine : err_;
+    err_ = nullptr;
+    lk.unlock();
+    if (first) std::rethrow_exception(first);
 }
 
 YuvStreamSource::~YuvStreamSource()

@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -82,6 +83,7 @@ private:
     unsigned long long gen_ = 0;
     unsigned pending_ = 0;
     bool stop_ = false;
+    std::exception_ptr err_; // first exception thrown by a piece of the current run() (rethrown by run() after every piece is done)
 };
 
 class YuvStreamSource : public FrameSource {

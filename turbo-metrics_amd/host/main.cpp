@@ -254,7 +254,7 @@ int main(int argc, char **argv)
                         uint32_t dc = 0;
                         tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { sh.scores.push_back(fs); }, &dc);
                         sh.decoded = dc - lo;
-                    } catch (const std::out_of_range &) { // a shard in which `every` selects no frame is empty, not an error
+                    } catch (const NoFramesSelected &) { // a shard in which `every` selects no frame is empty, not an error (any other exception is one)
                     } catch (const std::exception &e) { sh.err = e.what(); }
                 });
             for (auto &t : th) t.join();

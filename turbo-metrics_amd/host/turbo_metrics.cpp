@@ -216,7 +216,7 @@ MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Me
     MetricsResults res;
     res.frame_count = frames.size();
     if (frames.empty() && (a || b || c || d))
-        throw std::out_of_range("no frame pair was processed (the reference panics in Stats::compute: index out of bounds)");
+        throw NoFramesSelected();
     if (a) res.psnr = MetricAggregate::from(std::move(*a));
     if (b) res.ssim = MetricAggregate::from(std::move(*b));
     if (c) res.msssim = MetricAggregate::from(std::move(*c));
@@ -342,7 +342,7 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     MetricsResults res;
     res.frame_count = compute_count;
     if (compute_count == 0 && (s_psnr || s_ssim || s_msssim || s_ssimu))
-        throw std::out_of_range("no frame pair was processed (the reference panics in Stats::compute: index out of bounds)");
+        throw NoFramesSelected();
     if (s_psnr) res.psnr = MetricAggregate::from(std::move(*s_psnr));
     if (s_ssim) res.ssim = MetricAggregate::from(std::move(*s_ssim));
     if (s_msssim) res.msssim = MetricAggregate::from(std::move(*s_msssim));

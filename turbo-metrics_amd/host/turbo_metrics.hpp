@@ -155,6 +155,12 @@ public:
     virtual void set_lookahead(size_t frames) {}
 };
 
+// compute_all selected no frame pair at all (the reference panics in Stats::compute: index out of bounds)
+class NoFramesSelected : public std::out_of_range {
+public:
+    NoFramesSelected() : std::out_of_range("no frame pair was processed (the reference panics in Stats::compute: index out of bounds)") {}
+};
+
 class TmError : public std::runtime_error {
 public:
     int code;

@@ -712,20 +712,22 @@ VideoFrameSource::VideoFrameSource(std::unique_ptr<Demuxer> demuxer, const Sourc
     decoder_name_ = prog && *prog ? prog : "ffmpeg";
     const char *in_fmt = codec == Codec::H264 ? "h264" : (codec == Codec::MPEG2 ? "mpegvideo" : "ivf"); // AV1 packets are re-wrapped as IVF
     int to_child[2], from_child[2];
-    if (pipe(to_child) != 0 || pipe(from_child) != 0) vfail(std::string("pipe: ") + strerror(errno));
+    if (pipe2(to_child, O_CLOEXEC) != 0 || pipe2(from_child, O_CLOEXEC) != 0) vfail(std::string("pipe: ") + strerror(errno));
     signal(SIGPIPE, SIG_IGN);
     const pid_t pid = fork();
     if (pid < 0) vfail(std::string("fork: ") + strerror(errno));
     if (pid == 0) {
         dup2(to_child[0], 0); dup2(from_child[1], 1);
         close(to_child[0]); close(to_child[1]); close(from_child[0]); close(from_child[1]);
-        execlp(decoder_name_.c_str(), decoder_name_.c_str(), "-v", "error", "-f", in_fmt, "-i", "pipe:0", "-f", "yuv4mpegpipe", "-strict", "-1", "pipe:1",
-               (char *)nullptr);
+        // one output picture per decoded picture, whatever rate the muxer guesses (raw streams carry no timestamps): without
+        // passthrough a constant-frame-rate muxer may duplicate or drop pictures and misalign the reference / distorted pairs
+        // (the reference's NVDEC path emits exactly one picture per decode).  dup2 clears O_CLOEXEC on descriptors 0 and 1.
+        execlp(decoder_name_.c_str(), decoder_name_.c_str(), "-nostdin", "-v", "error", "-f", in_fmt, "-i", "pipe:0", "-fps_mode", "passthrough", "-f",
+               "yuv4mpegpipe", "-strict", "-1", "pipe:1", (char *)nullptr);
         _exit(127);
     }
     child_ = (int)pid;
     close(to_child[0]); close(from_child[1]);
-    fcntl(to_child[1], F_SETFD, FD_CLOEXEC); fcntl(from_child[0], F_SETFD, FD_CLOEXEC);
     const int wfd = to_child[1];
     Demuxer *dm = demuxer_.get();
     const uint32_t w = fmt_.width, h = fmt_.height;
