@@ -324,7 +324,7 @@ def test_video_source_feeds_the_decoder_and_takes_colour_from_the_sequence_heade
     assert open(out, "rb").read() == want
     es = open(env["TM_FAKE_ES"], "rb").read()
     args, stream = es.split(b"\n", 1)
-    assert args == b"-v error -f h264 -i pipe:0 -f yuv4mpegpipe -strict -1 pipe:1"
+    assert args == b"-nostdin -v error -f h264 -i pipe:0 -fps_mode passthrough -f yuv4mpegpipe -strict -1 pipe:1"  # one picture out per picture decoded
     assert stream == b"".join(b"\x00\x00\x00\x01" + n for n in [sps, pps] + nals)
     # AV1 in IVF: packets re-wrapped as IVF for the decoder; size and colour from the sequence header OBU, frame count from the header
     seq = av1_sequence_header_obu(w, h, color=(1, 1, 1), full=1)
