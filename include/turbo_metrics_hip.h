@@ -221,8 +221,11 @@ int tm_engine_set_graph(tm_engine *e, int on);
  * LDS-free kernels kept as the on-device cross-check (SSIMULACRA2 / PSNR only; they keep the linear pyramid and a transposed
  * XYB copy in HBM, allocated on first selection) -- the two produce identical bits (tests/test_gpu_parity.py).
  * TM_VARIANT_WIDE_ROWS (test hook, default pipeline only): the row-pass instantiation that frames wider than 2560 pixels get,
- * forced on any size.  TM_ERR_INVALID_ARG for any other value. */
-enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100, TM_VARIANT_TILE_INGEST = 0x200, TM_VARIANT_DEEP_ROWS = 0x400 };
+ * forced on any size.  TM_VARIANT_TILE_INGEST: the 32 x 8 tile ingest kernel for the 4:2:0 kinds too (default: the row-walking
+ * kernel).  TM_VARIANT_SPLIT_ROWS / TM_VARIANT_WHOLE_ROWS: force / forbid the three-wave row pass that small batches get by
+ * default.  Every combination produces the same bits.  TM_ERR_INVALID_ARG for any other value. */
+enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100, TM_VARIANT_TILE_INGEST = 0x200, TM_VARIANT_SPLIT_ROWS = 0x400,
+       TM_VARIANT_WHOLE_ROWS = 0x800 };
 int tm_engine_set_variant(tm_engine *e, int variant);
 
 /* ---- test hooks: read back intermediate planes of one slot (blocking) ------------------ */

@@ -269,7 +269,8 @@ static int g_ingest_rows = 4; // quad rows per wave of k_ingest_rows (even)
 void emul_set_ingest_rows(int r) { g_ingest_rows = r < 2 ? 2 : (r & ~1); }
 
 // variant: 0 = the default pipeline, 1 = the reference pipeline (TM_VARIANT_REFERENCE), 0x100 = default with the wide-frame row pass,
-// 0x200 = default with the tile ingest kernel for the 4:2:0 kinds too (TM_VARIANT_TILE_INGEST)
+// 0x200 = default with the tile ingest kernel for the 4:2:0 kinds too (TM_VARIANT_TILE_INGEST), 0x400 = the three-wave row pass
+// of small batches (TM_VARIANT_SPLIT_ROWS)
 void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lut, const float *coef, const double *tab, int want_sse,
                    float *LIN, float *XYB, float *XYBT, float *V, double *PART, double *SUMS, unsigned long long *SSE,
                    int variant, const double *weights, int full_sums, unsigned char *QU8, unsigned long long qplane, int qpitch)
@@ -311,7 +312,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
         launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
-        if (wide_rows) launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });
+        if (variant & 0x400) launch_wg_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), 192, [&] { tmk::k_blur_h_jobs_split(g, jobs, XYB, V, PART); });
+        else if (wide_rows) launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });
         else launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 32, 16>(g, jobs, XYB, V, PART); });
     }
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });

@@ -49,7 +49,7 @@ def check_against_oracle(em, frames, w, h, have_linear=True, have_xybt=True):
         assert int(em.SSE[slot]) == sse
 
 
-REFERENCE, DEFAULT, WIDE_ROWS, TILE_INGEST = 1, 0, 0x100, 0x200  # emul_pipeline variants == TM_VARIANT_* of the engine
+REFERENCE, DEFAULT, WIDE_ROWS, TILE_INGEST, SPLIT_ROWS = 1, 0, 0x100, 0x200, 0x400  # emul_pipeline variants == TM_VARIANT_* of the engine
 
 
 def nv12_frames(w, h, count=2):
@@ -241,6 +241,19 @@ def test_row_walking_ingest_matches_oracle_and_the_tile_kernel(w, h, rows):
         assert np.array_equal(em.SUMS, old.SUMS)
         if ssimw is not None:
             assert np.array_equal(em.QU8, old.QU8)
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (1, 1), (2, 5), (129, 20), (257, 131), (16, 200), (12, 64)])
+def test_three_wave_row_pass_writes_the_same_partial_sums(w, h):
+    """k_blur_h_jobs_split (small batches: two producer waves + one consumer wave per 64-row block, a 16-step LDS ring between them)
+    against the oracle, and bit-identical 108 sums with the one-wave row pass -- pruned and full job tables"""
+    frames = nv12_frames(w, h)
+    for full in (True, False):
+        em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=SPLIT_ROWS, weights=O.weights(), full_sums=full)
+        one = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=full)
+        assert np.array_equal(em.SUMS, one.SUMS) and np.array_equal(em.PART, one.PART)
+        if full:
+            check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
 
 
 def planar_frames(w, h, bits, count=2):

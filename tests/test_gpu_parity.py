@@ -156,6 +156,34 @@ def test_row_walking_ingest_equals_the_tile_ingest_and_the_oracle(kind, w, h):
     eng.close()
 
 
+@pytest.mark.parametrize("w,h,batch", [(333, 203, 2), (1920, 1080, 1), (70, 38, 3)])
+def test_three_wave_row_pass_is_bit_identical_with_the_one_wave_row_pass(w, h, batch):
+    """k_blur_h_jobs_split (what small batches run by default) against k_blur_h_jobs_x: the same 108 sums, bit for bit, pruned and
+    full job tables, and the oracle's"""
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=batch)
+    frames = [nv12_frames(w, h, n) for n in range(batch)]
+    for slot, (fr, fd) in enumerate(frames):
+        eng.set_pair(slot, fr, fd)
+    for full in (False, True):
+        eng.set_full_sums(full)
+        got = {}
+        for name, variant in (("split", F.TM_VARIANT_SPLIT_ROWS), ("whole", F.TM_VARIANT_WHOLE_ROWS), ("default", F.TM_VARIANT_DEFAULT)):
+            eng.set_variant(variant)
+            eng.compute_async()
+            eng.sync()
+            got[name] = [eng.raw_sums(i).copy() for i in range(batch)]
+        for i in range(batch):
+            assert np.array_equal(got["split"][i], got["whole"][i]) and np.array_equal(got["default"][i], got["whole"][i])
+    if w * h <= 333 * 203:
+        eng.set_variant(F.TM_VARIANT_SPLIT_ROWS)
+        eng.compute_async()
+        eng.sync()
+        for slot, (fr, fd) in enumerate(frames):
+            lin, sums = check_planes(eng, slot, fr, fd, w, h, scales=range(2))
+            check_scores(eng, slot, lin, sums, w, h)
+    eng.close()
+
+
 def test_every_input_kind_matches_oracle():
     w, h = 94, 58
     rng = np.random.default_rng(5)

@@ -17,32 +17,26 @@ for B in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2
         (rt, rp, rch), (dt, dp, dch) = pairs[slot % 4]
         eng.set_pair(slot, tm.HwFrame.nv12(rt, rp, rch), tm.HwFrame.nv12(dt, dp, dch))
     row = {"batch": B}
-    for graph in (False, True):
-        eng.set_graph(graph)
+    sc = None
+    for name, variant in (("whole", tm.ffi.TM_VARIANT_WHOLE_ROWS), ("split", tm.ffi.TM_VARIANT_SPLIT_ROWS)):
+        eng.set_variant(variant)
+        eng.set_profiling(False)
         for _ in range(30):
             eng.compute_async(); eng.sync()
-        eng.set_profiling(False)
         t0 = time.perf_counter()
         for _ in range(200):
             eng.compute_async(); eng.sync()
-        row["wall_ms_graph" if graph else "wall_ms"] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
-    eng.set_graph(False)
-    eng.set_profiling(True)
-    eng.stage_ms(reset=True)
-    for _ in range(100):
-        eng.compute_async(); eng.sync()
-    ms, n = eng.stage_ms(reset=True)
-    row["stage_ms[ingest,col,row,ssim]"] = [round(m / n, 4) for m in ms]
-    sc = [eng.scores(i).ssimulacra2 for i in range(B)]
-    eng.set_variant(tm.ffi.TM_VARIANT_DEEP_ROWS)
-    for _ in range(10):
-        eng.compute_async(); eng.sync()
-    eng.stage_ms(reset=True)
-    for _ in range(100):
-        eng.compute_async(); eng.sync()
-    ms, n = eng.stage_ms(reset=True)
-    row["deep_rows_stage_ms"] = [round(m / n, 4) for m in ms]
-    assert sc == [eng.scores(i).ssimulacra2 for i in range(B)]
+        row[name + "_wall_ms"] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
+        eng.set_profiling(True)
+        eng.stage_ms(reset=True)
+        for _ in range(100):
+            eng.compute_async(); eng.sync()
+        ms, n = eng.stage_ms(reset=True)
+        row[name + "_stage_ms[ingest,col,row,ssim]"] = [round(m / n, 4) for m in ms]
+        got = [eng.scores(i).ssimulacra2 for i in range(B)]
+        assert sc is None or sc == got
+        sc = got
+    row["pairs_per_s"] = {k: round(B / row[k + "_wall_ms"] * 1e3) for k in ("whole", "split")}
     # back-to-back submission without a sync per step (what a pipelined caller sees)
     eng.set_profiling(False)
     torch.cuda.synchronize()

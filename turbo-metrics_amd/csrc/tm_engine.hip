@@ -125,6 +125,7 @@ struct tm_engine {
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
     int variant = TM_VARIANT_DEFAULT;
+    long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms; TM_SPLIT_ROWS_BELOW overrides: tuning)
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (TM_INGEST_ROWS overrides: tuning)
 };
 
@@ -451,6 +452,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     auto fail = [&](int code) { tm_engine_destroy(e); return code; };
     if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
+    if (const char *sr = getenv("TM_SPLIT_ROWS_BELOW")) e->split_rows_below = atoll(sr);
     if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
     tm_make_jobs(&e->jobs, &e->g, k_weights, 0);
@@ -573,7 +575,7 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST | TM_VARIANT_DEEP_ROWS))) return TM_ERR_INVALID_ARG;
+    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST | TM_VARIANT_SPLIT_ROWS | TM_VARIANT_WHOLE_ROWS))) return TM_ERR_INVALID_ARG;
     const bool ref = (variant & TM_VARIANT_REFERENCE) != 0;
     // the reference pipeline is SSIMULACRA2 (+ PSNR) only: its ingest kernel neither writes the u8 planes of SSIM / MS-SSIM nor runs without the XYB arenas
     if (ref && ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) || !(e->mask & TM_METRIC_SSIMULACRA2))) return TM_ERR_INVALID_ARG;
@@ -680,7 +682,9 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART);
-        else if (e->variant & TM_VARIANT_DEEP_ROWS) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<32, 16, 32, 16>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
+        // few row blocks (small batches): three waves per block -- a wave's own issue rate, not the chip, bounds this pass then
+        else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * e->jobs.hstart[TM_MAX_JOBS] <= e->split_rows_below))
+            hipLaunchKernelGGL(tmk::k_blur_h_jobs_split, hgrid, dim3(192), 0, st, g, e->jobs, XYB, V, PART);
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));

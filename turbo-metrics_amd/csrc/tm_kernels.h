@@ -1385,6 +1385,162 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row pass for SMALL batches ("split"): the same arithmetic and the same per-lane order of accumulation as k_blur_h_jobs_x --
+// its PART entries are bit-identical --, cut across THREE waves per 64-row block.  Why: one wave issues at most one
+// instruction per four cycles, and a step of the FULL path is ~180 instructions (five recurrences, seven loads, the LDS
+// transposition, two IEEE divisions, six f64 accumulations), so the 1 924 steps of a 1080p row take 0.58 ms however idle the
+// chip is -- with fewer waves than SIMDs (8 pairs: 860 waves on 1 024 SIMDs) the pass sits at that latency.  Here
+//   wave 0  recurrences sigma11, sigma22 (FULL) + the ref / dis blocks: fetched in the normal orientation, parked transposed in LDS
+//   wave 1  recurrences sigma12, mu1, mu2 (FULL) / mu1, mu2 (EDGE)
+//   wave 2  the consumer: five (two) blurred values + ref, dis from LDS -> compute_error_maps -> f64 sums
+// and the longest of the three step bodies is ~70 instructions.  Steps run in phases of 16 with one LDS barrier per phase:
+// the producers fill half (phase & 1) of a two-phase ring [2][16][5][64] (40 KB) while the consumer empties the other half --
+// step t of the recurrences emits column t - 4, stored at ring position t --; ref / dis block b (columns 16 b .. + 15) is
+// loaded during phase b - 1, written during phase b, read during phases b + 1 and b + 2: four tile buffers (35 KB).
+// 75 KB of LDS per workgroup -> two workgroups per CU: for launches with fewer row blocks than the chip has wave slots only
+// (the engine switches by batch size; TM_VARIANT_SPLIT_ROWS forces it).  grid (slots, jobs.hstart[n]), block 192.
+// ------------------------------------------------------------------------------------------------
+template <int NP, int NA = (NP > 0 ? NP : 1)> // NP: planes of this producer
+__device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)[16][5][64], const float *const (&v)[NA], const int (&plane)[NA],
+                                                      float (*__restrict__ tile)[4][64][17], const float *__restrict__ rdn, bool fetch_rd,
+                                                      int y0, int w, int h, int pitch, int pt, int nphases)
+{
+    constexpr int WN = 16, P = WN - 10;
+    const int lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
+    auto ld_col = [&](const float *__restrict__ p, int x) { // column x of a transposed blurred plane, this lane's row; 0 outside
+        const int rc = x < w ? x : w - 1;
+        const float val = p[(size_t)rc * pt];
+        return x < w ? val : 0.0f;
+    };
+    float win[NA][WN];
+    tmdev::Iir f[NA];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        f[k] = tmdev::Iir{0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < WN; ++j) win[k][j] = j < P ? ld_col(v[k], j) : 0.0f;
+    }
+    // ref / dis block e: rows y0 + 4 * i + lr (i = 0 .. 15), columns 16 * e + lc: one 8-byte load per lane and row group
+    float qa[16], qb[16];
+    auto fetch_block = [&](int e) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int x = 16 * e + lc, y = y0 + 4 * i + lr;
+            const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
+            const float2 val = *(const float2 *)(rdn + 2 * ((size_t)yc * pitch + xc));
+            qa[i] = val.x; qb[i] = val.y;
+        }
+    };
+    if (fetch_rd) fetch_block(0);
+    for (int ph = 0; ph < nphases; ++ph) {
+        if (fetch_rd) { // block ph (in registers since the previous phase) -> its buffer; block ph + 1 requested
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[i]; tile[1][ph & 3][4 * i + lr][lc] = qb[i]; }
+            fetch_block(ph + 1);
+        }
+        if (NP > 0) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int t = 16 * ph + j; // row t lives in slot j, row t-10 in slot (j+P) % WN, which row t+P then takes over
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const float o = tmdev::iir_step(f[k], win[k][(j + P) % WN] + win[k][j]);
+                    win[k][(j + P) % WN] = ld_col(v[k], t + P);
+                    ring[ph & 1][j][plane[k]][lane] = o;
+                }
+            }
+        }
+        TM_LDS_BARRIER();
+    }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__ ring)[16][5][64], const float (*__restrict__ tile)[4][64][17],
+                                                      int w, bool valid, int nphases, double (&acc)[6])
+{
+    const int lane = threadIdx.x & 63;
+    const int T = w + 4;
+    for (int ph = 0; ph < nphases; ++ph) {
+        if (ph > 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = 16 * (ph - 1) + j;
+                if (t >= 4 && t < T) {
+                    const int u = t - 4; // the column whose maps are evaluated now
+                    const float (*r)[64] = ring[(ph - 1) & 1][j];
+                    const float mu1 = r[3][lane], mu2 = r[4][lane];
+                    const float src = tile[0][(u >> 4) & 3][lane][u & 15], dsv = tile[1][(u >> 4) & 3][lane][u & 15];
+                    float ssim = 0.0f, art, det;
+                    if (FULL) tmdev::error_maps(src, dsv, mu1, mu2, r[0][lane], r[1][lane], r[2][lane], ssim, art, det);
+                    else tmdev::edge_maps(src, dsv, mu1, mu2, art, det);
+                    if (valid) {
+                        float q;
+                        if (FULL) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
+                        acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
+                        acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
+                    }
+                }
+            }
+        }
+        TM_LDS_BARRIER();
+    }
+}
+
+__global__ void __launch_bounds__(192) k_blur_h_jobs_split(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, const float *__restrict__ V,
+                                                            double *__restrict__ PART)
+{
+    __shared__ float ring[2][16][5][64];
+    __shared__ float tile[2][4][64][17];
+    const int b = blockIdx.y, slot = blockIdx.x;
+    const int j = tm_find_job(jobs.hstart, b);
+    const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
+    const TmScaleGeom sg = g.s[s];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int y0 = (b - jobs.hstart[j]) * 64;
+    const int y = y0 + lane;
+    const bool valid = y < sg.h;
+    const int yy = valid ? y : sg.h - 1;
+    const size_t to = sg.off_t + c * sg.plane_t + (size_t)yy;
+    const float *rdn = XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane);
+    const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to, *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to,
+                *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to, *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to,
+                *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
+    const int nphases = (sg.w + 4 + 15) / 16 + 1; // the consumer runs one phase behind the producers
+    const bool full = mode == TM_MODE_FULL;
+    if (wave == 0) {
+        if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, true, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
+        else { const float *const pv[1] = {nullptr}; const int pl[1] = {0}; blur_h_split_producer<0>(ring, pv, pl, tile, rdn, true, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
+    } else if (wave == 1) {
+        if (full) { const float *const pv[3] = {v2, v3, v4}; const int pl[3] = {2, 3, 4}; blur_h_split_producer<3>(ring, pv, pl, tile, rdn, false, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
+        else { const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
+    } else {
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        if (full) blur_h_split_consumer<true>(ring, tile, sg.w, valid, nphases, acc);
+        else blur_h_split_consumer<false>(ring, tile, sg.w, valid, nphases, acc);
+#ifdef TM_EMULATE
+        { // the lockstep emulator runs the lanes as concurrent fibers: sum through memory, in lane order like the shuffle tree's result
+            __shared__ double redl[6][64];
+            for (int k = 0; k < 6; ++k) redl[k][lane] = acc[k];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
+                for (int k = 0; k < 6; ++k) { double tsum = 0.0; for (int i = 0; i < 64; ++i) tsum += redl[k][i]; o[k] = tsum; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#else
+        if (tm_wave_sum6(acc)) {
+            double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = acc[k];
+        }
+#endif
+    }
+}
+
 // fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no
 // job produces (weight 0.0 in the reference's table) are written as 0
 __global__ void __launch_bounds__(128) k_finish_jobs(TmJobs jobs, const double *__restrict__ PART, double *__restrict__ SUMS)
