@@ -38,12 +38,13 @@
  * bit-identical to the CPU oracle of this build (oracle/tm_oracle.c; a second, independently written numpy restatement agrees
  * with it bit for bit), so scores agree with that oracle to <= 1e-9.  Against the reference's own binary bit equality cannot
  * be claimed: it calls closed NVIDIA code (__nv_fast_powf, ~8 ulp; __nv_cbrtf, 1 ulp) whose last bits the score amplifies.  This
- * build evaluates the reference's expressions more accurately than the reference does -- the BT.709 transfer function on the
- * reference's own f32 base (v + a) / A, <= 0.69 ulp of that expression with an exact pow; the cube root <= 0.5003 ulp -- and
- * tests/golden/scores_accurate_frozen.json commits, per seeded case, the distance to the correctly rounded evaluation: 2e-5 ...
- * 3.2e-3 up to 640x360, 1.8e-2 on the 1080p NV12 case, whose score moves by 7e-3 ... 4e-2 when 0.8 % of its linear samples move
- * by ONE ulp (an exp2f(y * log2f(x))-shaped pow like libdevice's moves these cases by 3e-4 ... 1.1e-2; the reference's own
- * GPU-vs-CPU check allows 0.25).  Each case is held to max(2 x its committed distance, 1e-3) by tests/test_golden_accurate.py.
+ * build evaluates the reference's expressions more accurately than the reference does -- the BT.709 transfer function is the
+ * reference's expression correctly rounded (its own f32 base (v + a) / A, a binary64 cubic, one rounding: 117 of 15.4 M arguments
+ * are not the nearest float); the cube root is within 0.5003 ulp -- and tests/golden/scores_accurate_frozen.json commits, per
+ * seeded case, the distance to the correctly rounded evaluation of every expression: 3e-6 ... 2.4e-3 (all of it the cube root's;
+ * an exp2f(y * log2f(x))-shaped pow like libdevice's moves these cases by 3e-4 ... 1.1e-2, and the 1080p NV12 case moves by
+ * 7e-3 ... 4e-2 when 0.8 % of its linear samples move by ONE ulp; the reference's own GPU-vs-CPU check allows 0.25).  Each case is
+ * held to max(2 x its committed distance, 1e-3) by tests/test_golden_accurate.py.
  */
 #ifndef TURBO_METRICS_HIP_H
 #define TURBO_METRICS_HIP_H

@@ -14,7 +14,8 @@
  * integer bit manipulation; cbrtf: binary32 *, -, fma).  The HIP kernels execute
  * the same sequence (turbo-metrics_amd/csrc/tm_device_math.h, written separately), and
  * because every step is an exactly specified IEEE operation the two agree bit for bit.
- * Accuracy: |error| <= 0.50001 ulp(f32) (tests/test_oracle_pins.py); libdevice documents 1 ulp for
+ * Accuracy (tests/test_oracle_pins.py, exhaustive scans): cbrtf <= 0.5003 ulp; the BT.709 power branch is the correctly rounded
+ * value of the reference's expression for all but 117 of 15.4 M arguments; powf <= 0.50001 ulp.  libdevice documents 1 ulp for
  * cbrtf and ~2 ulp + for fast_powf, i.e. the oracle sits inside the reference's own error band.
  *
  * Compile with -ffp-contract=off (the fma calls below are the only fused operations).
@@ -101,30 +102,29 @@ static inline float tmo_powf(float xf, double y)
     return (float)tmo_u2d(tmo_d2u(res) + ((uint64_t)(int64_t)(ki >> 5) << 52));
 }
 
-/* BT.709 transfer function, power branch (cuda-colorspace-kernel/src/lib.rs:228): powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45).
- * The base x is formed exactly as the reference forms it -- one f32 addition, one IEEE f32 division -- and x^(1/0.45f) on
- * [21/128, 1) is one of 128 cubics in t = 128 x - k, k = floor(128 x) (both exact in f32), coefficients from
- * tools/gen_math_tables.py, c0 = hi + lo so that the last addition is the only rounding that matters.  So the one deviation
- * from the reference's expression evaluated with a correctly rounded pow is that last rounding (tmo_bt709_eotf_max_ulp scans
- * every float of the interval, tests/test_oracle_pins.py); the rounding of the base, which the power amplifies, is the
- * reference's.  The product runs the same sequence (tm_device_math.h bt709_eotf; its 4-operation constant division returns the
- * IEEE quotient, tools/check_div_const.c).  x >= 1 (v >= 1, or a sum that rounds up to ALPHA): the exact value is >= 1 and
- * every caller clamps to 1. */
-static const float tmo_eotf_c[516] = {TM_EOTF_C};
-static const float tmo_eotf_c0lo[129] = {TM_EOTF_C0LO};
+/* BT.709 transfer function, power branch (cuda-colorspace-kernel/src/lib.rs:228): powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45),
+ * in binary64: the reference's f32 base x (its two f32 operations: one addition, one IEEE division), then x^(1/0.45f) from one of 428 cubics in
+ * t = 512 x - k with binary64 coefficients, three binary64 fma, ONE rounding to binary32 -- the correctly rounded value of the
+ * reference's expression for all but ~1e-4 of the 15.4 M arguments (tmo_bt709_eotf_max_ulp2 counts them), i.e. practically the
+ * bits of "float64 pow of the f32 base, rounded once", which is what the independent numpy twin evaluates
+ * (oracle/twin_numpy.py eotf="exact").  The product runs the same sequence (tm_device_math.h bt709_eotf / bt709_power2; its
+ * 4-operation constant division returns the IEEE quotient, tools/check_div_const.c).  x >= 1 (v >= 1, or a sum that rounds up to
+ * ALPHA): the exact value is >= 1 and every caller clamps to 1. */
+static const double tmo_eotf64_c[4 * 513] = {TM_EOTF64_C};
 static inline float tmo_bt709_power(float v)
 {
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
     const float x = (v + (ALPHA - 1.0f)) / ALPHA;
-    const float s = x * 128.0f;
-    if (s >= 128.0f) return 1.0f;
+    const float s = x * 512.0f;
+    if (s >= 512.0f) return 1.0f;
     const int k = (int)s;
-    const float t = s - (float)k;
-    const float *c = tmo_eotf_c + 4 * k;
-    float q = fmaf(c[3], t, c[2]);
-    q = fmaf(q, t, c[1]);
-    return fmaf(q, t, tmo_eotf_c0lo[k]) + c[0];
+    const double t = (double)(s - (float)k);
+    const double *c = tmo_eotf64_c + 4 * k;
+    double p = fma(c[3], t, c[2]);
+    p = fma(p, t, c[1]);
+    p = fma(p, t, c[0]);
+    return (float)p;
 }
 
 #endif

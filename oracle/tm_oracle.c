@@ -20,8 +20,8 @@
  * in the repository): "parity unpinned" for the final score.
  * The two libdevice routines of the path are closed NVIDIA code (__nv_cbrtf, ~1 ulp; __nv_fast_powf, ~8 ulp): tm_math.h
  * restates them as fixed IEEE sequences that are CLOSER to the exact functions than the originals (cube root <= 0.5003 ulp,
- * BT.709 transfer function: the reference's f32 base, then <= 0.69 ulp of its exact power; sRGB pow <= 0.50001 ulp; each scanned
- * exhaustively by tests/test_oracle_pins.py).
+ * BT.709 transfer function: the reference's f32 base, then the correctly rounded power of it but for 117 of 15.4 M arguments; sRGB pow
+ * <= 0.50001 ulp; each scanned exhaustively by tests/test_oracle_pins.py).
  * The score reacts to such last-bit differences at the 1e-3 .. 2e-2 level (tools/score_sensitivity.py), the reference's own
  * GPU-vs-CPU check allows +-0.25.
  *
@@ -193,7 +193,7 @@ static inline float bt709_eotf(float v)
     const float ALPHA = 1.0f + 5.5f * BETA;
     const float THRESHOLD = 0.08124285829863521110029445797874f;
     /* the reference: powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (fast_powf = exp2(y log2 x), ~8 ulp); here the same f32
-     * base, then the piecewise cubic of tm_math.h (< 1 ulp from the exact power of that base) */
+     * base, then its power from the binary64 cubics of tm_math.h, rounded once (correctly rounded but for 117 of 15.4 M arguments) */
     (void)ALPHA; (void)BETA;
     if (v >= THRESHOLD) return tmo_bt709_power(v);
     return v / 4.5f;

@@ -28,18 +28,13 @@ def build():
 
 
 def product_pow_tables():
-    """the math table buffer of turbo-metrics_amd/csrc/tm_math_tables.inc as the kernels expect it (TM_TAB_DOUBLES = 419 doubles):
-    96 doubles (rcp, nlog, exp2 of pow_pos), then the BT.709 transfer-function cubics as 516 + 129 floats (+ one of padding)"""
+    """the math table buffer of turbo-metrics_amd/csrc/tm_math_tables.inc as the kernels expect it (TM_TAB_DOUBLES doubles):
+    96 doubles (rcp, nlog, exp2 of pow_pos), then the 513 x 4 binary64 coefficients of the BT.709 transfer-function cubics"""
     import re
     txt = open(os.path.join(_ROOT, "turbo-metrics_amd", "csrc", "tm_math_tables.inc")).read()
-    lits = re.findall(r"(-?0x[0-9a-f.]+p[-+]?[0-9]+)(f?)", txt)
-    dbl = [float.fromhex(v) for v, f in lits if not f]
-    flt = [float.fromhex(v) for v, f in lits if f]
-    assert len(dbl) == 96 and len(flt) == 645, (len(dbl), len(flt))
-    buf = np.zeros(419, np.float64)
-    buf[:96] = dbl
-    buf[96:].view(np.float32)[:645] = np.array(flt, np.float32)
-    return buf
+    dbl = [float.fromhex(v) for v in re.findall(r"(-?0x[0-9a-f.]+p[-+]?[0-9]+)", txt)]
+    assert len(dbl) == 96 + 513 * 4, len(dbl)
+    return np.array(dbl, np.float64)
 
 
 class ScaleGeom(C.Structure):

@@ -20,12 +20,12 @@ static bool lockstep_on();
 bool tm_wave_sum_u32x3(unsigned (&v)[3])
 {
     if (lockstep_on()) { // the 64 lanes are concurrent host threads: sum through memory
-        static unsigned buf[3][64];
-        const unsigned l = lane_id();
-        for (int k = 0; k < 3; ++k) buf[k][l] = v[k];
+        static unsigned buf[16][3][64]; // per wave of the workgroup
+        const unsigned l = lane_id(), wv = ((threadIdx.x + threadIdx.y * blockDim.x) >> 6) & 15;
+        for (int k = 0; k < 3; ++k) buf[wv][k][l] = v[k];
         tm_emul_wave_barrier();
         if (l == 0)
-            for (int k = 0; k < 3; ++k) { unsigned t = 0; for (int i = 0; i < 64; ++i) t += buf[k][i]; v[k] = t; }
+            for (int k = 0; k < 3; ++k) { unsigned t = 0; for (int i = 0; i < 64; ++i) t += buf[wv][k][i]; v[k] = t; }
         tm_emul_wave_barrier();
         return l == 0;
     }
@@ -135,25 +135,25 @@ static void run_fibers(unsigned n, unsigned tid0, void (*body)(void *), void *ar
 #endif
 
 // wave shuffle for the lockstep emulation (64 host threads = the lanes of one wave): exchange through memory
-static float g_shfl[64];
+static float g_shfl[16][64]; // per wave of the workgroup: the waves of a lockstep workgroup interleave at their barriers
 unsigned tm_shfl_xor_u32(unsigned v, int mask)
 {
-    static unsigned buf[64];
-    const unsigned l = threadIdx.x & 63;
+    static unsigned buf[16][64];
+    const unsigned l = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 15;
     tm_emul_wave_barrier();
-    buf[l] = v;
+    buf[wv][l] = v;
     tm_emul_wave_barrier();
-    const unsigned r = buf[l ^ (unsigned)mask];
+    const unsigned r = buf[wv][l ^ (unsigned)mask];
     tm_emul_wave_barrier();
     return r;
 }
 float tm_shfl_xor(float v, int mask)
 {
-    const unsigned l = threadIdx.x & 63;
+    const unsigned l = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 15;
     tm_emul_wave_barrier();
-    g_shfl[l] = v;
+    g_shfl[wv][l] = v;
     tm_emul_wave_barrier();
-    const float r = g_shfl[l ^ (unsigned)mask];
+    const float r = g_shfl[wv][l ^ (unsigned)mask];
     tm_emul_wave_barrier();
     return r;
 }
@@ -294,7 +294,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16;
         if (yuv && !(variant & 0x200)) { // the engine's choice for the 4:2:0 kinds: the side-packed row-walking kernel
             const int rpw = g_ingest_rows;
-            launch_wave_lockstep(dim3((qw + 63) / 64, (qh + rpw - 1) / rpw, n), [&] {
+            launch_wg_lockstep(dim3((qw + 63) / 64, (qh + 4 * rpw - 1) / (4 * rpw), n), 256, [&] {
                 switch (kind) {
                 case TM_KIND_NV12: tmk::k_ingest_rows<TM_KIND_NV12, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
                 case TM_KIND_P016: tmk::k_ingest_rows<TM_KIND_P016, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;

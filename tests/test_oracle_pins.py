@@ -108,13 +108,13 @@ def test_powf_is_correctly_rounded_on_samples():
         assert bad.sum() == 0
 
 
-def test_bt709_transfer_function_is_within_0p7_ulp_of_the_reference_expression_everywhere():
-    """the power branch: the reference's f32 base x = (v + a) / A (its two f32 operations), then x^(1/0.45f) from a table of 128
-    cubics in x (oracle/tm_math.h == tm_device_math.h): scanned over EVERY float v of [threshold, 1) against long-double powl
-    of that f32 base -- the reference's expression as written, with an exact pow"""
+def test_bt709_transfer_function_is_the_correctly_rounded_reference_expression():
+    """the power branch: the reference's f32 base x = (v + a) / A (its two f32 operations), then x^(1/0.45f) from 428 binary64 cubics,
+    rounded once (oracle/tm_math.h == tm_device_math.h): scanned over EVERY float v of [threshold, 1) against long-double powl of
+    that f32 base -- the reference's expression as written, with an exact pow"""
     worst, at, off = O.bt709_eotf_max_ulp()
-    assert worst < 0.70, (worst, at)
-    assert off < 500000  # of 15.4 M arguments: 3 % are not the correctly rounded value, none is further than the neighbour
+    assert worst < 0.5001, (worst, at)
+    assert off <= 150  # of 15.4 M arguments: 117 are not the correctly rounded value (by < 0.0001 ulp)
     v = np.array([0.0, 0.01, 0.0812, 0.08124286, 0.5, 0.99999994, 1.0, 1.3], np.float32)
     got = O.bt709_eotf(v)
     assert got[0] == 0.0 and got[1] == np.float32(0.01) / np.float32(4.5) and got[2] == np.float32(0.0812) / np.float32(4.5)  # linear branch: IEEE division
@@ -122,12 +122,12 @@ def test_bt709_transfer_function_is_within_0p7_ulp_of_the_reference_expression_e
     x = np.linspace(0.0813, 0.9999, 20001).astype(np.float32)
     y = O.bt709_eotf(x)
     assert (np.diff(y.astype(np.float64)) >= 0).all()  # monotone across the segment joints
-    # against the twin's own evaluation (float64 pow of the f32 base, rounded once): never more than one ulp apart
+    # the twin's own evaluation (float64 pow of the f32 base, rounded once) gives the same bits
     from oracle import twin_numpy as T
     rng = np.random.default_rng(3)
-    v = rng.uniform(0.0813, 1.0, 200000).astype(np.float32)
+    v = rng.uniform(0.0813, 1.0, 400000).astype(np.float32)
     d = np.abs(O.bt709_eotf(v).view(np.int32).astype(np.int64) - T.bt709_eotf(v, "exact").view(np.int32).astype(np.int64))
-    assert d.max() <= 1 and (d > 0).mean() < 0.05
+    assert d.max() <= 1 and (d > 0).sum() <= 20
 
 
 def test_yuv_matrix_constants():

@@ -108,8 +108,8 @@ def test_yuv_to_linear_is_bit_identical_with_the_shared_transfer_function(kind, 
     got = T.yuv420_biplanar_to_linear(rs, rp, rch, w, h, bits, matrix, eotf=O.bt709_eotf)
     assert np.array_equal(got, want)
     # with the twin's own transfer function -- the reference's expression evaluated as written, f32-rounded base (v + a) / A,
-    # then a correctly rounded pow -- the planes are never more than one ulp apart and most samples are equal: the stand-in
-    # takes the same f32 base and differs only by the last rounding of its cubic (round 2, a fit in v: up to 5 ulp)
+    # then a float64 pow rounded once -- the planes are THE SAME BITS (but for one sample in ~130 000 whose float64 cubic falls on
+    # the other side of a rounding boundary): the stand-in is that expression, correctly rounded (round 2, a fit in v: up to 5 ulp)
     exact = T.yuv420_biplanar_to_linear(rs, rp, rch, w, h, bits, matrix, eotf="exact")
     ulp = np.abs(exact.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
-    assert ulp.max() <= 1 and (ulp > 0).mean() < 0.05
+    assert ulp.max() <= 1 and (ulp > 0).sum() <= 2

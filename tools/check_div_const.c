@@ -9,7 +9,7 @@ static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 int main(void)
 {
     const float BETA = 0.018053968510807f, ALPHA = 1.0f + 5.5f * BETA;
-    const float cs[] = {ALPHA, ALPHA * 0.0078125f /* bt709_eotf forms 128 x directly */, 4.5f};
+    const float cs[] = {ALPHA, ALPHA * 0.001953125f /* bt709_eotf forms 512 x directly */, 4.5f};
     long total = 0;
     for (unsigned k = 0; k < sizeof cs / sizeof cs[0]; ++k) {
         volatile float c = cs[k];

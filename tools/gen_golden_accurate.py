@@ -8,7 +8,8 @@ replaced by correctly rounded ones: cbrtf -> float64 cbrt rounded once, __nv_fas
 f32-rounded base, rounded once.  Beside each accurate score the file records, for the same inputs,
   fast_powf_shape   the twin with the transfer function evaluated like libdevice's fast path, exp2f(y * log2f(x)) in f32
   build             the C oracle (= the HIP kernels, bit for bit) with the arithmetic of round `build_round`; `build_history`
-                    keeps the figures of earlier rounds (r02: transfer function fitted in v; r03: the reference's f32 base)
+                    keeps the figures of earlier versions (r02: transfer function fitted in v, f32; r03a: an f32 cubic on the reference's f32
+                    base, <= 0.69 ulp; r03: that base, binary64 cubic, correctly rounded)
   bound             max(2 x |build - accurate|, 1e-3): what tests/test_golden_accurate.py allows oracle and HIP path
 so that the distance between this build and the reference's own arithmetic is a committed number, not prose.
 `accurate` and `fast_powf_shape` are frozen; `--refresh-build` recomputes only the build's own columns (after a deliberate
@@ -78,8 +79,8 @@ def refresh_build():
         if "oracle_at_freeze" in c:  # round-2 layout
             hist["r02"] = c.pop("oracle_at_freeze") - c["accurate"]
             c.pop("oracle_minus_accurate", None)
-        elif c.get("build_round") not in (None, BUILD_ROUND):
-            hist[c["build_round"]] = c["build_minus_accurate"]
+        elif c.get("build_round") not in (None, BUILD_ROUND) or "--keep-as" in sys.argv:
+            hist[sys.argv[sys.argv.index("--keep-as") + 1] if "--keep-as" in sys.argv else c["build_round"]] = c["build_minus_accurate"]
         c["build"] = oracle_score(c["kind"], c["width"], c["height"], c["pair"], c["matrix"])
         c["build_round"] = BUILD_ROUND
         c["build_minus_accurate"] = c["build"] - c["accurate"]

@@ -32,7 +32,7 @@ for _ in range(30):
 ref = None
 out = {}
 for rnd in range(3):
-    for name, variant, r in [("tile", tm.ffi.TM_VARIANT_TILE_INGEST, 0)] + [(f"rows{r}", 0, r) for r in rows]:
+    for name, variant, r in ([] if "--no-tile" in args else [("tile", tm.ffi.TM_VARIANT_TILE_INGEST, 0)]) + [(f"rows{r}", 0, r) for r in rows]:
         eng.set_variant(variant)
         L.tm_engine_debug_set_ingest_rows(eng._h, r)
         eng.compute_async(); eng.sync()

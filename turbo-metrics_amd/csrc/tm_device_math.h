@@ -6,8 +6,9 @@
 // Here they are fixed sequences of IEEE-754 operations, deterministic and reproducible on any IEEE machine -- which is what
 // lets the parity tests demand bit equality for every plane:
 //   cbrt              f32 mul / sub / fma only, 20 operations, evaluated on pairs (v_pk_*_f32); <= 0.5003 ulp
-//   BT.709 transfer   the reference's f32 base (v + a) / A, then a table of 128 cubics in it: 10 f32 operations; <= 0.69 ulp of the
-//                     reference's expression with an exact pow (the reference's fast_powf: ~8 ulp)
+//   BT.709 transfer   the reference's f32 base (v + a) / A, then its power from a table of 428 binary64 cubics (three v_fma_f64, one
+//                     rounding): the correctly rounded value of the reference's expression for all but 117 of 15.4 M arguments
+//                     (the reference's fast_powf: ~8 ulp)
 //   pow (sRGB path of 16-bit / f32 RGB frames)  ~20 f64 operations, three 32-entry tables, one rounding to f32; <= 0.50001 ulp
 // Cost matters: the ingest kernel is bound by its arithmetic, so none of the routines divides.
 //
@@ -162,11 +163,14 @@ __device__ __forceinline__ float div_const(float x, float c, float rc)
     return __builtin_copysignf(__builtin_fmaf(r, rc, q1), x);
 }
 
-// Layout of the math table buffer every ingest kernel stages in LDS: 96 doubles of pow_pos, then (as floats) the BT.709
-// transfer-function table: TM_EOTF_SEGS x {c0hi, c1, c2, c3}, then TM_EOTF_SEGS x c0lo (tools/gen_math_tables.py ->
-// tm_math_tables.inc; segment 128 is the constant 1 for bases >= 1), one float of padding
-#define TM_EOTF_SEGS 129
-#define TM_TAB_DOUBLES 419
+// Layout of the math table buffer (tm_math_tables.inc, uploaded once per engine): 96 doubles of pow_pos {rcp[32], nlog[32], exp2[32]},
+// then the binary64 transfer-function table: TM_EOTF64_SEGS records {c0, c1, c2, c3} of the cubic in t = 512 x - k (segment 512 is the
+// constant 1 for bases >= 1; segments below 84 are never read).  32-byte records, 32-byte aligned.
+#define TM_EOTF64_SEGS 513
+#define TM_EOTF64_STRIDE 4
+#define TM_TAB_POW_DOUBLES 96
+#define TM_TAB_EOTF64 96 /* offset (doubles) of the transfer-function table */
+#define TM_TAB_DOUBLES (TM_TAB_EOTF64 + TM_EOTF64_STRIDE * TM_EOTF64_SEGS)
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
@@ -190,39 +194,32 @@ __device__ __forceinline__ float fract_pos(float s)
 
 // BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs).  Power branch: the reference
 // evaluates powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (exp2(y log2 x), ~8 ulp).  Here the base x is formed with the
-// reference's own two f32 operations -- the addition, then the IEEE quotient (div_const_pos by ALPHA / 128, which returns
-// s = 128 x exactly: a power-of-two scaling of divisor and reciprocal scales every intermediate exactly) -- and x^(1/0.45f) on
-// [21/128, 1) is one of 128 cubics in t = s - k, k = floor(s) (both exact in f32), c0 = hi + lo so that the last addition is the
-// only rounding that matters: 10 f32 operations instead of a division and the ~45 of pow_pos.  The only deviation from the
-// reference's expression evaluated with a correctly rounded pow is that last rounding: <= 0.69 ulp over every float v of
-// [THRESHOLD, 1), 3 % of them not the nearest float (scanned exhaustively by the CPU test tier, tests/test_oracle_pins.py).
-// (Round 2 fitted the real function of v: 8 operations, but up to 5 ulp from the expression as written because the rounding
-// of the base, which the power amplifies, was not the reference's.)  x >= 1: the exact value is >= 1 and every caller clamps.
-__device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ tab)
+// reference's own two f32 operations -- the addition, then the IEEE quotient (div_const_pos by ALPHA / 512, which returns
+// s = 512 x exactly: a power-of-two scaling of divisor and reciprocal scales every intermediate exactly) -- and x^(1/0.45f) is
+// the cubic of one of 428 segments (t = s - k, k = floor(s), both exact in f32) with BINARY64 coefficients, three v_fma_f64, one
+// rounding to binary32: the correctly rounded power of that base for all but 117 of the 15.4 M floats of [THRESHOLD, 1), never
+// further than 0.500025 ulp (tests/test_oracle_pins.py scans them against long-double powl) -- practically the bits of "float64
+// pow of the f32 base, rounded once", which the independent numpy twin evaluates (eotf = "exact").  History: round 2 fitted
+// the real function of v in f32 (<= 0.68 ulp of THAT, up to 5 ulp from the expression as written, the 1080p NV12 golden 2.1e-2
+// from the accurate evaluation); an f32 cubic on the f32 base (<= 0.69 ulp, 3 % of the arguments off by one ulp) still left
+// it at 1.8e-2 -- that case moves by 7e-3 ... 4e-2 whenever 0.8 % of its samples move by ONE ulp (tools/score_conditioning.py)
+// --; with this evaluation every golden sits at the level the 0.5003-ulp cube root alone costs (<= 2.4e-3).  x >= 1: the exact
+// value is >= 1 and every caller clamps.  et64: the table (TM_EOTF64_SEGS records of 4 doubles), in LDS or global memory.
+__device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ et64)
 {
     const float THRESHOLD = 0.08124285829863521110029445797874f;
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
-    // (a branchless form -- both branches evaluated, one selected, so that the table reads of a quad's twelve evaluations are
-    // not fenced by divergent regions -- was measured: 1.44 vs 1.44 ms per 64 1080p pairs, no difference)
     if (v >= THRESHOLD) {
-        const float s = div_const_pos(v + (ALPHA - 1.0f), ALPHA * 0.0078125f, 128.0f / ALPHA);
-        if (s >= 128.0f) return 1.0f;
-        const float *__restrict__ et = (const float *)(tab + 96);
+        const float s = div_const_pos(v + (ALPHA - 1.0f), ALPHA * 0.001953125f, 512.0f / ALPHA);
+        if (s >= 512.0f) return 1.0f;
         const int k = (int)s;
-        const float t = fract_pos(s);
-        // byte offsets of c0lo[k] and of the cubic {c0hi, c1, c2, c3}[k]: two shifts -- left to itself the compiler derives one
-        // address from the other with a v_mul_lo_u32 by -12 (a quarter-rate instruction per evaluation)
-        unsigned kb = (unsigned)k << 2;
-#ifndef TM_EMULATE
-        asm("" : "+v"(kb));
-#endif
-        const float c0lo = *(const float *)((const char *)(et + 4 * TM_EOTF_SEGS) + kb);
-        const float *cub = (const float *)((const char *)et + (kb << 2));
-        const float c0 = cub[0], c1 = cub[1], c2 = cub[2], c3 = cub[3];
-        float q = __builtin_fmaf(c3, t, c2);
-        q = __builtin_fmaf(q, t, c1);
-        return __builtin_fmaf(q, t, c0lo) + c0;
+        const double t = (double)fract_pos(s);
+        const double *c = et64 + TM_EOTF64_STRIDE * k;
+        double p = __builtin_fma(c[3], t, c[2]);
+        p = __builtin_fma(p, t, c[1]);
+        p = __builtin_fma(p, t, c[0]);
+        return (float)p;
     }
     return div_const(v, 4.5f, 1.0f / 4.5f);
 }
@@ -232,50 +229,35 @@ __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ 
 #ifdef TM_EMULATE
 #define TM_WAVE_ANY(c) true
 #define TM_NO_IF_CONVERSION() ((void)0)
-#define TM_KEEP_SCALAR(x) ((void)0)
 #else
-#define TM_KEEP_SCALAR(x) asm("" : "+v"(x))
 #define TM_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
 #define TM_NO_IF_CONVERSION() asm volatile("; rare path") /* keeps the compiler from turning the uniform branch into selects */
 #endif
 
 // The power branch of bt709_eotf for TWO values at once (the ref and the dis sample of one pixel-channel: the side-packed ingest
-// kernel), without a test: same operations as bt709_eotf on each component.  The base, its constant division (-> s = 128 x)
-// run on the pair; s is clamped into [21, 128] so that the table index is always valid -- a base >= 1 lands on segment 128, the
-// constant 1, an argument below THRESHOLD on some segment whose value the caller replaces (bt709_eotf_linear_fix) --; the two
-// cubics run as scalar-lane fma chains straight out of their ds_read_b128 (pairing them would cost six moves to line the
-// coefficients of two different segments up in register pairs, and a packed operation retires at half the rate anyway).
-// Returns the UNCLAMPED values; et16: the table as 16-byte records {c0hi, c1, c2, c3}[129], then {c0lo, -, -, -}[129].
-struct alignas(16) tm_eotf_rec { float c0, c1, c2, c3; };
-#define TM_EOTF_LDS_FLOATS (8 * TM_EOTF_SEGS)
-__device__ __forceinline__ tm_f2 bt709_power2(tm_f2 v, const tm_eotf_rec *__restrict__ et16)
+// kernel), without a test: same operations as bt709_eotf on each component.  The base and its constant division (-> s = 512 x)
+// run on the pair; s is clamped into [84, 512] so that the table index is always valid -- a base >= 1 lands on segment 512, the
+// constant 1, an argument below THRESHOLD on some segment whose value the caller replaces (bt709_eotf_linear_fix).  Returns the
+// UNCLAMPED values.
+__device__ __forceinline__ tm_f2 bt709_power2(tm_f2 v, const double *__restrict__ et64)
 {
     const float BETA = 0.018053968510807f;
     const float ALPHA = 1.0f + 5.5f * BETA;
-    const float C = ALPHA * 0.0078125f, RC = 128.0f / ALPHA;
+    const float C = ALPHA * 0.001953125f, RC = 512.0f / ALPHA; // ALPHA / 512: the quotient is s = 512 x exactly
     const tm_f2 a = v + f2_splat(ALPHA - 1.0f);
     const tm_f2 q1 = a * f2_splat(RC);
     const tm_f2 rem = f2_fma(-q1, f2_splat(C), a);
-    const tm_f2 s = f2_fma(rem, f2_splat(RC), q1); // 128 * RN((v + a) / A)
-    const float s0 = fminf(fmaxf(s.x, 21.0f), 128.0f), s1 = fminf(fmaxf(s.y, 21.0f), 128.0f);
+    const tm_f2 s = f2_fma(rem, f2_splat(RC), q1); // 512 * RN((v + a) / A)
+    const float s0 = fminf(fmaxf(s.x, 84.0f), 512.0f), s1 = fminf(fmaxf(s.y, 84.0f), 512.0f);
     const int k0 = (int)s0, k1 = (int)s1;
-    const float t0 = fract_pos(s0), t1 = fract_pos(s1);
-    const tm_eotf_rec ra = et16[k0], rb = et16[k1];
-    const float la = et16[TM_EOTF_SEGS + k0].c0, lb = et16[TM_EOTF_SEGS + k1].c0;
-    float qa = __builtin_fmaf(ra.c3, t0, ra.c2);
-    TM_KEEP_SCALAR(qa); // the SLP vectorizer would pair the two chains again (v_pk_fma_f32 + six moves per pair)
-    float qb = __builtin_fmaf(rb.c3, t1, rb.c2);
-    qa = __builtin_fmaf(qa, t0, ra.c1);
-    TM_KEEP_SCALAR(qa);
-    qb = __builtin_fmaf(qb, t1, rb.c1);
-    qa = __builtin_fmaf(qa, t0, la);
-    TM_KEEP_SCALAR(qa);
-    qb = __builtin_fmaf(qb, t1, lb);
-    qa = qa + ra.c0;
-    TM_KEEP_SCALAR(qa);
-    qb = qb + rb.c0;
-    return f2_make(qa, qb);
+    const double t0 = (double)fract_pos(s0), t1 = (double)fract_pos(s1);
+    const double *ca = et64 + TM_EOTF64_STRIDE * k0, *cb = et64 + TM_EOTF64_STRIDE * k1;
+    double pa = __builtin_fma(ca[3], t0, ca[2]), pb = __builtin_fma(cb[3], t1, cb[2]);
+    pa = __builtin_fma(pa, t0, ca[1]); pb = __builtin_fma(pb, t1, cb[1]);
+    pa = __builtin_fma(pa, t0, ca[0]); pb = __builtin_fma(pb, t1, cb[0]);
+    return f2_make((float)pa, (float)pb);
 }
+
 // the linear branch v / 4.5 for the components below THRESHOLD (negative arguments: the reference's quotient is negative and
 // clamps to 0; so does the sign-free three-operation quotient used here -- its magnitude does not matter below 0)
 __device__ __forceinline__ tm_f2 bt709_eotf_linear_fix(tm_f2 v, tm_f2 p)

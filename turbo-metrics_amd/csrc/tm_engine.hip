@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,15 +43,13 @@ int hip_fail(hipError_t e, const char *what)
 
 const uint32_t k_lut_bits[256] = {TM_SRGB_LUT_BITS};
 const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
-// the math table buffer of tm_device_math.h (TM_TAB_DOUBLES): pow_pos tables, then the transfer-function cubics as floats
+// the math table buffer of tm_device_math.h (TM_TAB_DOUBLES): pow_pos tables, then the binary64 transfer-function cubics
 struct TmMathTab {
-    double pow[96];
-    float eotf_c[4 * TM_EOTF_SEGS];
-    float eotf_c0lo[TM_EOTF_SEGS];
-    float pad_;
+    double pow[TM_TAB_POW_DOUBLES];
+    double eotf64[TM_EOTF64_SEGS * TM_EOTF64_STRIDE];
 };
-static_assert(sizeof(TmMathTab) == TM_TAB_DOUBLES * sizeof(double), "math table layout");
-const TmMathTab k_powtab = {{TM_POW_RCP, TM_POW_NLOG, TM_POW_EXP2}, {TM_EOTF_C}, {TM_EOTF_C0LO}};
+static_assert(sizeof(TmMathTab) == TM_TAB_DOUBLES * sizeof(double) && offsetof(TmMathTab, eotf64) == TM_TAB_EOTF64 * sizeof(double), "math table layout");
+const TmMathTab k_powtab = {{TM_POW_RCP, TM_POW_NLOG, TM_POW_EXP2}, {TM_EOTF64_C}};
 
 // ---- colour coefficients: same f32 operation order as the reference's const evaluation -----------
 struct V3 { float x, y, z; };
@@ -455,6 +454,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (const char *sr = getenv("TM_SPLIT_ROWS_BELOW")) e->split_rows_below = atoll(sr);
     if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
+    if (const char *pp = getenv("TM_PYRT_PAD")) e->g.pyr_t += (unsigned long long)atoll(pp) / 64 * 64; // experiment: distance between the planes / slots of the transposed arenas (tools/stride_probe.py)
     tm_make_jobs(&e->jobs, &e->g, k_weights, 0);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
@@ -649,11 +649,11 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             rpw = 8;
             while (rpw > 2 && (long long)((qw + 63) / 64) * ((qh + rpw - 1) / rpw) * n < 16384) rpw /= 2;
         }
-        dim3 rgrid((unsigned)((qw + 63) / 64), (unsigned)((qh + rpw - 1) / rpw), (unsigned)n);
+        dim3 rgrid((unsigned)((qw + 63) / 64), (unsigned)((qh + 4 * rpw - 1) / (4 * rpw)), (unsigned)n);
         const tmk::TmIngestGeom ig = tmk::tm_ingest_geom(g);
         const bool quant = want_sse || QU8 != nullptr;
-#define TM_LAUNCH_R(K) do { if (quant) hipLaunchKernelGGL((tmk::k_ingest_rows<K, true>), rgrid, dim3(64), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); \
-                        else hipLaunchKernelGGL((tmk::k_ingest_rows<K, false>), rgrid, dim3(64), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); } while (0)
+#define TM_LAUNCH_R(K) do { if (quant) hipLaunchKernelGGL((tmk::k_ingest_rows<K, true>), rgrid, dim3(256), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); \
+                        else hipLaunchKernelGGL((tmk::k_ingest_rows<K, false>), rgrid, dim3(256), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); } while (0)
         const bool rows = !(e->variant & TM_VARIANT_TILE_INGEST);
         switch (kind) {
         case TM_KIND_NV12: if (rows) TM_LAUNCH_R(TM_KIND_NV12); else TM_LAUNCH_W(TM_KIND_NV12); break;

@@ -254,8 +254,8 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
         if (inside) {
             if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016 || d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16) {
                 if (2 * qx + 1 < w && 2 * qy + 1 < h) {
-                    if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, qx, qy, px);
-                    else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, qx, qy, px);
+                    if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, tab + TM_TAB_EOTF64, qx, qy, px);
+                    else ingest_yuv_quad<unsigned short, 16>(d, coef, tab + TM_TAB_EOTF64, qx, qy, px);
                 }
             } else {
 #pragma unroll
@@ -369,7 +369,8 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                                                     unsigned long long *__restrict__ SSE, int want_sse,
                                                     unsigned char *__restrict__ QU8, unsigned long long qplane, int qpitch)
 {
-    __shared__ double tab[TM_TAB_DOUBLES];
+    __shared__ double tab[TM_TAB_POW_DOUBLES]; // pow_pos tables (RGB16 / RGBF32); the transfer-function table of the YUV kinds is read from
+    const double *__restrict__ et64 = gtab + TM_TAB_EOTF64; // global memory here (16 KB, cache resident): this kernel is the fallback of the 4:2:0 kinds
     const int lane = threadIdx.x;
     const int qx = lane & 15, qy = lane >> 4;
     const int slot = blockIdx.z;
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     const int w = g.s[0].w, h = g.s[0].h;
     unsigned qref[3] = {0, 0, 0};
     unsigned sse3[3] = {0, 0, 0};
-    for (int i = lane; i < TM_TAB_DOUBLES; i += 64) tab[i] = gtab[i];
+    for (int i = lane; i < TM_TAB_POW_DOUBLES; i += 64) tab[i] = gtab[i];
     __builtin_amdgcn_wave_barrier();
     // side 0's XYB (four level-0 pixels + the level-1 pixel) waits in LDS until side 1 is done ([value][lane]: wave-private,
     // conflict-free; holding it in 15 VGPRs cost the fifth wave per SIMD)
@@ -413,13 +414,13 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                 const unsigned prs[3] = {side ? pr1[0] : pr0[0], side ? pr1[1] : pr0[1], side ? pr1[2] : pr0[2]};
                 unsigned raw[6];
                 yuv_quad_unpack<YUV8 ? 8 : 16>(prs, raw);
-                if (YUV8) yuv_quad_convert<8>(d, raw, coef, tab, px);
-                else yuv_quad_convert<16>(d, raw, coef, tab, px);
+                if (YUV8) yuv_quad_convert<8>(d, raw, coef, et64, px);
+                else yuv_quad_convert<16>(d, raw, coef, et64, px);
             }
         } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16) {
             if (quad_ok) {
-                if (kind == TM_KIND_NV12 || kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, tab, X0 / 2, Y0 / 2, px);
-                else ingest_yuv_quad<unsigned short, 16>(d, coef, tab, X0 / 2, Y0 / 2, px);
+                if (kind == TM_KIND_NV12 || kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, et64, X0 / 2, Y0 / 2, px);
+                else ingest_yuv_quad<unsigned short, 16>(d, coef, et64, X0 / 2, Y0 / 2, px);
             }
         } else {
 #pragma unroll
@@ -527,13 +528,13 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
 //     (k_ingest_wave's 32-pixel tiles made four workgroups, on different XCDs, fetch every line: 1.59 GB read per 64 1080p
 //     pairs for 0.40 GB of frames), 1-KB runs of the pyramid per store;
 //   * it walks down `rows_per_wave` quad rows: the samples of the next row are requested before the arithmetic of this one
-//     (a wave hides its own load latency), the 3.3 KB of tables are staged once per wave instead of once per 768 input
-//     bytes, row addresses advance in SGPRs, and the level-2 linear pixel (2 x 2 level-1 pixels) takes its upper pair from
+//     (a wave hides its own load latency), the transfer-function table (16.4 KB) is staged once per four waves x rows_per_wave rows, row addresses advance in SGPRs, and the level-2 linear pixel (2 x 2 level-1 pixels) takes its upper pair from
 //     the previous iteration's registers and its right-hand column from lane ^ 1 (one DPP move);
 //   * no divergent branch: the transfer function is evaluated branch-free (tm_device_math.h bt709_eotf2_clamped).
 // Edge rules as k_ingest_wave: an incomplete quad (odd last column / row) is not converted and reads as linear 0
 // (cuda-colorspace/src/kernel.rs:64-65); downscale clamps (downscale.rs:22-30) become "take the in-range neighbour".
-// grid (ceil(ceil(w/2) / 64), ceil(ceil(h/2) / rows_per_wave), slots), block 64; rows_per_wave even, <= 128.
+// grid (ceil(ceil(w/2) / 64), ceil(ceil(h/2) / (4 * rows_per_wave)), slots), block 256 = four independent waves that share one
+// staging of the table; rows_per_wave even, <= 128.
 // ------------------------------------------------------------------------------------------------
 #ifdef TM_EMULATE
 __device__ __forceinline__ float tm_swap1(float v) { return tm_shfl_xor(v, 1); }
@@ -577,7 +578,7 @@ __host__ __device__ inline TmIngestGeom tm_ingest_geom(const TmGeom &g)
 // unchanged; 4K: no difference)
 #define TM_ROWS_STORE(v, p) __builtin_nontemporal_store(v, p)
 template <int KIND, bool QUANT>
-__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmIngestGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ coef,
+__global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmIngestGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ coef,
                                                     const double *__restrict__ gtab, float *__restrict__ XYB, float *__restrict__ LIN2,
                                                     unsigned long long *__restrict__ SSE, int want_sse, unsigned char *__restrict__ QU8,
                                                     unsigned long long qplane, int qpitch, int rows_per_wave)
@@ -588,20 +589,15 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmInges
     constexpr bool YUV8 = KIND == TM_KIND_NV12 || KIND == TM_KIND_I420_8;
     constexpr int BITS = YUV8 ? 8 : 16;
     using T = typename std::conditional<YUV8, unsigned char, unsigned short>::type;
-    __shared__ tm_eotf_rec et16[2 * TM_EOTF_SEGS]; // the transfer-function table as 16-byte records (tm_device_math.h bt709_power2)
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(32))) double et64[TM_EOTF64_STRIDE * TM_EOTF64_SEGS]; // the transfer-function table (tm_device_math.h bt709_power2), 16.4 KB per four waves
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // four independent waves share one staging of the table
     const int slot = blockIdx.z;
     const int w = g.w, h = g.h;
     const int qx = blockIdx.x * 64 + lane, X0 = 2 * qx;
-    const int qy_begin = blockIdx.y * rows_per_wave;
+    const int qy_begin = (blockIdx.y * 4 + wave) * rows_per_wave;
     const int qy_end = min(qy_begin + rows_per_wave, g.h1); // h1 == ceil(h / 2): quad rows, the incomplete last one included
-    {
-        const float *gt = (const float *)(gtab + 96); // {c0hi, c1, c2, c3}[129], then c0lo[129]
-        for (int i = lane; i < TM_EOTF_SEGS; i += 64) {
-            et16[i] = tm_eotf_rec{gt[4 * i], gt[4 * i + 1], gt[4 * i + 2], gt[4 * i + 3]};
-            et16[TM_EOTF_SEGS + i] = tm_eotf_rec{gt[4 * TM_EOTF_SEGS + i], 0.0f, 0.0f, 0.0f};
-        }
-    }
+    for (int i = threadIdx.x; i < TM_EOTF64_STRIDE * TM_EOTF64_SEGS; i += 256) et64[i] = gtab[TM_TAB_EOTF64 + i];
     const TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
     const float *kr = coef + (dd0.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5, *kd = coef + (dd1.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
     const tm_f2 k0 = f2_make(kr[0], kd[0]), k1 = f2_make(kr[1], kd[1]), k2 = f2_make(kr[2], kd[2]), k3 = f2_make(kr[3], kd[3]), k4 = f2_make(kr[4], kd[4]);
@@ -609,7 +605,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmInges
     const bool colq = X0 + 1 < w; // this lane's quads are complete along x
     unsigned prn0[3] = {0, 0, 0}, prn1[3] = {0, 0, 0};
     if (colq && 2 * qy_begin + 1 < h) { yuv_quad_load_pairs<T, PLANAR>(dd0, qx, qy_begin, prn0); yuv_quad_load_pairs<T, PLANAR>(dd1, qx, qy_begin, prn1); }
-    __builtin_amdgcn_wave_barrier();
+    TM_LDS_BARRIER(); // the table is in place (the only barrier: from here on the waves never meet again)
     float *xi = XYB ? XYB + (size_t)slot * 2 * g.pyr : nullptr; // the slot's interleaved pyramid
     unsigned sse3[3] = {0, 0, 0};
     tm_f2 up[3] = {f2_splat(0.0f), f2_splat(0.0f), f2_splat(0.0f)}; // level-1 linear pixel of the quad row above (even rows wait here)
@@ -639,9 +635,9 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmInges
                 const tm_f2 luma = (f2_make(fmaxf((float)ra[q], ymin), fmaxf((float)rb[q], ymin)) - f2_splat(ymin)) * k0;
                 vr[q] = luma + r_; vg[q] = luma + g_; vb[q] = luma + b_;
                 vmin = fminf(fminf(vmin, fminf(vr[q].x, vr[q].y)), fminf(fminf(vg[q].x, vg[q].y), fminf(vb[q].x, vb[q].y)));
-                pr[q] = bt709_power2(vr[q], et16);
-                pg[q] = bt709_power2(vg[q], et16);
-                pb[q] = bt709_power2(vb[q], et16);
+                pr[q] = bt709_power2(vr[q], et64);
+                pg[q] = bt709_power2(vg[q], et64);
+                pb[q] = bt709_power2(vb[q], et64);
             }
             // the linear branch (v < 0.0812: luma codes below ~35) is rare in pictures: a wave evaluates it only when one of
             // its 24 x 64 arguments needs it (same bits either way)
@@ -739,7 +735,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmInges
     }
     if (QUANT && want_sse) {
         if (tm_wave_sum_u32x3(sse3)) {
-            const unsigned bin = (blockIdx.x + blockIdx.y * 29) % TM_SSE_BINS;
+            const unsigned bin = (blockIdx.x + (blockIdx.y * 4 + wave) * 29) % TM_SSE_BINS;
 #pragma unroll
             for (int c = 0; c < 3; ++c) atomicAdd(&SSE[((size_t)slot * TM_SSE_BINS + bin) * 3 + c], (unsigned long long)sse3[c]);
         }
