@@ -635,9 +635,13 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(4) k_ingest_rows(TmInge
                 const tm_f2 luma = (f2_make(fmaxf((float)ra[q], ymin), fmaxf((float)rb[q], ymin)) - f2_splat(ymin)) * k0;
                 vr[q] = luma + r_; vg[q] = luma + g_; vb[q] = luma + b_;
                 vmin = fminf(fminf(vmin, fminf(vr[q].x, vr[q].y)), fminf(fminf(vg[q].x, vg[q].y), fminf(vb[q].x, vb[q].y)));
+#ifdef TM_ABLATE_EOTF /* tools/ingest_breakdown.py: what the kernel costs without the transfer function */
+                pr[q] = vr[q]; pg[q] = vg[q]; pb[q] = vb[q];
+#else
                 pr[q] = bt709_power2(vr[q], et64);
                 pg[q] = bt709_power2(vg[q], et64);
                 pb[q] = bt709_power2(vb[q], et64);
+#endif
             }
             // the linear branch (v < 0.0812: luma codes below ~35) is rare in pictures: a wave evaluates it only when one of
             // its 24 x 64 arguments needs it (same bits either way)
