@@ -21,7 +21,7 @@ def row(label, x, bold=True, r01=None):
     val = f"**{fmt(x['value'])}**" if bold else fmt(x["value"])
     if r01: val += f" (r01: {r01})"
     st = x["stages"]
-    return (f"| {label} | {val} | {x['ms_per_step']:.2f} | {k['k_ingest_wave']['avg_launch_ms']:.2f} | {k['k_blur_v_jobs']['avg_launch_ms']:.2f} | "
+    return (f"| {label} | {val} | {x['ms_per_step']:.2f} | {k['k_ingest_rows']['avg_launch_ms']:.2f} | {k['k_blur_v_jobs']['avg_launch_ms']:.2f} | "
             f"{k['k_blur_h_jobs_x']['avg_launch_ms']:.2f} | {ss} | {'**' if bold and not r01 else ''}{x['roofline']['frac']:.3f}{'**' if bold and not r01 else ''} | "
             f"{st['blur_reduce_stage_frac']:.3f} ({st['survey_8d_model_frac']:.3f} on the §8d model) |")
 c = d["compare"]
@@ -29,24 +29,31 @@ w = d["workloads"]
 rows = [
     f"| workload (1 GPU, inputs resident in HBM), `{T}_bench.json` | pairs/s | ms/step | ingest | column pass | row pass | SSIM stage | column-pass frac of 8 TB/s | blur+reduce stage frac |",
     "|---|---|---|---|---|---|---|---|---|",
-    row("1080p NV12, SSIMULACRA2, 64 pairs/step (headline)", d),
+    row("1080p NV12, SSIMULACRA2, 64 pairs/step (headline; r01 driver: 11 384, r02 driver: 11 033)", d),
     row(f"— the same command under rocprofv3, `{T}_prof_bench_1080p.json`", prof),
     f"| — with all 108 sums (`compare`) | {fmt(c['value'])} | {c['ms_per_step']:.2f} | {c['stage_ms']['ingest']:.2f} | {c['stage_ms']['blur_v']:.2f} | {c['stage_ms']['blur_h']:.2f} | — | "
     f"{14858e6 * 64 / 64 / c['stage_ms']['blur_v'] / 8e9 * 1e3 / 1e3:.2f} | {c['blur_reduce_stage_frac']:.3f} |",
-    row("4K P016, SSIMULACRA2, 24 pairs/step", w["4k_p016"]),
-    row("1080p fused PSNR + MS-SSIM + SSIMULACRA2", w["1080p_nv12_fused"], r01="6 545"),
-    row("4K fused PSNR + MS-SSIM + SSIMULACRA2", w["4k_p016_fused"], r01="1 633"),
+    row("4K P016, SSIMULACRA2, 24 pairs/step (r02 driver: 2 822)", w["4k_p016"]),
+    row("1080p fused PSNR + MS-SSIM + SSIMULACRA2", w["1080p_nv12_fused"], r01="6 545, r02: 8 292"),
+    row("4K fused PSNR + MS-SSIM + SSIMULACRA2", w["4k_p016_fused"], r01="1 633, r02: 2 059"),
 ]
 s1, sf, s4f = stats(f"{T}_kernel_stats_1080p_b64.csv"), stats(f"{T}_kernel_stats_1080p_b64_fused.csv"), stats(f"{T}_kernel_stats_4k_b24_fused.csv")
 pk = prof["kernels"]
 hf, cb, fx = d["host_fed"], d["cpu_baseline"], d["fixed_stream"]
+bc = d["batch_curve"]["points"]
+cli = d["cli_end_to_end"]
+curve = " · ".join(f"{p_['batch']}: {fmt(p_['value'])} ({p_['ms_per_step']:.2f} ms, {p_['engine_mem_GB']} GB)" for p_ in bc)
+ing = [k for k in s1 if "k_ingest_rows" in k][0]
 text = "\n".join(rows) + f"""
 
-(`python bench.py`, {wall[0].split()[1] if wall else '?'} wall; `fixed_stream` {fmt(fx['value'])} pairs/s over 2 048 pairs; `host_fed` {fmt(hf['1080p_nv12']['value'])} pairs/s at 1080p =
-{hf['1080p_nv12']['h2d_GBs_per_gpu']:.1f} GB/s over PCIe, {fmt(hf['4k_p016']['value'])} at 4K = {hf['4k_p016']['h2d_GBs_per_gpu']:.1f} GB/s; `cpu_baseline` {cb['value']:.2f} pairs/s on one core, {cb['all_cores']['value']:.1f} on {cb['all_cores']['cores']} threads.)
+(`python bench.py`, {wall[0].split()[1] if wall else '?'} wall; `fixed_stream` {fmt(fx['value'])} pairs/s over 2 048 pairs, {fmt(fx['long']['value'])} over 16 384; `host_fed` {fmt(hf['1080p_nv12']['value'])} pairs/s at 1080p =
+{hf['1080p_nv12']['h2d_GBs_per_gpu']:.1f} GB/s over PCIe, {fmt(hf['4k_p016']['value'])} at 4K = {hf['4k_p016']['h2d_GBs_per_gpu']:.1f} GB/s (40 steps each); `cpu_baseline` {cb['value']:.2f} pairs/s on one core, {cb['all_cores']['value']:.1f} on {cb['all_cores']['cores']} threads.)
+`batch_curve` (1080p, pairs per launch: pairs/s (ms per step, engine memory)): {curve}.
+`cli_end_to_end` (the C++ binary on Y4M clips in tmpfs, its own "Processed" figure): 1080p 8-bit {fmt(cli['1080p_yuv420p']['default']['pairs_per_s'])} pairs/s with the defaults (first run of the process tree) and {fmt(cli['1080p_yuv420p']['batch16']['pairs_per_s'])} with `--batch 16`;
+4K 10-bit {fmt(cli['4k_yuv420p10']['default']['pairs_per_s'])} / {fmt(cli['4k_yuv420p10']['batch16']['pairs_per_s'])}.
 rocprofv3 of the same command (`profiles/{T}_kernel_stats_1080p_b64.csv`): `k_blur_v_jobs<32,16,0>` {s1['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms average over {s1['tmk::k_blur_v_jobs<32, 16, 0>'][0]}
-launches vs {pk['k_blur_v_jobs']['avg_launch_ms']:.3f} ms from the HIP events of the timed steps of that run; row pass {s1['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} vs {pk['k_blur_h_jobs_x']['avg_launch_ms']:.3f}; `k_ingest_wave` {s1['tmk::k_ingest_wave<0>'][1]:.3f} +
-`k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_wave']['avg_launch_ms']:.3f}; the launches of the placement search are listed apart as `…, 1>`. Fused
+launches vs {pk['k_blur_v_jobs']['avg_launch_ms']:.3f} ms from the HIP events of the timed steps of that run; row pass {s1['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} vs {pk['k_blur_h_jobs_x']['avg_launch_ms']:.3f}; `k_ingest_rows` {s1[ing][1]:.3f} +
+`k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_rows']['avg_launch_ms']:.3f} for the stage; the launches of the placement search are listed apart as `…, 1>`. Fused
 (`{T}_kernel_stats_1080p_b64_fused.csv`): `k_ssim_stream` {sf['tmk::k_ssim_stream'][1]:.3f}, `k_ssim_pyramid` {sf['tmk::k_ssim_pyramid'][1]:.3f} (4K, `{T}_kernel_stats_4k_b24_fused.csv`:
 {s4f['tmk::k_ssim_stream'][1]:.3f} and {s4f['tmk::k_ssim_pyramid'][1]:.3f})."""
 p = os.path.join(ROOT, "DESIGN.md")
@@ -54,6 +61,6 @@ s = open(p).read()
 a, b = "<!-- bench-table:begin -->", "<!-- bench-table:end -->"
 i, j = s.index(a) + len(a), s.index(b)
 s = s[:i] + "\n" + text + "\n" + s[j:]
-s = re.sub(r"profiles/r02[a-z]_sq_counters_\*", f"profiles/{T}_sq_counters_*", s)
+s = re.sub(r"profiles/r0[0-9][a-z]_sq_counters_\*", f"profiles/{T}_sq_counters_*", s)
 open(p, "w").write(s)
 print(text)

@@ -18,13 +18,14 @@ rows = [int(x) for x in (args[args.index("--rows") + 1].split(",") if "--rows" i
 tm.init_hip(0)
 tm.set_placement_candidates(1)
 pairs = []
-for n in range(4):
+ND = int(args[args.index("--distinct") + 1]) if "--distinct" in args else 4
+for n in range(ND):
     (rs, rp, rch), (ds, dp, dch) = gen(w, h, n)
     pairs.append(((torch.from_numpy(rs).cuda(), rp, rch), (torch.from_numpy(ds).cuda(), dp, dch)))
 L = tm.ffi.lib()
 eng = tm.TurboMetrics(w, h, tm.Metrics(**{m: True for m in mets}), batch=B)
 for slot in range(B):
-    (rt, rp, rch), (dt, dp, dch) = pairs[slot % 4]
+    (rt, rp, rch), (dt, dp, dch) = pairs[slot % ND]
     eng.set_pair(slot, mk(rt, rp, rch), mk(dt, dp, dch))
 eng.set_profiling(True)
 for _ in range(30):
