@@ -577,13 +577,14 @@ __host__ __device__ inline TmIngestGeom tm_ingest_geom(const TmGeom &g)
 // pass through the caches (measured on one engine, 1080p: ingest stage 1.19 -> 1.12 ms, the column pass that reads them
 // unchanged; 4K: no difference)
 #define TM_ROWS_STORE(v, p) __builtin_nontemporal_store(v, p)
-// five waves per SIMD (<= 96 VGPRs, five dwords of scratch) against four (107 VGPRs, none): ingest stage 1.31 vs 1.34 ms per 64 1080p
-// pairs, 1.78 vs 1.97 ms per 24 4K pairs (tools/ingest_ab.py --distinct 32)
+// the SSIMULACRA2-only instantiation at five waves per SIMD (<= 96 VGPRs, five dwords of scratch) against four (107 VGPRs, none):
+// ingest stage 1.31 vs 1.34 ms per 64 1080p pairs, 1.78 vs 1.97 ms per 24 4K pairs (tools/ingest_ab.py --distinct 32); the
+// instantiation with the PSNR / u8-plane code needs 121 VGPRs and stays at four (held to 96 it spills: fused ingest 1.46 -> 2.10 ms)
 #ifndef TM_ROWS_WAVES
 #define TM_ROWS_WAVES 5
 #endif
 template <int KIND, bool QUANT>
-__global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(TM_ROWS_WAVES) k_ingest_rows(TmIngestGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ coef,
+__global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAVES) k_ingest_rows(TmIngestGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ coef,
                                                     const double *__restrict__ gtab, float *__restrict__ XYB, float *__restrict__ LIN2,
                                                     unsigned long long *__restrict__ SSE, int want_sse, unsigned char *__restrict__ QU8,
                                                     unsigned long long qplane, int qpitch, int rows_per_wave)
