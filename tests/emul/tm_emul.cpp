@@ -312,7 +312,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
         launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
-        if (variant & 0x400) launch_wg_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), 192, [&] { tmk::k_blur_h_jobs_split(g, jobs, XYB, V, PART); });
+        if ((variant & 0x400) && (variant & 0x2000)) launch_wg_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), 320, [&] { tmk::k_blur_h_jobs_split<5>(g, jobs, XYB, V, PART); });
+        else if (variant & 0x400) launch_wg_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), 192, [&] { tmk::k_blur_h_jobs_split<3>(g, jobs, XYB, V, PART); });
         else if (wide_rows) launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });
         else launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 32, 16>(g, jobs, XYB, V, PART); });
     }

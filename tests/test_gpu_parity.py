@@ -156,7 +156,7 @@ def test_row_walking_ingest_equals_the_tile_ingest_and_the_oracle(kind, w, h):
     eng.close()
 
 
-@pytest.mark.parametrize("w,h,batch", [(333, 203, 2), (1920, 1080, 1), (70, 38, 3)])
+@pytest.mark.parametrize("w,h,batch", [(333, 203, 2), (1920, 1080, 1), (70, 38, 3), (1920, 1080, 4)])  # 1080p: 108 row blocks per pair -> five waves per block at 1 pair, three at 4
 def test_three_wave_row_pass_is_bit_identical_with_the_one_wave_row_pass(w, h, batch):
     """k_blur_h_jobs_split (what small batches run by default) against k_blur_h_jobs_x: the same 108 sums, bit for bit, pruned and
     full job tables, and the oracle's"""

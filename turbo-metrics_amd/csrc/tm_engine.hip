@@ -125,6 +125,7 @@ struct tm_engine {
     bool in_flight = false, have_results = false;
     int variant = TM_VARIANT_DEFAULT;
     long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms; TM_SPLIT_ROWS_BELOW overrides: tuning)
+    long long split5_rows_below = 256; // ... and up to which that pass runs with five instead of three waves per row block (TM_SPLIT5_ROWS_BELOW)
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (TM_INGEST_ROWS overrides: tuning)
 };
 
@@ -452,6 +453,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
     if (const char *sr = getenv("TM_SPLIT_ROWS_BELOW")) e->split_rows_below = atoll(sr);
+    if (const char *sr = getenv("TM_SPLIT5_ROWS_BELOW")) e->split5_rows_below = atoll(sr);
     if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
     if (const char *pp = getenv("TM_PYRT_PAD")) e->g.pyr_t += (unsigned long long)atoll(pp) / 64 * 64; // experiment: distance between the planes / slots of the transposed arenas (tools/stride_probe.py)
@@ -683,8 +685,11 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         // ---- stage BLUR_H: row pass + error maps + reductions
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART);
         // few row blocks (small batches): three waves per block -- a wave's own issue rate, not the chip, bounds this pass then
-        else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * e->jobs.hstart[TM_MAX_JOBS] <= e->split_rows_below))
-            hipLaunchKernelGGL(tmk::k_blur_h_jobs_split, hgrid, dim3(192), 0, st, g, e->jobs, XYB, V, PART);
+        else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * e->jobs.hstart[TM_MAX_JOBS] <= e->split_rows_below)) {
+            // five waves per row block up to a quarter of a row block per SIMD (1-2 pairs of 1080p: 0.26 vs 0.35 ms), three above (8 pairs: 0.43 vs 0.58)
+            if ((long long)n * e->jobs.hstart[TM_MAX_JOBS] <= e->split5_rows_below) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5>), hgrid, dim3(320), 0, st, g, e->jobs, XYB, V, PART);
+            else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3>), hgrid, dim3(192), 0, st, g, e->jobs, XYB, V, PART);
+        }
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));

@@ -1393,19 +1393,23 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
 
 // ------------------------------------------------------------------------------------------------
 // Row pass for SMALL batches ("split"): the same arithmetic and the same per-lane order of accumulation as k_blur_h_jobs_x --
-// its PART entries are bit-identical --, cut across THREE waves per 64-row block.  Why: one wave issues at most one
+// its PART entries are bit-identical --, cut across THREE or FIVE waves per 64-row block.  Why: one wave issues at most one
 // instruction per four cycles, and a step of the FULL path is ~180 instructions (five recurrences, seven loads, the LDS
 // transposition, two IEEE divisions, six f64 accumulations), so the 1 924 steps of a 1080p row take 0.58 ms however idle the
 // chip is -- with fewer waves than SIMDs (8 pairs: 860 waves on 1 024 SIMDs) the pass sits at that latency.  Here
-//   wave 0  recurrences sigma11, sigma22 (FULL) + the ref / dis blocks: fetched in the normal orientation, parked transposed in LDS
-//   wave 1  recurrences sigma12, mu1, mu2 (FULL) / mu1, mu2 (EDGE)
-//   wave 2  the consumer: five (two) blurred values + ref, dis from LDS -> compute_error_maps -> f64 sums
-// and the longest of the three step bodies is ~70 instructions.  Steps run in phases of 16 with one LDS barrier per phase:
+//   NW = 3   wave 0  recurrences sigma11, sigma22 (FULL) + the ref / dis blocks: fetched in the normal orientation, parked transposed in LDS
+//            wave 1  recurrences sigma12, mu1, mu2 (FULL) / mu1, mu2 (EDGE)
+//            wave 2  the consumer: five (two) blurred values + ref, dis from LDS -> compute_error_maps -> f64 sums
+//   NW = 5   wave 0  sigma11, sigma22 (FULL; the ref / dis blocks of an EDGE job)     wave 1  sigma12 + the ref / dis blocks (FULL)
+//            wave 2  mu1, mu2          wave 3  the ssim map and its two sums (FULL)    wave 4  the two edge maps and their four sums
+// and the longest step body is ~70 (NW = 3) / ~45 (NW = 5) instructions: 0.35 / 0.26 ms per 1080p row block against 0.58.  Five waves
+// stop paying once a launch has more than a few hundred row blocks (8 pairs: 0.58 ms, three waves 0.43), so the engine picks by
+// size.  Steps run in phases of 16 with one LDS barrier per phase:
 // the producers fill half (phase & 1) of a two-phase ring [2][16][5][64] (40 KB) while the consumer empties the other half --
 // step t of the recurrences emits column t - 4, stored at ring position t --; ref / dis block b (columns 16 b .. + 15) is
 // loaded during phase b - 1, written during phase b, read during phases b + 1 and b + 2: four tile buffers (35 KB).
 // 75 KB of LDS per workgroup -> two workgroups per CU: for launches with fewer row blocks than the chip has wave slots only
-// (the engine switches by batch size; TM_VARIANT_SPLIT_ROWS forces it).  grid (slots, jobs.hstart[n]), block 192.
+// (the engine switches by batch size; TM_VARIANT_SPLIT_ROWS forces it).  grid (slots, jobs.hstart[n]), block 64 * NW.
 // ------------------------------------------------------------------------------------------------
 template <int NP, int NA = (NP > 0 ? NP : 1)> // NP: planes of this producer
 __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)[16][5][64], const float *const (&v)[NA], const int (&plane)[NA],
@@ -1462,7 +1466,10 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
     }
 }
 
-template <bool FULL>
+// WHAT (bits): 1 = the ssim map and its two sums (needs all five blurred values), 2 = the two edge maps and their four sums (mu1, mu2,
+// ref, dis); 3 = a FULL job in one wave, 2 alone also serves the EDGE jobs.  The per-lane order of accumulation is that of
+// k_blur_h_jobs_x either way
+template <int WHAT>
 __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__ ring)[16][5][64], const float (*__restrict__ tile)[4][64][17],
                                                       int w, bool valid, int nphases, double (&acc)[6])
 {
@@ -1478,14 +1485,17 @@ __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__
                     const float (*r)[64] = ring[(ph - 1) & 1][j];
                     const float mu1 = r[3][lane], mu2 = r[4][lane];
                     const float src = tile[0][(u >> 4) & 3][lane][u & 15], dsv = tile[1][(u >> 4) & 3][lane][u & 15];
-                    float ssim = 0.0f, art, det;
-                    if (FULL) tmdev::error_maps(src, dsv, mu1, mu2, r[0][lane], r[1][lane], r[2][lane], ssim, art, det);
+                    float ssim = 0.0f, art = 0.0f, det = 0.0f;
+                    // error_maps evaluates all three maps; the compiler drops the half whose results are not used
+                    if (WHAT & 1) tmdev::error_maps(src, dsv, mu1, mu2, r[0][lane], r[1][lane], r[2][lane], ssim, art, det);
                     else tmdev::edge_maps(src, dsv, mu1, mu2, art, det);
                     if (valid) {
                         float q;
-                        if (FULL) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
-                        acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
-                        acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
+                        if (WHAT & 1) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
+                        if (WHAT & 2) {
+                            acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
+                            acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
+                        }
                     }
                 }
             }
@@ -1494,9 +1504,17 @@ __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__
     }
 }
 
-__global__ void __launch_bounds__(192) k_blur_h_jobs_split(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, const float *__restrict__ V,
-                                                            double *__restrict__ PART)
+// a wave with nothing to do in this job: it only keeps the workgroup's barriers company
+__device__ __forceinline__ void blur_h_split_idle(int nphases)
 {
+    for (int ph = 0; ph < nphases; ++ph) TM_LDS_BARRIER();
+}
+
+template <int NW> // 3 or 5 waves per row block
+__global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, const float *__restrict__ V,
+                                                               double *__restrict__ PART)
+{
+    static_assert(NW == 3 || NW == 5, "three or five waves per row block");
     __shared__ float ring[2][16][5][64];
     __shared__ float tile[2][4][64][17];
     const int b = blockIdx.y, slot = blockIdx.x;
@@ -1514,37 +1532,71 @@ __global__ void __launch_bounds__(192) k_blur_h_jobs_split(TmGeom g, TmJobs jobs
     const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to, *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to,
                 *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to, *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to,
                 *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
-    const int nphases = (sg.w + 4 + 15) / 16 + 1; // the consumer runs one phase behind the producers
+    const int nphases = (sg.w + 4 + 15) / 16 + 1; // the consumers run one phase behind the producers
     const bool full = mode == TM_MODE_FULL;
-    if (wave == 0) {
-        if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, true, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
-        else { const float *const pv[1] = {nullptr}; const int pl[1] = {0}; blur_h_split_producer<0>(ring, pv, pl, tile, rdn, true, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
-    } else if (wave == 1) {
-        if (full) { const float *const pv[3] = {v2, v3, v4}; const int pl[3] = {2, 3, 4}; blur_h_split_producer<3>(ring, pv, pl, tile, rdn, false, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
-        else { const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases); }
+    const float *const none[1] = {nullptr};
+    const int pl0[1] = {0};
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    int mine = 0; // bits: which maps' sums this wave holds at the end
+#define TM_SPLIT_TAIL y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases
+    if (NW == 3) {
+        if (wave == 0) { // sigma11, sigma22 (FULL) + the ref / dis blocks
+            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
+            else blur_h_split_producer<0>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
+        } else if (wave == 1) { // sigma12, mu1, mu2 (FULL) / mu1, mu2 (EDGE)
+            if (full) { const float *const pv[3] = {v2, v3, v4}; const int pl[3] = {2, 3, 4}; blur_h_split_producer<3>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
+            else { const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
+        } else { // all maps and sums
+            if (full) { blur_h_split_consumer<3>(ring, tile, sg.w, valid, nphases, acc); mine = 3; }
+            else { blur_h_split_consumer<2>(ring, tile, sg.w, valid, nphases, acc); mine = 2; }
+        }
     } else {
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        if (full) blur_h_split_consumer<true>(ring, tile, sg.w, valid, nphases, acc);
-        else blur_h_split_consumer<false>(ring, tile, sg.w, valid, nphases, acc);
-#ifdef TM_EMULATE
-        { // the lockstep emulator runs the lanes as concurrent fibers: sum through memory, in lane order like the shuffle tree's result
-            __shared__ double redl[6][64];
-            for (int k = 0; k < 6; ++k) redl[k][lane] = acc[k];
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
-                for (int k = 0; k < 6; ++k) { double tsum = 0.0; for (int i = 0; i < 64; ++i) tsum += redl[k][i]; o[k] = tsum; }
-            }
-            __builtin_amdgcn_wave_barrier();
+        if (wave == 0) { // sigma11, sigma22 (FULL); the ref / dis blocks of an EDGE job
+            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
+            else blur_h_split_producer<0>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
+        } else if (wave == 1) { // sigma12 + the ref / dis blocks (FULL)
+            if (full) { const float *const pv[1] = {v2}; const int pl[1] = {2}; blur_h_split_producer<1>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
+            else blur_h_split_idle(nphases);
+        } else if (wave == 2) { // mu1, mu2
+            const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4};
+            blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL);
+        } else if (wave == 3) { // the ssim map and its sums (FULL)
+            if (full) { blur_h_split_consumer<1>(ring, tile, sg.w, valid, nphases, acc); mine = 1; }
+            else blur_h_split_idle(nphases);
+        } else { // the edge maps and their sums
+            blur_h_split_consumer<2>(ring, tile, sg.w, valid, nphases, acc); mine = 2;
         }
-#else
-        if (tm_wave_sum6(acc)) {
-            double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = acc[k];
-        }
-#endif
     }
+#undef TM_SPLIT_TAIL
+    if (mine == 0) return;
+    // a consumer holds some of the six sums of the row block (zeros elsewhere); the shuffle tree adds every entry in the order
+    // k_blur_h_jobs_x adds it, so the entries come out bit-identical.  An EDGE job has no ssim sums: zeros, as k_blur_h_jobs_x writes
+    const bool w_ssim = (mine & 1) || !full, w_edge = (mine & 2) != 0;
+#ifdef TM_EMULATE
+    { // the lockstep emulator runs the lanes as concurrent fibers: sum through memory, in lane order like the shuffle tree's result
+        __shared__ double redl[2][6][64];
+        const int slotw = wave == NW - 1 ? 1 : 0;
+        for (int k = 0; k < 6; ++k) redl[slotw][k][lane] = acc[k];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
+            for (int k = 0; k < 6; ++k) {
+                const bool is_ssim = k == 0 || k == 3;
+                if (is_ssim ? !w_ssim : !w_edge) continue;
+                double tsum = 0.0;
+                for (int i = 0; i < 64; ++i) tsum += redl[slotw][k][i];
+                o[k] = tsum;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#else
+    if (tm_wave_sum6(acc)) {
+        double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
+        if (w_ssim) { o[0] = acc[0]; o[3] = acc[3]; }
+        if (w_edge) { o[1] = acc[1]; o[2] = acc[2]; o[4] = acc[4]; o[5] = acc[5]; }
+    }
+#endif
 }
 
 // fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no
