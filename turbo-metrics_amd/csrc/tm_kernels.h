@@ -1,17 +1,20 @@
 // tm_kernels.h -- gfx950 kernels of the SSIMULACRA2 / PSNR frame-pair path.
 //
 // Two pipelines live here:
-//   default    k_ingest_wave<KIND> + k_ingest_upper_rd -> k_blur_v_jobs<32, 16> -> k_blur_h_jobs_x -> k_finish_jobs
+//   default    k_ingest_rows<KIND> (4:2:0 kinds; k_ingest_wave<KIND> for the RGB kinds and mixed launches) + k_ingest_upper_rd
+//              -> k_blur_v_jobs<32, 16> -> k_blur_h_jobs_x (k_blur_h_jobs_split<3 | 5> for small launches) -> k_finish_jobs
 //              over the ref/dis-interleaved XYB pyramid, job-table driven, slot-major grids (x = slot)
 //   reference  k_ingest + k_downscale + k_xyb -> k_blur_v -> k_blur_h_jobs -> k_finish_jobs: straight-line, LDS-free kernels
 //              whose only job is to be obviously correct (engine variant TM_VARIANT_REFERENCE); the GPU tier checks that the
 //              two pipelines produce identical bits on the device, and both against the CPU oracle.
 //
 // Launch geometry (64-lane wavefront == 1 workgroup unless noted):
+//   k_ingest_rows     grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/(4 rows_per_wave)), slots)  block 256  four waves, each 64 quads x rows_per_wave quad rows of both sides
 //   k_ingest_wave     grid (ceil(w/32), ceil(h/8), slots)            block 64    one 32 x 8 tile, both sides
 //   k_ingest_upper_rd grid (ceil(w2/32), ceil(h2/32), slots)         block 256   pyramid levels 2..5
 //   k_blur_v_jobs     grid (slots, jobs.vstart[n])                   block 320   column pass, five role-waves per 64 columns
 //   k_blur_h_jobs_x   grid (slots, jobs.hstart[n])                   block 64    row pass + error maps + sums, lane = image row
+//   k_blur_h_jobs_split<NW>  grid (slots, jobs.hstart[n])            block 64 NW the same row pass over NW = 3 or 5 waves per row block (small launches)
 //   k_finish_jobs     grid (slots)                                   block 128
 //   k_ingest          grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/4), slots)   block (64,4)
 //   k_downscale       grid (ceil(dw/64), dh, slots*2*3)              block 64
