@@ -346,9 +346,11 @@ void RowWorkers::run(size_t total, const std::function<void(size_t, size_t)> &fn
 
 YuvStreamSource::~YuvStreamSource()
 {
+    if (ring_alloc_.joinable()) ring_alloc_.join();
     workers_.reset();
     if (in_ && in_ != stdin) fclose(in_);
     for (unsigned char *p : ring_) {
+        if (!p) continue;
         if (ring_pinned_) tm_host_free(p);
         else free(p);
     }
@@ -382,24 +384,30 @@ void YuvStreamSource::ensure_ring()
 {
     if (!ring_.empty()) return;
     const size_t n = lookahead_ + 1;
-    ring_pinned_ = true;
-    for (size_t i = 0; i < n; ++i) {
-        unsigned char *p = (unsigned char *)tm_host_alloc(planar_bytes_);
-        if (!p) { // fall back to pageable memory for the whole ring (the engine then copies synchronously)
-            for (unsigned char *q : ring_) tm_host_free(q);
-            ring_.clear();
-            ring_pinned_ = false;
-            break;
-        }
-        memset(p, 0, planar_bytes_);
-        ring_.push_back(p);
-    }
-    if (!ring_pinned_)
+    ring_.assign(n, nullptr);
+    // slot 0 here (it decides pinned / pageable for the whole ring: the engine copies pageable surfaces synchronously) ...
+    ring_[0] = (unsigned char *)tm_host_alloc(planar_bytes_);
+    ring_pinned_ = ring_[0] != nullptr;
+    if (!ring_pinned_) {
         for (size_t i = 0; i < n; ++i) {
-            unsigned char *p = (unsigned char *)calloc(1, planar_bytes_);
-            if (!p) fail("out of memory for the frame ring");
-            ring_.push_back(p);
+            ring_[i] = (unsigned char *)calloc(1, planar_bytes_);
+            if (!ring_[i]) fail("out of memory for the frame ring");
         }
+        ring_ready_ = n;
+    } else {
+        ring_ready_ = 1;
+        // ... the others on a helper thread, in the order the reader will want them
+        ring_alloc_ = std::thread([this, n] {
+            for (size_t i = 1; i < n; ++i) {
+                unsigned char *p = (unsigned char *)tm_host_alloc(planar_bytes_);
+                std::lock_guard<std::mutex> g(ring_m_);
+                if (!p) { ring_failed_ = true; ring_cv_.notify_all(); return; }
+                ring_[i] = p;
+                ring_ready_ = i + 1;
+                ring_cv_.notify_all();
+            }
+        });
+    }
     // workers + the reader itself per stream for pictures worth splitting: an eighth of the host's threads, 2 .. 16
     // (TM_READER_THREADS overrides; 1 keeps it serial): pread from the page cache moves 2-4 GB/s per thread
     const char *env = getenv("TM_READER_THREADS");
@@ -409,6 +417,14 @@ void YuvStreamSource::ensure_ring()
     const unsigned by_size = (unsigned)std::min<size_t>(16, std::max<size_t>(2, planar_bytes_ / (384u << 10)));
     const unsigned want = env ? (unsigned)atoi(env) : std::min(by_size, std::max(2u, hw / 4));
     if (h_ >= 256 && want > 1) workers_ = std::make_unique<RowWorkers>(std::min(want, 32u) - 1);
+}
+
+unsigned char *YuvStreamSource::ring_slot(size_t i)
+{
+    std::unique_lock<std::mutex> lk(ring_m_);
+    ring_cv_.wait(lk, [&] { return ring_ready_ > i || ring_failed_; });
+    if (ring_ready_ <= i) fail("out of page-locked memory for the frame ring");
+    return ring_[i];
 }
 
 FormatIdentifier YuvStreamSource::format_id() const
@@ -486,7 +502,7 @@ void YuvStreamSource::skip_frames(uint32_t n)
 bool YuvStreamSource::next_frame(HwFrame &out)
 {
     ensure_ring();
-    unsigned char *surface = ring_[ring_pos_];
+    unsigned char *surface = ring_slot(ring_pos_);
     if (!read_picture(surface)) return false;
     ring_pos_ = (ring_pos_ + 1) % ring_.size();
     const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
