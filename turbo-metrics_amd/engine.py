@@ -96,7 +96,11 @@ class HwFrame:
     'i420': planar 4:2:0, `data` = (Y, Cb, Cr) arrays (uint8, or uint16 with the value in the low `bits` bits).
     data: numpy array (host memory) or any object with .data_ptr() (device memory, e.g. a torch
     tensor on the GPU).  For the biplanar kinds `data` is the whole surface (luma rows, then the CbCr
-    plane at pitch*coded_height); for RGB kinds it is (h, w, 3)."""
+    plane at pitch*coded_height); for RGB kinds it is (h, w, 3).
+    Lifetime and mutation: a numpy array or a pageable CPU tensor is copied before set_frame returns.  A device tensor is
+    BORROWED and a page-locked (pinned) CPU tensor is read by an asynchronous DMA: neither may be modified or freed until
+    TurboMetrics.sync() has returned for the batch it was set for -- a loader that refills one pinned staging tensor per frame
+    must wait for sync() (or use one staging tensor per slot in flight, as bench.py's host-fed leg and the CLI's frame ring do)."""
     kind: str
     data: object
     pitch: int = 0
