@@ -19,7 +19,7 @@
  * 17.398505 in ssimulacra2-cuda/examples/compare.rs:70-90, is for an image pair that is not
  * in the repository): "parity unpinned" for the final score.
  * The two libdevice routines of the path are closed NVIDIA code (__nv_cbrtf, ~1 ulp; __nv_fast_powf, ~8 ulp): tm_math.h
- * restates them as fixed IEEE sequences that are CLOSER to the exact functions than the originals (cube root <= 0.5003 ulp,
+ * restates them as fixed IEEE sequences that are CLOSER to the exact functions than the originals (cube root <= 0.500002 ulp, 11 of 25 M arguments not the nearest float;
  * BT.709 transfer function: the reference's f32 base, then the correctly rounded power of it but for 117 of 15.4 M arguments; sRGB pow
  * <= 0.50001 ulp; each scanned exhaustively by tests/test_oracle_pins.py).
  * The score reacts to such last-bit differences at the 1e-3 .. 2e-2 level (tools/score_sensitivity.py), the reference's own

@@ -1,17 +1,17 @@
 """FROZEN goldens (tests/golden/scores_accurate_frozen.json, tools/gen_golden_accurate.py): SSIMULACRA2 scores of the seeded
 synthetic pairs from the most accurate evaluation of the reference's expressions (numpy twin, correctly rounded cbrt and pow).
 `accurate` is never regenerated when the product's arithmetic changes; oracle and HIP path must stay within each case's own
-`bound` = max(2 x the committed |build - accurate|, 1e-3) of it (round 2: one flat band of 5e-2).
+`bound` = max(2 x the committed |build - accurate|, 1e-4) of it (round 2: one flat band of 5e-2).
 
 What the figures mean: the reference calls closed libdevice code (__nv_fast_powf ~ exp2f(y log2f x), __nv_cbrtf 1 ulp); the file
 also holds the score of a fast_powf-SHAPED evaluation of the same inputs, which lands 3e-4 ... 1.1e-2 away from `accurate`.
-Since round 3 the transfer function is the reference's expression CORRECTLY ROUNDED (its f32 base, a binary64 cubic, one rounding:
-the linear planes equal the twin's exact evaluation but for one sample in ~130 000), so what is left is the cube root (<= 0.5003
-ulp, 933 of 25 M arguments not the nearest float): 3e-6 ... 2.4e-3 on every case.  How sensitive the score is to such last bits:
-moving a random 0.8 % of the 1080p NV12 case's linear samples by ONE ulp moves its score by 7e-3 ... 4e-2
-(tools/score_conditioning.py; f32 cancellation in sigma - mu^2 against C2 at scales 2-4, where the distortion has averaged
-out) -- an f32 cubic that was within 0.69 ulp everywhere still left that case at 1.8e-2 (`build_history`).  North_star's 1e-4
-is held between HIP and oracle (bit-identical planes)."""
+Since round 3 both stand-ins are the reference's expressions CORRECTLY ROUNDED but for a handful of arguments (transfer function:
+the reference's f32 base, a binary64 cubic, one rounding, 117 of 15.4 M arguments not the nearest float; cube root: 11 of 25 M),
+so this build reproduces `accurate` itself: four of the seven cases to the last bit of the f64 score, the others within 4.3e-5 --
+inside north_star's 1e-4.  `build_history` keeps the road there: r02 2e-5 ... 2.1e-2 (transfer function fitted in v), r03a
+5e-4 ... 1.8e-2 (an f32 cubic within 0.69 ulp everywhere -- the 1080p NV12 case moves by 7e-3 ... 4e-2 when a random 0.8 % of its
+linear samples move by ONE ulp, tools/score_conditioning.py), r03b <= 2.4e-3 (transfer function correctly rounded, cube root
+0.5003 ulp).  What stays out of reach is libdevice's own deviation from these expressions (second column of DESIGN.md section 4)."""
 import json
 import os
 import sys
@@ -30,17 +30,17 @@ ID = lambda c: f'{c["kind"]}_{c["width"]}x{c["height"]}'  # noqa: E731
 
 
 def test_file_is_frozen_and_the_committed_deviation_figures_hold():
-    assert DOC["frozen"] is True and DOC["floor"] == 1e-3 and len(CASES) == 7
+    assert DOC["frozen"] is True and DOC["floor"] == 1e-4 and len(CASES) == 7
     for c in CASES:
         assert c["build_round"] == GA.BUILD_ROUND
-        assert c["bound"] == max(2.0 * abs(c["build_minus_accurate"]), 1e-3)
+        assert c["bound"] == max(2.0 * abs(c["build_minus_accurate"]), 1e-4)
         if "fast_powf_shape" in c:  # what libdevice's fast path alone would move the score by
             assert 1e-4 < abs(c["fast_powf_shape_minus_accurate"]) <= 5e-2
-    assert max(abs(c["build_minus_accurate"]) for c in CASES) <= 5e-3  # all seven at the level the 0.5003-ulp cube root alone costs
+    assert max(abs(c["build_minus_accurate"]) for c in CASES) <= 1e-4  # all seven inside north_star's tolerance of the accurate evaluation
+    assert sum(c["build_minus_accurate"] == 0.0 for c in CASES) >= 4  # ... four of them to the last bit
     # round 3 moved every YUV case towards `accurate` (the RGB8 cases do not use the transfer function)
     for c in CASES:
-        if c["kind"] != "rgb8":
-            assert abs(c["build_minus_accurate"]) < abs(c["build_history"]["r02"])
+        assert abs(c["build_minus_accurate"]) <= abs(c["build_history"]["r02"])
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["width"] <= 333], ids=ID)

@@ -84,11 +84,14 @@ def test_score_polynomial_known_points():
     assert O.score_from_sums(z, 64, 64) == 100.0
 
 
-def test_cbrtf_is_within_0p5003_ulp_everywhere():
-    """20-operation f32 cube root (oracle/tm_math.h == tm_device_math.h cbrt_core2): every float of [1, 8) -- all mantissas for
-    each exponent residue mod 3 -- against long-double cbrtl"""
+def test_cbrtf_is_the_correctly_rounded_cube_root_but_for_a_handful_of_arguments():
+    """21-operation f32 cube root (oracle/tm_math.h == tm_device_math.h cbrt_core2): every float of [1, 8) -- all mantissas for
+    each exponent residue mod 3 -- against long-double cbrtl: 11 of 25 M are not the nearest float (round 2's 20 operations: 933)"""
     worst, bad = O.cbrtf_scan(1.0, 8.0)
-    assert worst < 0.5003 and bad < 1000, (worst, bad)
+    assert worst < 0.50001 and bad <= 11, (worst, bad)
+    from oracle import twin_numpy as T
+    x = np.random.default_rng(5).uniform(0.0037, 1.004, 500000).astype(np.float32)
+    assert (O.cbrtf(x) != T.cbrt_exact(x)).sum() <= 2  # the twin's float64 cbrt, rounded once: the same bits
     a = np.concatenate([10 ** np.random.default_rng(1).uniform(-44, 38, 4000), [0.0, 1.0, 8.0, 27.0, 0.0037, 1.004]]).astype(np.float32)
     got = O.cbrtf(a)
     want = np.cbrt(a.astype(np.float64))

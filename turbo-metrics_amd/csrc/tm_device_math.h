@@ -5,7 +5,7 @@
 //   __nv_fast_powf in the BT.709 / sRGB EOTFs  (cuda-colorspace-kernel/src/lib.rs:228, srgb.rs:46)
 // Here they are fixed sequences of IEEE-754 operations, deterministic and reproducible on any IEEE machine -- which is what
 // lets the parity tests demand bit equality for every plane:
-//   cbrt              f32 mul / sub / fma only, 20 operations, evaluated on pairs (v_pk_*_f32); <= 0.5003 ulp
+//   cbrt              f32 mul / sub / fma only, 21 operations, evaluated on pairs (v_pk_*_f32); <= 0.500002 ulp (11 of 25 M arguments not the nearest float)
 //   BT.709 transfer   the reference's f32 base (v + a) / A, then its power from a table of 428 binary64 cubics (three v_fma_f64, one
 //                     rounding): the correctly rounded value of the reference's expression for all but 117 of 15.4 M arguments
 //                     (the reference's fast_powf: ~8 ulp)
@@ -46,16 +46,17 @@ __device__ __forceinline__ tm_f2 f2_splat(float a) { return f2_make(a, a); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
-// Cube root, f32 only (no f64, no division): 20 IEEE operations.
-//   r ~ a^(-1/3): exponent-trick seed (3.4 %), ONE fifth-order step r <- r (1 + e/3 + 2 e^2/9 + 14 e^3/81 + 35 e^4/243),
-//                 e = 1 - a r^3 (3.4e-2 -> 3e-6);
+// Cube root, f32 only (no f64, no division): 21 IEEE operations.
+//   r ~ a^(-1/3): exponent-trick seed (3.4 %), ONE sixth-order step r <- r (1 + e/3 + 2 e^2/9 + 14 e^3/81 + 35 e^4/243 + 91 e^5/729),
+//                 e = 1 - a r^3 (up to 0.1 -> 1e-7);
 //   y0 = (a r) r, then ONE Newton step on y whose residual a - y0^3 is formed exactly (s + se = y0^2 error-free, then two fma:
 //   a - s y0 is exact inside the first, the second adds the -se y0 part), correction factor 1/(3 y^2) ~ r^2/3:
-//   y = fma(res, c, y0) is the only rounding that matters -> |error| <= 0.5003 ulp.  Checked over EVERY float of [1, 8) (all
+//   y = fma(res, c, y0) is the only rounding that matters -> |error| <= 0.500002 ulp.  Checked over EVERY float of [1, 8) (all
 //   mantissas for each exponent residue mod 3; the sequence is exactly invariant under scaling by powers of 8) and of the
-//   pixel-value range [0.0037, 1.004] (tools/check_cbrt.c): 933 of 25 165 824 arguments are not the correctly rounded value.
-//   Valid for normal a in [2^-100, 2^100].  (The first version -- two third-order steps and a residual from four error-free
-//   operations, 27 operations -- missed the correctly rounded value for 2 arguments per three octaves.)
+//   pixel-value range [0.0037, 1.004] (tools/check_cbrt.c): 11 of 25 165 824 arguments are not the correctly rounded value.
+//   Valid for normal a in [2^-100, 2^100].  (Round 2's fifth-order step -- 20 operations -- left y0 up to 58 ulp out and the
+//   Newton step's own second-order term at 2.6e-4 ulp: 933 arguments off; the first version -- two third-order steps and a
+//   residual from four error-free operations, 27 operations -- missed the correctly rounded value for 2 arguments per three octaves.)
 __device__ __forceinline__ tm_f2 cbrt_core2(tm_f2 a)
 {
     // (floor(u / 3) through f64 -- three f64-rate instructions instead of v_mul_hi_u32 -- was measured: ingest 1.49 vs 1.44 ms, slower)
@@ -65,7 +66,8 @@ __device__ __forceinline__ tm_f2 cbrt_core2(tm_f2 a)
         tm_f2 t = r * r;
         t = t * r;
         const tm_f2 e = f2_fma(-a, t, one);
-        tm_f2 p = f2_fma(e, f2_splat(0x1.26fabcp-3f), f2_splat(0x1.61f9aep-3f)); // 35/243, 14/81
+        tm_f2 p = f2_fma(e, f2_splat(0x1.ff4c34p-4f), f2_splat(0x1.26fabcp-3f)); // 91/729, 35/243
+        p = f2_fma(p, e, f2_splat(0x1.61f9aep-3f));                                // 14/81
         p = f2_fma(p, e, f2_splat(0x1.c71c72p-3f));                                // 2/9
         p = f2_fma(p, e, c13);                                                     // 1/3
         p = p * e;
