@@ -49,7 +49,7 @@ text = "\n".join(rows) + f"""
 (`python bench.py`, {wall[0].split()[1] if wall else '?'} wall; `fixed_stream` {fmt(fx['value'])} pairs/s over 2 048 pairs, {fmt(fx['long']['value'])} over 16 384; `host_fed` {fmt(hf['1080p_nv12']['value'])} pairs/s at 1080p =
 {hf['1080p_nv12']['h2d_GBs_per_gpu']:.1f} GB/s over PCIe, {fmt(hf['4k_p016']['value'])} at 4K = {hf['4k_p016']['h2d_GBs_per_gpu']:.1f} GB/s (40 steps each); `cpu_baseline` {cb['value']:.2f} pairs/s on one core, {cb['all_cores']['value']:.1f} on {cb['all_cores']['cores']} threads.)
 `batch_curve` (1080p, pairs per launch: pairs/s (ms per step, engine memory)): {curve}.
-`cli_end_to_end` (the C++ binary on Y4M clips in tmpfs, its own "Processed" figure): 1080p 8-bit {fmt(cli['1080p_yuv420p']['default']['pairs_per_s'])} pairs/s with the defaults (first run of the process tree) and {fmt(cli['1080p_yuv420p']['batch16']['pairs_per_s'])} with `--batch 16`;
+`cli_end_to_end` (the C++ binary on Y4M clips in tmpfs, its own "Processed" figure): 1080p 8-bit {fmt(cli['1080p_yuv420p']['default']['pairs_per_s'])} pairs/s with the defaults and {fmt(cli['1080p_yuv420p']['batch16']['pairs_per_s'])} with `--batch 16`;
 4K 10-bit {fmt(cli['4k_yuv420p10']['default']['pairs_per_s'])} / {fmt(cli['4k_yuv420p10']['batch16']['pairs_per_s'])}.
 rocprofv3 of the same command (`profiles/{T}_kernel_stats_1080p_b64.csv`): `k_blur_v_jobs<32,16,0>` {s1['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms average over {s1['tmk::k_blur_v_jobs<32, 16, 0>'][0]}
 launches vs {pk['k_blur_v_jobs']['avg_launch_ms']:.3f} ms from the HIP events of the timed steps of that run; row pass {s1['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} vs {pk['k_blur_h_jobs_x']['avg_launch_ms']:.3f}; `k_ingest_rows` {s1[ing][1]:.3f} +
