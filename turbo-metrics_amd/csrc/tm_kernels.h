@@ -202,6 +202,41 @@ __device__ __forceinline__ void yuv_quad_load_pairs(const TmFrameDesc &d, int qx
         else raw[2] = (unsigned)((const T *)uv)[0] | ((unsigned)((const T *)uv)[1] << sh);
     }
 }
+// The same six samples for a wave whose lanes all sit in ONE quad row (k_ingest_rows: qy is wave-uniform): the row addresses stay in
+// SGPRs and a lane contributes a 32-bit byte offset that does not change from row to row (xo_y into a luma row, xo_c into a chroma
+// row) -- scalar-base + lane-offset global loads.  With per-lane 64-bit addresses (yuv_quad_load_pairs) the lane bases were spilled
+// around the row loop, and the reload's s_waitcnt vmcnt(0) drained the previous row's fifteen stores before every prefetch.
+template <typename T, bool PLANAR>
+__device__ __forceinline__ void yuv_row_load_pairs(const TmFrameDesc &d, unsigned xo_y, unsigned xo_c, int qy, unsigned (&raw)[3])
+{
+    const int sh = 8 * (int)sizeof(T);
+    const bool aligned = (((unsigned long long)d.p0 | (PLANAR ? 0ull : (unsigned long long)d.p1) | (unsigned long long)d.pitch) & (2 * sizeof(T) - 1)) == 0; // wave-uniform
+    TM_GLOBAL_AS const char *y0 = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p0 + (size_t)(2 * qy) * d.pitch);
+    TM_GLOBAL_AS const char *y1 = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch);
+    if (aligned) {
+        if (sizeof(T) == 1) { raw[0] = *(TM_GLOBAL_AS const unsigned short *)(y0 + xo_y); raw[1] = *(TM_GLOBAL_AS const unsigned short *)(y1 + xo_y); }
+        else { raw[0] = *(TM_GLOBAL_AS const unsigned *)(y0 + xo_y); raw[1] = *(TM_GLOBAL_AS const unsigned *)(y1 + xo_y); }
+    } else {
+        raw[0] = (unsigned)((TM_GLOBAL_AS const T *)(y0 + xo_y))[0] | ((unsigned)((TM_GLOBAL_AS const T *)(y0 + xo_y))[1] << sh);
+        raw[1] = (unsigned)((TM_GLOBAL_AS const T *)(y1 + xo_y))[0] | ((unsigned)((TM_GLOBAL_AS const T *)(y1 + xo_y))[1] << sh);
+    }
+    if (PLANAR) {
+        TM_GLOBAL_AS const char *cbp = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p1 + (size_t)qy * d.pitch2);
+        TM_GLOBAL_AS const char *crp = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p2 + (size_t)qy * d.pitch2);
+        const unsigned cb = *(TM_GLOBAL_AS const T *)(cbp + xo_c);
+        const unsigned cr = *(TM_GLOBAL_AS const T *)(crp + xo_c);
+        raw[2] = cb | (cr << sh);
+        if (sizeof(T) == 2) {
+            const unsigned keep = (0xFFFFu >> d.shift) * 0x10001u;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) raw[i] = (raw[i] & keep) << d.shift;
+        }
+    } else {
+        TM_GLOBAL_AS const char *uv = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p1 + (size_t)qy * d.pitch);
+        if (aligned) raw[2] = sizeof(T) == 1 ? (unsigned)*(TM_GLOBAL_AS const unsigned short *)(uv + xo_y) : *(TM_GLOBAL_AS const unsigned *)(uv + xo_y);
+        else raw[2] = (unsigned)((TM_GLOBAL_AS const T *)(uv + xo_y))[0] | ((unsigned)((TM_GLOBAL_AS const T *)(uv + xo_y))[1] << sh);
+    }
+}
 template <int BITS> __device__ __forceinline__ void yuv_quad_unpack(const unsigned (&pr)[3], unsigned (&raw)[6])
 {
     const unsigned m = BITS == 8 ? 0xFFu : 0xFFFFu;
@@ -613,7 +648,14 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
     const float neutral = (float)(1 << (BITS - 1)), ymin = (float)(16u << (BITS - 8));
     const bool colq = X0 + 1 < w; // this lane's quads are complete along x
     unsigned prn0[3] = {0, 0, 0}, prn1[3] = {0, 0, 0};
-    if (colq && 2 * qy_begin + 1 < h) { yuv_quad_load_pairs<T, PLANAR>(dd0, qx, qy_begin, prn0); yuv_quad_load_pairs<T, PLANAR>(dd1, qx, qy_begin, prn1); }
+    const unsigned xo_y = (unsigned)(2 * qx) * (unsigned)sizeof(T), xo_c = (unsigned)qx * (unsigned)sizeof(T); // this lane's byte offsets inside a luma (CbCr) / a planar chroma row
+    if (colq && 2 * qy_begin + 1 < h) { yuv_row_load_pairs<T, PLANAR>(dd0, xo_y, xo_c, qy_begin, prn0); yuv_row_load_pairs<T, PLANAR>(dd1, xo_y, xo_c, qy_begin, prn1); }
+#ifndef TM_EMULATE
+    // (taken before the loop for the same reason as inside it: a load still pending at the loop header would make the compiler wait
+    // for everything outstanding -- the previous row's stores included -- at the top of every iteration)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(prn0[i])); asm volatile("" : "+v"(prn1[i])); }
+#endif
     TM_LDS_BARRIER(); // the table is in place (the only barrier: from here on the waves never meet again)
     float *xi = XYB ? XYB + (size_t)slot * 2 * g.pyr : nullptr; // the slot's interleaved pyramid
     unsigned sse3[3] = {0, 0, 0};
@@ -625,7 +667,7 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
         const bool quad_ok = colq && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
         unsigned pr0[3] = {prn0[0], prn0[1], prn0[2]}, pr1[3] = {prn1[0], prn1[1], prn1[2]};
         if (qy + 1 < qy_end && colq && Y0 + 3 < h) { // the next row's samples, requested before this row's arithmetic
-            yuv_quad_load_pairs<T, PLANAR>(dd0, qx, qy + 1, prn0); yuv_quad_load_pairs<T, PLANAR>(dd1, qx, qy + 1, prn1);
+            yuv_row_load_pairs<T, PLANAR>(dd0, xo_y, xo_c, qy + 1, prn0); yuv_row_load_pairs<T, PLANAR>(dd1, xo_y, xo_c, qy + 1, prn1);
         }
         // ---- biplanar.rs:8-70 on {ref, dis} pairs
         tm_f2 pr[4], pg[4], pb[4];
@@ -673,6 +715,12 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
                 }
             }
         }
+#ifndef TM_EMULATE
+        if (QUANT) { // (see below: with the u8-plane stores ahead, the next row's samples are taken before them)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(prn0[i])); asm volatile("" : "+v"(prn1[i])); }
+        }
+#endif
         if (QUANT) { // sample_conv.rs:6-35 quantisation; out-of-image samples are 0 on both sides
             const tm_f2 *pc[3] = {pr, pg, pb};
 #pragma unroll
@@ -707,6 +755,14 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
         lg[4] = (((f2_splat(0.0f) + pg[0]) + pg[1]) + pg[2] + pg[3]) * f2_splat(0.25f);
         lb[4] = (((f2_splat(0.0f) + pb[0]) + pb[1]) + pb[2] + pb[3]) * f2_splat(0.25f);
         linear_to_xyb_sides<5>(lr, lg, lb, xa, xb, xc);
+        // the next row's samples (requested at the top of this iteration) are taken HERE, before this row's fifteen stores are
+        // issued: gfx950 counts stores in vmcnt in order, so waiting for those loads at the loop's latch would wait for the stores too
+#ifndef TM_EMULATE
+        if (!QUANT) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(prn0[i])); asm volatile("" : "+v"(prn1[i])); }
+        }
+#endif
         {
             const tm_f2 *xv[3] = {xa, xb, xc};
 #pragma unroll
