@@ -171,51 +171,57 @@ __device__ __forceinline__ void ssim_strip(TmSsimCol *__restrict__ bufE, TmSsimC
     // the lane's two samples of row y, both sides, as raw integers (rows past the image: 0)
     auto load = [&](int y, unsigned &a, unsigned &b) {
         const int yc = y < h ? y : h - 1;
-        unsigned va = 0, vb = 0;
-        if (in0) { // x is even and the pitch a multiple of 64 elements: the pair load stays inside the (padded) row
-            // the row's address is wave-uniform: pinned into SGPRs (scalar multiply) so that the lane part is a 32-bit offset -- left
-            // to the compiler it is a 64-bit vector multiply-add (quarter rate) per load
-            const size_t ro = (size_t)yc * (size_t)pitch * (S0 ? 1 : 2);
-            TM_GLOBAL_AS const char *ra = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)pr + ro);
-            TM_GLOBAL_AS const char *rb = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)pd + ro);
-            const unsigned xo = (unsigned)x * (S0 ? 1u : 2u);
-            if (S0) { va = *(TM_GLOBAL_AS const unsigned short *)(ra + xo); vb = *(TM_GLOBAL_AS const unsigned short *)(rb + xo); }
-            else { va = *(TM_GLOBAL_AS const unsigned *)(ra + xo); vb = *(TM_GLOBAL_AS const unsigned *)(rb + xo); }
-        }
-        const bool ok = y < h;
-        a = ok ? va : 0u; b = ok ? vb : 0u;
+        // x is even and the pitch a multiple of 64 elements: the pair load stays inside the (padded) row; lanes past the image load
+        // column 0 (no branch around the loads: the compiler then counts them exactly, s_waitcnt vmcnt(2 (PF - 1)))
+        // the row's address is wave-uniform: pinned into SGPRs (scalar multiply) so that the lane part is a 32-bit offset -- left
+        // to the compiler it is a 64-bit vector multiply-add (quarter rate) per load
+        const size_t ro = (size_t)yc * (size_t)pitch * (S0 ? 1 : 2);
+        TM_GLOBAL_AS const char *ra = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)pr + ro);
+        TM_GLOBAL_AS const char *rb = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)pd + ro);
+        const unsigned xo = in0 ? (unsigned)x * (S0 ? 1u : 2u) : 0u;
+        unsigned va, vb;
+        if (S0) { va = *(TM_GLOBAL_AS const unsigned short *)(ra + xo); vb = *(TM_GLOBAL_AS const unsigned short *)(rb + xo); }
+        else { va = *(TM_GLOBAL_AS const unsigned *)(ra + xo); vb = *(TM_GLOBAL_AS const unsigned *)(rb + xo); }
+        a = va; b = vb;
+        (void)y;
     };
-    auto unpack = [&](unsigned raw, float &v0, float &v1) {
+    auto unpack = [&](unsigned raw, int y, float &v0, float &v1) { // samples of row y; rows and columns past the image read as 0
         if (S0) { v0 = (float)(raw & 255u); v1 = (float)((raw >> 8) & 255u); }
         else { v0 = (float)(raw & 0xFFFFu) * inv; v1 = (float)(raw >> 16) * inv; }
-        if (!in1) v1 = 0.0f;
+        const bool ok = y < h;
+        if (!(ok && in0)) v0 = 0.0f;
+        if (!(ok && in1)) v1 = 0.0f;
     };
-    constexpr int PF = 3; // rows of load prefetch: a shift register (two moves per row; a ring with static slots would need an
-                          // unroll of 33, or 16 more registers at depth 11)
+    // Rows of load prefetch: a RING with static slots (slot = row % PF).  The step loop is unrolled by WS = 12 -- the window of
+    // row-filtered values below holds one row more than the 11 it needs, so that 12 % PF == 0 -- and no register that a load is
+    // still writing is ever moved: round 2's shift register (pa[k] = pa[k + 1]) made every step wait for the load of the step
+    // before (s_waitcnt vmcnt(0) ~180 instructions after its issue), i.e. a prefetch distance of ONE row whatever PF said.
+    constexpr int PF = 3, WS = 12;
+    static_assert(WS % PF == 0 && WS > TM_SSIM_TAPS, "ring and window sizes");
     unsigned pa[PF], pb[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) load(y_base + k, pa[k], pb[k]);
     tm_f2 g2[TM_SSIM_TAPS];
 #pragma unroll
     for (int k = 0; k < TM_SSIM_TAPS; ++k) g2[k] = f2_splat(gw[k]);
-    // the 11-row window of row-filtered values: per column the {x, y} and the {x^2 + y^2, xy} pair
-    tm_f2 w01[11][2], w23[11][2];
+    // the window of row-filtered values (WS slots, the newest 11 rows are read): per column the {x, y} and the {x^2 + y^2, xy} pair
+    tm_f2 w01[WS][2], w23[WS][2];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) { w01[k][0] = w01[k][1] = w23[k][0] = w23[k][1] = f2_splat(0.0f); }
+    for (int k = 0; k < WS; ++k) { w01[k][0] = w01[k][1] = w23[k][0] = w23[k][1] = f2_splat(0.0f); }
     const tm_f2 C1 = f2_splat(6.5025f), C2 = f2_splat(58.5225f), two = f2_splat(2.0f); // (0.01*255)^2, (0.03*255)^2
     double a_l[2] = {0.0, 0.0}, a_cs[2] = {0.0, 0.0};
     const int n_rows = (y_end - y_base) + 10; // input rows y_base .. y_end+9
-    for (int t0 = 0; t0 < n_rows; t0 += 11) {
+    // whole groups of WS steps (up to WS - 1 steps past the segment's last input row: their windows are not accumulated), so that the
+    // step body has no exit and its loads and waits are counted exactly
+    for (int t0 = 0; t0 < n_rows; t0 += WS) {
 #pragma unroll
-        for (int j = 0; j < 11; ++j) {
+        for (int j = 0; j < WS; ++j) {
             const int t = t0 + j;
-            if (t < n_rows) { // wave-uniform
+            {
                 float r0, r1, d0, d1;
-                unpack(pa[0], r0, r1);
-                unpack(pb[0], d0, d1);
-#pragma unroll
-                for (int k = 0; k + 1 < PF; ++k) { pa[k] = pa[k + 1]; pb[k] = pb[k + 1]; }
-                load(y_base + t + PF, pa[PF - 1], pb[PF - 1]);
+                unpack(pa[j % PF], y_base + t, r0, r1); // row t (requested PF steps ago)
+                unpack(pb[j % PF], y_base + t, d0, d1);
+                load(y_base + t + PF, pa[j % PF], pb[j % PF]);
                 // columns x .. x+11 as {ref, dis} and {ref^2 + dis^2, ref * dis} pairs: the own two computed here, ten from the neighbours
                 TmSsimCol c[12];
                 c[0].rd = f2_make(r0, d0); c[0].sp = f2_make(__builtin_fmaf(r0, r0, d0 * d0), r0 * d0);
@@ -232,12 +238,12 @@ __device__ __forceinline__ void ssim_strip(TmSsimCol *__restrict__ bufE, TmSsimC
                     if (i < 11) { a01[0] = f2_fma(g2[i], c[i].rd, a01[0]); a23[0] = f2_fma(g2[i], c[i].sp, a23[0]); }
                     if (i > 0) { a01[1] = f2_fma(g2[i - 1], c[i].rd, a01[1]); a23[1] = f2_fma(g2[i - 1], c[i].sp, a23[1]); }
                 }
-                w01[j % 11][0] = a01[0]; w01[j % 11][1] = a01[1]; w23[j % 11][0] = a23[0]; w23[j % 11][1] = a23[1];
-                if (t >= 10) { // window rows t-10 .. t are in slots (j+1)%11 .. j%11
+                w01[j][0] = a01[0]; w01[j][1] = a01[1]; w23[j][0] = a23[0]; w23[j][1] = a23[1];
+                if (t >= 10 && t < n_rows) { // window rows t-10 .. t are in slots (j+2)%WS .. j (wave-uniform test)
                     tm_f2 v01[2] = {f2_splat(0.0f), f2_splat(0.0f)}, v23[2] = {f2_splat(0.0f), f2_splat(0.0f)};
 #pragma unroll
                     for (int k = 0; k < TM_SSIM_TAPS; ++k) {
-                        const int q = (j + 1 + k) % 11;
+                        const int q = (j + WS - 10 + k) % WS;
                         v01[0] = f2_fma(g2[k], w01[q][0], v01[0]); v01[1] = f2_fma(g2[k], w01[q][1], v01[1]);
                         v23[0] = f2_fma(g2[k], w23[q][0], v23[0]); v23[1] = f2_fma(g2[k], w23[q][1], v23[1]);
                     }
