@@ -253,8 +253,12 @@ __device__ __forceinline__ tm_f2 bt709_power2(tm_f2 v, const double *__restrict_
     const float s0 = fminf(fmaxf(s.x, 84.0f), 512.0f), s1 = fminf(fmaxf(s.y, 84.0f), 512.0f);
     const int k0 = (int)s0, k1 = (int)s1;
     const double t0 = (double)fract_pos(s0), t1 = (double)fract_pos(s1);
-    const double *ca = et64 + TM_EOTF64_STRIDE * k0, *cb = et64 + TM_EOTF64_STRIDE * k1;
-    double pa = __builtin_fma(ca[3], t0, ca[2]), pb = __builtin_fma(cb[3], t1, cb[2]);
+    // et64 here is the SPLIT copy the ingest kernel stages in LDS: {c0, c1}[513], then {c2, c3}[513] -- 16-byte records, so that two
+    // lanes collide on a bank only when their segments are a multiple of 16 apart (32-byte records: 8; SQ_LDS_BANK_CONFLICT was two
+    // thirds of the kernel's LDS cycles)
+    const double *ca = et64 + 2 * k0, *cb = et64 + 2 * k1;
+    const double *ca2 = ca + 2 * TM_EOTF64_SEGS, *cb2 = cb + 2 * TM_EOTF64_SEGS;
+    double pa = __builtin_fma(ca2[1], t0, ca2[0]), pb = __builtin_fma(cb2[1], t1, cb2[0]);
     pa = __builtin_fma(pa, t0, ca[1]); pb = __builtin_fma(pb, t1, cb[1]);
     pa = __builtin_fma(pa, t0, ca[0]); pb = __builtin_fma(pb, t1, cb[0]);
     return f2_make((float)pa, (float)pb);

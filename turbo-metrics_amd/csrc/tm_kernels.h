@@ -641,7 +641,10 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
     const int qx = blockIdx.x * 64 + lane, X0 = 2 * qx;
     const int qy_begin = (blockIdx.y * 4 + wave) * rows_per_wave;
     const int qy_end = min(qy_begin + rows_per_wave, g.h1); // h1 == ceil(h / 2): quad rows, the incomplete last one included
-    for (int i = threadIdx.x; i < TM_EOTF64_STRIDE * TM_EOTF64_SEGS; i += 256) et64[i] = gtab[TM_TAB_EOTF64 + i];
+    for (int i = threadIdx.x; i < TM_EOTF64_STRIDE * TM_EOTF64_SEGS; i += 256) { // {c0, c1, c2, c3}[k] -> {c0, c1}[k] | {c2, c3}[k] (bt709_power2)
+        const int k = i >> 2, j = i & 3;
+        et64[(j >> 1) * 2 * TM_EOTF64_SEGS + 2 * k + (j & 1)] = gtab[TM_TAB_EOTF64 + i];
+    }
     const TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
     const float *kr = coef + (dd0.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5, *kd = coef + (dd1.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
     const tm_f2 k0 = f2_make(kr[0], kd[0]), k1 = f2_make(kr[1], kd[1]), k2 = f2_make(kr[2], kd[2]), k3 = f2_make(kr[3], kd[3]), k4 = f2_make(kr[4], kd[4]);
