@@ -277,7 +277,8 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
 {
     const bool reference = (variant & 1) != 0, wide_rows = (variant & 0x100) != 0;
     TmGeom g; tm_make_geom(&g, w, h);
-    TmJobs jobs; tm_make_jobs(&jobs, &g, weights, full_sums);
+    const bool fused_edge = (variant & 0x4000) != 0 && !reference; // TM_VARIANT_FUSED_EDGE: the EDGE jobs through k_blur_edge_fused
+    TmJobs jobs; tm_make_jobs(&jobs, &g, weights, full_sums, fused_edge ? 1 : 0);
     const int qw = (w + 1) / 2, qh = (h + 1) / 2;
     if (reference) {
         launch(dim3((qw + 63) / 64, (qh + 3) / 4, n), dim3(64, 4, 1), [&] { tmk::k_ingest(g, desc, lut, coef, tab, LIN, SSE, want_sse); });
@@ -311,11 +312,27 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
-        launch_wave_lockstep(dim3(n, jobs.vstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
-        if ((variant & 0x400) && (variant & 0x2000)) launch_wg_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), 320, [&] { tmk::k_blur_h_jobs_split<5>(g, jobs, XYB, V, PART); });
-        else if (variant & 0x400) launch_wg_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), 192, [&] { tmk::k_blur_h_jobs_split<3>(g, jobs, XYB, V, PART); });
-        else if (wide_rows) launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });
-        else launch_wave_lockstep(dim3(n, jobs.hstart[TM_MAX_JOBS], 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 32, 16>(g, jobs, XYB, V, PART); });
+        const int vb = jobs.vstart[jobs.nfull], hb = jobs.hstart[jobs.nfull]; // the two passes run jobs [0, nfull)
+        launch_wave_lockstep(dim3(n, vb, 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
+        if ((variant & 0x400) && (variant & 0x2000)) launch_wg_lockstep(dim3(n, hb, 1), 320, [&] { tmk::k_blur_h_jobs_split<5>(g, jobs, XYB, V, PART); });
+        else if (variant & 0x400) launch_wg_lockstep(dim3(n, hb, 1), 192, [&] { tmk::k_blur_h_jobs_split<3>(g, jobs, XYB, V, PART); });
+        else if (wide_rows) launch_wave_lockstep(dim3(n, hb, 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });
+        else launch_wave_lockstep(dim3(n, hb, 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 32, 16>(g, jobs, XYB, V, PART); });
+        if (jobs.n > jobs.nfull) { // the engine's buffers of the fused EDGE kernel, sized the same way
+            const int ne = jobs.n - jobs.nfull;
+            int tiles = 0, bands = 0;
+            for (int k = jobs.nfull; k < jobs.n; ++k) { tiles = std::max(tiles, (g.s[jobs.scale[k]].w + 31) / 32); bands = std::max(bands, (g.s[jobs.scale[k]].h + 31) / 32); }
+            std::vector<unsigned long long> hs((size_t)n * ne * 2 * tiles * 384, 0ull);
+            std::vector<double> erows((size_t)n * ne * bands * 128, 0.0);
+            unsigned epoch = 1; int status = 0;
+            for (int rep = 0; rep < 2; ++rep) { // twice: the second launch finds the first one's words (tags of another epoch) in HS
+                tmk::TmEdgeArgs ea;
+                tmk::tm_make_edge_args(&ea, &g, &jobs, tiles, bands);
+                launch_wave_lockstep(dim3(n * ne, bands, 1), [&] { tmk::k_blur_edge_fused<0>(ea, XYB, hs.data(), &epoch, erows.data(), &status); });
+                launch(dim3(n * ne), dim3(64), [&] { tmk::k_finish_edge(ea, erows.data(), PART, &epoch); });
+            }
+            if (status != 0 || epoch != 3) { fprintf(stderr, "tm_emul: k_blur_edge_fused status %d epoch %u\n", status, epoch); abort(); }
+        }
     }
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });
     if (!reference) { // test convenience: turn the interleaved pyramid back into two plain ones for the plane checks

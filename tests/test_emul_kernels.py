@@ -258,6 +258,32 @@ def test_three_wave_row_pass_writes_the_same_partial_sums(w, h):
             check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
 
 
+FUSED_EDGE = 0x4000
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (1, 1), (2, 5), (129, 20), (257, 131), (16, 200), (32, 32), (31, 96), (100, 33)])
+def test_fused_edge_kernel_writes_the_same_sums_as_the_two_passes(w, h):
+    """k_blur_edge_fused + k_finish_edge (both recurrences, the edge maps and their sums of an EDGE job in one kernel: bands of 32
+    rows chained through {value, tag} words, tiles of 32 columns through LDS) against the two-pass kernels: the 108 sums bit for
+    bit -- with the reference's weights (EDGE = scale 0 of X and B) and with a table that makes EVERY job an EDGE job (all six
+    scales, bands of every height) -- and against the oracle"""
+    frames = nv12_frames(w, h)
+    only_edges = O.weights().reshape(3, 6, 6).copy()
+    only_edges[:, :, 0] = 0.0; only_edges[:, :, 3] = 0.0   # no ssim weight anywhere ...
+    only_edges[:, :, 1] = 1.0                             # ... and an edge weight everywhere
+    for weights in (O.weights(), only_edges.ravel()):
+        two = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=weights, full_sums=False)
+        one = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=FUSED_EDGE, weights=weights, full_sums=False)
+        assert np.array_equal(one.SUMS, two.SUMS)
+    full = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
+    mask = weight_mask()
+    for slot in range(len(frames)):
+        assert np.array_equal(one.sums(slot)[:, [1, 2, 4, 5], :], full.sums(slot)[:, [1, 2, 4, 5], :])  # every edge sum of every scale
+    one = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=FUSED_EDGE, weights=O.weights(), full_sums=False)
+    for slot in range(len(frames)):
+        assert np.array_equal(one.sums(slot)[mask], full.sums(slot)[mask])
+
+
 def planar_frames(w, h, bits, count=2):
     frames = []
     dt = np.uint8 if bits == 8 else np.uint16

@@ -10,6 +10,7 @@
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstddef>
@@ -93,7 +94,14 @@ struct tm_engine {
     int device = 0;
     uint32_t w = 0, h = 0, mask = 0, cap = 0;
     TmGeom g{};
-    TmJobs jobs{};
+    TmJobs jobs{};                 // job table of the two blur passes (EDGE jobs inside their scale)
+    TmJobs jobs_f{};               // the same jobs with the EDGE jobs last: launches whose EDGE jobs run in k_blur_edge_fused
+    unsigned long long *HS = nullptr; // fused EDGE kernel: state hand-off words [plane][2][ef_tiles][6][64]
+    double *EROWS = nullptr;          // ... per-row sums [plane][ef_bands][64][2]
+    unsigned *d_epoch = nullptr;      // ... launch epoch of the hand-off tags (advanced by k_finish_edge)
+    int *d_status = nullptr, *h_status = nullptr; // ... a hand-off wait that timed out
+    int ef_tiles = 0, ef_bands = 0, ef_ne = 0;
+    long long fused_edge_from = 6; // slots per launch from which the EDGE jobs take the fused kernel (below, a launch is bound by the latency of one wave walking its band; TM_FUSED_EDGE_FROM overrides: tuning)
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
     bool use_graph = false;         // replay the per-batch launch sequence from a captured hipGraph (measured slower than direct launches: off)
@@ -119,7 +127,7 @@ struct tm_engine {
     size_t mem_bytes = 0;
     bool profiling = false, ev_pending = false;
     hipEvent_t ev[TM_STAGE_COUNT + 1] = {};
-    double stage_ms[TM_STAGE_COUNT] = {0, 0, 0, 0};
+    double stage_ms[TM_STAGE_COUNT] = {0, 0, 0, 0, 0};
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
@@ -301,6 +309,46 @@ unsigned long long slot_sse(const tm_engine *e, uint32_t slot)
 
 dim3 grid2(int w, int h, int z) { return dim3((unsigned)((w + 63) / 64), (unsigned)h, (unsigned)z); }
 
+// both orderings of the job table, and the buffers of the fused EDGE kernel for the EDGE jobs the table has
+int make_job_tables(tm_engine *e)
+{
+    tm_make_jobs(&e->jobs, &e->g, k_weights, e->full_sums ? 1 : 0, 0);
+    tm_make_jobs(&e->jobs_f, &e->g, k_weights, e->full_sums ? 1 : 0, 1);
+    const TmJobs &jf = e->jobs_f;
+    int tiles = 0, bands = 0;
+    for (int k = jf.nfull; k < jf.n; ++k) {
+        const TmScaleGeom &sg = e->g.s[jf.scale[k]];
+        tiles = std::max(tiles, (sg.w + 31) / 32); bands = std::max(bands, (sg.h + 31) / 32);
+    }
+    const int ne = jf.n - jf.nfull;
+    if (ne == 0 || !(e->mask & TM_METRIC_SSIMULACRA2)) { e->ef_ne = 0; return TM_OK; }
+    if (ne > e->ef_ne || tiles > e->ef_tiles || bands > e->ef_bands) {
+        if (e->HS) { (void)hipFree(e->HS); e->mem_bytes -= (size_t)e->cap * e->ef_ne * 2 * e->ef_tiles * 384 * sizeof(unsigned long long); e->HS = nullptr; }
+        if (e->EROWS) { (void)hipFree(e->EROWS); e->mem_bytes -= (size_t)e->cap * e->ef_ne * e->ef_bands * 128 * sizeof(double); e->EROWS = nullptr; }
+        e->ef_ne = ne; e->ef_tiles = tiles; e->ef_bands = bands;
+        int rc;
+        if ((rc = dev_alloc(e, &e->HS, (size_t)e->cap * ne * 2 * tiles * 384, true))) return rc;
+        if ((rc = dev_alloc(e, &e->EROWS, (size_t)e->cap * ne * bands * 128, true))) return rc;
+    }
+    if (!e->d_epoch) {
+        int rc;
+        if ((rc = dev_alloc(e, &e->d_epoch, 1, false))) return rc;
+        if ((rc = dev_alloc(e, &e->d_status, 1, true))) return rc;
+        const unsigned one = 1u;
+        HIPCHK(hipMemcpy(e->d_epoch, &one, sizeof one, hipMemcpyHostToDevice));
+        HIPCHK(hipHostMalloc((void **)&e->h_status, sizeof(int), hipHostMallocDefault));
+        *e->h_status = 0;
+    }
+    return TM_OK;
+}
+
+// does a launch of n slots send its EDGE jobs through k_blur_edge_fused?
+bool use_fused_edge(const tm_engine *e, int n)
+{
+    if ((e->variant & (TM_VARIANT_REFERENCE | TM_VARIANT_TWO_PASS_EDGE)) || e->ef_ne == 0 || e->jobs_f.n == e->jobs_f.nfull) return false;
+    return (e->variant & TM_VARIANT_FUSED_EDGE) || n >= e->fused_edge_from;
+}
+
 } // namespace
 
 extern "C" {
@@ -386,16 +434,16 @@ static int placement_search(tm_engine *e)
     int rc = TM_OK;
     // both kernels that touch the arena: the column pass writes it, the row pass reads it, and they do not always agree on a
     // placement (row pass 1.89 ... 1.98 ms per 64 pairs across candidates) -- the sum decides
+    // (with the fused EDGE kernel the two passes run the FULL jobs only: time them as they will run)
+    const TmJobs &jb = use_fused_edge(e, (int)e->cap) ? e->jobs_f : e->jobs;
+    const dim3 pvgrid((unsigned)e->cap, (unsigned)jb.vstart[jb.nfull], 1), phgrid((unsigned)e->cap, (unsigned)jb.hstart[jb.nfull], 1);
     auto run_once = [&](float *v, float &ms) -> bool {
         (void)hipEventRecord(e0, e->stream);
-        hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), dim3(320), 0, e->stream,
-                           e->g, e->jobs, e->XYB, v);
+        hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 1>), pvgrid, dim3(320), 0, e->stream, e->g, jb, e->XYB, v);
         if (e->g.s[0].w > 2560)
-            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
-                               e->g, e->jobs, e->XYB, v, e->PART);
+            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8, 1>), phgrid, dim3(64), 0, e->stream, e->g, jb, e->XYB, v, e->PART);
         else
-            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16, 1>), dim3((unsigned)e->cap, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1), dim3(64), 0, e->stream,
-                               e->g, e->jobs, e->XYB, v, e->PART);
+            hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16, 1>), phgrid, dim3(64), 0, e->stream, e->g, jb, e->XYB, v, e->PART);
         (void)hipEventRecord(e1, e->stream);
         return hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
     };
@@ -457,7 +505,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
     if (const char *pp = getenv("TM_PYRT_PAD")) e->g.pyr_t += (unsigned long long)atoll(pp) / 64 * 64; // experiment: distance between the planes / slots of the transposed arenas (tools/stride_probe.py)
-    tm_make_jobs(&e->jobs, &e->g, k_weights, 0);
+    if (const char *ff = getenv("TM_FUSED_EDGE_FROM")) e->fused_edge_from = atoll(ff);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
@@ -471,6 +519,15 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
         e->V = e->V_alloc;
         if ((rc = dev_alloc(e, &e->PART, B * 3 * (size_t)g.hblk[TM_SCALES] * 6, true))) return fail(rc);
         if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
+    }
+    if ((rc = make_job_tables(e))) return fail(rc);
+    if (getenv("TM_OCCUPANCY_DEBUG")) { // what the runtime thinks fits a CU
+        int nb = 0;
+        hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, e->device);
+        fprintf(stderr, "[tm] sharedMemPerBlock %zu maxSharedMemoryPerMultiProcessor %zu regsPerBlock %d\n", prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor, prop.regsPerBlock);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_edge_fused<0>, 64, 0); fprintf(stderr, "[tm] k_blur_edge_fused: %d blocks of 64 per CU\n", nb);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_v_jobs<32, 16, 0>, 320, 0); fprintf(stderr, "[tm] k_blur_v_jobs: %d blocks of 320 per CU\n", nb);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>, 64, 0); fprintf(stderr, "[tm] k_blur_h_jobs_x: %d blocks of 64 per CU\n", nb);
     }
     if ((rc = dev_alloc(e, &e->SSE, B * TM_SSE_BINS * 3, true))) return fail(rc);
     if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
@@ -517,6 +574,8 @@ void tm_engine_destroy(tm_engine *e)
     if (e->h_ssums) (void)hipHostFree(e->h_ssums);
     (void)hipFree(e->PART); (void)hipFree(e->SUMS); (void)hipFree(e->SSE); (void)hipFree(e->d_desc);
     (void)hipFree(e->d_lut); (void)hipFree(e->d_coef); (void)hipFree(e->d_powtab);
+    (void)hipFree(e->HS); (void)hipFree(e->EROWS); (void)hipFree(e->d_epoch); (void)hipFree(e->d_status);
+    if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_desc) (void)hipHostFree(e->h_desc);
     if (e->h_sums) (void)hipHostFree(e->h_sums);
     if (e->h_sse) (void)hipHostFree(e->h_sse);
@@ -577,7 +636,8 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST | TM_VARIANT_SPLIT_ROWS | TM_VARIANT_WHOLE_ROWS))) return TM_ERR_INVALID_ARG;
+    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST | TM_VARIANT_SPLIT_ROWS | TM_VARIANT_WHOLE_ROWS | TM_VARIANT_TWO_PASS_EDGE | TM_VARIANT_FUSED_EDGE))) return TM_ERR_INVALID_ARG;
+    if ((variant & TM_VARIANT_TWO_PASS_EDGE) && (variant & TM_VARIANT_FUSED_EDGE)) return TM_ERR_INVALID_ARG;
     const bool ref = (variant & TM_VARIANT_REFERENCE) != 0;
     // the reference pipeline is SSIMULACRA2 (+ PSNR) only: its ingest kernel neither writes the u8 planes of SSIM / MS-SSIM nor runs without the XYB arenas
     if (ref && ((e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) || !(e->mask & TM_METRIC_SSIMULACRA2))) return TM_ERR_INVALID_ARG;
@@ -604,10 +664,10 @@ int tm_engine_set_full_sums(tm_engine *e, int on)
 {
     if (!e) return TM_ERR_INVALID_ARG;
     if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+    TM_BIND(e);
     e->full_sums = on != 0;
-    tm_make_jobs(&e->jobs, &e->g, k_weights, on != 0);
     e->have_results = false;
-    return TM_OK;
+    return make_job_tables(e);
 }
 
 int tm_engine_get_job_modes(const tm_engine *e, int out[18])
@@ -677,26 +737,46 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
     // (the SSIM stage only needs the u8 planes of the ingest kernel and is bound by arithmetic while the blur passes are bound by
     // HBM -- but running it on a second stream beside them was measured: 7.63 k vs 7.77 k pairs/s)
     if (ssimu2) {
-        const dim3 vgrid((unsigned)n, (unsigned)e->jobs.vstart[TM_MAX_JOBS], 1), hgrid((unsigned)n, (unsigned)e->jobs.hstart[TM_MAX_JOBS], 1);
+        // the EDGE jobs (scale 0 of X and B with the reference's weights) go through ONE kernel without the pass-1 arena; the two
+        // passes then run the FULL jobs only (the first nfull entries of the edge-last table)
+        const bool fused = use_fused_edge(e, n);
+        const TmJobs &jobs = fused ? e->jobs_f : e->jobs;
+        const long long hblocks = jobs.hstart[jobs.nfull];
+        const dim3 vgrid((unsigned)n, (unsigned)jobs.vstart[jobs.nfull], 1), hgrid((unsigned)n, (unsigned)hblocks, 1);
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
-        else hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, e->jobs, XYB, V);
+        else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         // ---- stage BLUR_H: row pass + error maps + reductions
-        if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)e->jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, e->jobs, XYBT, V, PART);
+        if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, jobs, XYBT, V, PART);
+        else if (!hgrid.y) {}
         // few row blocks (small batches): three waves per block -- a wave's own issue rate, not the chip, bounds this pass then
-        else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * e->jobs.hstart[TM_MAX_JOBS] <= e->split_rows_below)) {
+        else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * hblocks <= e->split_rows_below)) {
             // five waves per row block up to a quarter of a row block per SIMD (1-2 pairs of 1080p: 0.26 vs 0.35 ms), three above (8 pairs: 0.43 vs 0.58)
-            if ((long long)n * e->jobs.hstart[TM_MAX_JOBS] <= e->split5_rows_below) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5>), hgrid, dim3(320), 0, st, g, e->jobs, XYB, V, PART);
-            else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3>), hgrid, dim3(192), 0, st, g, e->jobs, XYB, V, PART);
+            if ((long long)n * hblocks <= e->split5_rows_below) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
+            else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
         }
-        else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
-        else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, e->jobs, XYB, V, PART);
+        else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
+        else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, e->jobs, PART, SUMS);
+        // ---- stage EDGE: both recurrences, the edge maps and their sums of the EDGE jobs in one kernel
+        if (fused) {
+            const int ne = jobs.n - jobs.nfull;
+            int bands = 0;
+            for (int k = jobs.nfull; k < jobs.n; ++k) bands = std::max(bands, (g.s[jobs.scale[k]].h + 31) / 32);
+            tmk::TmEdgeArgs ea;
+            tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
+            static const int dbg = getenv("TM_EF_DEBUG") ? atoi(getenv("TM_EF_DEBUG")) : 0; // experiments: 1 = do not wait for the band above, 2 = do not publish
+            hipLaunchKernelGGL((tmk::k_blur_edge_fused<0>), dim3((unsigned)(n * ne), (unsigned)bands, 1), dim3(64), 0, st, ea, XYB, e->HS, e->d_epoch, e->EROWS, e->d_status, dbg);
+            hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)(n * ne)), dim3(64), 0, st, ea, e->EROWS, PART, e->d_epoch);
+            HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+        }
+        if (ev) HIPCHK(hipEventRecord(ev[4], st));
+        hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, jobs, PART, SUMS);
     } else if (ev) {
         HIPCHK(hipEventRecord(ev[2], st));
         HIPCHK(hipEventRecord(ev[3], st));
+        HIPCHK(hipEventRecord(ev[4], st));
     }
     if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
@@ -709,7 +789,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, need_l, QU8, e->SPYR, e->SPART);
         hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, nscales, e->SPART, e->SSUMS);
     }
-    if (ev) HIPCHK(hipEventRecord(ev[4], st));
+    if (ev) HIPCHK(hipEventRecord(ev[5], st));
     return TM_OK;
 }
 
@@ -784,15 +864,25 @@ int tm_engine_sync(tm_engine *e)
     TM_BIND(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->ev_pending) {
+        // events in stream order: ingest | column pass | row pass | fused EDGE kernel | finisher + SSIM stage
+        static const int first_event[TM_STAGE_COUNT] = {0, 1, 2, 4, 3}; // TM_STAGE_INGEST, BLUR_V, BLUR_H, SSIM, EDGE
         for (int i = 0; i < TM_STAGE_COUNT; ++i) {
             float ms = 0.0f;
-            HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, e->ev[first_event[i]], e->ev[first_event[i] + 1]));
             e->stage_ms[i] += (double)ms;
         }
         e->n_prof += 1;
         e->ev_pending = false;
     }
     if (e->in_flight) { e->in_flight = false; e->have_results = true; }
+    if (e->h_status && *e->h_status) { // k_blur_edge_fused gave up waiting for the band above: the sums of this launch are not valid
+        *e->h_status = 0;
+        (void)hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream);
+        (void)hipStreamSynchronize(e->stream);
+        e->have_results = false;
+        snprintf(g_hip_err, sizeof g_hip_err, "k_blur_edge_fused: a state hand-off between bands timed out");
+        return TM_ERR_HIP;
+    }
     return TM_OK;
 }
 

@@ -69,6 +69,8 @@ enum { TM_MODE_NONE = 0, TM_MODE_EDGE = 1, TM_MODE_FULL = 2 };
 
 struct TmJobs {
     int n;                        // jobs with mode != NONE
+    int nfull;                    // jobs [0, nfull) run in the two blur passes; [nfull, n) are the EDGE jobs of the fused kernel
+                                  // (k_blur_edge_fused); nfull == n when the table was made without `edge_last`
     int vstart[TM_MAX_JOBS + 1];  // prefix sums: workgroups of the column pass (FULL: one per 64-column block,
                                   // EDGE: one per two 64-column blocks)
     int hstart[TM_MAX_JOBS + 1];  // prefix sums: 64-row blocks (= waves) of the row pass; also indexes PART
@@ -101,15 +103,19 @@ static inline void tm_make_geom(TmGeom *g, int w, int h)
 }
 
 // weights: the reference's table [channel][scale][ssim1, art1, det1, ssim4, art4, det4]
-static inline void tm_make_jobs(TmJobs *j, const TmGeom *g, const double *weights, int full)
+// edge_last: the EDGE jobs come after ALL FULL jobs (they run in k_blur_edge_fused; the two passes then launch only the
+// workgroups of jobs [0, nfull), and PART keeps one layout for k_finish_jobs)
+static inline void tm_make_jobs(TmJobs *j, const TmGeom *g, const double *weights, int full, int edge_last = 0)
 {
-    j->n = 0;
+    j->n = 0; j->nfull = 0;
     j->vstart[0] = 0; j->hstart[0] = 0;
     for (int i = 0; i < TM_SCALES * 3; ++i) j->job_of[i] = -1;
     // longest columns/rows first (scale 0), FULL before EDGE inside a scale
+    for (int round = 0; round < (edge_last ? 2 : 1); ++round)
     for (int s = 0; s < TM_SCALES; ++s)
         for (int pass = TM_MODE_FULL; pass >= TM_MODE_EDGE; --pass)
             for (int c = 0; c < 3; ++c) {
+                if (edge_last && pass != (round == 0 ? TM_MODE_FULL : TM_MODE_EDGE)) continue;
                 const double *wt = weights + c * 36 + 6 * s;
                 const int ssim = wt[0] != 0.0 || wt[3] != 0.0;
                 const int edge = wt[1] != 0.0 || wt[2] != 0.0 || wt[4] != 0.0 || wt[5] != 0.0;
@@ -121,6 +127,7 @@ static inline void tm_make_jobs(TmJobs *j, const TmGeom *g, const double *weight
                 j->vstart[k + 1] = j->vstart[k] + (mode == TM_MODE_FULL ? cb : (cb + 1) / 2);
                 j->hstart[k + 1] = j->hstart[k] + rb;
                 j->job_of[s * 3 + c] = k;
+                if (!edge_last || mode == TM_MODE_FULL) j->nfull = j->n;
             }
     for (int k = j->n; k < TM_MAX_JOBS; ++k) {
         j->scale[k] = 0; j->chan[k] = 0; j->mode[k] = TM_MODE_NONE;

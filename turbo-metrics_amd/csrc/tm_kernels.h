@@ -1661,6 +1661,269 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// EDGE jobs in ONE kernel ("fused"): column recurrence, row recurrence, the edge half of compute_error_maps and its four sums
+// without the pass-1 arena.  An EDGE job (only mu1, mu2 carry weight: scale 0 of X and B = half of all pixels) costs the two
+// passes above 8 units of HBM traffic per pixel-channel (2 R + 2 W, then 4 R); here it costs the 2 units of its input.
+//   * one wave = one BAND of 32 image rows of one (slot, job), walking right in tiles of 32 columns; a lane is a
+//     (column, side) pair during the column phase of a tile and a (row, side) pair during its row phase -- ref and dis run the
+//     same recurrence, so both phases are plain f32 code on 64 full lanes;
+//   * column phase of a tile: the 42 input rows it needs (32 + the 10 rows of history; window slot k = image row 32 band - 6 + k)
+//     were requested a whole row phase earlier (one 256-B run per row and wave); 32 steps of the recurrence whose STATE comes from
+//     the band above (below: hand-off); every step parks {V, original} of its row in the wave's LDS tile -- the original four
+//     columns to the right, so that the row phase, which emits column x - 4 at step x, finds both in one 8-byte read;
+//   * row phase: lane (row, side) walks the 32 columns of the tile; recurrence state, the last ten V and the last four originals
+//     of its row stay in registers from tile to tile; e = 1 + |orig - mu| on each side, the partner's e through one DPP move,
+//     d1 = fma(e_dis, 1 / e_ref, -1) on both lanes of the pair, of which the ref lane accumulates the artifact sums and the dis
+//     lane the detail_loss sums, f64, in column order: exactly the per-row sums of k_blur_h_jobs_x.  They go to EROWS and
+//     k_finish_edge adds the rows of a 64-row block in the order of tm_wave_sum6 -> the PART entries, and everything after them,
+//     are bit-identical with the two-pass kernels (the GPU tier checks that);
+//   * hand-off: the six state values of a (column, side) after the last step of band b are what band b + 1 starts from.  They
+//     travel through HS as 8-byte {value, tag} words written and read with device-scope atomic accesses (tag = launch epoch and
+//     band: a reader spins until all six words carry the tag it expects; no fence, no flag: the word is its own flag), two
+//     buffers per plane alternate by band parity (band b + 2 cannot overwrite what band b + 1 still has to read: it needs band
+//     b + 1's state of that tile first).  The grid is plane-major (x = (slot, job), y = band): workgroups are dispatched in
+//     increasing order, a band only ever waits for the band above, i.e. for a workgroup with a smaller index that has been
+//     dispatched before it -- no deadlock --, and since all planes start band b before any starts b + 1 the producer is
+//     normally a whole tile row ahead.  A wait that lasts longer than ~2^22 polls sets *status (the host reports TM_ERR_HIP).
+// LDS: 32 rows x 148 floats (36 column slots x 2 sides x 2, + 4: eight rows cover the 32 banks in 8-byte reads) = 18.9 KB per
+// wave -> 8 waves per CU.  grid (slots * ne, max bands), block 64; plane = slot * ne + job.  HS[plane][2][hs_tiles][6][64],
+// EROWS[plane][er_bands][64][2].
+// ------------------------------------------------------------------------------------------------
+#define TM_EF_S 148
+#ifdef TM_EMULATE
+__device__ __forceinline__ void tm_ll_store(unsigned long long *p, float v, unsigned tag) { *(volatile unsigned long long *)p = ((unsigned long long)tag << 32) | __float_as_uint(v); }
+__device__ __forceinline__ unsigned long long tm_ll_load(const unsigned long long *p) { return *(const volatile unsigned long long *)p; }
+#define TM_WAVE_ALL(c) (c)
+#else
+__device__ __forceinline__ void tm_ll_store(unsigned long long *p, float v, unsigned tag)
+{
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long tm_ll_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define TM_WAVE_ALL(c) (__builtin_amdgcn_ballot_w64(c) == ~0ull)
+#endif
+
+// what the fused kernel needs to know about its jobs (a small kernarg: the tile loop keeps its scalars in registers)
+struct TmEdgeJob {
+    int w, h;
+    int rowf;                   // floats per row of the interleaved plane (2 * pitch)
+    int part0;                  // first PART row block of the job (jobs.hstart[j])
+    unsigned long long in_off;  // float offset of the job's plane inside a slot's interleaved pyramid
+};
+struct TmEdgeArgs {
+    TmEdgeJob job[TM_MAX_JOBS];
+    unsigned long long slot_stride; // floats per slot of the interleaved pyramid (2 * g.pyr)
+    int ne, hs_tiles, er_bands, part_stride /* PART row blocks per slot */;
+};
+static inline void tm_make_edge_args(TmEdgeArgs *a, const TmGeom *g, const TmJobs *jobs, int hs_tiles, int er_bands)
+{
+    a->ne = jobs->n - jobs->nfull; a->hs_tiles = hs_tiles; a->er_bands = er_bands; a->part_stride = jobs->hstart[TM_MAX_JOBS];
+    a->slot_stride = 2 * g->pyr;
+    for (int e = 0; e < TM_MAX_JOBS; ++e) {
+        const int j = jobs->nfull + (e < a->ne ? e : 0);
+        const TmScaleGeom *sg = &g->s[jobs->scale[j]];
+        a->job[e].w = sg->w; a->job[e].h = sg->h; a->job[e].rowf = 2 * sg->pitch; a->job[e].part0 = jobs->hstart[j];
+        a->job[e].in_off = 2 * (sg->off + (unsigned long long)jobs->chan[j] * sg->plane);
+    }
+}
+
+// one pixel of the edge maps on a (row, side) lane pair (error_maps.rs:45-59, the same operations as tmdev::edge_maps):
+//   * e = 1 + |orig - mu| on each lane; both lanes of the pair then hold e_ref (the even lane's) and e_dis (the odd lane's): two
+//     DPP quad broadcasts;
+//   * 1 / e_ref as the compiler's own IEEE division sequence without v_div_scale / v_div_fixup (1 <= e_ref, far from the ends of
+//     the exponent range: the same operations on the same values, like ssim_div; the numerator 1 makes the first product exact);
+//   * the ref lane keeps artifact = max(d1, 0), the dis lane detail_loss = max(-d1, 0): the sign flips by a per-lane mask and the
+//     maximum with 0 is an integer maximum (a float below or equal to zero is a negative integer or 0; no NaN can occur);
+//   * lanes of rows below the image accumulate whatever they compute: their sums are dropped at the end.
+__device__ __forceinline__ void ef_accumulate(float og, float mu, bool dis, unsigned sgn, double &a1, double &a4)
+{
+    const float e = 1.0f + fabsf(og - mu);
+#ifdef TM_EMULATE
+    const float pe = tm_swap1(e);
+    const float e_ref = dis ? pe : e, e_dis = dis ? e : pe;
+    const float denom = 1.0f / e_ref;
+#else
+    const float e_ref = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(e), 0xA0, 0xF, 0xF, true)); // quad_perm [0, 0, 2, 2]
+    const float e_dis = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(e), 0xF5, 0xF, 0xF, true)); // quad_perm [1, 1, 3, 3]
+    const float r0 = __builtin_amdgcn_rcpf(e_ref);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-e_ref, r0, 1.0f), r0, r0);
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-e_ref, r1, 1.0f), r1, r1);
+    const float denom = __builtin_fmaf(__builtin_fmaf(-e_ref, q1, 1.0f), r1, q1);                                           // 1 / (1 + |source - mu1|)
+#endif
+    const float d1 = __builtin_fmaf(e_dis, denom, -1.0f);                                                                    // numer = 1 + |distorted - mu2|
+    const int bits = (int)(__float_as_uint(d1) ^ sgn);
+    const float m = __uint_as_float((unsigned)(bits > 0 ? bits : 0));
+    a1 += (double)m;
+    float q = m * m; q = q * q;
+    a4 += (double)q;
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void ef_row_phase(const float *__restrict__ trow, int n0, int w, tmdev::Iir &fr, float (&vc)[10], float (&oc)[4],
+                                             bool dis, unsigned sgn, double &a1, double &a4)
+{
+    // trow: this lane's tile row + 2 * side; n0 = the column emitted at step 0 (32 tile - 4)
+    float v[32];
+#pragma unroll
+    for (int x = 0; x < 32; ++x) {
+        const tm_g2 pr = *(const tm_g2 *)(trow + 4 * x);
+        v[x] = pr.x;
+        const float mu = tmdev::iir_step(fr, (x >= 10 ? v[x >= 10 ? x - 10 : 0] : vc[x < 10 ? x : 0]) + pr.x);
+        if (!GUARD || (n0 + x >= 0 && n0 + x < w)) ef_accumulate(x >= 4 ? pr.y : oc[x & 3], mu, dis, sgn, a1, a4);
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) vc[k] = v[22 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oc[k] = trow[4 * (32 + k) + 1];
+}
+
+template <int PROBE = 0>
+__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmEdgeArgs A, const float *__restrict__ XYB, unsigned long long *__restrict__ HS,
+                                                                          const unsigned *__restrict__ epoch_p, double *__restrict__ EROWS,
+                                                                          int *__restrict__ status, int dbg = 0)
+{
+    __shared__ __attribute__((aligned(16))) float tile[32 * TM_EF_S];
+    const int p = blockIdx.x, band = blockIdx.y;
+    const int slot = p / A.ne;
+    const TmEdgeJob J = A.job[p - slot * A.ne];
+    const int h = J.h, w = J.w;
+    const int nbands = (h + 31) >> 5, ntiles = (w + 31) >> 5;
+    if (band >= nbands) return;
+    const int lane = threadIdx.x & 63, cl = lane >> 1, side = lane & 1;
+    const unsigned epoch = *epoch_p;
+    const unsigned tag_in = (epoch << 8) | (unsigned)((band - 1) & 255), tag_out = (epoch << 8) | (unsigned)(band & 255);
+    const int y0 = 32 * band - 6;                        // image row of window slot 0
+    const bool interior = y0 >= 0 && y0 + 41 < h;        // every window row exists
+    const unsigned rowb = (unsigned)J.rowf * 4u;         // bytes per interleaved row; a plane stays below 2^31 bytes (16 384 x 16 384 x 8)
+    // window loads take ONE scalar base and a 32-bit lane offset each (global_load ... s[base], one v_add per row): interior
+    // bands from row y0 on, the first / last bands from the top of the plane with clamped row numbers (and zeros afterwards)
+    TM_GLOBAL_AS const char *inb = (TM_GLOBAL_AS const char *)tm_uniform_ptr(XYB + (size_t)slot * A.slot_stride + J.in_off + (interior ? (size_t)y0 * J.rowf : 0));
+    const unsigned long long *hs_in = HS + ((size_t)p * 2 + ((band - 1) & 1)) * A.hs_tiles * 384 + lane;
+    unsigned long long *hs_out = HS + ((size_t)p * 2 + (band & 1)) * A.hs_tiles * 384 + lane;
+    const bool publish = band + 1 < nbands;
+    const bool valid = 32 * band + cl < h, dis = side != 0;
+    const unsigned sgn = (unsigned)side << 31;
+    float *tcol = tile + 4 * cl + 2 * side;                 // column phase: + row * TM_EF_S
+    const float *trow = tile + cl * TM_EF_S + 2 * side;     // row phase: + 4 * step
+
+    float win[42];
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    auto fetch = [&](int i) {
+        const unsigned xb = (unsigned)min(32 * i + cl, w - 1) * 8u + (unsigned)side * 4u; // lanes past the right edge shadow the last column (and are zeroed below)
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < 42; ++k) win[k] = *(TM_GLOBAL_AS const float *)(inb + (xb + (unsigned)k * rowb));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 42; ++k) {
+                const int y = y0 + k, yc = y < 0 ? 0 : (y < h ? y : h - 1);
+                win[k] = *(TM_GLOBAL_AS const float *)(inb + (xb + (unsigned)yc * rowb));
+            }
+        }
+        if (band > 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) st[k] = tm_ll_load(hs_in + (size_t)i * 384 + k * 64);
+        }
+    };
+    fetch(0);
+    tmdev::Iir fr = {0, 0, 0, 0, 0, 0};
+    float vc[10], oc[4];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) vc[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oc[k] = 0.0f;
+    double a1 = 0.0, a4 = 0.0;
+    for (int i = 0; i < ntiles; ++i) {
+        const bool colok = 32 * i + cl < w;
+        tmdev::Iir f = {0, 0, 0, 0, 0, 0};
+        if (band > 0) {
+            int polls = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ok = ok && (unsigned)(st[k] >> 32) == tag_in;
+                if (TM_WAVE_ALL(ok) || (dbg & 1)) break;
+                if (++polls > (1 << 22) || *(volatile int *)status) { *(volatile int *)status = 1; break; }
+#ifndef TM_EMULATE
+                __builtin_amdgcn_s_sleep(8);
+#endif
+#pragma unroll
+                for (int k = 0; k < 6; ++k) st[k] = tm_ll_load(hs_in + (size_t)i * 384 + k * 64);
+            }
+            f.p1a = __uint_as_float((unsigned)st[0]); f.p1b = __uint_as_float((unsigned)st[1]); f.p1c = __uint_as_float((unsigned)st[2]);
+            f.p2a = __uint_as_float((unsigned)st[3]); f.p2b = __uint_as_float((unsigned)st[4]); f.p2c = __uint_as_float((unsigned)st[5]);
+        }
+        if (!interior) { // rows above / below the image are zeros (blur.rs:104-110); here, not in fetch: a select behind every load would wait for it
+#pragma unroll
+            for (int k = 0; k < 42; ++k) win[k] = (y0 + k >= 0 && y0 + k < h) ? win[k] : 0.0f;
+        }
+        if (32 * i + 31 >= w) { // the last tile: columns past the right edge enter both recurrences as zeros (blur.rs:104-110)
+#pragma unroll
+            for (int k = 0; k < 42; ++k) win[k] = colok ? win[k] : 0.0f;
+        }
+        if (band == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) (void)tmdev::iir_step(f, 0.0f + win[6 + t]); // steps 0..3 of the recurrence: no output row yet
+        }
+        // ---- column phase: step j = image step 32 band + 4 + j reads rows win[j + 10] and win[j] and emits row 32 band + j
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) {
+            const float o = tmdev::iir_step(f, win[jj] + win[jj + 10]);
+            tcol[jj * TM_EF_S] = o;
+            tcol[jj * TM_EF_S + 16 + 1] = win[jj + 6];
+        }
+        if (publish && !(dbg & 2)) {
+            unsigned long long *o = hs_out + (size_t)i * 384;
+            tm_ll_store(o, f.p1a, tag_out); tm_ll_store(o + 64, f.p1b, tag_out); tm_ll_store(o + 128, f.p1c, tag_out);
+            tm_ll_store(o + 192, f.p2a, tag_out); tm_ll_store(o + 256, f.p2b, tag_out); tm_ll_store(o + 320, f.p2c, tag_out);
+        }
+        __builtin_amdgcn_wave_barrier();
+        fetch(min(i + 1, ntiles - 1)); // requested now, lands during the row phase (past the last tile: that tile again, never used)
+        // ---- row phase: step x = image step 32 i + x of this lane's row, emits column 32 i + x - 4
+        if (i == 0 || 32 * i + 27 >= w) ef_row_phase<true>(trow, 32 * i - 4, w, fr, vc, oc, dis, sgn, a1, a4);
+        else ef_row_phase<false>(trow, 32 * i - 4, w, fr, vc, oc, dis, sgn, a1, a4);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the last four steps of the row recurrence (image steps 32 ntiles .. + 3, input 0): columns up to w - 1
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const float mu = tmdev::iir_step(fr, vc[x] + 0.0f);
+        if (32 * ntiles - 4 + x < w) ef_accumulate(oc[x], mu, dis, sgn, a1, a4);
+    }
+    double *er = EROWS + (((size_t)p * A.er_bands + band) * 64 + lane) * 2;
+    er[0] = valid ? a1 : 0.0; er[1] = valid ? a4 : 0.0; // rows below the image: nothing (the two-pass kernels never add them)
+}
+
+// the rows of an EDGE job -> the PART entries k_blur_h_jobs_x would have written: per 64-row block, sum over rows in the order of
+// tm_wave_sum6 (row i with row i + 32, then the shuffle tree 16, 8, 4, 2, 1), kinds 1, 4 (artifact: ref lanes) and 2, 5 (detail_loss:
+// dis lanes).  Also advances the launch epoch of the hand-off tags.  grid (slots * ne), block 64: thread = (row block, kind).
+__global__ void __launch_bounds__(64) k_finish_edge(TmEdgeArgs A, const double *__restrict__ EROWS, double *__restrict__ PART, unsigned *__restrict__ epoch_p)
+{
+    const int p = blockIdx.x, slot = p / A.ne, er_bands = A.er_bands;
+    const TmEdgeJob J = A.job[p - slot * A.ne];
+    const int h = J.h, nbands = (h + 31) >> 5, nblk = (h + 63) >> 6;
+    for (int item = threadIdx.x; item < nblk * 4; item += 64) {
+        const int blk = item >> 2, q = item & 3, side = q & 1, pw = q >> 1; // q: 0 art, 1 det, 2 art^4, 3 det^4
+        double a[64];
+        for (int i = 0; i < 64; ++i) {
+            const int band = 2 * blk + (i >> 5);
+            a[i] = band < nbands ? EROWS[(((size_t)p * er_bands + band) * 64 + 2 * (i & 31) + side) * 2 + pw] : 0.0;
+        }
+        double tot;
+#ifdef TM_EMULATE
+        tot = 0.0; // the emulator's k_blur_h_jobs_x adds the lanes of a wave one after the other
+        for (int i = 0; i < 64; ++i) tot += a[i];
+#else
+        for (int off = 32; off > 0; off >>= 1)
+            for (int i = 0; i < off; ++i) a[i] += a[i + off];
+        tot = a[0];
+#endif
+        PART[((size_t)slot * A.part_stride + J.part0 + blk) * 6 + 1 + side + 3 * pw] = tot;
+    }
+    if (p == 0 && threadIdx.x == 0) *epoch_p = *epoch_p + 1u;
+}
+
 // fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no
 // job produces (weight 0.0 in the reference's table) are written as 0
 __global__ void __launch_bounds__(128) k_finish_jobs(TmJobs jobs, const double *__restrict__ PART, double *__restrict__ SUMS)

@@ -13,9 +13,10 @@ TM_TRANSFER_BT709 = 0
 TM_SIDE_REF, TM_SIDE_DIS = 0, 1
 TM_CHANNELS_POOLED, TM_CHANNELS_FIRST = 0, 1
 TM_MEM_HOST, TM_MEM_DEVICE, TM_MEM_HOST_PINNED = 0, 1, 2
-TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_SSIM, TM_STAGE_COUNT = 0, 1, 2, 3, 4
+TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_SSIM, TM_STAGE_EDGE, TM_STAGE_COUNT = 0, 1, 2, 3, 4, 5
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
 TM_VARIANT_DEFAULT, TM_VARIANT_REFERENCE, TM_VARIANT_WIDE_ROWS, TM_VARIANT_TILE_INGEST, TM_VARIANT_SPLIT_ROWS, TM_VARIANT_WHOLE_ROWS = 0, 1, 0x100, 0x200, 0x400, 0x800
+TM_VARIANT_TWO_PASS_EDGE, TM_VARIANT_FUSED_EDGE = 0x1000, 0x4000
 
 
 class FrameScoresC(C.Structure):
