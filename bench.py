@@ -248,8 +248,8 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         modes_o = eng.job_modes()
         scores_o = np.array([s.ssimulacra2 or 0.0 for s in eng.scores_batch(B)], np.float64)
         other = {"full_sums": not args.full_sums, "value": B * k / dt_o, "ms_per_step": dt_o / k * 1e3,
-                 "stage_ms": {"ingest": ms_o[0], "blur_v": ms_o[1], "blur_h": ms_o[2]},
-                 "scores_bit_identical": bool(np.array_equal(scores_o, scores_local)), "_modes": modes_o}
+                 "stage_ms": {"ingest": ms_o[0], "blur_v": ms_o[1], "blur_h": ms_o[2], "edge_fused": ms_o[tm.ffi.TM_STAGE_EDGE]},
+                 "scores_bit_identical": bool(np.array_equal(scores_o, scores_local)), "_modes": modes_o, "_fused": bool(eng.uses_fused_edge(B))}
         eng.set_full_sums(args.full_sums)
 
     pairs = ctx.world * B * steps
@@ -262,8 +262,13 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     # pass -- `job_bytes` is what THIS configuration must move.  Ingest reads the two surfaces and writes the planar XYB
     # pyramid once (24 B/px for the two sides).  The SSIM / MS-SSIM stage reads the u8-quantised planes (6 B/px per pair) and,
     # for MS-SSIM, builds and reads back the dyadic pyramid of box sums (u16, scales 1-4: 2 x 0.332 x 2 B per sample).
+    # Launches of six slots and more run the edge-only jobs in ONE kernel (k_blur_edge_fused) that reads the {ref, dis} plane
+    # once (2 f32 per pixel) and writes nothing: the two passes then move the bytes of the FULL jobs only.
     units = {0: 0, 1: 4, 2: 7}
-    job_bytes = sum(4 * units[int(modes[s, c])] * sizes[s] for s in range(6) for c in range(3))
+    fused_edge = bool(has_s2 and eng.uses_fused_edge(B))
+    pass_units = {0: 0, 1: 0 if fused_edge else 4, 2: 7}
+    job_bytes = sum(4 * pass_units[int(modes[s, c])] * sizes[s] for s in range(6) for c in range(3))
+    edge_bytes = sum(4 * 2 * sizes[s] for s in range(6) for c in range(3) if int(modes[s, c]) == 1) if fused_edge else 0
     model_bytes = 84 * spx
     has_ssim = bool(mets & {"ssim", "msssim"})
     ssim_bytes = int((6 + (6 * 0.332 * 2 * 2 if "msssim" in mets else 0)) * w * h)
@@ -283,6 +288,9 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     if has_s2:
         per_kernel["k_blur_v_jobs"] = roof(stage_ms[F.TM_STAGE_BLUR_V], job_bytes * B)
         per_kernel["k_blur_h_jobs_x"] = roof(stage_ms[F.TM_STAGE_BLUR_H], job_bytes * B)
+        if fused_edge:
+            per_kernel["k_blur_edge_fused"] = roof(stage_ms[F.TM_STAGE_EDGE], edge_bytes * B)
+            per_kernel["k_blur_edge_fused"]["bound"] = "instruction issue (both recurrences, the edge maps and their f64 sums of an edge-only job in one kernel: ~1 500 instructions per 32 x 32 pixel pairs against 8 KB of input; the HBM fraction is informative only)"
     if has_ssim:
         per_kernel["k_ssim_stage"] = roof(stage_ms[F.TM_STAGE_SSIM], ssim_bytes * B)
         per_kernel["k_ssim_stage"]["bound"] = "valu (11x11 separable window of 4 quantities: 88 fused multiply-adds per window and channel; HBM fraction is informative only)"
@@ -291,7 +299,10 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else ingest_name
     ms_v = per_kernel["k_blur_v_jobs"]["avg_launch_ms"] if has_s2 else 0.0
     ms_h = per_kernel["k_blur_h_jobs_x"]["avg_launch_ms"] if has_s2 else 0.0
-    stage_ach = 2 * job_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
+    ms_e = per_kernel["k_blur_edge_fused"]["avg_launch_ms"] if fused_edge else 0.0
+    # the blur + reduce stage = the two passes (+ the fused kernel): the bytes they have to move over the time they take
+    stage_bytes = 2 * job_bytes + edge_bytes
+    stage_ach = stage_bytes * B / ((ms_v + ms_h + ms_e) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
     res = {
         "value": pairs / elapsed,
         "unit": "frame-pairs/s",
@@ -311,19 +322,21 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
                                     "SURVEY 8d restricted to the planes that carry weight (job table)"},
         "kernels": per_kernel,
         "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
-                   "blur_reduce_stage_bytes_per_pair": 2 * job_bytes,
+                   "blur_reduce_stage_bytes_per_pair": stage_bytes,
+                   "blur_reduce_stage_ms": ms_v + ms_h + ms_e, "edge_jobs_fused": fused_edge,
                    "survey_8d_model_bytes_per_pair": 2 * model_bytes,
-                   "survey_8d_model_frac": 2 * model_bytes * B / ((ms_v + ms_h) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_v + ms_h > 0 else 0.0,
-                   "full_pipeline_GBs": (pairs / elapsed) * (2 * job_bytes + 24 * spx + in_bytes) / 1e9 / ctx.world}
+                   "survey_8d_model_frac": 2 * model_bytes * B / ((ms_v + ms_h + ms_e) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_v + ms_h > 0 else 0.0,
+                   "full_pipeline_GBs": (pairs / elapsed) * (stage_bytes + 24 * spx + in_bytes) / 1e9 / ctx.world}
         if has_s2 else {"full_pipeline_GBs": (pairs / elapsed) * (ingest_bytes / B) / 1e9 / ctx.world},
         "score_mean": float(np.mean(all_scores)) if all_scores is not None else None,
     }
     if other is not None:
-        mv, mh = other["stage_ms"]["blur_v"], other["stage_ms"]["blur_h"]
+        mv, mh, me = other["stage_ms"]["blur_v"], other["stage_ms"]["blur_h"], other["stage_ms"]["edge_fused"]
         modes_o = other.pop("_modes")
-        ob = sum(4 * units[int(modes_o[s, c])] * sizes[s] for s in range(6) for c in range(3))
-        other["blur_reduce_stage_bytes_per_pair"] = 2 * ob
-        other["blur_reduce_stage_frac"] = 2 * ob * B / ((mv + mh) * 1e-3) / 1e9 / HBM_PEAK_GBS if mv + mh > 0 else 0.0
+        fo = other.pop("_fused")
+        ob = sum(4 * (2 if fo and int(modes_o[s, c]) == 1 else 2 * units[int(modes_o[s, c])]) * sizes[s] for s in range(6) for c in range(3))
+        other["blur_reduce_stage_bytes_per_pair"] = ob
+        other["blur_reduce_stage_frac"] = ob * B / ((mv + mh + me) * 1e-3) / 1e9 / HBM_PEAK_GBS if mv + mh > 0 else 0.0
         res["compare"] = other
     if keep_engine:
         return res, eng, distinct

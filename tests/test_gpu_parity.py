@@ -184,6 +184,50 @@ def test_three_wave_row_pass_is_bit_identical_with_the_one_wave_row_pass(w, h, b
     eng.close()
 
 
+@pytest.mark.parametrize("w,h,batch", [(333, 203, 3), (70, 38, 2), (1, 1, 1), (31, 96, 2), (257, 131, 1), (1920, 1080, 3), (1920, 1080, 9), (3840, 2160, 2)])
+def test_fused_edge_kernel_is_bit_identical_with_the_two_passes(w, h, batch):
+    """k_blur_edge_fused (both recurrences, the edge maps and their sums of the edge-only jobs in one kernel, beside the two
+    passes on a second stream; what larger launches run by default) against the two-pass kernels: the same 108 sums, bit for
+    bit -- one wave and four waves per workgroup would be chosen by the engine, forced here on every size --, repeated
+    launches (the hand-off words of the previous launch are in place), and against the oracle on the small sizes"""
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=batch)
+    frames = [nv12_frames(w, h, n) for n in range(batch)]
+    for slot, (fr, fd) in enumerate(frames):
+        eng.set_pair(slot, fr, fd)
+    got = {}
+    for name, variant in (("two_pass", F.TM_VARIANT_TWO_PASS_EDGE), ("fused", F.TM_VARIANT_FUSED_EDGE), ("fused_again", F.TM_VARIANT_FUSED_EDGE),
+                          ("fused_split_rows", F.TM_VARIANT_FUSED_EDGE | F.TM_VARIANT_SPLIT_ROWS), ("default", F.TM_VARIANT_DEFAULT)):
+        eng.set_variant(variant)
+        assert eng.uses_fused_edge() == (name.startswith("fused") or (name == "default" and 2 * w * h * batch >= 30_000_000))
+        eng.compute_async()
+        eng.sync()
+        got[name] = [eng.raw_sums(i).copy() for i in range(batch)]
+    for i in range(batch):
+        for name in got:
+            assert np.array_equal(got[name][i], got["two_pass"][i]), (name, i)
+    if w * h <= 333 * 203:
+        eng.set_variant(F.TM_VARIANT_FUSED_EDGE)
+        eng.compute_async()
+        eng.sync()
+        for slot, (fr, fd) in enumerate(frames):
+            lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+            sums, _ = O.ssimulacra2_sums(lin[0], lin[1], want_xyb=True)
+            mask = (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
+            np.testing.assert_allclose(eng.raw_sums(slot)[mask], np.asarray(sums).reshape(6, 6, 3)[mask], rtol=1e-12, atol=1e-300)
+            assert abs(eng.scores(slot).ssimulacra2 - O.score_from_sums(sums, w, h)) <= 1e-9
+    eng.set_graph(True)  # the two-stream sequence captured into a hipGraph and replayed (the epoch of the hand-off tags lives in device memory)
+    eng.set_variant(F.TM_VARIANT_FUSED_EDGE)
+    for _ in range(3):
+        eng.compute_async()
+        eng.sync()
+        for i in range(batch):
+            assert np.array_equal(eng.raw_sums(i), got["two_pass"][i])
+    eng.set_graph(False)
+    eng.set_full_sums(True)  # no edge-only job left: nothing for the fused kernel
+    assert not eng.uses_fused_edge()
+    eng.close()
+
+
 def test_every_input_kind_matches_oracle():
     w, h = 94, 58
     rng = np.random.default_rng(5)

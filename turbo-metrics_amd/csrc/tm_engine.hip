@@ -101,7 +101,10 @@ struct tm_engine {
     unsigned *d_epoch = nullptr;      // ... launch epoch of the hand-off tags (advanced by k_finish_edge)
     int *d_status = nullptr, *h_status = nullptr; // ... a hand-off wait that timed out
     int ef_tiles = 0, ef_bands = 0, ef_ne = 0;
-    long long fused_edge_from = 6; // slots per launch from which the EDGE jobs take the fused kernel (below, a launch is bound by the latency of one wave walking its band; TM_FUSED_EDGE_FROM overrides: tuning)
+    long long fused_edge_from = 30000000; // pixels of EDGE planes per launch (slots x jobs x w x h) from which those jobs take the fused kernel: 8 pairs of
+                                          // 1080p, 4 of 4K (below, the launch is bound by the latency of one wave walking its band; TM_FUSED_EDGE_FROM overrides: tuning)
+    int ef_beside = 1;  // the fused kernel runs on stream2 beside the two blur passes: 1 = enqueued before the column pass, 2 = after it, 0 = behind the row pass on the engine's stream (TM_EF_BESIDE: tuning)
+    int ef_waves = 4;   // waves per workgroup of the fused kernel (TM_EF_WAVES: tuning)
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
     bool use_graph = false;         // replay the per-batch launch sequence from a captured hipGraph (measured slower than direct launches: off)
@@ -112,6 +115,8 @@ struct tm_engine {
     unsigned short *SPYR = nullptr; // [slot][side][3] box-sum pyramid, scales 1..4
     double *SPART = nullptr, *SSUMS = nullptr, *h_ssums = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // the fused EDGE kernel beside the two blur passes (fork after the ingest stage, join before the finisher)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr; // LIN, XYBT: reference pipeline only (TM_VARIANT_REFERENCE)
     float *V_alloc = nullptr; // the allocation behind V (V = V_alloc + an offset inside TM_V_SLACK, see tm_engine_debug_set_v_offset)
     float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_wave -> k_ingest_upper_rd
@@ -126,7 +131,8 @@ struct tm_engine {
     std::vector<size_t> staging_size;
     size_t mem_bytes = 0;
     bool profiling = false, ev_pending = false;
-    hipEvent_t ev[TM_STAGE_COUNT + 1] = {};
+    hipEvent_t ev[7] = {}; // 0..4: start | ingest | column pass | row pass | finisher + SSIM stage, on the engine's stream; 5, 6: around the fused EDGE kernel, on the stream it runs on
+    bool edge_timed = false; // the last profiled launch ran the fused kernel (events 5, 6 were recorded)
     double stage_ms[TM_STAGE_COUNT] = {0, 0, 0, 0, 0};
     uint64_t n_prof = 0;
     uint32_t last_n = 0;
@@ -333,10 +339,10 @@ int make_job_tables(tm_engine *e)
     if (!e->d_epoch) {
         int rc;
         if ((rc = dev_alloc(e, &e->d_epoch, 1, false))) return rc;
-        if ((rc = dev_alloc(e, &e->d_status, 1, true))) return rc;
+        if ((rc = dev_alloc(e, &e->d_status, 8 + (getenv("TM_EF_DEBUG") ? 6 * 16384 : 0), true))) return rc;
         const unsigned one = 1u;
         HIPCHK(hipMemcpy(e->d_epoch, &one, sizeof one, hipMemcpyHostToDevice));
-        HIPCHK(hipHostMalloc((void **)&e->h_status, sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&e->h_status, (8 + (getenv("TM_EF_DEBUG") ? 6 * 16384 : 0)) * sizeof(int), hipHostMallocDefault));
         *e->h_status = 0;
     }
     return TM_OK;
@@ -346,7 +352,10 @@ int make_job_tables(tm_engine *e)
 bool use_fused_edge(const tm_engine *e, int n)
 {
     if ((e->variant & (TM_VARIANT_REFERENCE | TM_VARIANT_TWO_PASS_EDGE)) || e->ef_ne == 0 || e->jobs_f.n == e->jobs_f.nfull) return false;
-    return (e->variant & TM_VARIANT_FUSED_EDGE) || n >= e->fused_edge_from;
+    if (e->variant & TM_VARIANT_FUSED_EDGE) return true;
+    long long px = 0;
+    for (int k = e->jobs_f.nfull; k < e->jobs_f.n; ++k) px += (long long)e->g.s[e->jobs_f.scale[k]].w * e->g.s[e->jobs_f.scale[k]].h;
+    return px * n >= e->fused_edge_from;
 }
 
 } // namespace
@@ -506,9 +515,13 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     tm_make_geom(&e->g, (int)width, (int)height);
     if (const char *pp = getenv("TM_PYRT_PAD")) e->g.pyr_t += (unsigned long long)atoll(pp) / 64 * 64; // experiment: distance between the planes / slots of the transposed arenas (tools/stride_probe.py)
     if (const char *ff = getenv("TM_FUSED_EDGE_FROM")) e->fused_edge_from = atoll(ff);
+    if (const char *ff = getenv("TM_EF_BESIDE")) e->ef_beside = atoi(ff);
+    if (const char *ff = getenv("TM_EF_WAVES")) e->ef_waves = atoi(ff);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
+    if ((he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
+    if ((he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     const size_t B = batch_capacity;
     const TmGeom &g = e->g;
     if (metrics_mask & TM_METRIC_SSIMULACRA2) { // PSNR / SSIM / MS-SSIM alone need none of the XYB machinery
@@ -525,7 +538,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
         int nb = 0;
         hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, e->device);
         fprintf(stderr, "[tm] sharedMemPerBlock %zu maxSharedMemoryPerMultiProcessor %zu regsPerBlock %d\n", prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor, prop.regsPerBlock);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_edge_fused<0>, 64, 0); fprintf(stderr, "[tm] k_blur_edge_fused: %d blocks of 64 per CU\n", nb);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_edge_fused<1>, 64, 0); fprintf(stderr, "[tm] k_blur_edge_fused: %d blocks of 64 per CU\n", nb);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_v_jobs<32, 16, 0>, 320, 0); fprintf(stderr, "[tm] k_blur_v_jobs: %d blocks of 320 per CU\n", nb);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>, 64, 0); fprintf(stderr, "[tm] k_blur_h_jobs_x: %d blocks of 64 per CU\n", nb);
     }
@@ -556,7 +569,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     for (size_t i = 0; i < B * 2; ++i) { e->h_desc[i] = TmFrameDesc{nullptr, nullptr, nullptr, 0, 0, TM_KIND_NONE, 0, 0, 0}; }
     e->staging.assign(B * 2, nullptr);
     e->staging_size.assign(B * 2, 0);
-    for (int i = 0; i <= TM_STAGE_COUNT; ++i)
+    for (int i = 0; i < 7; ++i)
         if ((he = hipEventCreate(&e->ev[i])) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     *out = e;
     return TM_OK;
@@ -567,6 +580,7 @@ void tm_engine_destroy(tm_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     for (void *p : e->staging) if (p) (void)hipFree(p);
     (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V_alloc);
@@ -579,7 +593,10 @@ void tm_engine_destroy(tm_engine *e)
     if (e->h_desc) (void)hipHostFree(e->h_desc);
     if (e->h_sums) (void)hipHostFree(e->h_sums);
     if (e->h_sse) (void)hipHostFree(e->h_sse);
-    for (int i = 0; i <= TM_STAGE_COUNT; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < 7; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -670,6 +687,12 @@ int tm_engine_set_full_sums(tm_engine *e, int on)
     return make_job_tables(e);
 }
 
+int tm_engine_uses_fused_edge(const tm_engine *e, uint32_t n_slots)
+{
+    if (!e || n_slots == 0 || n_slots > e->cap) return TM_ERR_INVALID_ARG;
+    return use_fused_edge(e, (int)n_slots) ? 1 : 0;
+}
+
 int tm_engine_get_job_modes(const tm_engine *e, int out[18])
 {
     if (!e || !out) return TM_ERR_INVALID_ARG;
@@ -743,10 +766,34 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         const TmJobs &jobs = fused ? e->jobs_f : e->jobs;
         const long long hblocks = jobs.hstart[jobs.nfull];
         const dim3 vgrid((unsigned)n, (unsigned)jobs.vstart[jobs.nfull], 1), hgrid((unsigned)n, (unsigned)hblocks, 1);
+        // The fused kernel is bound by what the SIMDs can issue and reads 2 of the 14 units of a FULL job; the two passes are bound
+        // by HBM: it runs on a second stream beside them (fork behind the ingest stage, join in front of the finisher).  Enqueued
+        // first it takes the chip and the column pass moves into the slots its long tail leaves; small launches, where it cannot
+        // fill the chip, gain most (8 1080p pairs 0.91 -> 0.85 ms, 64: 5.5 -> 4.7).
+        auto launch_fused = [&](hipStream_t fs) -> int {
+            const int ne = jobs.n - jobs.nfull, planes = n * ne;
+            int bands = 0;
+            for (int k = jobs.nfull; k < jobs.n; ++k) bands = std::max(bands, (g.s[jobs.scale[k]].h + 31) / 32);
+            tmk::TmEdgeArgs ea;
+            tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
+            static const int dbg = getenv("TM_EF_DEBUG") ? atoi(getenv("TM_EF_DEBUG")) : 0; // experiments: 1 = do not wait for the band above, 2 = do not publish, 4 = record when every wave ran
+            if (ev) HIPCHK(hipEventRecord(ev[5], fs));
+            if (e->ef_waves == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1>), dim3((unsigned)planes, (unsigned)bands, 1), dim3(64), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->EROWS, e->d_status, dbg);
+            else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4>), dim3((unsigned)((planes + 3) / 4), (unsigned)bands, 1), dim3(256), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->EROWS, e->d_status, dbg);
+            hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);
+            if (ev) HIPCHK(hipEventRecord(ev[6], fs));
+            HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (dbg & 4 ? 8 + 6 * std::min(16384, planes * bands) : 1) * sizeof(int), hipMemcpyDeviceToHost, fs));
+            return TM_OK;
+        };
+        const bool beside = fused && e->ef_beside > 0;
+        if (ev) e->edge_timed = fused;
+        if (beside) { HIPCHK(hipEventRecord(e->ev_fork, st)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); }
+        if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
+        if (beside && e->ef_beside != 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_H: row pass + error maps + reductions
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, jobs, XYBT, V, PART);
         else if (!hgrid.y) {}
@@ -759,24 +806,14 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
         else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
-        // ---- stage EDGE: both recurrences, the edge maps and their sums of the EDGE jobs in one kernel
-        if (fused) {
-            const int ne = jobs.n - jobs.nfull;
-            int bands = 0;
-            for (int k = jobs.nfull; k < jobs.n; ++k) bands = std::max(bands, (g.s[jobs.scale[k]].h + 31) / 32);
-            tmk::TmEdgeArgs ea;
-            tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
-            static const int dbg = getenv("TM_EF_DEBUG") ? atoi(getenv("TM_EF_DEBUG")) : 0; // experiments: 1 = do not wait for the band above, 2 = do not publish
-            hipLaunchKernelGGL((tmk::k_blur_edge_fused<0>), dim3((unsigned)(n * ne), (unsigned)bands, 1), dim3(64), 0, st, ea, XYB, e->HS, e->d_epoch, e->EROWS, e->d_status, dbg);
-            hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)(n * ne)), dim3(64), 0, st, ea, e->EROWS, PART, e->d_epoch);
-            HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
-        }
-        if (ev) HIPCHK(hipEventRecord(ev[4], st));
+        // ---- stage EDGE (when not beside the passes): both recurrences, the edge maps and their sums of the EDGE jobs in one kernel
+        if (fused && !beside) { int rc = launch_fused(st); if (rc) return rc; }
+        if (beside) { HIPCHK(hipEventRecord(e->ev_join, e->stream2)); HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0)); }
         hipLaunchKernelGGL(tmk::k_finish_jobs, dim3((unsigned)n), dim3(128), 0, st, jobs, PART, SUMS);
     } else if (ev) {
+        e->edge_timed = false;
         HIPCHK(hipEventRecord(ev[2], st));
         HIPCHK(hipEventRecord(ev[3], st));
-        HIPCHK(hipEventRecord(ev[4], st));
     }
     if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
@@ -789,7 +826,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, need_l, QU8, e->SPYR, e->SPART);
         hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, nscales, e->SPART, e->SSUMS);
     }
-    if (ev) HIPCHK(hipEventRecord(ev[5], st));
+    if (ev) HIPCHK(hipEventRecord(ev[4], st));
     return TM_OK;
 }
 
@@ -864,17 +901,42 @@ int tm_engine_sync(tm_engine *e)
     TM_BIND(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->ev_pending) {
-        // events in stream order: ingest | column pass | row pass | fused EDGE kernel | finisher + SSIM stage
-        static const int first_event[TM_STAGE_COUNT] = {0, 1, 2, 4, 3}; // TM_STAGE_INGEST, BLUR_V, BLUR_H, SSIM, EDGE
+        // TM_STAGE_INGEST, BLUR_V, BLUR_H, SSIM: consecutive events on the engine's stream (SSIM: finisher + SSIM kernels, and the wait
+        // for the fused kernel if it is still running beside); TM_STAGE_EDGE: the fused kernel's own pair, on the stream it ran on
         for (int i = 0; i < TM_STAGE_COUNT; ++i) {
             float ms = 0.0f;
-            HIPCHK(hipEventElapsedTime(&ms, e->ev[first_event[i]], e->ev[first_event[i] + 1]));
+            if (i == TM_STAGE_EDGE) { if (e->edge_timed) HIPCHK(hipEventElapsedTime(&ms, e->ev[5], e->ev[6])); }
+            else HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
             e->stage_ms[i] += (double)ms;
         }
         e->n_prof += 1;
         e->ev_pending = false;
     }
     if (e->in_flight) { e->in_flight = false; e->have_results = true; }
+    if (e->h_status && getenv("TM_EF_DEBUG") && (atoi(getenv("TM_EF_DEBUG")) & 4)) { // experiment: the schedule of the last launch
+        static int printed = 0;
+        const unsigned long long *c = (const unsigned long long *)(e->h_status + 8);
+        const int ne = e->jobs_f.n - e->jobs_f.nfull, planes = (int)e->last_n * ne;
+        int bands = 0;
+        for (int k = e->jobs_f.nfull; k < e->jobs_f.n; ++k) bands = std::max(bands, (e->g.s[e->jobs_f.scale[k]].h + 31) / 32);
+        if (c[1] && planes * bands <= 16384 && ++printed == 20) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < planes * bands; ++i) { if (c[3 * i] && c[3 * i] < t0) t0 = c[3 * i]; if (c[3 * i + 1] > t1) t1 = c[3 * i + 1]; }
+            fprintf(stderr, "[tm] k_blur_edge_fused: %d planes x %d bands, first start to last end %.1f us\n", planes, bands, (t1 - t0) / 100.0);
+            for (int pl : {0, planes / 2, planes - 1})
+                for (int b = 0; b < bands; ++b) {
+                    const unsigned long long *w = c + 3 * ((size_t)b * planes + pl);
+                    fprintf(stderr, "[tm]   plane %3d band %2d: start %7.1f us, ran %6.1f us, %llu cycles\n", pl, b, (w[0] - t0) / 100.0, (w[1] - w[0]) / 100.0, w[2]);
+                }
+            // concurrency over time
+            for (int t = 0; t < 24; ++t) {
+                const unsigned long long at = t0 + (t1 - t0) * t / 24;
+                int live = 0;
+                for (int i = 0; i < planes * bands; ++i) live += c[3 * i] <= at && c[3 * i + 1] > at;
+                fprintf(stderr, "[tm]   at %6.1f us: %d waves resident\n", (at - t0) / 100.0, live);
+            }
+        }
+    }
     if (e->h_status && *e->h_status) { // k_blur_edge_fused gave up waiting for the band above: the sums of this launch are not valid
         *e->h_status = 0;
         (void)hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream);

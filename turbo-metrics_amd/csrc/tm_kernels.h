@@ -1670,10 +1670,9 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 //     same recurrence, so both phases are plain f32 code on 64 full lanes;
 //   * column phase of a tile: the 42 input rows it needs (32 + the 10 rows of history; window slot k = image row 32 band - 6 + k)
 //     were requested a whole row phase earlier (one 256-B run per row and wave); 32 steps of the recurrence whose STATE comes from
-//     the band above (below: hand-off); every step parks {V, original} of its row in the wave's LDS tile -- the original four
-//     columns to the right, so that the row phase, which emits column x - 4 at step x, finds both in one 8-byte read;
-//   * row phase: lane (row, side) walks the 32 columns of the tile; recurrence state, the last ten V and the last four originals
-//     of its row stay in registers from tile to tile; e = 1 + |orig - mu| on each side, the partner's e through one DPP move,
+//     the band above (below: hand-off); every step parks {V, original} of its row in the wave's LDS tile;
+//   * row phase: lane (row, side) walks the 32 columns of the tile, one 8-byte read per step; it emits column x - 4 at step x;
+//     recurrence state, the last ten V and the last four originals of its row stay in registers from tile to tile; e = 1 + |orig - mu| on each side, the partner's e through one DPP move,
 //     d1 = fma(e_dis, 1 / e_ref, -1) on both lanes of the pair, of which the ref lane accumulates the artifact sums and the dis
 //     lane the detail_loss sums, f64, in column order: exactly the per-row sums of k_blur_h_jobs_x.  They go to EROWS and
 //     k_finish_edge adds the rows of a 64-row block in the order of tm_wave_sum6 -> the PART entries, and everything after them,
@@ -1686,11 +1685,11 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 //     increasing order, a band only ever waits for the band above, i.e. for a workgroup with a smaller index that has been
 //     dispatched before it -- no deadlock --, and since all planes start band b before any starts b + 1 the producer is
 //     normally a whole tile row ahead.  A wait that lasts longer than ~2^22 polls sets *status (the host reports TM_ERR_HIP).
-// LDS: 32 rows x 148 floats (36 column slots x 2 sides x 2, + 4: eight rows cover the 32 banks in 8-byte reads) = 18.9 KB per
-// wave -> 8 waves per CU.  grid (slots * ne, max bands), block 64; plane = slot * ne + job.  HS[plane][2][hs_tiles][6][64],
+// LDS: 32 rows x 132 floats (32 columns x 2 sides x 2, + 4: eight rows cover the 32 banks in 8-byte reads) = 16.9 KB per
+// wave -> 9 waves per CU (2 304 on the chip: the 4 352 bands of 64 1080p pairs run in two rounds; at 8 per CU they took three).  grid (slots * ne, max bands), block 64; plane = slot * ne + job.  HS[plane][2][hs_tiles][6][64],
 // EROWS[plane][er_bands][64][2].
 // ------------------------------------------------------------------------------------------------
-#define TM_EF_S 148
+#define TM_EF_S 132
 #ifdef TM_EMULATE
 __device__ __forceinline__ void tm_ll_store(unsigned long long *p, float v, unsigned tag) { *(volatile unsigned long long *)p = ((unsigned long long)tag << 32) | __float_as_uint(v); }
 __device__ __forceinline__ unsigned long long tm_ll_load(const unsigned long long *p) { return *(const volatile unsigned long long *)p; }
@@ -1764,33 +1763,41 @@ __device__ __forceinline__ void ef_row_phase(const float *__restrict__ trow, int
                                              bool dis, unsigned sgn, double &a1, double &a4)
 {
     // trow: this lane's tile row + 2 * side; n0 = the column emitted at step 0 (32 tile - 4)
-    float v[32];
+    float v[32], o[32];
 #pragma unroll
     for (int x = 0; x < 32; ++x) {
-        const tm_g2 pr = *(const tm_g2 *)(trow + 4 * x);
-        v[x] = pr.x;
+        const tm_g2 pr = *(const tm_g2 *)(trow + 4 * x); // {V, original} of column 32 tile + x
+        v[x] = pr.x; o[x] = pr.y;
         const float mu = tmdev::iir_step(fr, (x >= 10 ? v[x >= 10 ? x - 10 : 0] : vc[x < 10 ? x : 0]) + pr.x);
-        if (!GUARD || (n0 + x >= 0 && n0 + x < w)) ef_accumulate(x >= 4 ? pr.y : oc[x & 3], mu, dis, sgn, a1, a4);
+        if (!GUARD || (n0 + x >= 0 && n0 + x < w)) ef_accumulate(x >= 4 ? o[x >= 4 ? x - 4 : 0] : oc[x & 3], mu, dis, sgn, a1, a4);
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) vc[k] = v[22 + k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) oc[k] = trow[4 * (32 + k) + 1];
+    for (int k = 0; k < 4; ++k) oc[k] = o[28 + k];
 }
 
-template <int PROBE = 0>
-__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmEdgeArgs A, const float *__restrict__ XYB, unsigned long long *__restrict__ HS,
-                                                                          const unsigned *__restrict__ epoch_p, double *__restrict__ EROWS,
-                                                                          int *__restrict__ status, int dbg = 0)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmEdgeArgs A, int planes, const float *__restrict__ XYB, unsigned long long *__restrict__ HS,
+                                                                               const unsigned *__restrict__ epoch_p, double *__restrict__ EROWS,
+                                                                               int *__restrict__ status, int dbg = 0)
 {
-    __shared__ __attribute__((aligned(16))) float tile[32 * TM_EF_S];
-    const int p = blockIdx.x, band = blockIdx.y;
+    // NW waves per workgroup, each with its own plane and tile: the hardware spreads the waves of ONE workgroup over the SIMDs of
+    // its CU, single-wave workgroups land 2 / 3 / 4 to a SIMD
+    __shared__ __attribute__((aligned(16))) float tiles[NW][32 * TM_EF_S];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *tile = tiles[wv];
+    const int p = (int)blockIdx.x * NW + wv, band = blockIdx.y;
+    if (p >= planes) return;
     const int slot = p / A.ne;
     const TmEdgeJob J = A.job[p - slot * A.ne];
     const int h = J.h, w = J.w;
     const int nbands = (h + 31) >> 5, ntiles = (w + 31) >> 5;
     if (band >= nbands) return;
     const int lane = threadIdx.x & 63, cl = lane >> 1, side = lane & 1;
+#ifndef TM_EMULATE
+    const unsigned long long dbg_t0 = (dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull, dbg_r0 = (dbg & 4) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
     const unsigned epoch = *epoch_p;
     const unsigned tag_in = (epoch << 8) | (unsigned)((band - 1) & 255), tag_out = (epoch << 8) | (unsigned)(band & 255);
     const int y0 = 32 * band - 6;                        // image row of window slot 0
@@ -1871,7 +1878,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmE
         for (int jj = 0; jj < 32; ++jj) {
             const float o = tmdev::iir_step(f, win[jj] + win[jj + 10]);
             tcol[jj * TM_EF_S] = o;
-            tcol[jj * TM_EF_S + 16 + 1] = win[jj + 6];
+            tcol[jj * TM_EF_S + 1] = win[jj + 6];
         }
         if (publish && !(dbg & 2)) {
             unsigned long long *o = hs_out + (size_t)i * 384;
@@ -1893,6 +1900,12 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmE
     }
     double *er = EROWS + (((size_t)p * A.er_bands + band) * 64 + lane) * 2;
     er[0] = valid ? a1 : 0.0; er[1] = valid ? a4 : 0.0; // rows below the image: nothing (the two-pass kernels never add them)
+#ifndef TM_EMULATE
+    if ((dbg & 4) && lane == 0) { // experiment: when each wave ran (s_memrealtime ticks at 100 MHz) and its shader cycles
+        unsigned long long *o = (unsigned long long *)(status + 8) + ((size_t)band * planes + p) * 3;
+        o[0] = dbg_r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    }
+#endif
 }
 
 // the rows of an EDGE job -> the PART entries k_blur_h_jobs_x would have written: per 64-row block, sum over rows in the order of

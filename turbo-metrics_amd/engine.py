@@ -322,6 +322,12 @@ class TurboMetrics:
         _chk(self._L.tm_engine_get_job_modes(self._h, out), "tm_engine_get_job_modes")
         return np.array(out, np.int32).reshape(6, 3)
 
+    def uses_fused_edge(self, n_slots: Optional[int] = None) -> bool:
+        """does a compute of n_slots slots (default: the batch capacity) run its edge-only jobs in the fused kernel?"""
+        r = self._L.tm_engine_uses_fused_edge(self._h, int(self.batch if n_slots is None else n_slots))
+        _chk(min(r, 0), "tm_engine_uses_fused_edge")
+        return r > 0
+
     def set_graph(self, on: bool):
         _chk(self._L.tm_engine_set_graph(self._h, int(bool(on))), "tm_engine_set_graph")
 

@@ -49,6 +49,7 @@ SYMBOLS = {
     "tm_engine_get_raw_sums": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
     "tm_engine_set_full_sums": (_i, [_vp, _i]),
     "tm_engine_get_job_modes": (_i, [_vp, C.POINTER(C.c_int)]),
+    "tm_engine_uses_fused_edge": (_i, [_vp, C.c_uint32]),
     "tm_engine_get_sse": (_i, [_vp, _u32, C.POINTER(C.c_uint64)]),
     "tm_engine_get_sse_channels": (_i, [_vp, _u32, C.POINTER(C.c_uint64)]),
     "tm_psnr_from_sse": (C.c_double, [C.c_uint64, C.c_uint64]),
