@@ -237,6 +237,18 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     # the single collective of the path: per-frame scores reduced (sum into zeros) to rank 0
     all_scores = tm.shard.reduce_scores(scores_local, ctx.rank * B, ctx.world * B, 1, ctx.dist, ctx.cdev if ctx.dist is not None else "cpu")
 
+    alone = None
+    if has_s2 and eng.uses_fused_edge(B):
+        # the fused kernel of the edge-only jobs runs BESIDE the two blur passes (second stream): the stage times above overlap.
+        # A few steps with it BEHIND the row pass instead (outside the headline timing) time every kernel alone on the chip.
+        eng.debug_set_edge_beside(0)
+        step()
+        k = max(2, min(5, steps))
+        dt_a, ms_a = timed(k)
+        eng.debug_set_edge_beside(1)
+        step()
+        alone = {"ms_per_step": dt_a / k * 1e3, "value": B * k / dt_a, "stage_ms": ms_a}
+
     other = None
     if compare and ctx.world == 1 and has_s2:
         # the same batch with the other setting of full_sums (a few steps, outside the headline timing): by default the engine
@@ -296,11 +308,18 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         per_kernel["k_ssim_stage"]["bound"] = "valu (11x11 separable window of 4 quantities: 88 fused multiply-adds per window and channel; HBM fraction is informative only)"
     for kn in per_kernel:
         per_kernel[kn]["traffic"] = traffic.get(kn)
+    if alone is not None:  # the same kernels with nothing beside them
+        ma = alone.pop("stage_ms")
+        alone["kernels"] = {"k_blur_v_jobs": roof(ma[F.TM_STAGE_BLUR_V], job_bytes * B), "k_blur_h_jobs_x": roof(ma[F.TM_STAGE_BLUR_H], job_bytes * B),
+                            "k_blur_edge_fused": roof(ma[F.TM_STAGE_EDGE], edge_bytes * B)}
+        alone["note"] = "k_blur_edge_fused behind the row pass on the engine's stream (tm_engine_debug_set_edge_beside 0): every kernel alone on the chip"
     dom = max(("k_blur_v_jobs", "k_blur_h_jobs_x"), key=lambda k: per_kernel[k]["avg_launch_ms"]) if has_s2 else ingest_name
     ms_v = per_kernel["k_blur_v_jobs"]["avg_launch_ms"] if has_s2 else 0.0
     ms_h = per_kernel["k_blur_h_jobs_x"]["avg_launch_ms"] if has_s2 else 0.0
-    ms_e = per_kernel["k_blur_edge_fused"]["avg_launch_ms"] if fused_edge else 0.0
-    # the blur + reduce stage = the two passes (+ the fused kernel): the bytes they have to move over the time they take
+    # the blur + reduce stage = the two passes and the fused kernel BESIDE them: the bytes they have to move over the span from the
+    # end of the ingest stage to the end of the row pass (+ what the finisher then still waits for the fused kernel: that wait is
+    # in the SSIM stage's events; without SSIM metrics that stage is the wait and a 10-us finisher)
+    ms_e = (stage_ms[F.TM_STAGE_SSIM] if not has_ssim else 0.0) if fused_edge else 0.0
     stage_bytes = 2 * job_bytes + edge_bytes
     stage_ach = stage_bytes * B / ((ms_v + ms_h + ms_e) * 1e-3) / 1e9 if ms_v + ms_h > 0 else 0.0
     res = {
@@ -319,8 +338,11 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
                      "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
                      "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
                      "bytes_model": "SURVEY 8d (84 B/px/pass)" if args.full_sums else
-                                    "SURVEY 8d restricted to the planes that carry weight (job table)"},
+                                    "SURVEY 8d restricted to the planes that carry weight (job table)" + ("; the edge-only jobs run in k_blur_edge_fused" if fused_edge else ""),
+                     **({"shares_the_chip": "k_blur_edge_fused runs beside this kernel on a second stream for most of its duration (kernels.k_blur_edge_fused); alone on the chip: kernels_alone",
+                         "frac_alone": alone["kernels"][dom]["frac"], "avg_launch_ms_alone": alone["kernels"][dom]["avg_launch_ms"]} if alone is not None else {})},
         "kernels": per_kernel,
+        **({"kernels_alone": alone} if alone is not None else {}),
         "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
                    "blur_reduce_stage_bytes_per_pair": stage_bytes,
                    "blur_reduce_stage_ms": ms_v + ms_h + ms_e, "edge_jobs_fused": fused_edge,
@@ -604,7 +626,7 @@ def run_rank(args):
             "dtype": "f32",
             "data": "synthetic",
         }
-        for k in ("config", "roofline", "kernels", "stages", "score_mean", "compare"):
+        for k in ("config", "roofline", "kernels", "kernels_alone", "stages", "score_mean", "compare"):
             if k in res:
                 out[k] = res[k]
         if workloads:

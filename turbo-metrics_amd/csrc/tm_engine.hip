@@ -1135,6 +1135,15 @@ int tm_engine_debug_set_v_offset(tm_engine *e, size_t bytes)
     return TM_OK;
 }
 
+int tm_engine_debug_set_edge_beside(tm_engine *e, int mode)
+{
+    if (!e || mode < 0 || mode > 2) return TM_ERR_INVALID_ARG;
+    if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+    e->ef_beside = mode;
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; }
+    return TM_OK;
+}
+
 int tm_engine_debug_set_ingest_rows(tm_engine *e, int rows)
 {
     if (!e || rows < 0 || rows > 128 || (rows & 1)) return TM_ERR_INVALID_ARG;

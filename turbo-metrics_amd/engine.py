@@ -328,6 +328,10 @@ class TurboMetrics:
         _chk(min(r, 0), "tm_engine_uses_fused_edge")
         return r > 0
 
+    def debug_set_edge_beside(self, mode: int):
+        """measurement hook: 1 = the fused kernel of the edge-only jobs beside the two blur passes (default), 0 = behind them"""
+        _chk(self._L.tm_engine_debug_set_edge_beside(self._h, int(mode)), "tm_engine_debug_set_edge_beside")
+
     def set_graph(self, on: bool):
         _chk(self._L.tm_engine_set_graph(self._h, int(bool(on))), "tm_engine_set_graph")
 
