@@ -44,6 +44,7 @@ static inline long long __double_as_longlong(double d) { long long v; memcpy(&v,
 using std::min;
 using std::max;
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // lanes of one wave run back to back (x fastest), so a running total per wave is enough
 bool tm_wave_sum6(double (&a)[6]);

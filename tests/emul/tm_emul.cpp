@@ -324,14 +324,14 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             for (int k = jobs.nfull; k < jobs.n; ++k) { tiles = std::max(tiles, (g.s[jobs.scale[k]].w + 31) / 32); bands = std::max(bands, (g.s[jobs.scale[k]].h + 31) / 32); }
             std::vector<unsigned long long> hs((size_t)n * ne * 2 * tiles * 384, 0ull);
             std::vector<double> erows((size_t)n * ne * bands * 128, 0.0);
-            unsigned epoch = 1; int status = 0;
+            unsigned epoch[2] = {1u, 0u}; int status = 0; // launch epoch, ticket counter
             for (int rep = 0; rep < 2; ++rep) { // twice: the second launch finds the first one's words (tags of another epoch) in HS
                 tmk::TmEdgeArgs ea;
                 tmk::tm_make_edge_args(&ea, &g, &jobs, tiles, bands);
-                launch_wave_lockstep(dim3(n * ne, bands, 1), [&] { tmk::k_blur_edge_fused<1>(ea, n * ne, XYB, hs.data(), &epoch, erows.data(), &status); });
-                launch(dim3(n * ne), dim3(64), [&] { tmk::k_finish_edge(ea, erows.data(), PART, &epoch); });
+                launch_wave_lockstep(dim3(n * ne, bands, 1), [&] { tmk::k_blur_edge_fused<1>(ea, n * ne, XYB, hs.data(), epoch, epoch + 1, erows.data(), &status); });
+                launch(dim3(n * ne), dim3(64), [&] { tmk::k_finish_edge(ea, erows.data(), PART, epoch); });
             }
-            if (status != 0 || epoch != 3) { fprintf(stderr, "tm_emul: k_blur_edge_fused status %d epoch %u\n", status, epoch); abort(); }
+            if (status != 0 || epoch[0] != 3 || epoch[1] != 0) { fprintf(stderr, "tm_emul: k_blur_edge_fused status %d epoch %u\n", status, epoch[0]); abort(); }
         }
     }
     launch(dim3(n), dim3(128), [&] { tmk::k_finish_jobs(jobs, PART, SUMS); });

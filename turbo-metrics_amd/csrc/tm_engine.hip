@@ -338,7 +338,7 @@ int make_job_tables(tm_engine *e)
     }
     if (!e->d_epoch) {
         int rc;
-        if ((rc = dev_alloc(e, &e->d_epoch, 1, false))) return rc;
+        if ((rc = dev_alloc(e, &e->d_epoch, 2, true))) return rc; // [0] launch epoch of the hand-off tags, [1] ticket counter of the launch (k_finish_edge: epoch + 1, tickets from 0)
         if ((rc = dev_alloc(e, &e->d_status, 8 + (getenv("TM_EF_DEBUG") ? 6 * 16384 : 0), true))) return rc;
         const unsigned one = 1u;
         HIPCHK(hipMemcpy(e->d_epoch, &one, sizeof one, hipMemcpyHostToDevice));
@@ -778,8 +778,8 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
             static const int dbg = getenv("TM_EF_DEBUG") ? atoi(getenv("TM_EF_DEBUG")) : 0; // experiments: 1 = do not wait for the band above, 2 = do not publish, 4 = record when every wave ran
             if (ev) HIPCHK(hipEventRecord(ev[5], fs));
-            if (e->ef_waves == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1>), dim3((unsigned)planes, (unsigned)bands, 1), dim3(64), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->EROWS, e->d_status, dbg);
-            else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4>), dim3((unsigned)((planes + 3) / 4), (unsigned)bands, 1), dim3(256), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->EROWS, e->d_status, dbg);
+            if (e->ef_waves == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1>), dim3((unsigned)planes, (unsigned)bands, 1), dim3(64), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
+            else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4>), dim3((unsigned)((planes + 3) / 4), (unsigned)bands, 1), dim3(256), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);
             if (ev) HIPCHK(hipEventRecord(ev[6], fs));
             HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (dbg & 4 ? 8 + 6 * std::min(16384, planes * bands) : 1) * sizeof(int), hipMemcpyDeviceToHost, fs));

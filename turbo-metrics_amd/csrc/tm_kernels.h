@@ -3,7 +3,8 @@
 // Two pipelines live here:
 //   default    k_ingest_rows<KIND> (4:2:0 kinds; k_ingest_wave<KIND> for the RGB kinds and mixed launches) + k_ingest_upper_rd
 //              -> k_blur_v_jobs<32, 16> -> k_blur_h_jobs_x (k_blur_h_jobs_split<3 | 5> for small launches) -> k_finish_jobs
-//              over the ref/dis-interleaved XYB pyramid, job-table driven, slot-major grids (x = slot)
+//              over the ref/dis-interleaved XYB pyramid, job-table driven, slot-major grids (x = slot); larger launches send the
+//              edge-only jobs through k_blur_edge_fused + k_finish_edge (one kernel, no pass-1 planes) beside the two passes
 //   reference  k_ingest + k_downscale + k_xyb -> k_blur_v -> k_blur_h_jobs -> k_finish_jobs: straight-line, LDS-free kernels
 //              whose only job is to be obviously correct (engine variant TM_VARIANT_REFERENCE); the GPU tier checks that the
 //              two pipelines produce identical bits on the device, and both against the CPU oracle.
@@ -16,6 +17,8 @@
 //   k_blur_h_jobs_x   grid (slots, jobs.hstart[n])                   block 64    row pass + error maps + sums, lane = image row
 //   k_blur_h_jobs_split<NW>  grid (slots, jobs.hstart[n])            block 64 NW the same row pass over NW = 3 or 5 waves per row block (small launches)
 //   k_finish_jobs     grid (slots)                                   block 128
+//   k_blur_edge_fused<NW>  grid (ceil(slots * edge jobs / NW), bands of 32 rows)  block 64 NW   NW waves, each one band of one (slot, job)
+//   k_finish_edge     grid (slots * edge jobs)                       block 64
 //   k_ingest          grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/4), slots)   block (64,4)
 //   k_downscale       grid (ceil(dw/64), dh, slots*2*3)              block 64
 //   k_xyb             grid (ceil(w/64), h, slots*2)                  block 64
@@ -1672,22 +1675,28 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 //     were requested a whole row phase earlier (one 256-B run per row and wave); 32 steps of the recurrence whose STATE comes from
 //     the band above (below: hand-off); every step parks {V, original} of its row in the wave's LDS tile;
 //   * row phase: lane (row, side) walks the 32 columns of the tile, one 8-byte read per step; it emits column x - 4 at step x;
-//     recurrence state, the last ten V and the last four originals of its row stay in registers from tile to tile; e = 1 + |orig - mu| on each side, the partner's e through one DPP move,
-//     d1 = fma(e_dis, 1 / e_ref, -1) on both lanes of the pair, of which the ref lane accumulates the artifact sums and the dis
-//     lane the detail_loss sums, f64, in column order: exactly the per-row sums of k_blur_h_jobs_x.  They go to EROWS and
+//     recurrence state, the last ten V and the last four originals of its row stay in registers from tile to tile;
+//     e = 1 + |orig - mu| on each side, both e of the pixel through two DPP broadcasts, d1 = fma(e_dis, 1 / e_ref, -1) on both
+//     lanes of the pair, of which the ref lane accumulates the artifact sums and the dis lane the detail_loss sums, f64, in
+//     column order: exactly the per-row sums of k_blur_h_jobs_x.  They go to EROWS and
 //     k_finish_edge adds the rows of a 64-row block in the order of tm_wave_sum6 -> the PART entries, and everything after them,
 //     are bit-identical with the two-pass kernels (the GPU tier checks that);
 //   * hand-off: the six state values of a (column, side) after the last step of band b are what band b + 1 starts from.  They
 //     travel through HS as 8-byte {value, tag} words written and read with device-scope atomic accesses (tag = launch epoch and
 //     band: a reader spins until all six words carry the tag it expects; no fence, no flag: the word is its own flag), two
 //     buffers per plane alternate by band parity (band b + 2 cannot overwrite what band b + 1 still has to read: it needs band
-//     b + 1's state of that tile first).  The grid is plane-major (x = (slot, job), y = band): workgroups are dispatched in
-//     increasing order, a band only ever waits for the band above, i.e. for a workgroup with a smaller index that has been
-//     dispatched before it -- no deadlock --, and since all planes start band b before any starts b + 1 the producer is
-//     normally a whole tile row ahead.  A wait that lasts longer than ~2^22 polls sets *status (the host reports TM_ERR_HIP).
+//     b + 1's state of that tile first).  Work is handed out plane-major by TICKET (an atomic counter drawn at workgroup
+//     start; ticket = band * workgroups per band + planes): a band only ever waits for the band above, whose ticket is
+//     smaller and therefore held by a workgroup that has started -- no deadlock whatever the dispatch order --, and since
+//     all planes start band b before any starts b + 1 the producer is normally tiles ahead (the wait costs 3 % of the kernel).  A wait that lasts longer than ~2^22 polls sets *status (the host reports TM_ERR_HIP).
 // LDS: 32 rows x 132 floats (32 columns x 2 sides x 2, + 4: eight rows cover the 32 banks in 8-byte reads) = 16.9 KB per
-// wave -> 9 waves per CU (2 304 on the chip: the 4 352 bands of 64 1080p pairs run in two rounds; at 8 per CU they took three).  grid (slots * ne, max bands), block 64; plane = slot * ne + job.  HS[plane][2][hs_tiles][6][64],
-// EROWS[plane][er_bands][64][2].
+// wave.  NW = 4 waves form a workgroup, each with its own plane and tile: the hardware spreads the waves of one workgroup over
+// the four SIMDs of its CU (two such workgroups per CU = two waves per SIMD), while single-wave workgroups land 2 / 3 / 4 to a
+// SIMD and the waves of the crowded SIMDs take 1.4-1.9 x as long (measured: 0.98 vs 1.09 ms per 64 1080p pairs).  What bounds
+// the kernel is what a SIMD can issue: ~1 550 instructions per tile (row phase 970: 12 for the recurrence, 8 for the division,
+// 4 binary64 ones for the two sums, per step), ~3 300 VALU-pipe cycles; one wave alone on a SIMD walks its band of a 1080p plane
+// in 0.28 ms, two share the SIMD at 0.31 / 0.45 ms (the older wave wins the arbitration).
+// grid (ceil(planes / NW), max bands), block 64 NW; plane = slot * ne + job.  HS[plane][2][hs_tiles][6][64], EROWS[plane][er_bands][64][2].
 // ------------------------------------------------------------------------------------------------
 #define TM_EF_S 132
 #ifdef TM_EMULATE
@@ -1779,15 +1788,22 @@ __device__ __forceinline__ void ef_row_phase(const float *__restrict__ trow, int
 
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmEdgeArgs A, int planes, const float *__restrict__ XYB, unsigned long long *__restrict__ HS,
-                                                                               const unsigned *__restrict__ epoch_p, double *__restrict__ EROWS,
-                                                                               int *__restrict__ status, int dbg = 0)
+                                                                               const unsigned *__restrict__ epoch_p, unsigned *__restrict__ ticket,
+                                                                               double *__restrict__ EROWS, int *__restrict__ status, int dbg = 0)
 {
     // NW waves per workgroup, each with its own plane and tile: the hardware spreads the waves of ONE workgroup over the SIMDs of
     // its CU, single-wave workgroups land 2 / 3 / 4 to a SIMD
     __shared__ __attribute__((aligned(16))) float tiles[NW][32 * TM_EF_S];
+    __shared__ unsigned s_ticket;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *tile = tiles[wv];
-    const int p = (int)blockIdx.x * NW + wv, band = blockIdx.y;
+    // which (planes, band) this workgroup runs is decided by a TICKET drawn when it starts, not by its block index: whoever
+    // holds ticket t knows that every smaller ticket is held by a workgroup that is already running (or done), whatever order
+    // the hardware dispatches the grid in -- the bands above, which this one waits for, have smaller tickets
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const unsigned tk = s_ticket;
+    const int p = (int)(tk % gridDim.x) * NW + wv, band = (int)(tk / gridDim.x);
     if (p >= planes) return;
     const int slot = p / A.ne;
     const TmEdgeJob J = A.job[p - slot * A.ne];
@@ -1934,7 +1950,7 @@ __global__ void __launch_bounds__(64) k_finish_edge(TmEdgeArgs A, const double *
 #endif
         PART[((size_t)slot * A.part_stride + J.part0 + blk) * 6 + 1 + side + 3 * pw] = tot;
     }
-    if (p == 0 && threadIdx.x == 0) *epoch_p = *epoch_p + 1u;
+    if (p == 0 && threadIdx.x == 0) { *epoch_p = *epoch_p + 1u; epoch_p[1] = 0u; } // next launch: new tags, tickets from 0
 }
 
 // fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no
