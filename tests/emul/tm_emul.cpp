@@ -328,7 +328,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             for (int rep = 0; rep < 2; ++rep) { // twice: the second launch finds the first one's words (tags of another epoch) in HS
                 tmk::TmEdgeArgs ea;
                 tmk::tm_make_edge_args(&ea, &g, &jobs, tiles, bands);
-                launch_wave_lockstep(dim3(n * ne, bands, 1), [&] { tmk::k_blur_edge_fused<1>(ea, n * ne, XYB, hs.data(), epoch, epoch + 1, erows.data(), &status); });
+                launch_wave_lockstep(dim3(rep == 0 ? n * ne * bands : std::max(1, n * ne * bands / 3), 1, 1), [&] { tmk::k_blur_edge_fused<1>(ea, n * ne, n * ne, (unsigned)(n * ne * bands), XYB, hs.data(), epoch, epoch + 1, erows.data(), &status); }); // second launch: a third of the workgroups share the tickets
                 launch(dim3(n * ne), dim3(64), [&] { tmk::k_finish_edge(ea, erows.data(), PART, epoch); });
             }
             if (status != 0 || epoch[0] != 3 || epoch[1] != 0) { fprintf(stderr, "tm_emul: k_blur_edge_fused status %d epoch %u\n", status, epoch[0]); abort(); }

@@ -21,21 +21,27 @@ def row(label, x, bold=True, r01=None):
     val = f"**{fmt(x['value'])}**" if bold else fmt(x["value"])
     if r01: val += f" (r01: {r01})"
     st = x["stages"]
-    return (f"| {label} | {val} | {x['ms_per_step']:.2f} | {k['k_ingest_rows']['avg_launch_ms']:.2f} | {k['k_blur_v_jobs']['avg_launch_ms']:.2f} | "
-            f"{k['k_blur_h_jobs_x']['avg_launch_ms']:.2f} | {ss} | {'**' if bold and not r01 else ''}{x['roofline']['frac']:.3f}{'**' if bold and not r01 else ''} | "
+    al = x.get("kernels_alone", {}).get("kernels")
+    ef = f'{k["k_blur_edge_fused"]["avg_launch_ms"]:.2f}' if "k_blur_edge_fused" in k else "—"
+    def pair(name):  # beside the fused kernel (as the step runs) / alone on the chip
+        return f'{k[name]["avg_launch_ms"]:.2f}' + (f' ({al[name]["avg_launch_ms"]:.2f})' if al else "")
+    frac = f"{x['roofline']['frac']:.3f}" + (f" ({x['roofline']['frac_alone']:.3f})" if "frac_alone" in x["roofline"] else "")
+    if al: ef += f' ({al["k_blur_edge_fused"]["avg_launch_ms"]:.2f})'
+    return (f"| {label} | {val} | {x['ms_per_step']:.2f} | {k['k_ingest_rows']['avg_launch_ms']:.2f} | {pair('k_blur_v_jobs')} | "
+            f"{pair('k_blur_h_jobs_x')} | {ef} | {ss} | {'**' if bold and not r01 else ''}{frac}{'**' if bold and not r01 else ''} | "
             f"{st['blur_reduce_stage_frac']:.3f} ({st['survey_8d_model_frac']:.3f} on the §8d model) |")
 c = d["compare"]
 w = d["workloads"]
 rows = [
-    f"| workload (1 GPU, inputs resident in HBM), `{T}_bench.json` | pairs/s | ms/step | ingest | column pass | row pass | SSIM stage | column-pass frac of 8 TB/s | blur+reduce stage frac |",
-    "|---|---|---|---|---|---|---|---|---|",
-    row("1080p NV12, SSIMULACRA2, 64 pairs/step (headline; r01 driver: 11 384, r02 driver: 11 033)", d),
+    f"| workload (1 GPU, inputs resident in HBM), `{T}_bench.json`; in brackets: every kernel alone on the chip (`kernels_alone`) | pairs/s | ms/step | ingest | column pass (FULL jobs) | row pass (FULL jobs) | fused kernel of the EDGE jobs, beside the passes | SSIM stage | column-pass frac of 8 TB/s | blur+reduce stage frac |",
+    "|---|---|---|---|---|---|---|---|---|---|",
+    row("1080p NV12, SSIMULACRA2, 64 pairs/step (headline; r01 driver: 11 384, r02 driver: 11 033; this round before the fused kernel: 11 747)", d),
     row(f"— the same command under rocprofv3, `{T}_prof_bench_1080p.json`", prof),
-    f"| — with all 108 sums (`compare`) | {fmt(c['value'])} | {c['ms_per_step']:.2f} | {c['stage_ms']['ingest']:.2f} | {c['stage_ms']['blur_v']:.2f} | {c['stage_ms']['blur_h']:.2f} | — | "
+    f"| — with all 108 sums (`compare`: every job FULL, no fused kernel) | {fmt(c['value'])} | {c['ms_per_step']:.2f} | {c['stage_ms']['ingest']:.2f} | {c['stage_ms']['blur_v']:.2f} | {c['stage_ms']['blur_h']:.2f} | — | — | "
     f"{14858e6 * 64 / 64 / c['stage_ms']['blur_v'] / 8e9 * 1e3 / 1e3:.2f} | {c['blur_reduce_stage_frac']:.3f} |",
-    row("4K P016, SSIMULACRA2, 24 pairs/step (r02 driver: 2 822)", w["4k_p016"]),
-    row("1080p fused PSNR + MS-SSIM + SSIMULACRA2", w["1080p_nv12_fused"], r01="6 545, r02: 8 292"),
-    row("4K fused PSNR + MS-SSIM + SSIMULACRA2", w["4k_p016_fused"], r01="1 633, r02: 2 059"),
+    row("4K P016, SSIMULACRA2, 24 pairs/step (r02 driver: 2 822; before the fused kernel: 3 010)", w["4k_p016"]),
+    row("1080p PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["1080p_nv12_fused"], r01="6 545, r02: 8 292, before the fused kernel: 8 725"),
+    row("4K PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["4k_p016_fused"], r01="1 633, r02: 2 059, before the fused kernel: 2 188"),
 ]
 s1, sf, s4f = stats(f"{T}_kernel_stats_1080p_b64.csv"), stats(f"{T}_kernel_stats_1080p_b64_fused.csv"), stats(f"{T}_kernel_stats_4k_b24_fused.csv")
 pk = prof["kernels"]
@@ -53,7 +59,8 @@ text = "\n".join(rows) + f"""
 4K 10-bit {fmt(cli['4k_yuv420p10']['default']['pairs_per_s'])} / {fmt(cli['4k_yuv420p10']['batch16']['pairs_per_s'])}.
 rocprofv3 of the same command (`profiles/{T}_kernel_stats_1080p_b64.csv`): `k_blur_v_jobs<32,16,0>` {s1['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms average over {s1['tmk::k_blur_v_jobs<32, 16, 0>'][0]}
 launches vs {pk['k_blur_v_jobs']['avg_launch_ms']:.3f} ms from the HIP events of the timed steps of that run; row pass {s1['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} vs {pk['k_blur_h_jobs_x']['avg_launch_ms']:.3f}; `k_ingest_rows` {s1[ing][1]:.3f} +
-`k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_rows']['avg_launch_ms']:.3f} for the stage; the launches of the placement search are listed apart as `…, 1>`. Fused
+`k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_rows']['avg_launch_ms']:.3f} for the stage; `k_blur_edge_fused<4>` {s1['tmk::k_blur_edge_fused<4>'][1]:.3f} vs {pk['k_blur_edge_fused']['avg_launch_ms']:.3f} (+ `k_finish_edge`
+{s1['tmk::k_finish_edge'][1]:.3f}); the launches of the placement search are listed apart as `…, 1>`. With the SSIM stage
 (`{T}_kernel_stats_1080p_b64_fused.csv`): `k_ssim_stream` {sf['tmk::k_ssim_stream'][1]:.3f}, `k_ssim_pyramid` {sf['tmk::k_ssim_pyramid'][1]:.3f} (4K, `{T}_kernel_stats_4k_b24_fused.csv`:
 {s4f['tmk::k_ssim_stream'][1]:.3f} and {s4f['tmk::k_ssim_pyramid'][1]:.3f})."""
 p = os.path.join(ROOT, "DESIGN.md")

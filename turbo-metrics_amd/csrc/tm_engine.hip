@@ -778,8 +778,13 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
             static const int dbg = getenv("TM_EF_DEBUG") ? atoi(getenv("TM_EF_DEBUG")) : 0; // experiments: 1 = do not wait for the band above, 2 = do not publish, 4 = record when every wave ran
             if (ev) HIPCHK(hipEventRecord(ev[5], fs));
-            if (e->ef_waves == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1>), dim3((unsigned)planes, (unsigned)bands, 1), dim3(64), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
-            else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4>), dim3((unsigned)((planes + 3) / 4), (unsigned)bands, 1), dim3(256), 0, fs, ea, planes, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
+            const int nw = e->ef_waves == 1 ? 1 : 4, groups = (planes + nw - 1) / nw;
+            const unsigned total = (unsigned)groups * (unsigned)bands;
+            // TM_EF_PERSIST = k: k workgroups per CU share the tickets (experiment); default: one workgroup per ticket
+            static const int persist = getenv("TM_EF_PERSIST") ? atoi(getenv("TM_EF_PERSIST")) : 0;
+            const unsigned wgs = persist > 0 ? std::min(total, (unsigned)persist * 256u) : total;
+            if (nw == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1>), dim3(wgs), dim3(64), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
+            else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);
             if (ev) HIPCHK(hipEventRecord(ev[6], fs));
             HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (dbg & 4 ? 8 + 6 * std::min(16384, planes * bands) : 1) * sizeof(int), hipMemcpyDeviceToHost, fs));

@@ -1786,25 +1786,10 @@ __device__ __forceinline__ void ef_row_phase(const float *__restrict__ trow, int
     for (int k = 0; k < 4; ++k) oc[k] = o[28 + k];
 }
 
-template <int NW>
-__global__ void __launch_bounds__(64 * NW) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmEdgeArgs A, int planes, const float *__restrict__ XYB, unsigned long long *__restrict__ HS,
-                                                                               const unsigned *__restrict__ epoch_p, unsigned *__restrict__ ticket,
-                                                                               double *__restrict__ EROWS, int *__restrict__ status, int dbg = 0)
+// one band of one plane (see above); tile: this wave's LDS tile
+__device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeArgs &A, int p, int band, int planes, const float *__restrict__ XYB,
+                                        unsigned long long *__restrict__ HS, unsigned epoch, double *__restrict__ EROWS, int *__restrict__ status, int dbg)
 {
-    // NW waves per workgroup, each with its own plane and tile: the hardware spreads the waves of ONE workgroup over the SIMDs of
-    // its CU, single-wave workgroups land 2 / 3 / 4 to a SIMD
-    __shared__ __attribute__((aligned(16))) float tiles[NW][32 * TM_EF_S];
-    __shared__ unsigned s_ticket;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float *tile = tiles[wv];
-    // which (planes, band) this workgroup runs is decided by a TICKET drawn when it starts, not by its block index: whoever
-    // holds ticket t knows that every smaller ticket is held by a workgroup that is already running (or done), whatever order
-    // the hardware dispatches the grid in -- the bands above, which this one waits for, have smaller tickets
-    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const unsigned tk = s_ticket;
-    const int p = (int)(tk % gridDim.x) * NW + wv, band = (int)(tk / gridDim.x);
-    if (p >= planes) return;
     const int slot = p / A.ne;
     const TmEdgeJob J = A.job[p - slot * A.ne];
     const int h = J.h, w = J.w;
@@ -1814,7 +1799,6 @@ __global__ void __launch_bounds__(64 * NW) TM_WAVES_PER_SIMD(2) k_blur_edge_fuse
 #ifndef TM_EMULATE
     const unsigned long long dbg_t0 = (dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull, dbg_r0 = (dbg & 4) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
-    const unsigned epoch = *epoch_p;
     const unsigned tag_in = (epoch << 8) | (unsigned)((band - 1) & 255), tag_out = (epoch << 8) | (unsigned)(band & 255);
     const int y0 = 32 * band - 6;                        // image row of window slot 0
     const bool interior = y0 >= 0 && y0 + 41 < h;        // every window row exists
@@ -1922,6 +1906,32 @@ __global__ void __launch_bounds__(64 * NW) TM_WAVES_PER_SIMD(2) k_blur_edge_fuse
         o[0] = dbg_r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = __builtin_amdgcn_s_memtime() - dbg_t0;
     }
 #endif
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmEdgeArgs A, int planes, int groups, unsigned total, const float *__restrict__ XYB,
+                                                                               unsigned long long *__restrict__ HS, const unsigned *__restrict__ epoch_p,
+                                                                               unsigned *__restrict__ ticket, double *__restrict__ EROWS, int *__restrict__ status, int dbg = 0)
+{
+    // NW waves per workgroup, each with its own plane and tile: the hardware spreads the waves of ONE workgroup over the SIMDs of
+    // its CU, single-wave workgroups land 2 / 3 / 4 to a SIMD
+    __shared__ __attribute__((aligned(16))) float tiles[NW][32 * TM_EF_S];
+    __shared__ unsigned s_ticket;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned epoch = *epoch_p;
+    // which (planes, band) a workgroup runs is decided by a TICKET it draws, not by its block index: whoever holds ticket t knows
+    // that every smaller ticket is held by a workgroup that is already running (or done), whatever order the hardware dispatches
+    // the grid in -- the bands above, which this one waits for, have smaller tickets.  A workgroup draws tickets until none is
+    // left: `groups * bands` workgroups run one each, fewer (a persistent launch) share them.
+    for (;;) {
+        __syncthreads(); // everybody has read the previous ticket
+        if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const unsigned tk = s_ticket;
+        if (tk >= total) break;
+        const int p = (int)(tk % (unsigned)groups) * NW + wv, band = (int)(tk / (unsigned)groups);
+        if (p < planes) ef_band(tiles[wv], A, p, band, planes, XYB, HS, epoch, EROWS, status, dbg);
+    }
 }
 
 // the rows of an EDGE job -> the PART entries k_blur_h_jobs_x would have written: per 64-row block, sum over rows in the order of
