@@ -101,10 +101,13 @@ struct tm_engine {
     unsigned *d_epoch = nullptr;      // ... launch epoch of the hand-off tags (advanced by k_finish_edge)
     int *d_status = nullptr, *h_status = nullptr; // ... a hand-off wait that timed out
     int ef_tiles = 0, ef_bands = 0, ef_ne = 0;
-    long long fused_edge_from = 30000000; // pixels of EDGE planes per launch (slots x jobs x w x h) from which those jobs take the fused kernel: 8 pairs of
-                                          // 1080p, 4 of 4K (below, the launch is bound by the latency of one wave walking its band; TM_FUSED_EDGE_FROM overrides: tuning)
+    long long fused_edge_from = 512; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 8 pairs of
+                                     // 1080p, 4 of 4K (below, the launch is bound by the latency of one wave walking its band and of the chain of bands; TM_FUSED_EDGE_FROM overrides: tuning)
     int ef_beside = 1;  // the fused kernel runs on stream2 beside the two blur passes: 1 = enqueued before the column pass, 2 = after it, 0 = behind the row pass on the engine's stream (TM_EF_BESIDE: tuning)
     int ef_waves = 4;   // waves per workgroup of the fused kernel (TM_EF_WAVES: tuning)
+    int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket (TM_EF_PERSIST_WGS: tuning)
+    int ef_pass_prio = 1;   // the two passes raise their waves' issue priority while the fused kernel runs beside them (TM_PASS_PRIO: tuning)
+    int n_cus = 256;
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
     bool use_graph = false;         // replay the per-batch launch sequence from a captured hipGraph (measured slower than direct launches: off)
@@ -353,9 +356,9 @@ bool use_fused_edge(const tm_engine *e, int n)
 {
     if ((e->variant & (TM_VARIANT_REFERENCE | TM_VARIANT_TWO_PASS_EDGE)) || e->ef_ne == 0 || e->jobs_f.n == e->jobs_f.nfull) return false;
     if (e->variant & TM_VARIANT_FUSED_EDGE) return true;
-    long long px = 0;
-    for (int k = e->jobs_f.nfull; k < e->jobs_f.n; ++k) px += (long long)e->g.s[e->jobs_f.scale[k]].w * e->g.s[e->jobs_f.scale[k]].h;
-    return px * n >= e->fused_edge_from;
+    long long walks = 0;
+    for (int k = e->jobs_f.nfull; k < e->jobs_f.n; ++k) walks += (e->g.s[e->jobs_f.scale[k]].h + 31) / 32;
+    return walks * n >= e->fused_edge_from;
 }
 
 } // namespace
@@ -517,6 +520,9 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (const char *ff = getenv("TM_FUSED_EDGE_FROM")) e->fused_edge_from = atoll(ff);
     if (const char *ff = getenv("TM_EF_BESIDE")) e->ef_beside = atoi(ff);
     if (const char *ff = getenv("TM_EF_WAVES")) e->ef_waves = atoi(ff);
+    if (const char *ff = getenv("TM_EF_PERSIST_WGS")) e->ef_persist_wgs = atoi(ff);
+    if (const char *ff = getenv("TM_PASS_PRIO")) e->ef_pass_prio = atoi(ff);
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
@@ -763,7 +769,8 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         // the EDGE jobs (scale 0 of X and B with the reference's weights) go through ONE kernel without the pass-1 arena; the two
         // passes then run the FULL jobs only (the first nfull entries of the edge-last table)
         const bool fused = use_fused_edge(e, n);
-        const TmJobs &jobs = fused ? e->jobs_f : e->jobs;
+        TmJobs jobs = fused ? e->jobs_f : e->jobs;
+        jobs.prio = fused && e->ef_beside > 0 ? e->ef_pass_prio : 0;
         const long long hblocks = jobs.hstart[jobs.nfull];
         const dim3 vgrid((unsigned)n, (unsigned)jobs.vstart[jobs.nfull], 1), hgrid((unsigned)n, (unsigned)hblocks, 1);
         // The fused kernel is bound by what the SIMDs can issue and reads 2 of the 14 units of a FULL job; the two passes are bound
@@ -780,9 +787,12 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             if (ev) HIPCHK(hipEventRecord(ev[5], fs));
             const int nw = e->ef_waves == 1 ? 1 : 4, groups = (planes + nw - 1) / nw;
             const unsigned total = (unsigned)groups * (unsigned)bands;
-            // TM_EF_PERSIST = k: k workgroups per CU share the tickets (experiment); default: one workgroup per ticket
-            static const int persist = getenv("TM_EF_PERSIST") ? atoi(getenv("TM_EF_PERSIST")) : 0;
-            const unsigned wgs = persist > 0 ? std::min(total, (unsigned)persist * 256u) : total;
+            // beside the two passes the kernel is a PERSISTENT launch of 7/8 of a workgroup per CU (four waves: one per SIMD) that share
+            // the tickets: it then never holds more than a share of a CU the passes can work beside (they keep two of three column-pass
+            // workgroups / five of eight row-pass waves per CU and, with raised wave priority, the issue slots they need), runs for
+            // about as long as they do and hides behind them -- 64 1080p pairs 4.70 ms with one workgroup per ticket, 4.54 so.
+            // Alone on the chip (behind the row pass): one workgroup per ticket.
+            const unsigned wgs = fs == st || e->ef_persist_wgs < 0 ? total : std::min(total, (unsigned)(e->ef_persist_wgs > 0 ? e->ef_persist_wgs : e->n_cus * 7 / 8));
             if (nw == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1>), dim3(wgs), dim3(64), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);

@@ -76,6 +76,7 @@ struct TmJobs {
     int hstart[TM_MAX_JOBS + 1];  // prefix sums: 64-row blocks (= waves) of the row pass; also indexes PART
     int scale[TM_MAX_JOBS], chan[TM_MAX_JOBS], mode[TM_MAX_JOBS];
     int job_of[TM_SCALES * 3];    // [scale*3 + channel] -> job index, -1 for TM_MODE_NONE
+    int prio;                     // > 0: the two passes raise their waves' issue priority (they share the chip with the fused EDGE kernel)
 };
 
 static inline int tm_round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -107,7 +108,7 @@ static inline void tm_make_geom(TmGeom *g, int w, int h)
 // workgroups of jobs [0, nfull), and PART keeps one layout for k_finish_jobs)
 static inline void tm_make_jobs(TmJobs *j, const TmGeom *g, const double *weights, int full, int edge_last = 0)
 {
-    j->n = 0; j->nfull = 0;
+    j->n = 0; j->nfull = 0; j->prio = 0;
     j->vstart[0] = 0; j->hstart[0] = 0;
     for (int i = 0; i < TM_SCALES * 3; ++i) j->job_of[i] = -1;
     // longest columns/rows first (scale 0), FULL before EDGE inside a scale

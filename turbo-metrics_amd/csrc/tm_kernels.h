@@ -17,7 +17,7 @@
 //   k_blur_h_jobs_x   grid (slots, jobs.hstart[n])                   block 64    row pass + error maps + sums, lane = image row
 //   k_blur_h_jobs_split<NW>  grid (slots, jobs.hstart[n])            block 64 NW the same row pass over NW = 3 or 5 waves per row block (small launches)
 //   k_finish_jobs     grid (slots)                                   block 128
-//   k_blur_edge_fused<NW>  grid (ceil(slots * edge jobs / NW), bands of 32 rows)  block 64 NW   NW waves, each one band of one (slot, job)
+//   k_blur_edge_fused<NW>  grid (tickets = ceil(slots * edge jobs / NW) * bands of 32 rows, or fewer: persistent)  block 64 NW   NW waves, each one band of one (slot, job) per ticket
 //   k_finish_edge     grid (slots * edge jobs)                       block 64
 //   k_ingest          grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/4), slots)   block (64,4)
 //   k_downscale       grid (ceil(dw/64), dh, slots*2*3)              block 64
@@ -1166,6 +1166,11 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
 {
     using TT = BlurVTile<R>;
     __shared__ float tiles[5 * R * TT::S];
+#ifndef TM_EMULATE
+    // the fused kernel of the EDGE jobs runs beside this pass (k_blur_edge_fused, second stream): its waves are the oldest on their
+    // SIMDs and would win every issue arbitration; this pass needs few issue slots but needs them promptly to keep HBM busy
+    if (jobs.prio > 0) __builtin_amdgcn_s_setprio(2);
+#endif
     const int b = blockIdx.y, slot = blockIdx.x;
     const int j = tm_find_job(jobs.vstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
@@ -1418,6 +1423,9 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
                                                       const float *__restrict__ V, double *__restrict__ PART)
 {
     __shared__ float tile[2][2][64][17];
+#ifndef TM_EMULATE
+    if (jobs.prio > 0) __builtin_amdgcn_s_setprio(2);
+#endif
     const int b = blockIdx.y, slot = blockIdx.x;
     const int j = tm_find_job(jobs.hstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
@@ -1696,7 +1704,9 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 // the kernel is what a SIMD can issue: ~1 550 instructions per tile (row phase 970: 12 for the recurrence, 8 for the division,
 // 4 binary64 ones for the two sums, per step), ~3 300 VALU-pipe cycles; one wave alone on a SIMD walks its band of a 1080p plane
 // in 0.28 ms, two share the SIMD at 0.31 / 0.45 ms (the older wave wins the arbitration).
-// grid (ceil(planes / NW), max bands), block 64 NW; plane = slot * ne + job.  HS[plane][2][hs_tiles][6][64], EROWS[plane][er_bands][64][2].
+// grid: one workgroup per ticket (ceil(planes / NW) * bands) when the kernel has the chip to itself; beside the two blur passes a
+// persistent launch of 7/8 of a workgroup per CU that share the tickets (tm_engine.hip).  block 64 NW; plane = slot * ne + job.
+// HS[plane][2][hs_tiles][6][64], EROWS[plane][er_bands][64][2].
 // ------------------------------------------------------------------------------------------------
 #define TM_EF_S 132
 #ifdef TM_EMULATE
