@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -41,6 +42,28 @@ int hip_fail(hipError_t e, const char *what)
         hipError_t e_ = (call);                             \
         if (e_ != hipSuccess) return hip_fail(e_, #call);   \
     } while (0)
+
+// The second stream (the fused EDGE kernel beside the two blur passes) is ONE per device and process, shared by all engines:
+// the runtime maps streams onto a handful of hardware queues (4 by default), and a second stream per engine put the upload
+// stream of one engine of a ping-pong pair on the queue of the other engine's kernels -- host-fed 4K 1 080 -> 930 pairs/s.
+// Engines that compute at the same time take turns on it (each launch is ordered by its own fork / join events).
+std::mutex g_side_mutex;
+hipStream_t g_side_stream[64] = {};
+int g_side_users[64] = {};
+hipStream_t side_stream_acquire(int device)
+{
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    if (device < 0 || device >= 64) return nullptr;
+    if (!g_side_stream[device] && hipStreamCreateWithFlags(&g_side_stream[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_side_stream[device] = nullptr; return nullptr; }
+    ++g_side_users[device];
+    return g_side_stream[device];
+}
+void side_stream_release(int device)
+{
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    if (device < 0 || device >= 64 || g_side_users[device] <= 0) return;
+    if (--g_side_users[device] == 0 && g_side_stream[device]) { (void)hipStreamSynchronize(g_side_stream[device]); (void)hipStreamDestroy(g_side_stream[device]); g_side_stream[device] = nullptr; }
+}
 
 const uint32_t k_lut_bits[256] = {TM_SRGB_LUT_BITS};
 const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
@@ -526,7 +549,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
-    if ((he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
+    if (!(e->stream2 = side_stream_acquire(e->device))) return fail(hip_fail(hipErrorOutOfMemory, "hipStreamCreate (side stream)"));
     if ((he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     const size_t B = batch_capacity;
     const TmGeom &g = e->g;
@@ -602,7 +625,7 @@ void tm_engine_destroy(tm_engine *e)
     for (int i = 0; i < 7; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    if (e->stream2) side_stream_release(e->device);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -770,7 +793,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         // passes then run the FULL jobs only (the first nfull entries of the edge-last table)
         const bool fused = use_fused_edge(e, n);
         TmJobs jobs = fused ? e->jobs_f : e->jobs;
-        jobs.prio = fused && e->ef_beside > 0 ? e->ef_pass_prio : 0;
+        jobs.prio = fused && e->ef_beside > 0 && !e->use_graph ? e->ef_pass_prio : 0;
         const long long hblocks = jobs.hstart[jobs.nfull];
         const dim3 vgrid((unsigned)n, (unsigned)jobs.vstart[jobs.nfull], 1), hgrid((unsigned)n, (unsigned)hblocks, 1);
         // The fused kernel is bound by what the SIMDs can issue and reads 2 of the 14 units of a FULL job; the two passes are bound
@@ -800,7 +823,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (dbg & 4 ? 8 + 6 * std::min(16384, planes * bands) : 1) * sizeof(int), hipMemcpyDeviceToHost, fs));
             return TM_OK;
         };
-        const bool beside = fused && e->ef_beside > 0;
+        const bool beside = fused && e->ef_beside > 0 && !e->use_graph; // (a captured sequence stays on the engine's own stream: the side stream is shared between engines)
         if (ev) e->edge_timed = fused;
         if (beside) { HIPCHK(hipEventRecord(e->ev_fork, st)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); }
         if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
