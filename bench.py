@@ -302,7 +302,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         per_kernel["k_blur_h_jobs_x"] = roof(stage_ms[F.TM_STAGE_BLUR_H], job_bytes * B)
         if fused_edge:
             per_kernel["k_blur_edge_fused"] = roof(stage_ms[F.TM_STAGE_EDGE], edge_bytes * B)
-            per_kernel["k_blur_edge_fused"]["bound"] = "instruction issue (both recurrences, the edge maps and their f64 sums of an edge-only job in one kernel: ~1 500 instructions per 32 x 32 pixel pairs against 8 KB of input; the HBM fraction is informative only)"
+            per_kernel["k_blur_edge_fused"]["bound"] = "instruction issue when alone on the chip (both recurrences, the edge maps and their f64 sums of an edge-only job in one kernel: ~1 550 instructions per 32 x 32 pixel pairs against 8 KB of input); algorithmic bytes = the input read once -- its PMC traffic is twice that (10 of every 42 input rows read again by the next band, 6 B per pixel pair of state hand-off words)"
     if has_ssim:
         per_kernel["k_ssim_stage"] = roof(stage_ms[F.TM_STAGE_SSIM], ssim_bytes * B)
         per_kernel["k_ssim_stage"]["bound"] = "valu (11x11 separable window of 4 quantities: 88 fused multiply-adds per window and channel; HBM fraction is informative only)"
@@ -346,6 +346,11 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,
                    "blur_reduce_stage_bytes_per_pair": stage_bytes,
                    "blur_reduce_stage_ms": ms_v + ms_h + ms_e, "edge_jobs_fused": fused_edge,
+                   # what the stage really moves through HBM (PMC traffic of its kernels: the fused kernel re-reads 10 of every 42 input
+                   # rows and hands the column recurrence's state from band to band through memory) over the same span
+                   **({"blur_reduce_stage_traffic_bytes_per_pair": sum(traffic[k] for k in ("k_blur_v_jobs", "k_blur_h_jobs_x") + (("k_blur_edge_fused",) if fused_edge else ())) // B,
+                       "blur_reduce_stage_traffic_frac": sum(traffic[k] for k in ("k_blur_v_jobs", "k_blur_h_jobs_x") + (("k_blur_edge_fused",) if fused_edge else ())) / ((ms_v + ms_h + ms_e) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                      if all(traffic.get(k) for k in ("k_blur_v_jobs", "k_blur_h_jobs_x") + (("k_blur_edge_fused",) if fused_edge else ())) and ms_v + ms_h > 0 else {}),
                    "survey_8d_model_bytes_per_pair": 2 * model_bytes,
                    "survey_8d_model_frac": 2 * model_bytes * B / ((ms_v + ms_h + ms_e) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_v + ms_h > 0 else 0.0,
                    "full_pipeline_GBs": (pairs / elapsed) * (stage_bytes + 24 * spx + in_bytes) / 1e9 / ctx.world}
