@@ -25,6 +25,7 @@ void tm_emul_wave_barrier();
 #define __builtin_amdgcn_s_barrier() ((void)0)
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 void tm_emul_syncthreads();
+void tm_emul_yield(); // a lane polling memory that another wave of its workgroup writes: lets the other lanes run
 #define __syncthreads() tm_emul_syncthreads()
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };

@@ -55,6 +55,7 @@ void tm_emul_wave_barrier()
     else pthread_barrier_wait(&g_wave_bar);
 }
 void tm_emul_syncthreads() { if (g_lockstep) pthread_barrier_wait(&g_wave_bar); }
+void tm_emul_yield() { sched_yield(); }
 #else
 // ---- lanes as cooperative fibers on ONE host thread: a barrier is a yield to the scheduler, a context switch is six pushes.
 // (64 .. 320 host threads meeting at pthread barriers millions of times cost minutes of futex traffic per test.)
@@ -88,6 +89,14 @@ void tm_emul_wave_barrier()
     fiber_barrier(g_per_wave ? (int)(threadIdx.x >> 6) : 16);
 }
 void tm_emul_syncthreads() { if (g_lockstep) fiber_barrier(16); }
+// a lane that polls memory written by another wave of its workgroup: let the other fibers run
+void tm_emul_yield()
+{
+    if (!g_lockstep || g_cur < 0) return;
+    TmFiber &f = g_fibers[g_cur];
+    f.wait_bar = -1;
+    tm_ctx_switch(&f.sp, g_sched_sp);
+}
 static void fiber_entry()
 {
     g_fiber_body(g_fiber_arg);
@@ -328,7 +337,11 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             for (int rep = 0; rep < 2; ++rep) { // twice: the second launch finds the first one's words (tags of another epoch) in HS
                 tmk::TmEdgeArgs ea;
                 tmk::tm_make_edge_args(&ea, &g, &jobs, tiles, bands);
-                launch_wave_lockstep(dim3(rep == 0 ? n * ne * bands : std::max(1, n * ne * bands / 3), 1, 1), [&] { tmk::k_blur_edge_fused<1>(ea, n * ne, n * ne, (unsigned)(n * ne * bands), XYB, hs.data(), epoch, epoch + 1, erows.data(), &status); }); // second launch: a third of the workgroups share the tickets
+                if (variant & 0x8000) { // four adjacent bands of one plane per workgroup (what the engine launches); second launch: a third of the workgroups share the tickets
+                    const int groups = (bands + 3) / 4, total = n * ne * groups;
+                    launch_wg_lockstep(dim3(rep == 0 ? total : std::max(1, total / 3), 1, 1), 256, [&] { tmk::k_blur_edge_fused<4, true>(ea, n * ne, groups, (unsigned)total, XYB, hs.data(), epoch, epoch + 1, erows.data(), &status); });
+                } else
+                launch_wave_lockstep(dim3(rep == 0 ? n * ne * bands : std::max(1, n * ne * bands / 3), 1, 1), [&] { tmk::k_blur_edge_fused<1, false>(ea, n * ne, n * ne, (unsigned)(n * ne * bands), XYB, hs.data(), epoch, epoch + 1, erows.data(), &status); });
                 launch(dim3(n * ne), dim3(64), [&] { tmk::k_finish_edge(ea, erows.data(), PART, epoch); });
             }
             if (status != 0 || epoch[0] != 3 || epoch[1] != 0) { fprintf(stderr, "tm_emul: k_blur_edge_fused status %d epoch %u\n", status, epoch[0]); abort(); }

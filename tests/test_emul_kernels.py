@@ -275,6 +275,9 @@ def test_fused_edge_kernel_writes_the_same_sums_as_the_two_passes(w, h):
         two = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=weights, full_sums=False)
         one = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=FUSED_EDGE, weights=weights, full_sums=False)
         assert np.array_equal(one.SUMS, two.SUMS)
+        # what the engine launches: four adjacent bands of one plane per workgroup, the state through an LDS mailbox inside the group
+        grp = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=FUSED_EDGE | 0x8000, weights=weights, full_sums=False)
+        assert np.array_equal(grp.SUMS, two.SUMS)
     full = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
     mask = weight_mask()
     for slot in range(len(frames)):

@@ -567,7 +567,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
         int nb = 0;
         hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, e->device);
         fprintf(stderr, "[tm] sharedMemPerBlock %zu maxSharedMemoryPerMultiProcessor %zu regsPerBlock %d\n", prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor, prop.regsPerBlock);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_edge_fused<1>, 64, 0); fprintf(stderr, "[tm] k_blur_edge_fused: %d blocks of 64 per CU\n", nb);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_edge_fused<4, true>, 256, 0); fprintf(stderr, "[tm] k_blur_edge_fused<4, grouped>: %d blocks of 256 per CU\n", nb);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_v_jobs<32, 16, 0>, 320, 0); fprintf(stderr, "[tm] k_blur_v_jobs: %d blocks of 320 per CU\n", nb);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>, 64, 0); fprintf(stderr, "[tm] k_blur_h_jobs_x: %d blocks of 64 per CU\n", nb);
     }
@@ -808,16 +808,20 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
             static const int dbg = getenv("TM_EF_DEBUG") ? atoi(getenv("TM_EF_DEBUG")) : 0; // experiments: 1 = do not wait for the band above, 2 = do not publish, 4 = record when every wave ran
             if (ev) HIPCHK(hipEventRecord(ev[5], fs));
-            const int nw = e->ef_waves == 1 ? 1 : 4, groups = (planes + nw - 1) / nw;
-            const unsigned total = (unsigned)groups * (unsigned)bands;
+            // four waves per workgroup: four adjacent bands of one plane (ef_waves 4, default: the state crosses three of four band
+            // boundaries through LDS), or the same band of four planes (ef_waves 5: tuning), or single-wave workgroups (1: tuning)
+            const bool grouped = e->ef_waves == 4;
+            const int nw = e->ef_waves == 1 ? 1 : 4, groups = grouped ? (bands + 3) / 4 : (planes + nw - 1) / nw;
+            const unsigned total = grouped ? (unsigned)planes * (unsigned)groups : (unsigned)groups * (unsigned)bands;
             // beside the two passes the kernel is a PERSISTENT launch of 7/8 of a workgroup per CU (four waves: one per SIMD) that share
             // the tickets: it then never holds more than a share of a CU the passes can work beside (they keep two of three column-pass
             // workgroups / five of eight row-pass waves per CU and, with raised wave priority, the issue slots they need), runs for
             // about as long as they do and hides behind them -- 64 1080p pairs 4.70 ms with one workgroup per ticket, 4.54 so.
             // Alone on the chip (behind the row pass): one workgroup per ticket.
             const unsigned wgs = fs == st || e->ef_persist_wgs < 0 ? total : std::min(total, (unsigned)(e->ef_persist_wgs > 0 ? e->ef_persist_wgs : e->n_cus * 7 / 8));
-            if (nw == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1>), dim3(wgs), dim3(64), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
-            else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
+            if (nw == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1, false>), dim3(wgs), dim3(64), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
+            else if (grouped) hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, true>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
+            else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, false>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);
             if (ev) HIPCHK(hipEventRecord(ev[6], fs));
             HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (dbg & 4 ? 8 + 6 * std::min(16384, planes * bands) : 1) * sizeof(int), hipMemcpyDeviceToHost, fs));

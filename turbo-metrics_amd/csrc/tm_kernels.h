@@ -17,7 +17,7 @@
 //   k_blur_h_jobs_x   grid (slots, jobs.hstart[n])                   block 64    row pass + error maps + sums, lane = image row
 //   k_blur_h_jobs_split<NW>  grid (slots, jobs.hstart[n])            block 64 NW the same row pass over NW = 3 or 5 waves per row block (small launches)
 //   k_finish_jobs     grid (slots)                                   block 128
-//   k_blur_edge_fused<NW>  grid (tickets = ceil(slots * edge jobs / NW) * bands of 32 rows, or fewer: persistent)  block 64 NW   NW waves, each one band of one (slot, job) per ticket
+//   k_blur_edge_fused<4, grouped>  grid (tickets = slots * edge jobs * ceil(bands of 32 rows / 4), or fewer: persistent)  block 256   four waves = four adjacent bands of one (slot, job) per ticket
 //   k_finish_edge     grid (slots * edge jobs)                       block 64
 //   k_ingest          grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/4), slots)   block (64,4)
 //   k_downscale       grid (ceil(dw/64), dh, slots*2*3)              block 64
@@ -1698,9 +1698,12 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 //     smaller and therefore held by a workgroup that has started -- no deadlock whatever the dispatch order --, and since
 //     all planes start band b before any starts b + 1 the producer is normally tiles ahead (the wait costs 3 % of the kernel).  A wait that lasts longer than ~2^22 polls sets *status (the host reports TM_ERR_HIP).
 // LDS: 32 rows x 132 floats (32 columns x 2 sides x 2, + 4: eight rows cover the 32 banks in 8-byte reads) = 16.9 KB per
-// wave.  NW = 4 waves form a workgroup, each with its own plane and tile: the hardware spreads the waves of one workgroup over
+// wave.  NW = 4 waves form a workgroup, each with its own band and tile: the hardware spreads the waves of one workgroup over
 // the four SIMDs of its CU (two such workgroups per CU = two waves per SIMD), while single-wave workgroups land 2 / 3 / 4 to a
-// SIMD and the waves of the crowded SIMDs take 1.4-1.9 x as long (measured: 0.98 vs 1.09 ms per 64 1080p pairs).  What bounds
+// SIMD and the waves of the crowded SIMDs take 1.4-1.9 x as long (measured: 0.98 vs 1.09 ms per 64 1080p pairs).  GROUPED (what
+// the engine launches): the four waves are four ADJACENT bands of one plane, and the state crosses the three boundaries inside
+// the group through an LDS mailbox (TmEfMailbox) -- PMC: 4.4 GB of HBM traffic per 64 1080p pairs with every boundary through
+// memory (2.1 GB of input, 0.7 GB of it read twice -- 10 of the 42 window rows --, 0.8 GB of words written and as many read).  What bounds
 // the kernel is what a SIMD can issue: ~1 550 instructions per tile (row phase 970: 12 for the recurrence, 8 for the division,
 // 4 binary64 ones for the two sums, per step), ~3 300 VALU-pipe cycles; one wave alone on a SIMD walks its band of a 1080p plane
 // in 0.28 ms, two share the SIMD at 0.31 / 0.45 ms (the older wave wins the arbitration).
@@ -1796,9 +1799,28 @@ __device__ __forceinline__ void ef_row_phase(const float *__restrict__ trow, int
     for (int k = 0; k < 4; ++k) oc[k] = o[28 + k];
 }
 
+// GROUPED launches: the four waves of a workgroup take four vertically adjacent bands of ONE plane, and the column recurrence's
+// state crosses the three band boundaries inside the group through LDS -- a two-slot mailbox per boundary, `full` / `done`
+// counters (tile number + 1) as flow control -- instead of through memory: a quarter of the hand-off words (and their polls) reach
+// HBM, and the ten input rows two neighbouring bands share are read by two waves of one CU within microseconds of each other.
+#define TM_EF_MS 2
+struct TmEfMailbox {
+    float v[3][TM_EF_MS][6][64];
+    unsigned full[3][TM_EF_MS], done[3][TM_EF_MS];
+};
+#ifdef TM_EMULATE
+#define TM_EF_SPIN_PAUSE() ::tm_emul_yield()
+#define TM_EF_LDS_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#else
+#define TM_EF_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+#define TM_EF_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#endif
+
 // one band of one plane (see above); tile: this wave's LDS tile
-__device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeArgs &A, int p, int band, int planes, const float *__restrict__ XYB,
-                                        unsigned long long *__restrict__ HS, unsigned epoch, double *__restrict__ EROWS, int *__restrict__ status, int dbg)
+template <bool GROUPED>
+__device__ __forceinline__ void ef_band(float *__restrict__ tile, TmEfMailbox *__restrict__ mb, int wv, const TmEdgeArgs &A, int p, int band, int planes,
+                                        const float *__restrict__ XYB, unsigned long long *__restrict__ HS, unsigned epoch, double *__restrict__ EROWS,
+                                        int *__restrict__ status, int dbg)
 {
     const int slot = p / A.ne;
     const TmEdgeJob J = A.job[p - slot * A.ne];
@@ -1818,7 +1840,9 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeAr
     TM_GLOBAL_AS const char *inb = (TM_GLOBAL_AS const char *)tm_uniform_ptr(XYB + (size_t)slot * A.slot_stride + J.in_off + (interior ? (size_t)y0 * J.rowf : 0));
     const unsigned long long *hs_in = HS + ((size_t)p * 2 + ((band - 1) & 1)) * A.hs_tiles * 384 + lane;
     unsigned long long *hs_out = HS + ((size_t)p * 2 + (band & 1)) * A.hs_tiles * 384 + lane;
-    const bool publish = band + 1 < nbands;
+    // where the state comes from and goes to: memory (tagged words) across groups, the LDS mailbox inside a group
+    const bool in_mem = band > 0 && (!GROUPED || wv == 0), in_lds = GROUPED && wv > 0;
+    const bool out_mem = band + 1 < nbands && (!GROUPED || wv == 3), out_lds = GROUPED && wv < 3 && band + 1 < nbands;
     const bool valid = 32 * band + cl < h, dis = side != 0;
     const unsigned sgn = (unsigned)side << 31;
     float *tcol = tile + 4 * cl + 2 * side;                 // column phase: + row * TM_EF_S
@@ -1838,7 +1862,7 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeAr
                 win[k] = *(TM_GLOBAL_AS const float *)(inb + (xb + (unsigned)yc * rowb));
             }
         }
-        if (band > 0) {
+        if (in_mem) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) st[k] = tm_ll_load(hs_in + (size_t)i * 384 + k * 64);
         }
@@ -1854,7 +1878,7 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeAr
     for (int i = 0; i < ntiles; ++i) {
         const bool colok = 32 * i + cl < w;
         tmdev::Iir f = {0, 0, 0, 0, 0, 0};
-        if (band > 0) {
+        if (in_mem) {
             int polls = 0;
             for (;;) {
                 bool ok = true;
@@ -1870,6 +1894,20 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeAr
             }
             f.p1a = __uint_as_float((unsigned)st[0]); f.p1b = __uint_as_float((unsigned)st[1]); f.p1c = __uint_as_float((unsigned)st[2]);
             f.p2a = __uint_as_float((unsigned)st[3]); f.p2b = __uint_as_float((unsigned)st[4]); f.p2c = __uint_as_float((unsigned)st[5]);
+        }
+        if (GROUPED && in_lds) { // the band above is wave wv - 1 of this workgroup
+            const int sl = i % TM_EF_MS;
+            int polls = 0;
+            while (*(volatile unsigned *)&mb->full[wv - 1][sl] != (unsigned)i + 1u) {
+                if (++polls > (1 << 24) || *(volatile int *)status) { *(volatile int *)status = 1; break; }
+                TM_EF_SPIN_PAUSE();
+            }
+            TM_EF_LDS_FENCE();
+            const float (*src)[64] = mb->v[wv - 1][sl];
+            f.p1a = src[0][lane]; f.p1b = src[1][lane]; f.p1c = src[2][lane]; f.p2a = src[3][lane]; f.p2b = src[4][lane]; f.p2c = src[5][lane];
+            TM_EF_LDS_FENCE();
+            __builtin_amdgcn_wave_barrier(); // (the 64 lanes are one instruction stream: every lane has read before lane 0 says so)
+            if (lane == 0) *(volatile unsigned *)&mb->done[wv - 1][sl] = (unsigned)i + 1u;
         }
         if (!interior) { // rows above / below the image are zeros (blur.rs:104-110); here, not in fetch: a select behind every load would wait for it
 #pragma unroll
@@ -1890,10 +1928,24 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeAr
             tcol[jj * TM_EF_S] = o;
             tcol[jj * TM_EF_S + 1] = win[jj + 6];
         }
-        if (publish && !(dbg & 2)) {
+        if (out_mem && !(dbg & 2)) {
             unsigned long long *o = hs_out + (size_t)i * 384;
             tm_ll_store(o, f.p1a, tag_out); tm_ll_store(o + 64, f.p1b, tag_out); tm_ll_store(o + 128, f.p1c, tag_out);
             tm_ll_store(o + 192, f.p2a, tag_out); tm_ll_store(o + 256, f.p2b, tag_out); tm_ll_store(o + 320, f.p2c, tag_out);
+        }
+        if (GROUPED && out_lds) { // the band below is wave wv + 1 of this workgroup: wait until it has taken what this slot held
+            const int sl = i % TM_EF_MS;
+            int polls = 0;
+            while (i >= TM_EF_MS && *(volatile unsigned *)&mb->done[wv][sl] != (unsigned)(i - TM_EF_MS) + 1u) {
+                if (++polls > (1 << 24) || *(volatile int *)status) { *(volatile int *)status = 1; break; }
+                TM_EF_SPIN_PAUSE();
+            }
+            TM_EF_LDS_FENCE();
+            float (*dst)[64] = mb->v[wv][sl];
+            dst[0][lane] = f.p1a; dst[1][lane] = f.p1b; dst[2][lane] = f.p1c; dst[3][lane] = f.p2a; dst[4][lane] = f.p2b; dst[5][lane] = f.p2c;
+            TM_EF_LDS_FENCE();
+            __builtin_amdgcn_wave_barrier(); // (every lane has written before lane 0 says so)
+            if (lane == 0) *(volatile unsigned *)&mb->full[wv][sl] = (unsigned)i + 1u;
         }
         __builtin_amdgcn_wave_barrier();
         fetch(min(i + 1, ntiles - 1)); // requested now, lands during the row phase (past the last tile: that tile again, never used)
@@ -1918,29 +1970,35 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, const TmEdgeAr
 #endif
 }
 
-template <int NW>
+template <int NW, bool GROUPED = false>
 __global__ void __launch_bounds__(64 * NW) TM_WAVES_PER_SIMD(2) k_blur_edge_fused(TmEdgeArgs A, int planes, int groups, unsigned total, const float *__restrict__ XYB,
                                                                                unsigned long long *__restrict__ HS, const unsigned *__restrict__ epoch_p,
                                                                                unsigned *__restrict__ ticket, double *__restrict__ EROWS, int *__restrict__ status, int dbg = 0)
 {
-    // NW waves per workgroup, each with its own plane and tile: the hardware spreads the waves of ONE workgroup over the SIMDs of
-    // its CU, single-wave workgroups land 2 / 3 / 4 to a SIMD
+    // NW waves per workgroup, each with its own band and tile: the hardware spreads the waves of ONE workgroup over the SIMDs of
+    // its CU, single-wave workgroups land 2 / 3 / 4 to a SIMD.  !GROUPED: the same band of NW planes (ticket = band * groups +
+    // plane group); GROUPED (NW = 4): four adjacent bands of one plane (ticket = band group * planes + plane).
+    static_assert(!GROUPED || NW == 4, "grouped launches: four bands per workgroup");
     __shared__ __attribute__((aligned(16))) float tiles[NW][32 * TM_EF_S];
+    __shared__ typename std::conditional<GROUPED, TmEfMailbox, unsigned>::type mbox_s; // (not GROUPED: a placeholder that is never read)
+    TmEfMailbox *const mbox = (TmEfMailbox *)&mbox_s;
     __shared__ unsigned s_ticket;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned epoch = *epoch_p;
     // which (planes, band) a workgroup runs is decided by a TICKET it draws, not by its block index: whoever holds ticket t knows
     // that every smaller ticket is held by a workgroup that is already running (or done), whatever order the hardware dispatches
     // the grid in -- the bands above, which this one waits for, have smaller tickets.  A workgroup draws tickets until none is
-    // left: `groups * bands` workgroups run one each, fewer (a persistent launch) share them.
+    // left: `total` workgroups run one each, fewer (a persistent launch) share them.
     for (;;) {
-        __syncthreads(); // everybody has read the previous ticket
+        __syncthreads(); // everybody has read the previous ticket (and is done with the mailbox)
         if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+        if (GROUPED && threadIdx.x < 3 * TM_EF_MS) { (&mbox->full[0][0])[threadIdx.x] = 0u; (&mbox->done[0][0])[threadIdx.x] = 0u; }
         __syncthreads();
         const unsigned tk = s_ticket;
         if (tk >= total) break;
-        const int p = (int)(tk % (unsigned)groups) * NW + wv, band = (int)(tk / (unsigned)groups);
-        if (p < planes) ef_band(tiles[wv], A, p, band, planes, XYB, HS, epoch, EROWS, status, dbg);
+        const int p = GROUPED ? (int)(tk % (unsigned)planes) : (int)(tk % (unsigned)groups) * NW + wv;
+        const int band = GROUPED ? (int)(tk / (unsigned)planes) * 4 + wv : (int)(tk / (unsigned)groups);
+        if (p < planes) ef_band<GROUPED>(tiles[wv], mbox, wv, A, p, band, planes, XYB, HS, epoch, EROWS, status, dbg);
     }
 }
 
