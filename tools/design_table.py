@@ -50,6 +50,7 @@ bc = d["batch_curve"]["points"]
 cli = d["cli_end_to_end"]
 curve = " · ".join(f"{p_['batch']}: {fmt(p_['value'])} ({p_['ms_per_step']:.2f} ms, {p_['engine_mem_GB']} GB)" for p_ in bc)
 ing = [k for k in s1 if "k_ingest_rows" in k][0]
+efk = [k for k in s1 if "k_blur_edge_fused" in k][0]
 text = "\n".join(rows) + f"""
 
 (`python bench.py`, {wall[0].split()[1] if wall else '?'} wall; `fixed_stream` {fmt(fx['value'])} pairs/s over 2 048 pairs, {fmt(fx['long']['value'])} over 16 384; `host_fed` {fmt(hf['1080p_nv12']['value'])} pairs/s at 1080p =
@@ -59,7 +60,7 @@ text = "\n".join(rows) + f"""
 4K 10-bit {fmt(cli['4k_yuv420p10']['default']['pairs_per_s'])} / {fmt(cli['4k_yuv420p10']['batch16']['pairs_per_s'])}.
 rocprofv3 of the same command (`profiles/{T}_kernel_stats_1080p_b64.csv`): `k_blur_v_jobs<32,16,0>` {s1['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms average over {s1['tmk::k_blur_v_jobs<32, 16, 0>'][0]}
 launches vs {pk['k_blur_v_jobs']['avg_launch_ms']:.3f} ms from the HIP events of the timed steps of that run; row pass {s1['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} vs {pk['k_blur_h_jobs_x']['avg_launch_ms']:.3f}; `k_ingest_rows` {s1[ing][1]:.3f} +
-`k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_rows']['avg_launch_ms']:.3f} for the stage; `k_blur_edge_fused<4>` {s1['tmk::k_blur_edge_fused<4>'][1]:.3f} vs {pk['k_blur_edge_fused']['avg_launch_ms']:.3f} (+ `k_finish_edge`
+`k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_rows']['avg_launch_ms']:.3f} for the stage; `{efk.replace('tmk::', '')}` {s1[efk][1]:.3f} vs {pk['k_blur_edge_fused']['avg_launch_ms']:.3f} (+ `k_finish_edge`
 {s1['tmk::k_finish_edge'][1]:.3f}); the launches of the placement search are listed apart as `…, 1>`. With the SSIM stage
 (`{T}_kernel_stats_1080p_b64_fused.csv`): `k_ssim_stream` {sf['tmk::k_ssim_stream'][1]:.3f}, `k_ssim_pyramid` {sf['tmk::k_ssim_pyramid'][1]:.3f} (4K, `{T}_kernel_stats_4k_b24_fused.csv`:
 {s4f['tmk::k_ssim_stream'][1]:.3f} and {s4f['tmk::k_ssim_pyramid'][1]:.3f})."""
