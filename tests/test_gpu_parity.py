@@ -228,6 +228,41 @@ def test_fused_edge_kernel_is_bit_identical_with_the_two_passes(w, h, batch):
     eng.close()
 
 
+def test_two_engines_on_one_device_share_the_side_stream():
+    """the fused kernel of the edge-only jobs runs on ONE side stream per device, shared by the engines: two engines driven from two
+    host threads at the same time (the CLI's ping-pong pair, `--devices N` on a shared device) each get the sums they get alone"""
+    import threading
+    w, h, batch = 640, 360, 3
+    engs = [tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=batch) for _ in range(2)]
+    frames = [[nv12_frames(w, h, 10 * k + n) for n in range(batch)] for k in range(2)]
+    want = []
+    for k, eng in enumerate(engs):
+        for slot, (fr, fd) in enumerate(frames[k]):
+            eng.set_pair(slot, fr, fd)
+        eng.set_variant(F.TM_VARIANT_TWO_PASS_EDGE)
+        eng.compute_async(); eng.sync()
+        want.append([eng.raw_sums(i).copy() for i in range(batch)])
+        eng.set_variant(F.TM_VARIANT_FUSED_EDGE)
+    errors = []
+
+    def worker(k):
+        try:
+            for _ in range(40):
+                engs[k].compute_async(); engs[k].sync()
+                for i in range(batch):
+                    if not np.array_equal(engs[k].raw_sums(i), want[k][i]):
+                        raise AssertionError(f"engine {k} slot {i}")
+        except Exception as exc:  # noqa: BLE001 -- reported below, in the main thread
+            errors.append(exc)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for eng in engs:
+        eng.close()
+    assert not errors, errors
+
+
 def test_every_input_kind_matches_oracle():
     w, h = 94, 58
     rng = np.random.default_rng(5)

@@ -786,6 +786,21 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
+    // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
+    bool ssim_done = false;
+    auto launch_ssim = [&](hipStream_t ss) {
+        const TmSsimGeom &sg = e->sg;
+        const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
+        if (nscales > 1)
+            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 127) / 128), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(64), 0, ss, sg, QU8, e->SPYR);
+        // the sum of l * cs is needed on scale 0 for SSIM and on the last scale for MS-SSIM (the others use cs alone)
+        const unsigned need_l = e->full_sums ? 31u : ((e->mask & TM_METRIC_SSIM) ? 1u : 0u) | ((e->mask & TM_METRIC_MSSSIM) ? 1u << (TM_SSIM_SCALES - 1) : 0u);
+        hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, ss, sg, nscales, need_l, QU8, e->SPYR, e->SPART);
+        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, ss, sg, nscales, e->SPART, e->SSUMS);
+        ssim_done = true;
+    };
+    const bool has_ssim_stage = (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) != 0;
+    static const int ssim_beside = getenv("TM_SSIM_BESIDE") ? atoi(getenv("TM_SSIM_BESIDE")) : 0; // experiment: the SSIM stage on the side stream behind the fused EDGE kernel
     // (the SSIM stage only needs the u8 planes of the ingest kernel and is bound by arithmetic while the blur passes are bound by
     // HBM -- but running it on a second stream beside them was measured: 7.63 k vs 7.77 k pairs/s)
     if (ssimu2) {
@@ -830,7 +845,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         const bool beside = fused && e->ef_beside > 0 && !e->use_graph; // (a captured sequence stays on the engine's own stream: the side stream is shared between engines)
         if (ev) e->edge_timed = fused;
         if (beside) { HIPCHK(hipEventRecord(e->ev_fork, st)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); }
-        if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
+        if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; if (has_ssim_stage && ssim_beside && !ev) launch_ssim(e->stream2); }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
@@ -857,17 +872,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         HIPCHK(hipEventRecord(ev[2], st));
         HIPCHK(hipEventRecord(ev[3], st));
     }
-    if (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
-        // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
-        const TmSsimGeom &sg = e->sg;
-        const int nscales = (e->mask & TM_METRIC_MSSSIM) ? TM_SSIM_SCALES : 1;
-        if (nscales > 1)
-            hipLaunchKernelGGL(tmk::k_ssim_pyramid, dim3((unsigned)((sg.w[0] + 127) / 128), (unsigned)((sg.h[0] + 31) / 32), (unsigned)(n * 6)), dim3(64), 0, st, sg, QU8, e->SPYR);
-        // the sum of l * cs is needed on scale 0 for SSIM and on the last scale for MS-SSIM (the others use cs alone)
-        const unsigned need_l = e->full_sums ? 31u : ((e->mask & TM_METRIC_SSIM) ? 1u : 0u) | ((e->mask & TM_METRIC_MSSSIM) ? 1u << (TM_SSIM_SCALES - 1) : 0u);
-        hipLaunchKernelGGL(tmk::k_ssim_stream, dim3((unsigned)(n * 3), (unsigned)sg.item_off[nscales], 1), dim3(64), 0, st, sg, nscales, need_l, QU8, e->SPYR, e->SPART);
-        hipLaunchKernelGGL(tmk::k_ssim_finish, dim3((unsigned)n, 30, 1), dim3(64), 0, st, sg, nscales, e->SPART, e->SSUMS);
-    }
+    if (has_ssim_stage && !ssim_done) launch_ssim(st);
     if (ev) HIPCHK(hipEventRecord(ev[4], st));
     return TM_OK;
 }

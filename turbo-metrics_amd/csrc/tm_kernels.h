@@ -1963,7 +1963,7 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, TmEfMailbox *_
     double *er = EROWS + (((size_t)p * A.er_bands + band) * 64 + lane) * 2;
     er[0] = valid ? a1 : 0.0; er[1] = valid ? a4 : 0.0; // rows below the image: nothing (the two-pass kernels never add them)
 #ifndef TM_EMULATE
-    if ((dbg & 4) && lane == 0) { // experiment: when each wave ran (s_memrealtime ticks at 100 MHz) and its shader cycles
+    if ((dbg & 4) && lane == 0 && (size_t)band * planes + p < 16384) { // experiment (TM_EF_DEBUG=4; the engine sizes the buffer): when each wave ran (s_memrealtime ticks at 100 MHz) and its shader cycles
         unsigned long long *o = (unsigned long long *)(status + 8) + ((size_t)band * planes + p) * 3;
         o[0] = dbg_r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = __builtin_amdgcn_s_memtime() - dbg_t0;
     }
