@@ -165,6 +165,7 @@ struct tm_engine {
     bool in_flight = false, have_results = false;
     int variant = TM_VARIANT_DEFAULT;
     long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms; TM_SPLIT_ROWS_BELOW overrides: tuning)
+    bool split_rows_env = false;      // TM_SPLIT_ROWS_BELOW was given: used as it is
     long long split5_rows_below = 256; // ... and up to which that pass runs with five instead of three waves per row block (TM_SPLIT5_ROWS_BELOW)
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (TM_INGEST_ROWS overrides: tuning)
 };
@@ -535,7 +536,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     auto fail = [&](int code) { tm_engine_destroy(e); return code; };
     if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
-    if (const char *sr = getenv("TM_SPLIT_ROWS_BELOW")) e->split_rows_below = atoll(sr);
+    if (const char *sr = getenv("TM_SPLIT_ROWS_BELOW")) { e->split_rows_below = atoll(sr); e->split_rows_env = true; }
     if (const char *sr = getenv("TM_SPLIT5_ROWS_BELOW")) e->split5_rows_below = atoll(sr);
     if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
@@ -855,7 +856,9 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, jobs, XYBT, V, PART);
         else if (!hgrid.y) {}
         // few row blocks (small batches): three waves per block -- a wave's own issue rate, not the chip, bounds this pass then
-        else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * hblocks <= e->split_rows_below)) {
+        // (with the fused kernel beside it the three-wave pass pays up to twice as many row blocks: 16 1080p pairs = 1 216 blocks of FULL
+        // jobs 1.48 -> 1.36 ms, 20 pairs 1.74 -> 1.63, 32 pairs = 2 432 blocks the same either way)
+        else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * hblocks <= (beside && !e->split_rows_env ? 2 * e->split_rows_below : e->split_rows_below))) {
             // five waves per row block up to a quarter of a row block per SIMD (1-2 pairs of 1080p: 0.26 vs 0.35 ms), three above (8 pairs: 0.43 vs 0.58)
             if ((long long)n * hblocks <= e->split5_rows_below) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
             else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
