@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""GPU box: the fused kernel of the EDGE jobs under repetition -- thousands of launches at several batch sizes (every launch: new
+hand-off tags, tickets from zero, the side stream forked and joined), alternating with two-pass launches and with engines created
+and destroyed in between; every launch must return the sums of the first one, bit for bit, and no hand-off wait may time out."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from tm_pkg import tm
+tm.init_hip(0)
+free0 = torch.cuda.mem_get_info()[0]
+t_start = time.time()
+for rnd, (w, h, B, steps) in enumerate([(1920, 1080, 64, 1500), (1920, 1080, 8, 4000), (3840, 2160, 6, 600), (640, 360, 64, 3000), (1920, 1080, 9, 2000)]):
+    p016 = w > 3000
+    pairs = []
+    for n in range(min(B, 4)):
+        (rs, rp, rch), (ds, dp, dch) = (tm.synth.p016_pair if p016 else tm.synth.nv12_pair)(w, h, n)
+        pairs.append(((torch.from_numpy(rs).cuda(), rp, rch), (torch.from_numpy(ds).cuda(), dp, dch)))
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=(rnd % 2 == 1)), batch=B)
+    mk = tm.HwFrame.p016 if p016 else tm.HwFrame.nv12
+    for slot in range(B):
+        (rt, rp, rch), (dt, dp, dch) = pairs[slot % len(pairs)]
+        eng.set_pair(slot, mk(rt, rp, rch), mk(dt, dp, dch))
+    eng.set_variant(tm.ffi.TM_VARIANT_TWO_PASS_EDGE)
+    eng.compute_async(); eng.sync()
+    want = np.stack([eng.raw_sums(i) for i in range(B)])
+    eng.set_variant(tm.ffi.TM_VARIANT_FUSED_EDGE)
+    t0 = time.time()
+    bad = 0
+    for k in range(steps):
+        if k % 500 == 499:  # now and then the other path in between
+            eng.set_variant(tm.ffi.TM_VARIANT_TWO_PASS_EDGE); eng.compute_async(); eng.sync(); eng.set_variant(tm.ffi.TM_VARIANT_FUSED_EDGE)
+        eng.compute_async(); eng.sync()
+        if k % 50 == 0 or k == steps - 1:
+            got = np.stack([eng.raw_sums(i) for i in range(B)])
+            bad += int(not np.array_equal(got.view(np.uint64), want.view(np.uint64)))
+    dt = time.time() - t0
+    eng.close()
+    print(f"{w}x{h} x{B}: {steps} launches in {dt:.1f} s ({steps * B / dt:.0f} pairs/s incl. the checks), mismatching checks: {bad}", flush=True)
+    assert bad == 0
+free1 = torch.cuda.mem_get_info()[0]
+print("leak MiB", round((free0 - free1) / 2**20, 1), "total s", round(time.time() - t_start, 1))
