@@ -215,6 +215,12 @@ def test_fused_edge_kernel_is_bit_identical_with_the_two_passes(w, h, batch):
             mask = (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
             np.testing.assert_allclose(eng.raw_sums(slot)[mask], np.asarray(sums).reshape(6, 6, 3)[mask], rtol=1e-12, atol=1e-300)
             assert abs(eng.scores(slot).ssimulacra2 - O.score_from_sums(sums, w, h)) <= 1e-9
+    eng.debug_set_edge_epoch(0xFFFFFE)  # the tags hold 24 bits of the launch epoch: across the wrap (..FE, ..FF, 1, 2) nothing changes
+    for _ in range(4):
+        eng.compute_async()
+        eng.sync()
+        for i in range(batch):
+            assert np.array_equal(eng.raw_sums(i), got["two_pass"][i])
     eng.set_graph(True)  # the two-stream sequence captured into a hipGraph and replayed (the epoch of the hand-off tags lives in device memory)
     eng.set_variant(F.TM_VARIANT_FUSED_EDGE)
     for _ in range(3):

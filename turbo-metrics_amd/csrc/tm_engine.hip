@@ -1194,6 +1194,16 @@ int tm_engine_debug_set_edge_beside(tm_engine *e, int mode)
     return TM_OK;
 }
 
+int tm_engine_debug_set_edge_epoch(tm_engine *e, uint32_t epoch)
+{
+    if (!e || !e->d_epoch || epoch == 0 || epoch > 0xFFFFFFu) return TM_ERR_INVALID_ARG;
+    TM_BIND(e);
+    if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->d_epoch, &epoch, sizeof epoch, hipMemcpyHostToDevice));
+    return TM_OK;
+}
+
 int tm_engine_debug_set_ingest_rows(tm_engine *e, int rows)
 {
     if (!e || rows < 0 || rows > 128 || (rows & 1)) return TM_ERR_INVALID_ARG;

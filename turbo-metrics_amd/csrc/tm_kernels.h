@@ -2028,7 +2028,11 @@ __global__ void __launch_bounds__(64) k_finish_edge(TmEdgeArgs A, const double *
 #endif
         PART[((size_t)slot * A.part_stride + J.part0 + blk) * 6 + 1 + side + 3 * pw] = tot;
     }
-    if (p == 0 && threadIdx.x == 0) { *epoch_p = *epoch_p + 1u; epoch_p[1] = 0u; } // next launch: new tags, tickets from 0
+    if (p == 0 && threadIdx.x == 0) { // next launch: new tags (the tag holds 24 bits of the epoch; 0 is never used: memory starts out as zeros), tickets from 0
+        const unsigned next = (*epoch_p + 1u) & 0xFFFFFFu;
+        *epoch_p = next ? next : 1u;
+        epoch_p[1] = 0u;
+    }
 }
 
 // fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no

@@ -332,6 +332,9 @@ class TurboMetrics:
         """measurement hook: 1 = the fused kernel of the edge-only jobs beside the two blur passes (default), 0 = behind them"""
         _chk(self._L.tm_engine_debug_set_edge_beside(self._h, int(mode)), "tm_engine_debug_set_edge_beside")
 
+    def debug_set_edge_epoch(self, epoch: int):
+        _chk(self._L.tm_engine_debug_set_edge_epoch(self._h, int(epoch)), "tm_engine_debug_set_edge_epoch")
+
     def set_graph(self, on: bool):
         _chk(self._L.tm_engine_set_graph(self._h, int(bool(on))), "tm_engine_set_graph")
 
