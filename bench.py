@@ -340,7 +340,10 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
                      "bytes_model": "SURVEY 8d (84 B/px/pass)" if args.full_sums else
                                     "SURVEY 8d restricted to the planes that carry weight (job table)" + ("; the edge-only jobs run in k_blur_edge_fused" if fused_edge else ""),
                      **({"shares_the_chip": "k_blur_edge_fused runs beside this kernel on a second stream for most of its duration (kernels.k_blur_edge_fused); alone on the chip: kernels_alone",
-                         "frac_alone": alone["kernels"][dom]["frac"], "avg_launch_ms_alone": alone["kernels"][dom]["avg_launch_ms"]} if alone is not None else {})},
+                         "frac_alone": alone["kernels"][dom]["frac"], "avg_launch_ms_alone": alone["kernels"][dom]["avg_launch_ms"],
+                         # the three kernels of the blur region as the one concurrent group they run as: their algorithmic bytes over the
+                         # span from the end of the ingest stage to the end of the row pass (stages.blur_reduce_stage_*)
+                         "region_frac": stage_ach / HBM_PEAK_GBS, "region_ms": ms_v + ms_h + ms_e} if alone is not None else {})},
         "kernels": per_kernel,
         **({"kernels_alone": alone} if alone is not None else {}),
         "stages": {"blur_reduce_stage_GBs": stage_ach, "blur_reduce_stage_frac": stage_ach / HBM_PEAK_GBS,

@@ -8,6 +8,7 @@ cp gpurun_out/${T}_pmc_traffic_1080p_nv12_full.json profiles/pmc_traffic_1080p_n
 cp gpurun_out/${T}_pmc_traffic_4k_p016.json profiles/pmc_traffic_4k_p016_b24.json
 cp "$(latest gpurun_out/${T}_prof)" profiles/${T}_kernel_stats_1080p_b64.csv
 cp "$(latest gpurun_out/${T}_fused_prof)" profiles/${T}_kernel_stats_1080p_b64_fused.csv
+if [ -d gpurun_out/${T}_alone_prof ]; then cp "$(latest gpurun_out/${T}_alone_prof)" profiles/${T}_kernel_stats_1080p_b64_alone.csv; fi
 cp "$(latest gpurun_out/${T}_4k_prof)" profiles/${T}_kernel_stats_4k_b24.csv
 cp "$(latest gpurun_out/${T}_fused4k_prof)" profiles/${T}_kernel_stats_4k_b24_fused.csv
 grep -h '^{"metric"' gpurun_out/${T}_prof_bench.log | tail -1 > profiles/${T}_prof_bench_1080p.json
