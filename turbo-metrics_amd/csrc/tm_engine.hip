@@ -835,6 +835,11 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             // about as long as they do and hides behind them -- 64 1080p pairs 4.70 ms with one workgroup per ticket, 4.54 so.
             // Alone on the chip (behind the row pass): one workgroup per ticket.
             const unsigned wgs = fs == st || e->ef_persist_wgs < 0 ? total : std::min(total, (unsigned)(e->ef_persist_wgs > 0 ? e->ef_persist_wgs : e->n_cus * 7 / 8));
+            static const int ef_repeat = getenv("TM_EF_REPEAT") ? atoi(getenv("TM_EF_REPEAT")) : 1; // experiment: the background work more than once (how much issue-bound work hides beside the passes?)
+            for (int rep = 1; rep < ef_repeat; ++rep) {
+                hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, true>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
+                hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);
+            }
             if (nw == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1, false>), dim3(wgs), dim3(64), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             else if (grouped) hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, true>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, false>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
