@@ -234,6 +234,23 @@ def test_fused_edge_kernel_is_bit_identical_with_the_two_passes(w, h, batch):
     eng.close()
 
 
+@pytest.mark.parametrize("w,h", [(4100, 37), (37, 2100), (7680, 4320)])
+def test_fused_edge_kernel_on_extreme_shapes(w, h):
+    """wide and short (129 tiles, two bands), narrow and tall (two tiles, 66 bands = 17 groups chained through memory), 8K
+    (240 tiles x 135 bands): the fused kernel's sums against the two-pass kernels', bit for bit"""
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)
+    fr, fd = nv12_frames(w, h, 5)
+    eng.set_pair(0, fr, fd)
+    got = {}
+    for name, variant in (("two_pass", F.TM_VARIANT_TWO_PASS_EDGE), ("fused", F.TM_VARIANT_FUSED_EDGE), ("fused_again", F.TM_VARIANT_FUSED_EDGE)):
+        eng.set_variant(variant)
+        eng.compute_async()
+        eng.sync()
+        got[name] = eng.raw_sums(0).copy()
+    assert np.array_equal(got["fused"], got["two_pass"]) and np.array_equal(got["fused_again"], got["two_pass"])
+    eng.close()
+
+
 def test_two_engines_on_one_device_share_the_side_stream():
     """the fused kernel of the edge-only jobs runs on ONE side stream per device, shared by the engines: two engines driven from two
     host threads at the same time (the CLI's ping-pong pair, `--devices N` on a shared device) each get the sums they get alone"""
