@@ -1899,7 +1899,7 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, TmEfMailbox *_
             const int sl = i % TM_EF_MS;
             int polls = 0;
             while (*(volatile unsigned *)&mb->full[wv - 1][sl] != (unsigned)i + 1u) {
-                if (++polls > (1 << 24) || *(volatile int *)status) { *(volatile int *)status = 1; break; }
+                if (++polls > (1 << 24) || ((polls & 1023) == 0 && *(volatile int *)status)) { *(volatile int *)status = 1; break; } // (the status word lives in memory: looked at now and then)
                 TM_EF_SPIN_PAUSE();
             }
             TM_EF_LDS_FENCE();
@@ -1937,7 +1937,7 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, TmEfMailbox *_
             const int sl = i % TM_EF_MS;
             int polls = 0;
             while (i >= TM_EF_MS && *(volatile unsigned *)&mb->done[wv][sl] != (unsigned)(i - TM_EF_MS) + 1u) {
-                if (++polls > (1 << 24) || *(volatile int *)status) { *(volatile int *)status = 1; break; }
+                if (++polls > (1 << 24) || ((polls & 1023) == 0 && *(volatile int *)status)) { *(volatile int *)status = 1; break; } // (the status word lives in memory: looked at now and then)
                 TM_EF_SPIN_PAUSE();
             }
             TM_EF_LDS_FENCE();
