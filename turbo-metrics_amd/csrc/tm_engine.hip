@@ -131,6 +131,7 @@ struct tm_engine {
     int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket (TM_EF_PERSIST_WGS: tuning)
     int ef_pass_prio = 1;   // the two passes raise their waves' issue priority while the fused kernel runs beside them (TM_PASS_PRIO: tuning)
     int n_cus = 256;
+    int ef_dbg = 0;     // TM_EF_DEBUG at creation (experiments: 1 = do not wait for the band above, 2 = do not publish, 4 = record when every wave ran; sizes the status buffer)
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
     bool use_graph = false;         // replay the per-batch launch sequence from a captured hipGraph (measured slower than direct launches: off)
@@ -366,10 +367,10 @@ int make_job_tables(tm_engine *e)
     if (!e->d_epoch) {
         int rc;
         if ((rc = dev_alloc(e, &e->d_epoch, 2, true))) return rc; // [0] launch epoch of the hand-off tags, [1] ticket counter of the launch (k_finish_edge: epoch + 1, tickets from 0)
-        if ((rc = dev_alloc(e, &e->d_status, 8 + (getenv("TM_EF_DEBUG") ? 6 * 16384 : 0), true))) return rc;
+        if ((rc = dev_alloc(e, &e->d_status, 8 + ((e->ef_dbg & 4) ? 6 * 16384 : 0), true))) return rc;
         const unsigned one = 1u;
         HIPCHK(hipMemcpy(e->d_epoch, &one, sizeof one, hipMemcpyHostToDevice));
-        HIPCHK(hipHostMalloc((void **)&e->h_status, (8 + (getenv("TM_EF_DEBUG") ? 6 * 16384 : 0)) * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&e->h_status, (8 + ((e->ef_dbg & 4) ? 6 * 16384 : 0)) * sizeof(int), hipHostMallocDefault));
         *e->h_status = 0;
     }
     return TM_OK;
@@ -544,6 +545,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (const char *ff = getenv("TM_FUSED_EDGE_FROM")) e->fused_edge_from = atoll(ff);
     if (const char *ff = getenv("TM_EF_BESIDE")) e->ef_beside = atoi(ff);
     if (const char *ff = getenv("TM_EF_WAVES")) e->ef_waves = atoi(ff);
+    if (const char *ff = getenv("TM_EF_DEBUG")) e->ef_dbg = atoi(ff);
     if (const char *ff = getenv("TM_EF_PERSIST_WGS")) e->ef_persist_wgs = atoi(ff);
     if (const char *ff = getenv("TM_PASS_PRIO")) e->ef_pass_prio = atoi(ff);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
@@ -822,7 +824,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             for (int k = jobs.nfull; k < jobs.n; ++k) bands = std::max(bands, (g.s[jobs.scale[k]].h + 31) / 32);
             tmk::TmEdgeArgs ea;
             tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
-            static const int dbg = getenv("TM_EF_DEBUG") ? atoi(getenv("TM_EF_DEBUG")) : 0; // experiments: 1 = do not wait for the band above, 2 = do not publish, 4 = record when every wave ran
+            const int dbg = e->ef_dbg;
             if (ev) HIPCHK(hipEventRecord(ev[5], fs));
             // four waves per workgroup: four adjacent bands of one plane (ef_waves 4, default: the state crosses three of four band
             // boundaries through LDS), or the same band of four planes (ef_waves 5: tuning), or single-wave workgroups (1: tuning)
@@ -968,7 +970,7 @@ int tm_engine_sync(tm_engine *e)
         e->ev_pending = false;
     }
     if (e->in_flight) { e->in_flight = false; e->have_results = true; }
-    if (e->h_status && getenv("TM_EF_DEBUG") && (atoi(getenv("TM_EF_DEBUG")) & 4)) { // experiment: the schedule of the last launch
+    if (e->h_status && (e->ef_dbg & 4)) { // experiment: the schedule of the last launch
         static int printed = 0;
         const unsigned long long *c = (const unsigned long long *)(e->h_status + 8);
         const int ne = e->jobs_f.n - e->jobs_f.nfull, planes = (int)e->last_n * ne;
