@@ -124,8 +124,8 @@ struct tm_engine {
     unsigned *d_epoch = nullptr;      // ... launch epoch of the hand-off tags (advanced by k_finish_edge)
     int *d_status = nullptr, *h_status = nullptr; // ... a hand-off wait that timed out
     int ef_tiles = 0, ef_bands = 0, ef_ne = 0;
-    long long fused_edge_from = 512; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 8 pairs of
-                                     // 1080p, 4 of 4K (below, the launch is bound by the latency of one wave walking its band and of the chain of bands; TM_FUSED_EDGE_FROM overrides: tuning)
+    long long fused_edge_from = 400; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 6 pairs of
+                                     // 1080p, 3 of 4K (below, the launch is bound by the latency of one wave walking its band and of the chain of bands; TM_FUSED_EDGE_FROM overrides: tuning)
     int ef_beside = 1;  // the fused kernel runs on stream2 beside the two blur passes: 1 = enqueued before the column pass, 2 = after it, 0 = behind the row pass on the engine's stream (TM_EF_BESIDE: tuning)
     int ef_waves = 4;   // waves per workgroup of the fused kernel (TM_EF_WAVES: tuning)
     int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket (TM_EF_PERSIST_WGS: tuning)
@@ -166,8 +166,8 @@ struct tm_engine {
     bool in_flight = false, have_results = false;
     int variant = TM_VARIANT_DEFAULT;
     long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms; TM_SPLIT_ROWS_BELOW overrides: tuning)
-    bool split_rows_env = false;      // TM_SPLIT_ROWS_BELOW was given: used as it is
-    long long split5_rows_below = 256; // ... and up to which that pass runs with five instead of three waves per row block (TM_SPLIT5_ROWS_BELOW)
+    bool split_rows_env = false, split5_rows_env = false; // TM_SPLIT_ROWS_BELOW / TM_SPLIT5_ROWS_BELOW were given: used as they are
+    long long split5_rows_below = 400; // ... and up to which that pass runs with five instead of three waves per row block (TM_SPLIT5_ROWS_BELOW)
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (TM_INGEST_ROWS overrides: tuning)
 };
 
@@ -538,7 +538,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
     if (const char *sr = getenv("TM_SPLIT_ROWS_BELOW")) { e->split_rows_below = atoll(sr); e->split_rows_env = true; }
-    if (const char *sr = getenv("TM_SPLIT5_ROWS_BELOW")) e->split5_rows_below = atoll(sr);
+    if (const char *sr = getenv("TM_SPLIT5_ROWS_BELOW")) { e->split5_rows_below = atoll(sr); e->split5_rows_env = true; }
     if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
     if (const char *pp = getenv("TM_PYRT_PAD")) e->g.pyr_t += (unsigned long long)atoll(pp) / 64 * 64; // experiment: distance between the planes / slots of the transposed arenas (tools/stride_probe.py)
@@ -867,7 +867,9 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         // jobs 1.48 -> 1.36 ms, 20 pairs 1.74 -> 1.63, 32 pairs = 2 432 blocks the same either way)
         else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * hblocks <= (beside && !e->split_rows_env ? 2 * e->split_rows_below : e->split_rows_below))) {
             // five waves per row block up to a quarter of a row block per SIMD (1-2 pairs of 1080p: 0.26 vs 0.35 ms), three above (8 pairs: 0.43 vs 0.58)
-            if ((long long)n * hblocks <= e->split5_rows_below) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
+            // (five waves: 3 1080p pairs = 324 blocks 0.35 -> 0.26 ms, 6 pairs = 648 blocks 0.36 -> 0.45; with the fused kernel beside, FULL jobs only: 6 pairs = 456 blocks
+            // 0.45 -> 0.35, 8 pairs = 608 blocks 0.44 -> 0.40, 10 pairs = 760 blocks 0.44 -> 0.47)
+            if ((long long)n * hblocks <= (beside && !e->split5_rows_env ? 700 : e->split5_rows_below)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
             else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
         }
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
