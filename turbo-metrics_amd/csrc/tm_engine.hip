@@ -124,8 +124,8 @@ struct tm_engine {
     unsigned *d_epoch = nullptr;      // ... launch epoch of the hand-off tags (advanced by k_finish_edge)
     int *d_status = nullptr, *h_status = nullptr; // ... a hand-off wait that timed out
     int ef_tiles = 0, ef_bands = 0, ef_ne = 0;
-    long long fused_edge_from = 400; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 6 pairs of
-                                     // 1080p, 3 of 4K (below, the launch is bound by the latency of one wave walking its band and of the chain of bands; TM_FUSED_EDGE_FROM overrides: tuning)
+    long long fused_edge_from = 340; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 5 pairs of
+                                     // 1080p, 3 of 4K, 4 of 1440p, 8 of 720p (below, the launch is bound by the latency of one wave walking its band and of the chain of bands; TM_FUSED_EDGE_FROM overrides: tuning)
     int ef_beside = 1;  // the fused kernel runs on stream2 beside the two blur passes: 1 = enqueued before the column pass, 2 = after it, 0 = behind the row pass on the engine's stream (TM_EF_BESIDE: tuning)
     int ef_waves = 4;   // waves per workgroup of the fused kernel (TM_EF_WAVES: tuning)
     int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket (TM_EF_PERSIST_WGS: tuning)
