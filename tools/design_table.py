@@ -25,7 +25,7 @@ def row(label, x, bold=True, r01=None):
     ef = f'{k["k_blur_edge_fused"]["avg_launch_ms"]:.2f}' if "k_blur_edge_fused" in k else "—"
     def pair(name):  # beside the fused kernel (as the step runs) / alone on the chip
         return f'{k[name]["avg_launch_ms"]:.2f}' + (f' ({al[name]["avg_launch_ms"]:.2f})' if al else "")
-    frac = f"{x['roofline']['frac']:.3f}" + (f" ({x['roofline']['frac_alone']:.3f})" if "frac_alone" in x["roofline"] else "")
+    frac = f"{k['k_blur_v_jobs']['frac']:.3f}" + (f" ({al['k_blur_v_jobs']['frac']:.3f})" if al else "")
     if al: ef += f' ({al["k_blur_edge_fused"]["avg_launch_ms"]:.2f})'
     return (f"| {label} | {val} | {x['ms_per_step']:.2f} | {k['k_ingest_rows']['avg_launch_ms']:.2f} | {pair('k_blur_v_jobs')} | "
             f"{pair('k_blur_h_jobs_x')} | {ef} | {ss} | {'**' if bold and not r01 else ''}{frac}{'**' if bold and not r01 else ''} | "
@@ -33,7 +33,7 @@ def row(label, x, bold=True, r01=None):
 c = d["compare"]
 w = d["workloads"]
 rows = [
-    f"| workload (1 GPU, inputs resident in HBM), `{T}_bench.json`; in brackets: every kernel alone on the chip (`kernels_alone`) | pairs/s | ms/step | ingest | column pass (FULL jobs) | row pass (FULL jobs) | fused kernel of the EDGE jobs, beside the passes | SSIM stage | column-pass frac of 8 TB/s | blur+reduce stage frac |",
+    f"| workload (1 GPU, inputs resident in HBM), `{T}_bench.json`; in brackets: every kernel alone on the chip (`kernels_alone`) | pairs/s | ms/step | ingest | column pass (FULL jobs) | row pass (FULL jobs) | fused kernel of the EDGE jobs, beside the passes | SSIM stage | column-pass frac of 8 TB/s | blur+reduce stage frac (= `roofline.frac`: the three kernels as one concurrent group) |",
     "|---|---|---|---|---|---|---|---|---|---|",
     row("1080p NV12, SSIMULACRA2, 64 pairs/step (headline; r01 driver: 11 384, r02 driver: 11 033; this round before the fused kernel: 11 747)", d),
     row(f"— the same command under rocprofv3, `{T}_prof_bench_1080p.json`", prof),
