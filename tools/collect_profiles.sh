@@ -16,4 +16,5 @@ grep -h '^{"metric"' gpurun_out/${T}_bench_2ranks_gloo.json | tail -1 > profiles
 cp gpurun_out/${T}_bench.json gpurun_out/${T}_pytest_gpu.log gpurun_out/${T}_smoke.log gpurun_out/${T}_env.log profiles/
 cp gpurun_out/${T}_sq_summary.txt profiles/${T}_sq_counters_1080p_b64.txt
 cp gpurun_out/${T}_fused_sq_summary.txt profiles/${T}_sq_counters_1080p_b64_fused.txt
+python3 tools/trace_timeline.py "$(ls -t gpurun_out/${T}_prof/runc/*_kernel_trace.csv | head -1)" 2 > profiles/${T}_timeline_1080p_b64.txt
 ls profiles | grep ${T}
