@@ -72,6 +72,8 @@ def parse_args():
                     f"plus a second leg of {STREAM_PAIRS_LONG}); given explicitly the leg also runs under --no-extras")
     ap.add_argument("--no-cli", action="store_true", help="skip the cli_end_to_end leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail-file", default=None, help="where the full record goes (default: bench_detail.json beside bench.py, and a copy "
+                    "under gpurun_out/ when that directory exists); the stdout line is the compact one (<= 4 KB)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs timed for cpu_baseline (0 = auto, ~15 s)")
     return ap.parse_args()
 
@@ -274,7 +276,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     # pass -- `job_bytes` is what THIS configuration must move.  Ingest reads the two surfaces and writes the planar XYB
     # pyramid once (24 B/px for the two sides).  The SSIM / MS-SSIM stage reads the u8-quantised planes (6 B/px per pair) and,
     # for MS-SSIM, builds and reads back the dyadic pyramid of box sums (u16, scales 1-4: 2 x 0.332 x 2 B per sample).
-    # Launches of six slots and more run the edge-only jobs in ONE kernel (k_blur_edge_fused) that reads the {ref, dis} plane
+    # Launches of >= 340 bands of EDGE planes (5 pairs of 1080p, 3 of 4K) run the edge-only jobs in ONE kernel (k_blur_edge_fused) that reads the {ref, dis} plane
     # once (2 f32 per pixel) and writes nothing: the two passes then move the bytes of the FULL jobs only.
     units = {0: 0, 1: 4, 2: 7}
     fused_edge = bool(has_s2 and eng.uses_fused_edge(B))
@@ -332,7 +334,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         # with the HIP events of the timed steps; every member's own figures, beside the others and alone, are listed.
         grp = ("k_blur_v_jobs", "k_blur_h_jobs_x", "k_blur_edge_fused")
         gtraffic = sum(traffic[k] for k in grp) if all(traffic.get(k) for k in grp) else None
-        roofline = {"bound": "hbm", "kernel": "k_blur_v_jobs + k_blur_h_jobs_x + k_blur_edge_fused (one concurrent group)",
+        roofline = {"bound": "hbm", "kind": "group", "kernel": "k_blur_v_jobs + k_blur_h_jobs_x + k_blur_edge_fused (one concurrent group)",
                     "achieved": stage_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stage_ach / HBM_PEAK_GBS,
                     "traffic": gtraffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": stage_bytes * B, "avg_launch_ms": ms_v + ms_h + ms_e, "bytes_model": bytes_model,
@@ -342,7 +344,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
                     "longest_hbm_bound_member": dom, "frac_alone": alone["kernels"][dom]["frac"], "avg_launch_ms_alone": alone["kernels"][dom]["avg_launch_ms"],
                     "region_frac": stage_ach / HBM_PEAK_GBS, "region_ms": ms_v + ms_h + ms_e}
     else:
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kind": "kernel", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": per_kernel[dom]["traffic"], "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
                     "avg_launch_ms": per_kernel[dom]["avg_launch_ms"], "bytes_model": bytes_model}
@@ -599,6 +601,104 @@ def cpu_baseline(tm, w, h, kind, n_pairs):
             "gpu_arithmetic_oracle_1thread_pairs_per_s": 1.0 / dt_gpu_arith}
 
 
+LINE_LIMIT = 4096  # bytes: the driver reads the LAST stdout line; BENCH_r03's 22-KB line came back unparsed (tests/test_bench_line.py)
+
+
+def _r(x, nd=4):
+    """numbers on the compact line: 4 significant decimals are what the figures are good for"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return round(float(x), nd) if abs(x) < 1e6 else float(f"{x:.7g}")
+
+
+def compact_line(d):
+    """The ONE line the driver parses: the contract fields, `roofline`, `cpu_baseline` and a one-level `summary`, <= LINE_LIMIT
+    bytes.  `d` is the full record (every leg with its kernels, members, stages ...), which goes to bench_detail.json."""
+    cfg = d.get("config", {})
+    out = {k: _r(d.get(k)) for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "baseline_config", "width", "height", "input", "pairs_per_step_per_gpu",
+                                             "metrics", "full_sums", "pipeline_depth", "engine_mem_GB", "parallelism") if k in cfg}
+    rf = d.get("roofline") or {}
+    keep = ("bound", "kind", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+            "bytes_model", "frac_alone", "avg_launch_ms_alone", "longest_hbm_bound_member")
+    out["roofline"] = {k: _r(rf.get(k)) for k in keep if k in rf}
+    cmp_ = d.get("compare") or {}
+    if cmp_.get("full_sums"):  # like for like with the reference (all 108 sums): SURVEY 8d's unrestricted byte model
+        out["roofline"]["full_sums_frac"] = _r(cmp_.get("blur_reduce_stage_frac"))
+        out["roofline"]["full_sums_value"] = _r(cmp_.get("value"), 1)
+    if len(out["roofline"].get("bytes_model", "")) > 160:
+        out["roofline"]["bytes_model"] = out["roofline"]["bytes_model"][:157] + "..."
+    cb = d.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": (cb.get("sample") or "")[:150], "host_cpus": cb.get("host_cpus")}
+        if cb.get("all_cores"):
+            out["cpu_baseline"]["all_cores"] = {k: _r(cb["all_cores"].get(k)) for k in ("value", "cores", "scaling_vs_1core", "bound") if k in cb["all_cores"]}
+        if cb.get("points"):
+            out["cpu_baseline"]["points"] = [[p["cores"], _r(p["value"], 2)] for p in cb["points"]]
+    sm = {}
+    for name, w in (d.get("workloads") or {}).items():
+        sm[name] = [_r(w.get("value"), 1), _r((w.get("roofline") or {}).get("frac"))]
+    if sm:
+        sm["_workloads"] = "name: [pairs/s, blur+reduce stage frac of 8 TB/s]"
+    fs = d.get("fixed_stream")
+    if fs:
+        sm["fixed_stream"] = {"pairs": fs.get("total_pairs"), "value": _r(fs.get("value"), 1), "scaling": fs.get("scaling"),
+                              "bit_identical": fs.get("scores_periodic_bit_identical"), "sha": fs.get("scores_sha256_16")}
+        if fs.get("long"):
+            sm["fixed_stream_long"] = {"pairs": fs["long"].get("total_pairs"), "value": _r(fs["long"].get("value"), 1),
+                                       "bit_identical": fs["long"].get("scores_periodic_bit_identical"), "sha": fs["long"].get("scores_sha256_16")}
+    hf = d.get("host_fed")
+    if hf:
+        sm["host_fed"] = {k: [_r(v.get("value"), 1), _r(v.get("h2d_GBs_per_gpu"), 1)] for k, v in hf.items()}
+        sm["_host_fed"] = "[pairs/s, H2D GB/s] PCIe-inclusive, never `value`"
+    bc = d.get("batch_curve")
+    if bc:
+        sm["batch_curve"] = [[p["batch"], _r(p["value"], 0)] for p in bc.get("points", [])]
+    cli = d.get("cli_end_to_end")
+    if cli:
+        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("first_pass", "default", "batch16") if isinstance(v.get(lab), dict)}
+                                if isinstance(v, dict) and "error" not in v else (v.get("error", "")[:60] if isinstance(v, dict) else None)
+                                for tag, v in cli.items() if tag != "note"}
+    pl = d.get("pipeline")
+    if pl:
+        sm["pipeline"] = {k: _r(v) for k, v in pl.items() if not isinstance(v, (dict, list))}
+    if d.get("score_mean") is not None:
+        sm["score_mean"] = _r(d["score_mean"], 6)
+    sm["detail"] = d.get("detail_file")
+    out["summary"] = sm
+    line = json.dumps(out, separators=(",", ":"))
+    # never let an unforeseen long string take the line over the limit: drop the least important entries first
+    for victim in ("cli_end_to_end", "batch_curve", "host_fed", "_host_fed", "_workloads", "pipeline", "fixed_stream_long"):
+        if len(line) <= LINE_LIMIT:
+            break
+        sm.pop(victim, None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:
+        out.pop("summary", None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def write_detail(d, path=None):
+    """the full record: bench_detail.json beside bench.py (and under gpurun_out/ when that exists, so that it comes back from a GPU box)"""
+    paths = [path] if path else [os.path.join(ROOT, "bench_detail.json")]
+    if not path and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                json.dump(d, f, indent=1)
+            written = written or os.path.relpath(pth, ROOT)
+        except OSError:
+            pass
+    return written
+
+
 def run_rank(args):
     ctx = Ctx(args)
     head_name = args.workload or "1080p_nv12"
@@ -663,7 +763,9 @@ def run_rank(args):
         if ctx.world == 1 and not args.no_cpu_baseline:
             w, h, kind = WORKLOADS[head_name][:3]
             out["cpu_baseline"] = cpu_baseline(ctx.tm, w, h, kind, args.cpu_pairs)
-        print(json.dumps(out), flush=True)
+        out["detail_file"] = args.detail_file or "bench_detail.json"
+        write_detail(out, args.detail_file)
+        print(compact_line(out), flush=True)
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()
 

@@ -13,14 +13,34 @@ COMMON = ["--workload", "1080p_nv12", "--steps", "2", "--warmup", "1", "--settle
           "--batch", "8", "--stream-pairs", "72"]
 
 
-def _bench(extra, env_extra=None):
+def _run(extra, common, env_extra=None):
+    """bench.py as the driver runs it: ONE compact JSON line on stdout (<= 4 KB, the contract fields + roofline + summary);
+    returns the full record (bench_detail.json, --detail-file) after checking the line against it"""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + COMMON, capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common + ["--detail-file", detail],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+        assert len(lines[0]) <= 4096, len(lines[0])
+        line = json.loads(lines[0])
+        full = json.load(open(detail))
+    for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "scaling", "dtype", "data", "config", "roofline", "summary"):
+        assert k in line, k
+    assert line["n_gpus"] == full["n_gpus"] and abs(line["value"] - full["value"]) < 1e-3 * full["value"]
+    assert line["roofline"]["kind"] in ("group", "kernel") and abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-3
+    if "fixed_stream" in full:
+        assert line["summary"]["fixed_stream"]["sha"] == full["fixed_stream"]["scores_sha256_16"]
+    full["_line"] = line
+    return full
+
+
+def _bench(extra, env_extra=None):
+    return _run(extra, COMMON, env_extra)
 
 
 def test_two_ranks_are_really_started_and_reproduce_the_one_rank_scores():
@@ -48,14 +68,8 @@ def test_eight_ranks_rendezvous_shard_and_reduce_like_one_rank():
             "--batch", "2", "--stream-pairs", "2048", "--no-extras"]
 
     def run(extra, env_extra=None):
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-        env.update(env_extra or {})
         t0 = time.time()
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + args, capture_output=True, text=True, timeout=900, env=env)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        assert len(lines) == 1, r.stdout
-        return json.loads(lines[0]), time.time() - t0
+        return _run(extra, args, env_extra), time.time() - t0
 
     one, _ = run(["--gpus", "1"])
     eight, wall = run(["--gpus", "8"], {"TM_BENCH_BACKEND": "gloo"})
@@ -64,6 +78,8 @@ def test_eight_ranks_rendezvous_shard_and_reduce_like_one_rank():
     assert eight["fixed_stream"]["scores_periodic_bit_identical"]
     assert eight["fixed_stream"]["scores_sha256_16"] == one["fixed_stream"]["scores_sha256_16"]
     assert "workloads" not in eight and "batch_curve" not in eight  # --no-extras
+    assert "gloo" in eight["_line"]["config"]["parallelism"]  # the line states the backend that carried the reduce
+    assert eight["_line"]["summary"]["fixed_stream"]["pairs"] == 2048
     assert wall < 120.0, wall
 
 
