@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--stream-pairs", type=int, default=None, help=f"pairs of the fixed-size stream (strong scaling leg; default {STREAM_PAIRS} "
                     f"plus a second leg of {STREAM_PAIRS_LONG}); given explicitly the leg also runs under --no-extras")
     ap.add_argument("--no-cli", action="store_true", help="skip the cli_end_to_end leg")
+    ap.add_argument("--edge-beside", type=int, default=1, choices=(0, 1, 2), help="measurement: 0 = the fused kernel of the edge-only jobs behind the row pass "
+                    "(every kernel alone on the chip: per-kernel profiles), 1 = beside the two passes (the default, what ships)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail-file", default=None, help="where the full record goes (default: bench_detail.json beside bench.py, and a copy "
                     "under gpurun_out/ when that directory exists); the stdout line is the compact one (<= 4 KB)")
@@ -225,6 +227,8 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         return dt, [m / max(n, 1) for m in ms]
 
     eng.set_full_sums(args.full_sums)
+    if args.edge_beside != 1:
+        eng.debug_set_edge_beside(args.edge_beside)
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
         step()
@@ -240,7 +244,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     all_scores = tm.shard.reduce_scores(scores_local, ctx.rank * B, ctx.world * B, 1, ctx.dist, ctx.cdev if ctx.dist is not None else "cpu")
 
     alone = None
-    if has_s2 and eng.uses_fused_edge(B):
+    if has_s2 and eng.uses_fused_edge(B) and args.edge_beside == 1:
         # the fused kernel of the edge-only jobs runs BESIDE the two blur passes (second stream): the stage times above overlap.
         # A few steps with it BEHIND the row pass instead (outside the headline timing) time every kernel alone on the chip.
         eng.debug_set_edge_beside(0)
@@ -555,49 +559,49 @@ def run_cli_end_to_end(ctx):
 
 
 def cpu_baseline(tm, w, h, kind, n_pairs):
-    """CPU baselines on this host, bounded to 10-15 s in total (reported, never the target):
-    the restated reference CPU path (oracle/tm_cpu_path.c == examples/cpu.rs, single-threaded like the original)
-    after the same YUV->linear conversion the GPU path applies, timed on 1 thread and with frame-level
-    parallelism on the host cores; plus the GPU-arithmetic oracle on 1 thread."""
-    from concurrent.futures import ThreadPoolExecutor
+    """CPU baselines on this host, bounded to ~15-20 s in total (reported, never the target): the restated reference CPU path
+    (oracle/tm_cpu_path.c == examples/cpu.rs, single-threaded per pair like the original) after the same YUV->linear conversion
+    the GPU path applies.  The frame-level parallel loop lives in the oracle library (tmo_cpu_path_run: pthreads, one pair per
+    worker at a time, every worker's buffers allocated and touched once before the clock starts) -- round 3 ran Python threads around
+    ctypes calls that malloc'ed 200 MB per pair and measured the page allocator (256 threads: 8 x one core).  Points: 1 thread,
+    64 threads, one thread per host CPU; plus the GPU-arithmetic oracle on 1 thread."""
     from oracle import oracle as O
     gen = tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair
     bits = 8 if kind == "nv12" else 16
     pairs = [gen(w, h, n) for n in range(2)]
-
-    def one(i, fn):
-        (rs, rp, rch), (ds, dp, dch) = pairs[i % len(pairs)]
-        lr = O.yuv420_biplanar_to_linear(rs, rp, rch, w, h, bits, 0)
-        ld = O.yuv420_biplanar_to_linear(ds, dp, dch, w, h, bits, 0)
-        return fn(lr, ld)
-
     if n_pairs <= 0:
-        n_pairs = 12 if w * h <= 1920 * 1080 else 3  # ~5 s on one core; with the two other legs the whole baseline is 10-15 s
+        n_pairs = 12 if w * h <= 1920 * 1080 else 3  # ~5 s on one core
+    dt1, _ = O.cpu_path_run(pairs, w, h, bits, n_pairs, 1)
+    one = n_pairs / dt1
+    (rs, rp, rch), (ds, dp, dch) = pairs[0]
+    lr = O.yuv420_biplanar_to_linear(rs, rp, rch, w, h, bits, 0)
+    ld = O.yuv420_biplanar_to_linear(ds, dp, dch, w, h, bits, 0)
     t0 = time.perf_counter()
-    for i in range(n_pairs):
-        one(i, O.cpu_path_score_linear)
-    dt1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for i in range(max(1, n_pairs // 2)):
-        one(i, lambda a, b: O.ssimulacra2_from_linear(a, b)[0])
-    dt_gpu_arith = (time.perf_counter() - t0) / max(1, n_pairs // 2)
-    # every host core (SURVEY 8d), bounded by memory: a 1080p pair of the restated CPU path holds ~0.6 GB while it runs
-    threads = os.cpu_count() or 1
+    for _ in range(2):
+        O.ssimulacra2_from_linear(lr, ld)
+    dt_gpu_arith = (time.perf_counter() - t0) / 2
+    cpus = os.cpu_count() or 1
+    per_worker = 31 * 4 * w * h  # 25 planes of workspace + two linear RGB images
     try:
         import psutil
-        per = 0.6e9 * (w * h) / (1920 * 1080)
-        threads = max(1, min(threads, int(psutil.virtual_memory().available * 0.5 / per)))
+        cap = max(1, int(psutil.virtual_memory().available * 0.5 / per_worker))
     except Exception:
-        threads = min(threads, 64)
-    n_par = threads
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL: real frame-level parallelism
-        list(ex.map(lambda i: one(i, O.cpu_path_score_linear), range(n_par)))
-    dtp = time.perf_counter() - t0
-    return {"value": n_pairs / dt1, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+        cap = 64
+    points = [{"cores": 1, "value": one, "pairs": n_pairs, "seconds": dt1}]
+    for threads in sorted({min(64, cpus, cap), min(cpus, cap)}):
+        if threads <= 1:
+            continue
+        k = 3 * threads  # three pairs per worker: ~1.5 s per pair at full load
+        dtp, _ = O.cpu_path_run(pairs, w, h, bits, k, threads)
+        points.append({"cores": threads, "value": k / dtp, "pairs": k, "seconds": dtp})
+    top = points[-1]
+    return {"value": one, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": f"{n_pairs} {w}x{h} {kind} pairs, YUV->linear + restated reference CPU path (oracle/tm_cpu_path.c == examples/cpu.rs), 1 thread",
-            "seconds": dt1, "host_cpus": os.cpu_count(),
-            "all_cores": {"value": n_par / dtp, "cores": threads, "sample": f"{n_par} pairs, one pair per worker thread, one thread per host CPU (bounded by free memory)", "seconds": dtp},
+            "seconds": dt1, "host_cpus": cpus,
+            "all_cores": {"value": top["value"], "cores": top["cores"], "scaling_vs_1core": top["value"] / one, "efficiency": top["value"] / one / top["cores"],
+                          "sample": f"{top['pairs']} pairs over {top['cores']} pthreads (tmo_cpu_path_run: one pair per worker at a time, buffers allocated once per worker)",
+                          "seconds": top["seconds"]},
+            "points": points,
             "gpu_arithmetic_oracle_1thread_pairs_per_s": 1.0 / dt_gpu_arith}
 
 
@@ -636,7 +640,7 @@ def compact_line(d):
         out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                                "sample": (cb.get("sample") or "")[:150], "host_cpus": cb.get("host_cpus")}
         if cb.get("all_cores"):
-            out["cpu_baseline"]["all_cores"] = {k: _r(cb["all_cores"].get(k)) for k in ("value", "cores", "scaling_vs_1core", "bound") if k in cb["all_cores"]}
+            out["cpu_baseline"]["all_cores"] = {k: _r(cb["all_cores"].get(k)) for k in ("value", "cores", "scaling_vs_1core", "efficiency") if k in cb["all_cores"]}
         if cb.get("points"):
             out["cpu_baseline"]["points"] = [[p["cores"], _r(p["value"], 2)] for p in cb["points"]]
     sm = {}

@@ -45,6 +45,8 @@ def lib():
         L.tmo_ssimulacra2_from_linear.argtypes = [fp, fp, C.c_int, C.c_int, dp]
         L.tmo_cpu_path_score_linear.restype = C.c_double
         L.tmo_cpu_path_score_linear.argtypes = [fp, fp, C.c_int, C.c_int]
+        L.tmo_cpu_path_run.restype = C.c_double
+        L.tmo_cpu_path_run.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
         L.tmo_cpu_path_score_srgb8.restype = C.c_double
         L.tmo_cpu_path_score_srgb8.argtypes = [vp, vp, C.c_int, C.c_int]
         L.tmo_ssim_from_sums.restype = C.c_double; L.tmo_ssim_from_sums.argtypes = [dp, C.c_int, C.c_int]
@@ -279,6 +281,23 @@ def cpu_path_score_linear(ref_lin, dis_lin):
     dis_lin = np.ascontiguousarray(dis_lin, np.float32)
     _, h, w = ref_lin.shape
     return float(lib().tmo_cpu_path_score_linear(_fp(ref_lin), _fp(dis_lin), w, h))
+
+
+def cpu_path_run(surfaces, w, h, bits, n_pairs, n_threads):
+    """Frame-level parallel run of the restated reference CPU path (tmo_cpu_path_run): `surfaces` = [((ref bytes, pitch, coded
+    height), (dis bytes, pitch, coded height)), ...] decoded 4:2:0 biplanar surfaces (pair i of the run takes entry i % len);
+    every worker thread converts its pair to linear RGB and scores it, buffers allocated once per worker.  Returns (seconds, scores)."""
+    refs = [np.ascontiguousarray(np.asarray(r[0]).view(np.uint8)) for r, _ in surfaces]
+    diss = [np.ascontiguousarray(np.asarray(d[0]).view(np.uint8)) for _, d in surfaces]
+    pitch, coded_h = int(surfaces[0][0][1]), int(surfaces[0][0][2])
+    assert all(int(r[1]) == pitch and int(r[2]) == coded_h and int(d[1]) == pitch and int(d[2]) == coded_h for r, d in surfaces)
+    pa = (C.c_void_p * len(refs))(*[a.ctypes.data for a in refs])
+    pb = (C.c_void_p * len(diss))(*[a.ctypes.data for a in diss])
+    scores = np.zeros(n_pairs, np.float64)
+    secs = float(lib().tmo_cpu_path_run(pa, pb, len(refs), pitch, coded_h, int(w), int(h), int(bits), int(n_pairs), int(n_threads), _dp(scores)))
+    if secs < 0:
+        raise RuntimeError("tmo_cpu_path_run failed (out of memory or threads)")
+    return secs, scores
 
 
 def cpu_path_score_srgb8(ref_rgb, dis_rgb):

@@ -128,15 +128,22 @@ static inline double pow4(double d) { const double d2 = d * d; return d2 * d2; }
 
 /* compute_frame_ssimulacra2, cpu.rs:342-410 + ssim_map :581-638 + edge_diff_map :640-683 + Msssim::score :728-871.
  * ref_lin / dis_lin: planar linear RGB. */
-double tmo_cpu_path_score_linear(const float *ref_lin, const float *dis_lin, int w0, int h0)
+/* workspace of one evaluation: 25 planes of w0 * h0 floats (the three image buffers of each side + seven planes of scratch).
+ * tmo_cpu_path_score_linear allocates one per call, like the original allocates per frame; the threaded runner below (the all-core
+ * CPU baseline of bench.py) gives every worker ONE for its whole run -- 256 threads that each mmap and fault in 200 MB per pair
+ * measure the kernel's page allocator, not the path. */
+size_t tmo_cpu_path_ws_bytes(int w0, int h0) { return (size_t)25 * (size_t)w0 * (size_t)h0 * sizeof(float); }
+
+double tmo_cpu_path_score_linear_ws(const float *ref_lin, const float *dis_lin, int w0, int h0, void *ws)
 {
     int w = w0, h = h0;
     const size_t n0 = (size_t)w * h;
     float *img[2], *nxt[2], *xyb[2];
-    for (int i = 0; i < 2; ++i) { img[i] = malloc(3 * n0 * 4); nxt[i] = malloc(3 * n0 * 4); xyb[i] = malloc(3 * n0 * 4); }
+    float *cur = (float *)ws;
+    for (int i = 0; i < 2; ++i) { img[i] = cur; cur += 3 * n0; nxt[i] = cur; cur += 3 * n0; xyb[i] = cur; cur += 3 * n0; }
     memcpy(img[0], ref_lin, 3 * n0 * 4); memcpy(img[1], dis_lin, 3 * n0 * 4);
-    float *mul = malloc(n0 * 4), *temp = malloc(n0 * 4);
-    float *s11 = malloc(n0 * 4), *s22 = malloc(n0 * 4), *s12 = malloc(n0 * 4), *mu1 = malloc(n0 * 4), *mu2 = malloc(n0 * 4);
+    float *mul = cur, *temp = cur + n0;
+    float *s11 = cur + 2 * n0, *s22 = cur + 3 * n0, *s12 = cur + 4 * n0, *mu1 = cur + 5 * n0, *mu2 = cur + 6 * n0;
     double avg_ssim[6][6], avg_edge[6][12];
     int nscales = 0;
     for (int scale = 0; scale < 6; ++scale) {
@@ -200,9 +207,88 @@ double tmo_cpu_path_score_linear(const float *ref_lin, const float *dis_lin, int
     ssim = fma(6.248496625763138e-5 * ssim * ssim, ssim, fma(2.326765642916932, ssim, -0.020884521182843837 * ssim * ssim));
     if (ssim > 0.0) ssim = fma(pow(ssim, 0.6276336467831387), -10.0, 100.0);
     else ssim = 100.0;
-    for (int k = 0; k < 2; ++k) { free(img[k]); free(nxt[k]); free(xyb[k]); }
-    free(mul); free(temp); free(s11); free(s22); free(s12); free(mu1); free(mu2);
     return ssim;
+}
+
+double tmo_cpu_path_score_linear(const float *ref_lin, const float *dis_lin, int w0, int h0)
+{
+    void *ws = malloc(tmo_cpu_path_ws_bytes(w0, h0));
+    if (!ws) return NAN;
+    const double s = tmo_cpu_path_score_linear_ws(ref_lin, dis_lin, w0, h0, ws);
+    free(ws);
+    return s;
+}
+
+/* ---- frame-level parallel run of the path (SURVEY 8d "CPU baseline beside it": all host cores, one pair per worker) -----------
+ * n_pairs frame pairs of ONE decoded 4:2:0 surface format; pair i takes surface pair i % n_inputs.  Every worker thread converts
+ * its pair to linear RGB (the oracle's restatement of the reference conversion kernel -- what the GPU path does before the metric)
+ * and runs the restated CPU path on it, with buffers allocated ONCE per worker; pairs are handed out by an atomic counter.
+ * Returns the wall-clock seconds from the moment all workers stand at the start line to the last one finishing (negative on
+ * failure); scores[i] (optional) receives pair i's score. */
+#include <pthread.h>
+#include <stdatomic.h>
+#include <time.h>
+
+int tmo_yuv420_biplanar_to_linear(const void *ybase, const void *uvbase, size_t pitch, int w, int h, int bits, int matrix, float *lin);
+
+typedef struct {
+    const void *const *ref, *const *dis; /* n_inputs surfaces each: luma rows at `pitch`, CbCr rows from row `coded_h` on */
+    int n_inputs;
+    size_t pitch;
+    int coded_h, w, h, bits, n_pairs;
+    double *scores;
+    atomic_int next, failed, ready, go;
+} tmo_run_t;
+
+static void tmo_nap(void) { const struct timespec ts = {0, 200000}; nanosleep(&ts, NULL); }
+
+static void *tmo_run_worker(void *arg)
+{
+    tmo_run_t *r = (tmo_run_t *)arg;
+    const size_t n = (size_t)r->w * r->h;
+    float *lr = malloc(3 * n * sizeof(float)), *ld = malloc(3 * n * sizeof(float));
+    void *ws = malloc(tmo_cpu_path_ws_bytes(r->w, r->h));
+    if (lr && ld && ws) { /* touch everything before the clock starts: the run measures the path, not first-touch page faults */
+        memset(lr, 0, 3 * n * sizeof(float)); memset(ld, 0, 3 * n * sizeof(float)); memset(ws, 0, tmo_cpu_path_ws_bytes(r->w, r->h));
+    } else atomic_store(&r->failed, 1);
+    atomic_fetch_add(&r->ready, 1);
+    while (!atomic_load(&r->go)) tmo_nap(); /* the start line */
+    if (!atomic_load(&r->failed))
+        for (;;) {
+            const int i = atomic_fetch_add(&r->next, 1);
+            if (i >= r->n_pairs) break;
+            const char *a = (const char *)r->ref[i % r->n_inputs], *b = (const char *)r->dis[i % r->n_inputs];
+            tmo_yuv420_biplanar_to_linear(a, a + r->pitch * (size_t)r->coded_h, r->pitch, r->w, r->h, r->bits, 0, lr);
+            tmo_yuv420_biplanar_to_linear(b, b + r->pitch * (size_t)r->coded_h, r->pitch, r->w, r->h, r->bits, 0, ld);
+            const double s = tmo_cpu_path_score_linear_ws(lr, ld, r->w, r->h, ws);
+            if (r->scores) r->scores[i] = s;
+        }
+    free(lr); free(ld); free(ws);
+    return NULL;
+}
+
+double tmo_cpu_path_run(const void *const *ref, const void *const *dis, int n_inputs, size_t pitch, int coded_h, int w, int h, int bits,
+                        int n_pairs, int n_threads, double *scores)
+{
+    if (n_inputs < 1 || n_pairs < 1 || n_threads < 1 || n_threads > 4096 || (bits != 8 && bits != 16)) return -1.0;
+    tmo_run_t r;
+    r.ref = ref; r.dis = dis; r.n_inputs = n_inputs; r.pitch = pitch; r.coded_h = coded_h; r.w = w; r.h = h; r.bits = bits; r.n_pairs = n_pairs; r.scores = scores;
+    atomic_init(&r.next, 0); atomic_init(&r.failed, 0); atomic_init(&r.ready, 0); atomic_init(&r.go, 0);
+    pthread_t *th = malloc((size_t)n_threads * sizeof *th);
+    if (!th) return -1.0;
+    int started = 0;
+    for (; started < n_threads; ++started)
+        if (pthread_create(&th[started], NULL, tmo_run_worker, &r)) break;
+    if (started < n_threads) atomic_store(&r.failed, 1); /* not the run that was asked for: the workers that exist leave at once */
+    while (atomic_load(&r.ready) < started) tmo_nap();
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    atomic_store(&r.go, 1);
+    for (int k = 0; k < started; ++k) pthread_join(th[k], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    if (atomic_load(&r.failed)) return -1.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
 /* CpuImg::from_srgb (cpu.rs:280-296) + compute_frame_ssimulacra2: packed sRGB u8 in, score out */

@@ -156,3 +156,23 @@ def test_cpu_path_restatement_properties():
     c = O.cpu_path_score_srgb8(r8, d8)
     g, _ = O.ssimulacra2_from_linear(O.rgb8_to_linear(r8), O.rgb8_to_linear(d8))
     assert 0.0 < c < 100.0 and abs(c - g) < 0.25
+
+
+def test_threaded_cpu_path_runner_reproduces_the_single_call():
+    """tmo_cpu_path_run (bench.py's all-core CPU baseline: pthreads, one pair per worker at a time, workspace allocated once per
+    worker) returns, for every pair, exactly the score of tmo_cpu_path_score_linear on the oracle's YUV -> linear conversion"""
+    import numpy as np
+    from oracle import oracle as O
+    from tm_pkg import tm
+    w, h = 160, 96
+    pairs = [tm.synth.nv12_pair(w, h, n) for n in range(3)]
+    want = []
+    for (rs, rp, rch), (ds, dp, dch) in pairs:
+        want.append(O.cpu_path_score_linear(O.yuv420_biplanar_to_linear(rs, rp, rch, w, h, 8, 0), O.yuv420_biplanar_to_linear(ds, dp, dch, w, h, 8, 0)))
+    for threads in (1, 3, 7):
+        secs, scores = O.cpu_path_run(pairs, w, h, 8, 11, threads)
+        assert secs > 0 and np.array_equal(scores, np.resize(np.array(want), 11)), threads
+    p16 = [tm.synth.p016_pair(w, h, 0)]
+    secs, scores = O.cpu_path_run(p16, w, h, 16, 2, 2)
+    (rs, rp, rch), (ds, dp, dch) = p16[0]
+    assert scores[0] == scores[1] == O.cpu_path_score_linear(O.yuv420_biplanar_to_linear(rs, rp, rch, w, h, 16, 0), O.yuv420_biplanar_to_linear(ds, dp, dch, w, h, 16, 0))

@@ -14,7 +14,7 @@ cp gpurun_out/${TAG}_pmc_traffic_1080p_nv12_full.json profiles/pmc_traffic_1080p
 cp gpurun_out/${TAG}_pmc_traffic_4k_p016.json profiles/pmc_traffic_4k_p016_b24.json
 bash tools/gpu_check.sh $TAG
 bash tools/gpu_prof.sh ${TAG}_fused --metrics psnr,msssim,ssimulacra2
-TM_EF_BESIDE=0 bash tools/gpu_prof.sh ${TAG}_alone   # every kernel alone on the chip: the fused kernel of the EDGE jobs behind the row pass
+bash tools/gpu_prof.sh ${TAG}_alone --edge-beside 0   # every kernel alone on the chip: the fused kernel of the EDGE jobs behind the row pass
 bash tools/gpu_prof.sh ${TAG}_4k --workload 4k_p016
 bash tools/gpu_prof.sh ${TAG}_fused4k --workload 4k_p016 --metrics psnr,msssim,ssimulacra2
 bash tools/pmc_sq.sh $TAG > /dev/null 2>&1

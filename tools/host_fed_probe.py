@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: the host-fed leg of bench.py alone (page-locked host -> H2D every step, two engines ping-pong), per workload and batch.
-usage: host_fed_probe.py [workload:batch,...]   (environment: the engine's tuning variables, e.g. TM_PASS_PRIO, TM_FUSED_EDGE_FROM)"""
+usage: host_fed_probe.py [workload:batch,...]   (tuning values: tm_engine_debug_set_param on the engines run_host_fed creates)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench

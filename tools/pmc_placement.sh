@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: which hardware counter tells a slow placement of the pass-1 arena from a fast one?  The placement search itself is the
-# experiment: it runs the column pass (k_blur_v_jobs<32,16,1>) on each of 8 candidate arenas in turns and, with TM_PLACEMENT_DEBUG,
+# experiment: it runs the column pass (k_blur_v_jobs<32,16,1>) on each of 8 candidate arenas in turns and, with tm_set_debug_log(1),
 # prints each candidate's time; rocprofv3 --pmc gives the counters per dispatch.  One process per counter set.
 set -u
 TAG=${1:-r02}

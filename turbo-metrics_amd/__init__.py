@@ -10,4 +10,4 @@ the operators raise.
 """
 from . import ffi, launch, shard, synth  # noqa: F401
 from .engine import (ColorMatrix, FrameScores, HwFrame, Metrics, Ssimulacra2, TmError,  # noqa: F401
-                     TurboMetrics, init_hip, set_placement_candidates)
+                     TurboMetrics, init_hip, set_debug_log, set_placement_candidates)

@@ -124,14 +124,18 @@ struct tm_engine {
     unsigned *d_epoch = nullptr;      // ... launch epoch of the hand-off tags (advanced by k_finish_edge)
     int *d_status = nullptr, *h_status = nullptr; // ... a hand-off wait that timed out
     int ef_tiles = 0, ef_bands = 0, ef_ne = 0;
+    size_t hs_elems = 0, erows_elems = 0; // what HS / EROWS hold (mem_bytes bookkeeping; the geometry above is what the kernels index with)
+    unsigned ef_epoch_host = 1;      // host mirror of d_epoch[0] (one step per fused launch): HS is cleared when the 24-bit tag epoch wraps
+    // The tuning values below are fixed in a release build's behaviour: no environment variable reaches them.  tools/ and tests move
+    // them through tm_engine_debug_set_param (TM_DBG_*), per engine.
     long long fused_edge_from = 340; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 5 pairs of
-                                     // 1080p, 3 of 4K, 4 of 1440p, 8 of 720p (below, the launch is bound by the latency of one wave walking its band and of the chain of bands; TM_FUSED_EDGE_FROM overrides: tuning)
-    int ef_beside = 1;  // the fused kernel runs on stream2 beside the two blur passes: 1 = enqueued before the column pass, 2 = after it, 0 = behind the row pass on the engine's stream (TM_EF_BESIDE: tuning)
-    int ef_waves = 4;   // waves per workgroup of the fused kernel (TM_EF_WAVES: tuning)
-    int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket (TM_EF_PERSIST_WGS: tuning)
-    int ef_pass_prio = 1;   // the two passes raise their waves' issue priority while the fused kernel runs beside them (TM_PASS_PRIO: tuning)
+                                     // 1080p, 3 of 4K, 4 of 1440p, 8 of 720p (below, the launch is bound by the latency of one wave walking its band and of the chain of bands)
+    int ef_beside = 1;  // the fused kernel runs on stream2 beside the two blur passes: 1 = enqueued before the column pass, 2 = after it, 0 = behind the row pass on the engine's stream
+    int ef_waves = 4;   // waves per workgroup of the fused kernel
+    int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket
+    int ef_pass_prio = 1;   // the two passes raise their waves' issue priority while the fused kernel runs beside them
     int n_cus = 256;
-    int ef_dbg = 0;     // TM_EF_DEBUG at creation (experiments: 1 = do not wait for the band above, 2 = do not publish, 4 = record when every wave ran; sizes the status buffer)
+    int ef_fault = 0;   // fault injection (TM_DBG_EF_FAULT): 1 = do not wait for the band above, 2 = do not publish the state (the hand-off then times out: TM_ERR_HIP from tm_engine_sync)
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
     bool use_graph = false;         // replay the per-batch launch sequence from a captured hipGraph (measured slower than direct launches: off)
@@ -165,10 +169,10 @@ struct tm_engine {
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
     int variant = TM_VARIANT_DEFAULT;
-    long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms; TM_SPLIT_ROWS_BELOW overrides: tuning)
-    bool split_rows_env = false, split5_rows_env = false; // TM_SPLIT_ROWS_BELOW / TM_SPLIT5_ROWS_BELOW were given: used as they are
-    long long split5_rows_below = 400; // ... and up to which that pass runs with five instead of three waves per row block (TM_SPLIT5_ROWS_BELOW)
-    int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (TM_INGEST_ROWS overrides: tuning)
+    long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms)
+    bool split_rows_env = false, split5_rows_env = false; // TM_DBG_SPLIT_ROWS_BELOW / TM_DBG_SPLIT5_ROWS_BELOW were set: used as they are
+    long long split5_rows_below = 400; // ... and up to which that pass runs with five instead of three waves per row block
+    int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (tm_engine_debug_set_ingest_rows)
 };
 
 namespace {
@@ -218,8 +222,10 @@ int ensure_staging(tm_engine *e, size_t idx, size_t bytes)
     return TM_OK;
 }
 
+// coded_rows: 0 = two planes (p0, p1); > 0 = ONE surface declared by the caller: `coded_rows` luma rows at p0, then the CbCr rows
+// (tm_engine_set_surface_*: the reference's decoded-surface contract, cudarse-video/src/dec.rs:299-393)
 int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void *p0, const void *p1, size_t pitch,
-                     int matrix, int mem)
+                     int matrix, int mem, size_t coded_rows = 0)
 {
     int rc = check_slot_side(e, slot, side);
     if (rc) return rc;
@@ -243,18 +249,19 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         const size_t idx = slot * 2 + side;
         const size_t spitch = (row_bytes + 255) / 256 * 256;
         const size_t chroma_rows = (e->h + 1) / 2;
-        const size_t need = yuv ? spitch * (e->h + 64 + chroma_rows) : spitch * e->h; // room for a surface's padding rows (below)
+        const size_t need = yuv ? spitch * ((coded_rows > e->h ? coded_rows : e->h) + chroma_rows) : spitch * e->h; // room for a declared surface's padding rows (below)
         rc = ensure_staging(e, idx, need);
         if (rc) return rc;
         char *s = (char *)e->staging[idx];
         const size_t uv_bytes = yuv ? (size_t)((e->w + 1) / 2) * 2 * bps : 0, uv_row = uv_bytes <= pitch ? uv_bytes : pitch;
-        // a decoder's surface: the CbCr rows follow the luma rows at the same pitch (after a few padding rows) -> ONE 2-D copy of
-        // all rows instead of two (the per-copy cost is what limits small frames: DESIGN.md section 5, host-fed)
+        // ONE 2-D copy of all rows instead of two (the per-copy cost is what limits small frames: DESIGN.md section 5, host-fed) in
+        // exactly two cases, neither of which reads a byte the caller has not declared:
+        //   * the caller declared a surface (tm_engine_set_surface_*: coded_rows luma rows, the padding rows included, then the CbCr rows);
+        //   * the CbCr rows start exactly where the h luma rows end (gap == pitch * h): every row of the copy belongs to one of the two planes.
+        // Round 3 inferred "one allocation" from any distance of h .. h + 64 rows and then read the rows in between.
         const size_t gap = yuv && (const char *)p1 >= (const char *)p0 ? (size_t)((const char *)p1 - (const char *)p0) : 0;
-        const size_t luma_rows = yuv && gap % pitch == 0 ? gap / pitch : 0;
-        // (documented in the header: a CbCr pointer that sits a whole number of rows, h .. h + 64, behind the luma pointer declares
-        // ONE allocation -- the reference's decoded-surface contract, cudarse-video/src/dec.rs:299-393 -- whose padding rows may be read)
-        if (luma_rows >= e->h && luma_rows <= (size_t)e->h + 64) {
+        const size_t luma_rows = coded_rows ? coded_rows : (yuv && gap == pitch * (size_t)e->h ? (size_t)e->h : 0);
+        if (luma_rows >= e->h) {
             rc = stage_rows(e, s, spitch, p0, pitch, row_bytes > uv_row ? row_bytes : uv_row, luma_rows + chroma_rows);
             if (rc) return rc;
             d.p1 = s + spitch * luma_rows;
@@ -355,22 +362,31 @@ int make_job_tables(tm_engine *e)
         tiles = std::max(tiles, (sg.w + 31) / 32); bands = std::max(bands, (sg.h + 31) / 32);
     }
     const int ne = jf.n - jf.nfull;
-    if (ne == 0 || !(e->mask & TM_METRIC_SSIMULACRA2)) { e->ef_ne = 0; return TM_OK; }
+    // a table without EDGE jobs (full_sums, or no SSIMULACRA2) keeps whatever the buffers hold: use_fused_edge looks at the table
+    // (jobs_f.n == jobs_f.nfull), and the sizes below stay those of the allocations (resetting ef_ne to 0 here made the
+    // next toggle free "0 bytes" and allocate again: mem_usage grew by the buffers' size with every set_full_sums pair)
+    if (ne == 0 || !(e->mask & TM_METRIC_SSIMULACRA2)) return TM_OK;
     if (ne > e->ef_ne || tiles > e->ef_tiles || bands > e->ef_bands) {
-        if (e->HS) { (void)hipFree(e->HS); e->mem_bytes -= (size_t)e->cap * e->ef_ne * 2 * e->ef_tiles * 384 * sizeof(unsigned long long); e->HS = nullptr; }
-        if (e->EROWS) { (void)hipFree(e->EROWS); e->mem_bytes -= (size_t)e->cap * e->ef_ne * e->ef_bands * 128 * sizeof(double); e->EROWS = nullptr; }
-        e->ef_ne = ne; e->ef_tiles = tiles; e->ef_bands = bands;
+        if (e->HS) { (void)hipFree(e->HS); e->mem_bytes -= e->hs_elems * sizeof(unsigned long long); e->HS = nullptr; e->hs_elems = 0; }
+        if (e->EROWS) { (void)hipFree(e->EROWS); e->mem_bytes -= e->erows_elems * sizeof(double); e->EROWS = nullptr; e->erows_elems = 0; }
+        const int ne2 = std::max(ne, e->ef_ne), tiles2 = std::max(tiles, e->ef_tiles), bands2 = std::max(bands, e->ef_bands);
+        e->ef_ne = 0; // nothing usable until both allocations exist (use_fused_edge checks it)
+        const size_t hs = (size_t)e->cap * ne2 * 2 * tiles2 * 384, er = (size_t)e->cap * ne2 * bands2 * 128;
         int rc;
-        if ((rc = dev_alloc(e, &e->HS, (size_t)e->cap * ne * 2 * tiles * 384, true))) return rc;
-        if ((rc = dev_alloc(e, &e->EROWS, (size_t)e->cap * ne * bands * 128, true))) return rc;
+        if ((rc = dev_alloc(e, &e->HS, hs, true))) { e->HS = nullptr; return rc; }
+        e->hs_elems = hs;
+        if ((rc = dev_alloc(e, &e->EROWS, er, true))) { e->EROWS = nullptr; return rc; }
+        e->erows_elems = er;
+        e->ef_ne = ne2; e->ef_tiles = tiles2; e->ef_bands = bands2; // only now: both buffers are there
     }
     if (!e->d_epoch) {
         int rc;
         if ((rc = dev_alloc(e, &e->d_epoch, 2, true))) return rc; // [0] launch epoch of the hand-off tags, [1] ticket counter of the launch (k_finish_edge: epoch + 1, tickets from 0)
-        if ((rc = dev_alloc(e, &e->d_status, 8 + ((e->ef_dbg & 4) ? 6 * 16384 : 0), true))) return rc;
+        if ((rc = dev_alloc(e, &e->d_status, 8, true))) return rc;
         const unsigned one = 1u;
         HIPCHK(hipMemcpy(e->d_epoch, &one, sizeof one, hipMemcpyHostToDevice));
-        HIPCHK(hipHostMalloc((void **)&e->h_status, (8 + ((e->ef_dbg & 4) ? 6 * 16384 : 0)) * sizeof(int), hipHostMallocDefault));
+        e->ef_epoch_host = 1;
+        HIPCHK(hipHostMalloc((void **)&e->h_status, 8 * sizeof(int), hipHostMallocDefault));
         *e->h_status = 0;
     }
     return TM_OK;
@@ -379,7 +395,7 @@ int make_job_tables(tm_engine *e)
 // does a launch of n slots send its EDGE jobs through k_blur_edge_fused?
 bool use_fused_edge(const tm_engine *e, int n)
 {
-    if ((e->variant & (TM_VARIANT_REFERENCE | TM_VARIANT_TWO_PASS_EDGE)) || e->ef_ne == 0 || e->jobs_f.n == e->jobs_f.nfull) return false;
+    if ((e->variant & (TM_VARIANT_REFERENCE | TM_VARIANT_TWO_PASS_EDGE)) || e->ef_ne == 0 || !e->HS || !e->EROWS || e->jobs_f.n == e->jobs_f.nfull) return false;
     if (e->variant & TM_VARIANT_FUSED_EDGE) return true;
     long long walks = 0;
     for (int k = e->jobs_f.nfull; k < e->jobs_f.n; ++k) walks += (e->g.s[e->jobs_f.scale[k]].h + 31) / 32;
@@ -443,6 +459,9 @@ int tm_init(int device)
 
 #define TM_V_SLACK ((size_t)4 << 20) /* bytes allocated beyond the pass-1 arena so that its start can be moved */
 static std::atomic<int> g_placement_candidates{-1}; // -1: not set -> environment or default
+static std::atomic<int> g_debug_log{0};             // tm_set_debug_log: diagnostics on stderr (what the placement search measured)
+
+void tm_set_debug_log(int on) { g_debug_log.store(on); }
 
 void tm_set_placement_candidates(int n) { g_placement_candidates.store(n < 1 ? 1 : n); }
 
@@ -503,7 +522,7 @@ static int placement_search(tm_engine *e)
     size_t win = 0;
     for (size_t i = 1; i < cand.size(); ++i)
         if (best_of[i] < best_of[win]) win = i;
-    if (getenv("TM_PLACEMENT_DEBUG")) // tools/pmc_placement.sh: which candidate is which in the counters
+    if (g_debug_log.load()) // tools/pmc_placement.sh: which candidate is which in the counters
         for (size_t i = 0; i < cand.size(); ++i) fprintf(stderr, "[tm] candidate %zu at %p: %.3f ms%s\n", i, (void *)cand[i], best_of[i], i == win ? " <- kept" : "");
     for (size_t i = 0; i < cand.size(); ++i)
         if (i != win) { (void)hipFree(cand[i]); e->mem_bytes -= bytes; }
@@ -537,17 +556,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     auto fail = [&](int code) { tm_engine_destroy(e); return code; };
     if (hipGetDevice(&e->device) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipGetDevice"));
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
-    if (const char *sr = getenv("TM_SPLIT_ROWS_BELOW")) { e->split_rows_below = atoll(sr); e->split_rows_env = true; }
-    if (const char *sr = getenv("TM_SPLIT5_ROWS_BELOW")) { e->split5_rows_below = atoll(sr); e->split5_rows_env = true; }
-    if (const char *ir = getenv("TM_INGEST_ROWS")) { const int v = atoi(ir); if (v >= 2 && v <= 128) e->ingest_rows = v & ~1; }
     tm_make_geom(&e->g, (int)width, (int)height);
-    if (const char *pp = getenv("TM_PYRT_PAD")) e->g.pyr_t += (unsigned long long)atoll(pp) / 64 * 64; // experiment: distance between the planes / slots of the transposed arenas (tools/stride_probe.py)
-    if (const char *ff = getenv("TM_FUSED_EDGE_FROM")) e->fused_edge_from = atoll(ff);
-    if (const char *ff = getenv("TM_EF_BESIDE")) e->ef_beside = atoi(ff);
-    if (const char *ff = getenv("TM_EF_WAVES")) e->ef_waves = atoi(ff);
-    if (const char *ff = getenv("TM_EF_DEBUG")) e->ef_dbg = atoi(ff);
-    if (const char *ff = getenv("TM_EF_PERSIST_WGS")) e->ef_persist_wgs = atoi(ff);
-    if (const char *ff = getenv("TM_PASS_PRIO")) e->ef_pass_prio = atoi(ff);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
@@ -566,14 +575,6 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
         if ((rc = dev_alloc(e, &e->SUMS, B * 108, true))) return fail(rc);
     }
     if ((rc = make_job_tables(e))) return fail(rc);
-    if (getenv("TM_OCCUPANCY_DEBUG")) { // what the runtime thinks fits a CU
-        int nb = 0;
-        hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, e->device);
-        fprintf(stderr, "[tm] sharedMemPerBlock %zu maxSharedMemoryPerMultiProcessor %zu regsPerBlock %d\n", prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor, prop.regsPerBlock);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_edge_fused<4, true>, 256, 0); fprintf(stderr, "[tm] k_blur_edge_fused<4, grouped>: %d blocks of 256 per CU\n", nb);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_v_jobs<32, 16, 0>, 320, 0); fprintf(stderr, "[tm] k_blur_v_jobs: %d blocks of 320 per CU\n", nb);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>, 64, 0); fprintf(stderr, "[tm] k_blur_h_jobs_x: %d blocks of 64 per CU\n", nb);
-    }
     if ((rc = dev_alloc(e, &e->SSE, B * TM_SSE_BINS * 3, true))) return fail(rc);
     if (metrics_mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) {
         float gw[TM_SSIM_TAPS];
@@ -649,6 +650,29 @@ int tm_engine_set_frame_p016(tm_engine *e, uint32_t slot, int side, const void *
     int rc = check_yuv_args(matrix, transfer, full_range);
     if (rc) return rc;
     return set_frame_common(e, slot, side, TM_KIND_P016, y, uv, pitch, matrix, mem);
+}
+
+// a decoded surface as the reference's decoder hands it over (NvDecNV12 / NvDecP016::from_mapping, cudarse-video/src/dec.rs:299-393):
+// ONE allocation, coded_height luma rows at `pitch`, then the interleaved CbCr rows at the same pitch
+static int set_surface(tm_engine *e, uint32_t slot, int side, int kind, const void *base, size_t pitch, uint32_t coded_height,
+                       int matrix, int transfer, int full_range, int mem)
+{
+    int rc = check_yuv_args(matrix, transfer, full_range);
+    if (rc) return rc;
+    if (!e || !base || coded_height < e->h || coded_height > 65536) return TM_ERR_INVALID_ARG;
+    return set_frame_common(e, slot, side, kind, base, (const char *)base + pitch * (size_t)coded_height, pitch, matrix, mem, coded_height);
+}
+
+int tm_engine_set_surface_nv12(tm_engine *e, uint32_t slot, int side, const void *base, size_t pitch, uint32_t coded_height,
+                               int matrix, int transfer, int full_range, int mem)
+{
+    return set_surface(e, slot, side, TM_KIND_NV12, base, pitch, coded_height, matrix, transfer, full_range, mem);
+}
+
+int tm_engine_set_surface_p016(tm_engine *e, uint32_t slot, int side, const void *base, size_t pitch, uint32_t coded_height,
+                               int matrix, int transfer, int full_range, int mem)
+{
+    return set_surface(e, slot, side, TM_KIND_P016, base, pitch, coded_height, matrix, transfer, full_range, mem);
 }
 
 int tm_engine_set_frame_i420(tm_engine *e, uint32_t slot, int side, const void *y, const void *u, const void *v, size_t pitch_y,
@@ -803,7 +827,6 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         ssim_done = true;
     };
     const bool has_ssim_stage = (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) != 0;
-    static const int ssim_beside = getenv("TM_SSIM_BESIDE") ? atoi(getenv("TM_SSIM_BESIDE")) : 0; // experiment: the SSIM stage on the side stream behind the fused EDGE kernel
     // (the SSIM stage only needs the u8 planes of the ingest kernel and is bound by arithmetic while the blur passes are bound by
     // HBM -- but running it on a second stream beside them was measured: 7.63 k vs 7.77 k pairs/s)
     if (ssimu2) {
@@ -824,7 +847,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             for (int k = jobs.nfull; k < jobs.n; ++k) bands = std::max(bands, (g.s[jobs.scale[k]].h + 31) / 32);
             tmk::TmEdgeArgs ea;
             tmk::tm_make_edge_args(&ea, &g, &jobs, e->ef_tiles, e->ef_bands);
-            const int dbg = e->ef_dbg;
+            const int dbg = e->ef_fault;
             if (ev) HIPCHK(hipEventRecord(ev[5], fs));
             // four waves per workgroup: four adjacent bands of one plane (ef_waves 4, default: the state crosses three of four band
             // boundaries through LDS), or the same band of four planes (ef_waves 5: tuning), or single-wave workgroups (1: tuning)
@@ -837,23 +860,18 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             // about as long as they do and hides behind them -- 64 1080p pairs 4.70 ms with one workgroup per ticket, 4.54 so.
             // Alone on the chip (behind the row pass): one workgroup per ticket.
             const unsigned wgs = fs == st || e->ef_persist_wgs < 0 ? total : std::min(total, (unsigned)(e->ef_persist_wgs > 0 ? e->ef_persist_wgs : e->n_cus * 7 / 8));
-            static const int ef_repeat = getenv("TM_EF_REPEAT") ? atoi(getenv("TM_EF_REPEAT")) : 1; // experiment: the background work more than once (how much issue-bound work hides beside the passes?)
-            for (int rep = 1; rep < ef_repeat; ++rep) {
-                hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, true>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
-                hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);
-            }
             if (nw == 1) hipLaunchKernelGGL((tmk::k_blur_edge_fused<1, false>), dim3(wgs), dim3(64), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             else if (grouped) hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, true>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             else hipLaunchKernelGGL((tmk::k_blur_edge_fused<4, false>), dim3(wgs), dim3(256), 0, fs, ea, planes, groups, total, XYB, e->HS, e->d_epoch, e->d_epoch + 1, e->EROWS, e->d_status, dbg);
             hipLaunchKernelGGL(tmk::k_finish_edge, dim3((unsigned)planes), dim3(64), 0, fs, ea, e->EROWS, PART, e->d_epoch);
             if (ev) HIPCHK(hipEventRecord(ev[6], fs));
-            HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (dbg & 4 ? 8 + 6 * std::min(16384, planes * bands) : 1) * sizeof(int), hipMemcpyDeviceToHost, fs));
+            HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, sizeof(int), hipMemcpyDeviceToHost, fs));
             return TM_OK;
         };
         const bool beside = fused && e->ef_beside > 0 && !e->use_graph; // (a captured sequence stays on the engine's own stream: the side stream is shared between engines)
         if (ev) e->edge_timed = fused;
         if (beside) { HIPCHK(hipEventRecord(e->ev_fork, st)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); }
-        if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; if (has_ssim_stage && ssim_beside && !ev) launch_ssim(e->stream2); }
+        if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
@@ -920,6 +938,15 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     // The sequence is the same from batch to batch (frame pointers travel through h_desc, which the captured copy node
     // re-reads at every replay), so it is captured once into a hipGraph and replayed: one submission instead of ~10.
     // Key = everything the launch code branches on.  Profiling (events between the stages) launches directly.
+    if ((e->mask & TM_METRIC_SSIMULACRA2) && use_fused_edge(e, n)) {
+        // The hand-off tags carry 24 bits of the launch epoch, and words of planes that recent launches did not touch (fewer slots)
+        // keep their old tags: after a wrap an old tag could match a new launch's.  Whenever the epoch is back at 1 --
+        // every 2^24 - 1 fused launches -- the words are cleared first (tag 0 is never expected); on the engine's stream, in front of
+        // everything this launch enqueues or replays.
+        if (e->ef_epoch_host == 1u && e->HS) HIPCHK(hipMemsetAsync(e->HS, 0, e->hs_elems * sizeof(unsigned long long), st));
+        const unsigned next = (e->ef_epoch_host + 1u) & 0xFFFFFFu; // what k_finish_edge does on the device
+        e->ef_epoch_host = next ? next : 1u;
+    }
     int kind = e->h_desc[0].kind;
     for (int i = 1; i < 2 * n; ++i) if (e->h_desc[i].kind != kind) kind = -1;
     const long long key = ((long long)n << 40) ^ ((long long)(kind + 2) << 32) ^ ((long long)e->variant << 4) ^ (e->full_sums ? 1 : 0);
@@ -972,30 +999,6 @@ int tm_engine_sync(tm_engine *e)
         e->ev_pending = false;
     }
     if (e->in_flight) { e->in_flight = false; e->have_results = true; }
-    if (e->h_status && (e->ef_dbg & 4)) { // experiment: the schedule of the last launch
-        static int printed = 0;
-        const unsigned long long *c = (const unsigned long long *)(e->h_status + 8);
-        const int ne = e->jobs_f.n - e->jobs_f.nfull, planes = (int)e->last_n * ne;
-        int bands = 0;
-        for (int k = e->jobs_f.nfull; k < e->jobs_f.n; ++k) bands = std::max(bands, (e->g.s[e->jobs_f.scale[k]].h + 31) / 32);
-        if (c[1] && planes * bands <= 16384 && ++printed == 20) {
-            unsigned long long t0 = ~0ull, t1 = 0;
-            for (int i = 0; i < planes * bands; ++i) { if (c[3 * i] && c[3 * i] < t0) t0 = c[3 * i]; if (c[3 * i + 1] > t1) t1 = c[3 * i + 1]; }
-            fprintf(stderr, "[tm] k_blur_edge_fused: %d planes x %d bands, first start to last end %.1f us\n", planes, bands, (t1 - t0) / 100.0);
-            for (int pl : {0, planes / 2, planes - 1})
-                for (int b = 0; b < bands; ++b) {
-                    const unsigned long long *w = c + 3 * ((size_t)b * planes + pl);
-                    fprintf(stderr, "[tm]   plane %3d band %2d: start %7.1f us, ran %6.1f us, %llu cycles\n", pl, b, (w[0] - t0) / 100.0, (w[1] - w[0]) / 100.0, w[2]);
-                }
-            // concurrency over time
-            for (int t = 0; t < 24; ++t) {
-                const unsigned long long at = t0 + (t1 - t0) * t / 24;
-                int live = 0;
-                for (int i = 0; i < planes * bands; ++i) live += c[3 * i] <= at && c[3 * i + 1] > at;
-                fprintf(stderr, "[tm]   at %6.1f us: %d waves resident\n", (at - t0) / 100.0, live);
-            }
-        }
-    }
     if (e->h_status && *e->h_status) { // k_blur_edge_fused gave up waiting for the band above: the sums of this launch are not valid
         *e->h_status = 0;
         (void)hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream);
@@ -1210,6 +1213,25 @@ int tm_engine_debug_set_edge_epoch(tm_engine *e, uint32_t epoch)
     if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->d_epoch, &epoch, sizeof epoch, hipMemcpyHostToDevice));
+    e->ef_epoch_host = epoch;
+    return TM_OK;
+}
+
+int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
+{
+    if (!e) return TM_ERR_INVALID_ARG;
+    if (e->in_flight) { int rc = tm_engine_sync(e); if (rc && param != TM_DBG_EF_FAULT) return rc; }
+    switch (param) {
+    case TM_DBG_FUSED_EDGE_FROM: if (value < 0) return TM_ERR_INVALID_ARG; e->fused_edge_from = value; break;
+    case TM_DBG_EF_WAVES: if (value != 1 && value != 4 && value != 5) return TM_ERR_INVALID_ARG; e->ef_waves = (int)value; break;
+    case TM_DBG_EF_PERSIST_WGS: if (value < -1 || value > 65536) return TM_ERR_INVALID_ARG; e->ef_persist_wgs = (int)value; break;
+    case TM_DBG_PASS_PRIO: if (value < 0 || value > 1) return TM_ERR_INVALID_ARG; e->ef_pass_prio = (int)value; break;
+    case TM_DBG_SPLIT_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split_rows_below = value; e->split_rows_env = true; break;
+    case TM_DBG_SPLIT5_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split5_rows_below = value; e->split5_rows_env = true; break;
+    case TM_DBG_EF_FAULT: if (value < 0 || value > 3) return TM_ERR_INVALID_ARG; e->ef_fault = (int)value; break;
+    default: return TM_ERR_INVALID_ARG;
+    }
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values
     return TM_OK;
 }
 

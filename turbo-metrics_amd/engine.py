@@ -40,6 +40,11 @@ def init_hip(device: int = 0):
     _chk(ffi.lib().tm_init(int(device)), "tm_init")
 
 
+def set_debug_log(on: bool):
+    """tm_set_debug_log: diagnostics on stderr (what the placement search measured per candidate)"""
+    ffi.lib().tm_set_debug_log(int(bool(on)))
+
+
 def set_placement_candidates(n: int):
     """tm_set_placement_candidates: allocations of the pass-1 arena that engine creation tries (it keeps the one on which the
     column pass runs fastest); 1 = off.  Process-wide, applies to engines created afterwards."""
@@ -193,10 +198,10 @@ class TurboMetrics:
         self._keep[(slot, side)] = keep  # device pointers must outlive the compute
         L, h = self._L, self._h
         if f.kind in ("nv12", "p016"):
-            fn = L.tm_engine_set_frame_nv12 if f.kind == "nv12" else L.tm_engine_set_frame_p016
-            uv = ptr + f.pitch * f.coded_height
-            _chk(fn(h, slot, side, ptr, uv, f.pitch, int(f.matrix), int(f.transfer), int(bool(f.full_range)), mem),
-                 f"tm_engine_set_frame_{f.kind}")
+            # a decoder surface: ONE allocation, coded_height luma rows, then the CbCr rows (NvDecNV12 / NvDecP016::from_mapping)
+            fn = L.tm_engine_set_surface_nv12 if f.kind == "nv12" else L.tm_engine_set_surface_p016
+            _chk(fn(h, slot, side, ptr, f.pitch, int(f.coded_height), int(f.matrix), int(f.transfer), int(bool(f.full_range)), mem),
+                 f"tm_engine_set_surface_{f.kind}")
         else:
             shape = tuple(f.data.shape)
             if len(shape) != 3 or shape[2] != 3 or shape[0] != self.height or shape[1] != self.width:
@@ -331,6 +336,10 @@ class TurboMetrics:
     def debug_set_edge_beside(self, mode: int):
         """measurement hook: 1 = the fused kernel of the edge-only jobs beside the two blur passes (default), 0 = behind them"""
         _chk(self._L.tm_engine_debug_set_edge_beside(self._h, int(mode)), "tm_engine_debug_set_edge_beside")
+
+    def debug_set_param(self, param: int, value: int):
+        """tuning values / fault injection of this engine (ffi.TM_DBG_*; see the header)"""
+        _chk(self._L.tm_engine_debug_set_param(self._h, int(param), int(value)), "tm_engine_debug_set_param")
 
     def debug_set_edge_epoch(self, epoch: int):
         _chk(self._L.tm_engine_debug_set_edge_epoch(self._h, int(epoch)), "tm_engine_debug_set_edge_epoch")

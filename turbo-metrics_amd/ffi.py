@@ -17,6 +17,8 @@ TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_SSIM, TM_STAGE_EDGE,
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
 TM_VARIANT_DEFAULT, TM_VARIANT_REFERENCE, TM_VARIANT_WIDE_ROWS, TM_VARIANT_TILE_INGEST, TM_VARIANT_SPLIT_ROWS, TM_VARIANT_WHOLE_ROWS = 0, 1, 0x100, 0x200, 0x400, 0x800
 TM_VARIANT_TWO_PASS_EDGE, TM_VARIANT_FUSED_EDGE = 0x1000, 0x4000
+(TM_DBG_FUSED_EDGE_FROM, TM_DBG_EF_WAVES, TM_DBG_EF_PERSIST_WGS, TM_DBG_PASS_PRIO, TM_DBG_SPLIT_ROWS_BELOW, TM_DBG_SPLIT5_ROWS_BELOW,
+ TM_DBG_EF_FAULT) = range(7)
 
 
 class FrameScoresC(C.Structure):
@@ -32,11 +34,14 @@ SYMBOLS = {
     "tm_host_alloc": (_vp, [_sz]),
     "tm_host_free": (None, [_vp]),
     "tm_set_placement_candidates": (None, [_i]),
+    "tm_set_debug_log": (None, [_i]),
     "tm_engine_create": (_i, [C.POINTER(_vp), _u32, _u32, _u32, _u32]),
     "tm_engine_destroy": (None, [_vp]),
     "tm_engine_mem_usage": (_sz, [_vp]),
     "tm_engine_set_frame_nv12": (_i, [_vp, _u32, _i, _vp, _vp, _sz, _i, _i, _i, _i]),
     "tm_engine_set_frame_p016": (_i, [_vp, _u32, _i, _vp, _vp, _sz, _i, _i, _i, _i]),
+    "tm_engine_set_surface_nv12": (_i, [_vp, _u32, _i, _vp, _sz, _u32, _i, _i, _i, _i]),
+    "tm_engine_set_surface_p016": (_i, [_vp, _u32, _i, _vp, _sz, _u32, _i, _i, _i, _i]),
     "tm_engine_set_frame_i420": (_i, [_vp, _u32, _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _i, _i, _i]),
     "tm_engine_set_frame_rgb8": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
     "tm_engine_set_frame_rgb16": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
@@ -69,6 +74,7 @@ SYMBOLS = {
     "tm_engine_debug_set_ingest_rows": (_i, [_vp, _i]),
     "tm_engine_debug_set_edge_beside": (_i, [_vp, _i]),
     "tm_engine_debug_set_edge_epoch": (_i, [_vp, C.c_uint32]),
+    "tm_engine_debug_set_param": (_i, [_vp, _i, C.c_longlong]),
     "tm_engine_debug_read_plane": (_i, [_vp, _u32, _i, _i, _i, _i, C.POINTER(C.c_float), _sz]),
     "tm_strerror": (C.c_char_p, [_i]),
     "tm_last_hip_error": (C.c_char_p, []),
