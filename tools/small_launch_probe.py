@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GPU box: launches of 1 .. 16 pairs of 1080p (the reference's compute_one is ONE pair per call) under the round-4 variants of
+the two passes: column pass with a 32-row window, multi-wave row pass with a 32-row producer window, eight waves per row block.
+Per batch and configuration: wall ms per step (compute_async + sync), stage ms, pairs/s; scores must not change.
+usage: small_launch_probe.py [batches] [WxH]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from tm_pkg import tm
+F = tm.ffi
+w, h = (int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1920x1080").split("x"))
+tm.init_hip(0)
+tm.set_placement_candidates(1)
+gen = tm.synth.nv12_pair
+pairs = []
+for n in range(4):
+    (rs, rp, rch), (ds, dp, dch) = gen(w, h, n)
+    pairs.append(((torch.from_numpy(rs).cuda(), rp, rch), (torch.from_numpy(ds).cuda(), dp, dch)))
+BIG = 1 << 40
+CONFIGS = [  # name, {param: value}, graph
+    ("base", {}, False),
+    ("colw32", {F.TM_DBG_COL_WINDOW32_BELOW: BIG}, False),
+    ("w32", {F.TM_DBG_SPLIT_WINDOW: 32}, False),
+    ("colw32+w32", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32}, False),
+    ("colw32+w32+split5", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT5_ROWS_BELOW: BIG}, False),
+    ("colw32+w32+split8", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
+    ("colw32+w16+split8", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
+    ("colw32+w32+split8+graph", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, True),
+]
+for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4,6,8,12,16").split(",")]:
+    sc = None
+    for name, params, graph in CONFIGS:
+        eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B)
+        for slot in range(B):
+            (rt, rp, rch), (dt, dp, dch) = pairs[slot % 4]
+            eng.set_pair(slot, tm.HwFrame.nv12(rt, rp, rch), tm.HwFrame.nv12(dt, dp, dch))
+        for k, v in params.items():
+            eng.debug_set_param(k, v)
+        eng.set_graph(graph)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.08:
+            eng.compute_async(); eng.sync()
+        k = 300 if B <= 4 else 150
+        t0 = time.perf_counter()
+        for _ in range(k):
+            eng.compute_async(); eng.sync()
+        wall = (time.perf_counter() - t0) / k * 1e3
+        stages = None
+        if not graph:
+            eng.set_profiling(True); eng.stage_ms(reset=True)
+            for _ in range(60):
+                eng.compute_async(); eng.sync()
+            ms, n = eng.stage_ms(reset=True)
+            stages = [round(m / n, 4) for m in ms]
+            eng.set_profiling(False)
+        got = [eng.scores(i).ssimulacra2 for i in range(B)]
+        assert sc is None or sc == got, (name, B)
+        sc = got
+        print(json.dumps({"batch": B, "config": name, "wall_ms": round(wall, 4), "pairs_per_s": round(B / wall * 1e3), "fused_edge": eng.uses_fused_edge(B),
+                          "stage_ms[ingest,col,row,finish,edge]": stages}), flush=True)
+        eng.close()

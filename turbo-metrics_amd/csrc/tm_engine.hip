@@ -172,6 +172,9 @@ struct tm_engine {
     long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms)
     bool split_rows_env = false, split5_rows_env = false; // TM_DBG_SPLIT_ROWS_BELOW / TM_DBG_SPLIT5_ROWS_BELOW were set: used as they are
     long long split5_rows_below = 400; // ... and up to which that pass runs with five instead of three waves per row block
+    long long split8_rows_below = 0;  // ... and up to which it runs with eight waves (one recurrence per wave): launches of a pair or two
+    int split_window = 16;            // register window of the multi-wave row pass' producers: 16 or 32 rows
+    long long col_window32_below = 0; // column-pass workgroups per launch up to which the pass runs with a 32-row register window (22 rows of loads in flight)
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (tm_engine_debug_set_ingest_rows)
 };
 
@@ -874,6 +877,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
+        else if (vgrid.y && (long long)n * vgrid.y <= e->col_window32_below) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 32>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         if (beside && e->ef_beside != 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
@@ -887,8 +891,17 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             // five waves per row block up to a quarter of a row block per SIMD (1-2 pairs of 1080p: 0.26 vs 0.35 ms), three above (8 pairs: 0.43 vs 0.58)
             // (five waves: 3 1080p pairs = 324 blocks 0.35 -> 0.26 ms, 6 pairs = 648 blocks 0.36 -> 0.45; with the fused kernel beside, FULL jobs only: 6 pairs = 456 blocks
             // 0.45 -> 0.35, 8 pairs = 608 blocks 0.44 -> 0.40, 10 pairs = 760 blocks 0.44 -> 0.47)
-            if ((long long)n * hblocks <= (beside && !e->split5_rows_env ? 700 : e->split5_rows_below)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
-            else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
+            const bool w32 = e->split_window == 32;
+            if ((long long)n * hblocks <= e->split8_rows_below) {
+                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<8, 32>), hgrid, dim3(512), 0, st, g, jobs, XYB, V, PART);
+                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<8, 16>), hgrid, dim3(512), 0, st, g, jobs, XYB, V, PART);
+            } else if ((long long)n * hblocks <= (beside && !e->split5_rows_env ? 700 : e->split5_rows_below)) {
+                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5, 32>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
+                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5, 16>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
+            } else {
+                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3, 32>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
+                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3, 16>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
+            }
         }
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
         else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
@@ -1229,6 +1242,9 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     case TM_DBG_SPLIT_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split_rows_below = value; e->split_rows_env = true; break;
     case TM_DBG_SPLIT5_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split5_rows_below = value; e->split5_rows_env = true; break;
     case TM_DBG_EF_FAULT: if (value < 0 || value > 3) return TM_ERR_INVALID_ARG; e->ef_fault = (int)value; break;
+    case TM_DBG_SPLIT8_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split8_rows_below = value; break;
+    case TM_DBG_SPLIT_WINDOW: if (value != 16 && value != 32) return TM_ERR_INVALID_ARG; e->split_window = (int)value; break;
+    case TM_DBG_COL_WINDOW32_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->col_window32_below = value; break;
     default: return TM_ERR_INVALID_ARG;
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values

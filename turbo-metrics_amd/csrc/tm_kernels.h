@@ -1161,6 +1161,8 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
 
 // PROBE: a second instantiation of the same code for the placement probe of tm_engine_create, so that profilers list its
 // launches (cold caches, zeros) apart from the batch launches
+// W = 16 is what large launches run (bound by their write stream: a deeper window changed nothing); W = 32 (22 rows of
+// loads in flight instead of 6) is for launches that leave most of the chip idle, where a wave waits for its own loads
 template <int R, int W, int PROBE = 0>
 __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V)
 {
@@ -1484,12 +1486,18 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
 // 75 KB of LDS per workgroup -> two workgroups per CU: for launches with fewer row blocks than the chip has wave slots only
 // (the engine switches by batch size; TM_VARIANT_SPLIT_ROWS forces it).  grid (slots, jobs.hstart[n]), block 64 * NW.
 // ------------------------------------------------------------------------------------------------
-template <int NP, int NA = (NP > 0 ? NP : 1)> // NP: planes of this producer
+// WN: register window of a producer's planes, 16 or 32 rows (rows t - 10 .. t + WN - 11 in registers or in flight).  A producer's
+// step is ~20 instructions per plane, so the 6 rows of look-ahead of WN = 16 are ~0.4 us of its own time -- less than a load from
+// HBM takes on an idle chip: with few waves in flight (the launches this kernel exists for) the producers wait for their loads.
+// WN = 32 looks 22 rows ahead (the one-wave pass is different: ~180 instructions per step, 6 rows = 1.8 us, and a deeper window
+// changed nothing there).
+template <int NP, int WN = 16, int NA = (NP > 0 ? NP : 1)> // NP: planes of this producer
 __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)[16][5][64], const float *const (&v)[NA], const int (&plane)[NA],
                                                       float (*__restrict__ tile)[4][64][17], const float *__restrict__ rdn, bool fetch_rd,
                                                       int y0, int w, int h, int pitch, int pt, int nphases)
 {
-    constexpr int WN = 16, P = WN - 10;
+    static_assert(WN == 16 || WN == 32, "window: one or two phases of 16 steps");
+    constexpr int P = WN - 10, SUB = WN / 16;
     const int lane = threadIdx.x & 63;
     const int lr = lane >> 4, lc = lane & 15;
     auto ld_col = [&](const float *__restrict__ p, int x) { // column x of a transposed blurred plane, this lane's row; 0 outside
@@ -1517,25 +1525,31 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
         }
     };
     if (fetch_rd) fetch_block(0);
-    for (int ph = 0; ph < nphases; ++ph) {
-        if (fetch_rd) { // block ph (in registers since the previous phase) -> its buffer; block ph + 1 requested
+    for (int ph0 = 0; ph0 < nphases; ph0 += SUB) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[i]; tile[1][ph & 3][4 * i + lr][lc] = qb[i]; }
-            fetch_block(ph + 1);
-        }
-        if (NP > 0) {
+        for (int sub = 0; sub < SUB; ++sub) {
+            const int ph = ph0 + sub;
+            if (ph >= nphases) break; // (the same for every wave of the workgroup: they all meet at the same barriers)
+            if (fetch_rd) { // block ph (in registers since the previous phase) -> its buffer; block ph + 1 requested
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int t = 16 * ph + j; // row t lives in slot j, row t-10 in slot (j+P) % WN, which row t+P then takes over
+                for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[i]; tile[1][ph & 3][4 * i + lr][lc] = qb[i]; }
+                fetch_block(ph + 1);
+            }
+            if (NP > 0) {
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const float o = tmdev::iir_step(f[k], win[k][(j + P) % WN] + win[k][j]);
-                    win[k][(j + P) % WN] = ld_col(v[k], t + P);
-                    ring[ph & 1][j][plane[k]][lane] = o;
+                for (int j = 0; j < 16; ++j) {
+                    const int t = 16 * ph + j; // row t lives in slot t % WN = 16 sub + j (ph0 is a multiple of SUB), row t-10 in slot (. + P) % WN, which row t+P then takes over
+                    const int sl = 16 * sub + j;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const float o = tmdev::iir_step(f[k], win[k][(sl + P) % WN] + win[k][sl]);
+                        win[k][(sl + P) % WN] = ld_col(v[k], t + P);
+                        ring[ph & 1][j][plane[k]][lane] = o;
+                    }
                 }
             }
+            TM_LDS_BARRIER();
         }
-        TM_LDS_BARRIER();
     }
 }
 
@@ -1583,11 +1597,15 @@ __device__ __forceinline__ void blur_h_split_idle(int nphases)
     for (int ph = 0; ph < nphases; ++ph) TM_LDS_BARRIER();
 }
 
-template <int NW> // 3 or 5 waves per row block
+// NW = 8 (launches of a pair or two: the reference's compute_one granularity): one recurrence per wave --
+//            wave 0 sigma11   wave 1 sigma22   wave 2 sigma12 (FULL only)   wave 3 mu1   wave 4 mu2   wave 5 the ref / dis blocks
+//            wave 6 the ssim map and its two sums (FULL)   wave 7 the two edge maps and their four sums
+// the longest step body is then a consumer's (~40 instructions); 512 threads, the same 75 KB of LDS.
+template <int NW, int WN = 16> // 3, 5 or 8 waves per row block; WN: register window of the producers (16 or 32 rows)
 __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, const float *__restrict__ V,
                                                                double *__restrict__ PART)
 {
-    static_assert(NW == 3 || NW == 5, "three or five waves per row block");
+    static_assert(NW == 3 || NW == 5 || NW == 8, "three, five or eight waves per row block");
     __shared__ float ring[2][16][5][64];
     __shared__ float tile[2][4][64][17];
     const int b = blockIdx.y, slot = blockIdx.x;
@@ -1614,26 +1632,41 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 #define TM_SPLIT_TAIL y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases
     if (NW == 3) {
         if (wave == 0) { // sigma11, sigma22 (FULL) + the ref / dis blocks
-            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
-            else blur_h_split_producer<0>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
+            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
+            else blur_h_split_producer<0, WN>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
         } else if (wave == 1) { // sigma12, mu1, mu2 (FULL) / mu1, mu2 (EDGE)
-            if (full) { const float *const pv[3] = {v2, v3, v4}; const int pl[3] = {2, 3, 4}; blur_h_split_producer<3>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
-            else { const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
+            if (full) { const float *const pv[3] = {v2, v3, v4}; const int pl[3] = {2, 3, 4}; blur_h_split_producer<3, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
+            else { const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4}; blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
         } else { // all maps and sums
             if (full) { blur_h_split_consumer<3>(ring, tile, sg.w, valid, nphases, acc); mine = 3; }
             else { blur_h_split_consumer<2>(ring, tile, sg.w, valid, nphases, acc); mine = 2; }
         }
-    } else {
+    } else if (NW == 5) {
         if (wave == 0) { // sigma11, sigma22 (FULL); the ref / dis blocks of an EDGE job
-            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
-            else blur_h_split_producer<0>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
+            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
+            else blur_h_split_producer<0, WN>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
         } else if (wave == 1) { // sigma12 + the ref / dis blocks (FULL)
-            if (full) { const float *const pv[1] = {v2}; const int pl[1] = {2}; blur_h_split_producer<1>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
+            if (full) { const float *const pv[1] = {v2}; const int pl[1] = {2}; blur_h_split_producer<1, WN>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
             else blur_h_split_idle(nphases);
         } else if (wave == 2) { // mu1, mu2
             const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4};
-            blur_h_split_producer<2>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL);
+            blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL);
         } else if (wave == 3) { // the ssim map and its sums (FULL)
+            if (full) { blur_h_split_consumer<1>(ring, tile, sg.w, valid, nphases, acc); mine = 1; }
+            else blur_h_split_idle(nphases);
+        } else { // the edge maps and their sums
+            blur_h_split_consumer<2>(ring, tile, sg.w, valid, nphases, acc); mine = 2;
+        }
+    } else {
+        if (wave < 3) { // sigma11 | sigma22 | sigma12 (FULL)
+            if (full) { const float *const pv[1] = {wave == 0 ? v0 : (wave == 1 ? v1 : v2)}; const int pl[1] = {wave}; blur_h_split_producer<1, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
+            else blur_h_split_idle(nphases);
+        } else if (wave < 5) { // mu1 | mu2
+            const float *const pv[1] = {wave == 3 ? v3 : v4}; const int pl[1] = {wave};
+            blur_h_split_producer<1, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL);
+        } else if (wave == 5) { // the ref / dis blocks
+            blur_h_split_producer<0, WN>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
+        } else if (wave == 6) { // the ssim map and its sums (FULL)
             if (full) { blur_h_split_consumer<1>(ring, tile, sg.w, valid, nphases, acc); mine = 1; }
             else blur_h_split_idle(nphases);
         } else { // the edge maps and their sums
