@@ -867,7 +867,14 @@ def test_shipping_configuration_against_the_oracle(kind, w, h, batch):
         want, sums = O.ssimulacra2_from_linear(lin[0], lin[1])
         got = eng.raw_sums(slot)
         np.testing.assert_allclose(got[m], np.asarray(sums).reshape(6, 6, 3)[m], rtol=1e-12, atol=1e-300, err_msg=f"slot {slot}")
-        assert np.all(got[~m] == 0.0)  # pruned: the zero-weight sums are not computed
+        modes = eng.job_modes()  # pruned by job: a (scale, channel) image without any weight is not computed at all, an edge-only one has no ssim sums
+        for sc in range(6):
+            for c in range(3):
+                if modes[sc, c] == 0:
+                    assert np.all(got[sc, :, c] == 0.0)
+                elif modes[sc, c] == 1:
+                    assert got[sc, 0, c] == 0.0 and got[sc, 3, c] == 0.0
+        assert (modes == 1).sum() == 2 and (modes == 0).sum() >= 1
         assert abs(eng.scores(slot).ssimulacra2 - want) <= 1e-9, slot
     eng.close()
 

@@ -54,6 +54,14 @@ for rnd in range(3):
     dt = time.perf_counter() - t0
     out.setdefault("two_engines_pairs_per_s", []).append(round(B * steps / dt, 1))
     assert s0 == [s.ssimulacra2 for s in engs[1].scores_batch(B)] == [s.ssimulacra2 for s in engs[0].scores_batch(B)]
+# shaped: A's ingest beside B's row pass and the other way round (tm_engine_debug_chain)
+engs[0].debug_chain(engs[1]); engs[1].debug_chain(engs[0])
+for rnd in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); two(steps); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out.setdefault("two_engines_chained_pairs_per_s", []).append(round(B * steps / dt, 1))
+    assert s0 == [s.ssimulacra2 for s in engs[1].scores_batch(B)] == [s.ssimulacra2 for s in engs[0].scores_batch(B)]
+engs[0].debug_chain(None); engs[1].debug_chain(None)
 print(json.dumps(out), flush=True)
 for e in engs:
     e.close()

@@ -148,6 +148,8 @@ struct tm_engine {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // the fused EDGE kernel beside the two blur passes (fork after the ingest stage, join before the finisher)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_col_done = nullptr, ev_row_done = nullptr; // recorded behind the column pass / the row pass of every launch (an engine chained to this one waits for them)
+    tm_engine *chain_peer = nullptr; // tm_engine_debug_chain: this engine's ingest stage waits for the peer's column pass, its column pass for the peer's row pass
     float *LIN = nullptr, *XYB = nullptr, *XYBT = nullptr, *V = nullptr; // LIN, XYBT: reference pipeline only (TM_VARIANT_REFERENCE)
     float *V_alloc = nullptr; // the allocation behind V (V = V_alloc + an offset inside TM_V_SLACK, see tm_engine_debug_set_v_offset)
     float *LIN2 = nullptr; // level-2 linear RGB [slot][side][3 planes]: hand-off k_ingest_wave -> k_ingest_upper_rd
@@ -566,6 +568,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
     if (!(e->stream2 = side_stream_acquire(e->device))) return fail(hip_fail(hipErrorOutOfMemory, "hipStreamCreate (side stream)"));
     if ((he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
+    if ((he = hipEventCreateWithFlags(&e->ev_col_done, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_row_done, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     const size_t B = batch_capacity;
     const TmGeom &g = e->g;
     if (metrics_mask & TM_METRIC_SSIMULACRA2) { // PSNR / SSIM / MS-SSIM alone need none of the XYB machinery
@@ -632,6 +635,8 @@ void tm_engine_destroy(tm_engine *e)
     for (int i = 0; i < 7; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->ev_col_done) (void)hipEventDestroy(e->ev_col_done);
+    if (e->ev_row_done) (void)hipEventDestroy(e->ev_row_done);
     if (e->stream2) side_stream_release(e->device);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -770,6 +775,8 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
     unsigned long long *SSE = e->SSE;
     unsigned char *QU8 = e->QU8;
     const bool reference = (e->variant & TM_VARIANT_REFERENCE) != 0;
+    const bool chained = e->chain_peer != nullptr && !e->use_graph;
+    if (chained) HIPCHK(hipStreamWaitEvent(st, e->chain_peer->ev_col_done, 0)); // (an event never recorded counts as complete)
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     // ---- stage INGEST: frames -> linear RGB -> XYB pyramid
     if (reference) { // separate straight-line kernels, linear pyramid in HBM, two plain XYB pyramids [side][scale][channel]
@@ -873,6 +880,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         };
         const bool beside = fused && e->ef_beside > 0 && !e->use_graph; // (a captured sequence stays on the engine's own stream: the side stream is shared between engines)
         if (ev) e->edge_timed = fused;
+        if (chained) HIPCHK(hipStreamWaitEvent(st, e->chain_peer->ev_row_done, 0));
         if (beside) { HIPCHK(hipEventRecord(e->ev_fork, st)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); }
         if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
@@ -880,6 +888,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         else if (vgrid.y && (long long)n * vgrid.y <= e->col_window32_below) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 32>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
+        if (!e->use_graph) HIPCHK(hipEventRecord(e->ev_col_done, st));
         if (beside && e->ef_beside != 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_H: row pass + error maps + reductions
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, jobs, XYBT, V, PART);
@@ -906,6 +915,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
         else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
+        if (!e->use_graph) HIPCHK(hipEventRecord(e->ev_row_done, st));
         // ---- stage EDGE (when not beside the passes): both recurrences, the edge maps and their sums of the EDGE jobs in one kernel
         if (fused && !beside) { int rc = launch_fused(st); if (rc) return rc; }
         if (beside) { HIPCHK(hipEventRecord(e->ev_join, e->stream2)); HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0)); }
@@ -1248,6 +1258,14 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     default: return TM_ERR_INVALID_ARG;
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values
+    return TM_OK;
+}
+
+int tm_engine_debug_chain(tm_engine *e, tm_engine *peer)
+{
+    if (!e || peer == e || (peer && peer->device != e->device)) return TM_ERR_INVALID_ARG;
+    if (e->in_flight) { int rc = tm_engine_sync(e); if (rc) return rc; }
+    e->chain_peer = peer;
     return TM_OK;
 }
 

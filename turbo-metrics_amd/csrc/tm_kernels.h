@@ -1562,32 +1562,59 @@ __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__
 {
     const int lane = threadIdx.x & 63;
     const int T = w + 4;
+    // one step: the maps of column u = t - 4 and their sums.  Lanes of rows below the image accumulate too (their inputs are the
+    // clamped last row's: finite) and are zeroed at the end -- a per-step `if (valid)` put every step into its own exec-masked block,
+    // so that no LDS read of step j + 1 could be issued before the arithmetic of step j: the consumer then took ~340 cycles per step
+    // (LDS latency + ~47 instructions) and the whole workgroup waited for it at every phase barrier (SQ counters, one 1080p pair:
+    // 58 % of the wave-cycles parked; 8 waves per row block instead of 5 changed nothing).
+    // The LDS reads of a block of eight steps are issued together, in front of its arithmetic (the latency of an LDS read is then paid
+    // once per eight steps).
+    struct In { float mu1, mu2, s11, s22, s12, src, dsv; };
+    auto fetch = [&](int ph1, int j, int t) __attribute__((always_inline)) {
+        const int u = t - 4; // the column whose maps are evaluated at step t
+        const float (*r)[64] = ring[ph1 & 1][j];
+        In v;
+        v.mu1 = r[3][lane]; v.mu2 = r[4][lane];
+        v.s11 = v.s22 = v.s12 = 0.0f; v.src = v.dsv = 0.0f;
+        if (WHAT & 1) { v.s11 = r[0][lane]; v.s22 = r[1][lane]; v.s12 = r[2][lane]; }
+        if (WHAT & 2) { v.src = tile[0][(u >> 4) & 3][lane][u & 15]; v.dsv = tile[1][(u >> 4) & 3][lane][u & 15]; }
+        return v;
+    };
+    auto step = [&](const In &v) __attribute__((always_inline)) {
+        float ssim = 0.0f, art = 0.0f, det = 0.0f;
+        // error_maps evaluates all three maps; the compiler drops the half whose results are not used
+        if (WHAT & 1) tmdev::error_maps(v.src, v.dsv, v.mu1, v.mu2, v.s11, v.s22, v.s12, ssim, art, det);
+        else tmdev::edge_maps(v.src, v.dsv, v.mu1, v.mu2, art, det);
+        float q;
+        if (WHAT & 1) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
+        if (WHAT & 2) {
+            acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
+            acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
+        }
+    };
     for (int ph = 0; ph < nphases; ++ph) {
         if (ph > 0) {
+            const int tb = 16 * (ph - 1);
+            if (tb >= 4 && tb + 15 < T) { // every step of the phase emits a column (all phases but the first and the last one or two): straight-line code
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int t = 16 * (ph - 1) + j;
-                if (t >= 4 && t < T) {
-                    const int u = t - 4; // the column whose maps are evaluated now
-                    const float (*r)[64] = ring[(ph - 1) & 1][j];
-                    const float mu1 = r[3][lane], mu2 = r[4][lane];
-                    const float src = tile[0][(u >> 4) & 3][lane][u & 15], dsv = tile[1][(u >> 4) & 3][lane][u & 15];
-                    float ssim = 0.0f, art = 0.0f, det = 0.0f;
-                    // error_maps evaluates all three maps; the compiler drops the half whose results are not used
-                    if (WHAT & 1) tmdev::error_maps(src, dsv, mu1, mu2, r[0][lane], r[1][lane], r[2][lane], ssim, art, det);
-                    else tmdev::edge_maps(src, dsv, mu1, mu2, art, det);
-                    if (valid) {
-                        float q;
-                        if (WHAT & 1) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
-                        if (WHAT & 2) {
-                            acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
-                            acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
-                        }
-                    }
+                for (int j0 = 0; j0 < 16; j0 += 8) {
+                    In v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fetch(ph - 1, j0 + j, tb + j0 + j);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) step(v[j]);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (tb + j >= 4 && tb + j < T) step(fetch(ph - 1, j, tb + j));
             }
         }
         TM_LDS_BARRIER();
+    }
+    if (!valid) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = 0.0;
     }
 }
 

@@ -341,6 +341,10 @@ class TurboMetrics:
         """tuning values / fault injection of this engine (ffi.TM_DBG_*; see the header)"""
         _chk(self._L.tm_engine_debug_set_param(self._h, int(param), int(value)), "tm_engine_debug_set_param")
 
+    def debug_chain(self, peer):
+        """measurement hook: this engine's ingest waits for `peer`'s column pass, its column pass for `peer`'s row pass (None unchains)"""
+        _chk(self._L.tm_engine_debug_chain(self._h, peer._h if peer is not None else None), "tm_engine_debug_chain")
+
     def debug_set_edge_epoch(self, epoch: int):
         _chk(self._L.tm_engine_debug_set_edge_epoch(self._h, int(epoch)), "tm_engine_debug_set_edge_epoch")
 

@@ -75,6 +75,7 @@ SYMBOLS = {
     "tm_engine_debug_set_edge_beside": (_i, [_vp, _i]),
     "tm_engine_debug_set_edge_epoch": (_i, [_vp, C.c_uint32]),
     "tm_engine_debug_set_param": (_i, [_vp, _i, C.c_longlong]),
+    "tm_engine_debug_chain": (_i, [_vp, _vp]),
     "tm_engine_debug_read_plane": (_i, [_vp, _u32, _i, _i, _i, _i, C.POINTER(C.c_float), _sz]),
     "tm_strerror": (C.c_char_p, [_i]),
     "tm_last_hip_error": (C.c_char_p, []),
