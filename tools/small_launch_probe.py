@@ -17,6 +17,7 @@ for n in range(4):
     (rs, rp, rch), (ds, dp, dch) = gen(w, h, n)
     pairs.append(((torch.from_numpy(rs).cuda(), rp, rch), (torch.from_numpy(ds).cuda(), dp, dch)))
 BIG = 1 << 40
+SEL = os.environ.get("PROBE_CONFIGS")  # comma list of config names (default: all)
 CONFIGS = [  # name, {param: value}, graph
     ("base", {}, False),
     ("colw32", {F.TM_DBG_COL_WINDOW32_BELOW: BIG}, False),
@@ -25,17 +26,25 @@ CONFIGS = [  # name, {param: value}, graph
     ("colw32+w32+split5", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT5_ROWS_BELOW: BIG}, False),
     ("colw32+w32+split8", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
     ("colw32+w16+split8", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
+    ("w32+split8", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
+    ("w32+split8+forced", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG, "variant": F.TM_VARIANT_SPLIT_ROWS}, False),
+    ("whole_rows", {"variant": F.TM_VARIANT_WHOLE_ROWS}, False),
     ("colw32+w32+split8+graph", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, True),
 ]
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4,6,8,12,16").split(",")]:
     sc = None
     for name, params, graph in CONFIGS:
+        if SEL and name not in SEL.split(","):
+            continue
         eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B)
         for slot in range(B):
             (rt, rp, rch), (dt, dp, dch) = pairs[slot % 4]
             eng.set_pair(slot, tm.HwFrame.nv12(rt, rp, rch), tm.HwFrame.nv12(dt, dp, dch))
         for k, v in params.items():
-            eng.debug_set_param(k, v)
+            if k == "variant":
+                eng.set_variant(v)
+            else:
+                eng.debug_set_param(k, v)
         eng.set_graph(graph)
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.08:
