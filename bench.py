@@ -558,13 +558,37 @@ def run_cli_end_to_end(ctx):
     return out
 
 
+def effective_cpus():
+    """CPUs this process may really use: the smallest of the visible CPUs, the affinity mask and the cgroup CPU quota.  The GPU boxes
+    of this pool show 256 CPUs and allow 16 CPUs' worth of time (cpu.max = "1600000 100000"): more busy threads than that only buy
+    throttling (round 3's "all cores" figure: 256 threads delivered less than 64)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if period_file is None:
+                q, per = open(quota_file).read().split()[:2]
+            else:
+                q, per = open(quota_file).read().strip(), open(period_file).read().strip()
+            if q != "max" and int(q) > 0 and int(per) > 0:
+                n = min(n, max(1, -(-int(q) // int(per))))
+                break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(tm, w, h, kind, n_pairs):
     """CPU baselines on this host, bounded to ~15-20 s in total (reported, never the target): the restated reference CPU path
     (oracle/tm_cpu_path.c == examples/cpu.rs, single-threaded per pair like the original) after the same YUV->linear conversion
     the GPU path applies.  The frame-level parallel loop lives in the oracle library (tmo_cpu_path_run: pthreads, one pair per
     worker at a time, every worker's buffers allocated and touched once before the clock starts) -- round 3 ran Python threads around
-    ctypes calls that malloc'ed 200 MB per pair and measured the page allocator (256 threads: 8 x one core).  Points: 1 thread,
-    64 threads, one thread per host CPU; plus the GPU-arithmetic oracle on 1 thread."""
+    ctypes calls that malloc'ed 200 MB per pair.  Points: 1 thread, and one thread per CPU the process may really use
+    (effective_cpus(): the container's cgroup quota, 16 on this pool's boxes, not the 256 CPUs it can see -- more threads than the
+    quota only get the group throttled: 64 threads 33 pairs/s, 256 threads 20); plus the GPU-arithmetic oracle on 1 thread."""
     from oracle import oracle as O
     gen = tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair
     bits = 8 if kind == "nv12" else 16
@@ -580,7 +604,7 @@ def cpu_baseline(tm, w, h, kind, n_pairs):
     for _ in range(2):
         O.ssimulacra2_from_linear(lr, ld)
     dt_gpu_arith = (time.perf_counter() - t0) / 2
-    cpus = os.cpu_count() or 1
+    cpus = effective_cpus()
     per_worker = 31 * 4 * w * h  # 25 planes of workspace + two linear RGB images
     try:
         import psutil
@@ -588,18 +612,18 @@ def cpu_baseline(tm, w, h, kind, n_pairs):
     except Exception:
         cap = 64
     points = [{"cores": 1, "value": one, "pairs": n_pairs, "seconds": dt1}]
-    for threads in sorted({min(64, cpus, cap), min(cpus, cap)}):
+    for threads in sorted({min(cpus, cap)}):
         if threads <= 1:
             continue
-        k = 3 * threads  # three pairs per worker: ~1.5 s per pair at full load
+        k = 4 * threads  # four pairs per worker: ~0.5 s per pair
         dtp, _ = O.cpu_path_run(pairs, w, h, bits, k, threads)
         points.append({"cores": threads, "value": k / dtp, "pairs": k, "seconds": dtp})
     top = points[-1]
     return {"value": one, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": f"{n_pairs} {w}x{h} {kind} pairs, YUV->linear + restated reference CPU path (oracle/tm_cpu_path.c == examples/cpu.rs), 1 thread",
-            "seconds": dt1, "host_cpus": cpus,
+            "seconds": dt1, "host_cpus": os.cpu_count(), "usable_cpus": cpus,
             "all_cores": {"value": top["value"], "cores": top["cores"], "scaling_vs_1core": top["value"] / one, "efficiency": top["value"] / one / top["cores"],
-                          "sample": f"{top['pairs']} pairs over {top['cores']} pthreads (tmo_cpu_path_run: one pair per worker at a time, buffers allocated once per worker)",
+                          "sample": f"{top['pairs']} pairs over {top['cores']} pthreads = the CPUs this container may use (cgroup quota / affinity; {os.cpu_count()} visible); tmo_cpu_path_run: one pair per worker at a time, buffers allocated once per worker",
                           "seconds": top["seconds"]},
             "points": points,
             "gpu_arithmetic_oracle_1thread_pairs_per_s": 1.0 / dt_gpu_arith}
@@ -638,7 +662,7 @@ def compact_line(d):
     cb = d.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
-                               "sample": (cb.get("sample") or "")[:150], "host_cpus": cb.get("host_cpus")}
+                               "sample": (cb.get("sample") or "")[:150], "host_cpus": cb.get("host_cpus"), "usable_cpus": cb.get("usable_cpus")}
         if cb.get("all_cores"):
             out["cpu_baseline"]["all_cores"] = {k: _r(cb["all_cores"].get(k)) for k in ("value", "cores", "scaling_vs_1core", "efficiency") if k in cb["all_cores"]}
         if cb.get("points"):

@@ -69,17 +69,21 @@ int main(int argc, char **argv)
             // stdout: one description line, then one line per frame
             SourceHints h;
             uint32_t skip = 0;
+            int readahead = -1, lookahead = -1;
             for (int i = 4; i + 1 < argc; i += 2) {
                 const std::string k = argv[i];
                 const int v = atoi(argv[i + 1]);
                 if (k == "--width") h.width = v; else if (k == "--height") h.height = v; else if (k == "--bits") h.bits = v;
                 else if (k == "--cp") h.cp = v; else if (k == "--mc") h.mc = v; else if (k == "--tc") h.tc = v; else if (k == "--skip") skip = v;
+                else if (k == "--readahead") readahead = v; else if (k == "--lookahead") lookahead = v;
             }
             auto src = create_source(argv[2], h);
             const auto cc = src->color_characteristics();
             std::cout << src->format_id().str() << " " << src->width() << " " << src->height() << " " << to_string(cc.first.cp) << " "
                       << to_string(cc.first.mc) << " " << to_string(cc.first.tc) << " " << to_string(cc.second) << " " << src->frame_count() << "\n";
             std::ofstream out(argv[3], std::ios::binary);
+            if (readahead >= 0) src->set_readahead(readahead != 0);
+            if (lookahead >= 0) src->set_lookahead((size_t)lookahead);
             src->skip_frames(skip);
             HwFrame f;
             while (src->next_frame(f)) {

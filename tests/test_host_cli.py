@@ -280,6 +280,34 @@ def test_y4m_pictures_reach_the_engine_as_planar_frames(helper, tmp_path, w, h, 
         assert np.array_equal(np.fromfile(outp, np.uint8), data)
 
 
+@pytest.mark.parametrize("w,h,bits,frames", [(322, 271, 8, 41), (1920, 1080, 10, 9)])
+def test_read_ahead_delivers_the_stream_in_order_through_a_small_ring(helper, tmp_path, w, h, bits, frames):
+    """regular files are read AHEAD of the next_frame calls by a pool of readers (pieces of 2 MB: the 1080p 10-bit picture is three)
+    into a ring of lookahead + 1 + ahead surfaces: more pictures than ring slots, every picture's bytes in stream order, the same
+    as the synchronous reader; a stream cut in the middle of picture N delivers N pictures and then fails like the synchronous one"""
+    rng = np.random.default_rng(7)
+    bps, cw, ch = (1 if bits == 8 else 2), (w + 1) // 2, (h + 1) // 2
+    pics = []
+    for n in range(frames):
+        hi = 256 if bits == 8 else 1024
+        pics.append([rng.integers(0, hi, (h, w), dtype=np.uint16), rng.integers(0, hi, (ch, cw), dtype=np.uint16), rng.integers(0, hi, (ch, cw), dtype=np.uint16)])
+    p = str(tmp_path / "v.y4m")
+    write_y4m(p, pics, w, h, bits)
+    want = b"".join(b"".join(pl.astype(np.uint8 if bits == 8 else "<u2").tobytes() for pl in pr) for pr in pics)
+    for extra in (("--readahead", 1), ("--readahead", 0), ("--readahead", 1, "--lookahead", 4), ("--readahead", 1, "--skip", 3)):
+        head, fr, data = read_dump(helper, p, str(tmp_path / "o.bin"), *extra)
+        skip = 3 if "--skip" in extra else 0
+        assert len(fr) == frames - skip and data.tobytes() == want[skip * len(want) // frames:], extra
+    per = len(want) // frames
+    cut = str(tmp_path / "cut.y4m")
+    blob = open(p, "rb").read()
+    open(cut, "wb").write(blob[: len(blob) - per // 2])  # the last picture is incomplete
+    outs = [run(helper, "source", cut, str(tmp_path / f"c{i}.bin"), "--readahead", i) for i in (0, 1)]
+    for o in outs:
+        assert o.strip().split("\n")[-1].startswith("ERROR: truncated picture") and len(o.strip().split("\n")) == 1 + (frames - 1) + 1, o[-300:]
+    assert np.array_equal(np.fromfile(str(tmp_path / "c0.bin"), np.uint8), np.fromfile(str(tmp_path / "c1.bin"), np.uint8))
+
+
 def test_y4m_rejects_what_the_reference_cannot_represent(helper, tmp_path):
     p = str(tmp_path / "v.y4m")
     open(p, "wb").write(b"YUV4MPEG2 W64 H64 F30:1 Ip A1:1 C444\nFRAME\n" + bytes(64 * 64 * 3))

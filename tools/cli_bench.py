@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from tm_pkg import tm
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=0, help="pairs per clip (0 = 1536 at 1080p, 256 at 4K: long enough that ring page-locking and first-touch of the mapping stop dominating)"); ap.add_argument("--size", default="1080p"); ap.add_argument("--dir", default="/tmp")
+ap.add_argument("--frames", type=int, default=0, help="pairs per clip (0 = 1536 at 1080p, 256 at 4K: long enough that ring page-locking and first-touch of the mapping stop dominating)"); ap.add_argument("--size", default="1080p"); ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
 a = ap.parse_args()
 w, h, bits = (1920, 1080, 8) if a.size == "1080p" else (3840, 2160, 10)
 if a.frames <= 0:
@@ -23,9 +23,12 @@ for side, p in enumerate(paths):
         for i in range(a.frames):
             f.write(blobs[i % distinct])
 print("files:", [round(os.path.getsize(p) / 1e6) for p in paths], "MB", flush=True)
-for extra in (["--batch", "1", "--no-pipeline"], ["--batch", "8"], ["--batch", "16"], ["--batch", "32"], ["--batch", "64"], ["--batch", "32", "-m", "psnr", "-m", "msssim"]):
+for extra, env in (([], {}), ([], {}), (["--batch", "1", "--no-pipeline"], {}), (["--batch", "4"], {}), (["--batch", "8"], {}), (["--batch", "16"], {}), (["--batch", "32"], {}),
+                   ([], {"TM_READER_THREADS": "2"}), ([], {"TM_READER_THREADS": "4"}), ([], {"TM_READER_THREADS": "7"}), ([], {"TM_READER_THREADS": "12"}), ([], {"TM_READER_THREADS": "16"}),
+                   (["-m", "psnr", "-m", "msssim"], {})):
     t0 = time.time()
-    r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True)
+    r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, env={**os.environ, **env})
+    extra = extra + [f"{k}={v}" for k, v in env.items()] or ["(defaults)"]
     dt = time.time() - t0
     line = [l for l in r.stderr.split("\n") if "Processed" in l]
     print(" ".join(extra), "| rc", r.returncode, "| wall %.2fs |" % dt, line[0].strip() if line else r.stderr[-300:], flush=True)

@@ -160,6 +160,8 @@ struct tm_engine {
     unsigned long long *h_sse = nullptr;
     float *d_lut = nullptr, *d_coef = nullptr;
     double *d_powtab = nullptr;
+    std::vector<hipEvent_t> up_ev;    // upload fences (tm_engine_upload_fence): a small ring of events on the engine's stream
+    uint64_t up_next = 0;             // tokens handed out so far (token t lives in up_ev[t % size] until token t + size is taken)
     std::vector<void *> staging;      // [slot*2+side], lazily allocated
     std::vector<size_t> staging_size;
     size_t mem_bytes = 0;
@@ -635,6 +637,7 @@ void tm_engine_destroy(tm_engine *e)
     if (e->h_sums) (void)hipHostFree(e->h_sums);
     if (e->h_sse) (void)hipHostFree(e->h_sse);
     for (int i = 0; i < 7; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (hipEvent_t ev : e->up_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_col_done) (void)hipEventDestroy(e->ev_col_done);
@@ -708,6 +711,45 @@ int tm_engine_set_frame_rgbf32(tm_engine *e, uint32_t slot, int side, const void
 int tm_engine_set_frame_linear_f32(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
 {
     return set_frame_common(e, slot, side, TM_KIND_LINEARF32, rgb, nullptr, pitch, 0, mem);
+}
+
+// ---- upload fences: when may a page-locked host frame be overwritten? --------------------------------------------------------
+// A TM_MEM_HOST_PINNED frame is pulled by an asynchronous DMA into an engine-owned device surface; the host bytes are free again
+// when THAT copy is done, long before the batch it belongs to has been computed.  A fence marks "every upload enqueued so far".
+#define TM_UPLOAD_FENCES 256
+int tm_engine_upload_fence(tm_engine *e, uint64_t *token)
+{
+    if (!e || !token) return TM_ERR_INVALID_ARG;
+    TM_BIND(e);
+    if (e->up_ev.empty()) {
+        e->up_ev.assign(TM_UPLOAD_FENCES, nullptr);
+        for (hipEvent_t &ev : e->up_ev)
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventCreate");
+    }
+    HIPCHK(hipEventRecord(e->up_ev[e->up_next % TM_UPLOAD_FENCES], e->stream));
+    *token = e->up_next++;
+    return TM_OK;
+}
+
+// 1: every upload enqueued before the fence has left host memory; 0: not yet (block = 0) -- with block != 0 the call waits for it.
+// A token older than the last TM_UPLOAD_FENCES fences counts as done (its event has been reused by a later fence on the same
+// in-order stream).  < 0: error (the negated TM_* code).
+int tm_engine_upload_done(tm_engine *e, uint64_t token, int block)
+{
+    if (!e || token >= e->up_next) return -TM_ERR_INVALID_ARG;
+    if (e->up_next - token > TM_UPLOAD_FENCES) return 1;
+    if (hipSetDevice(e->device) != hipSuccess) { (void)hip_fail(hipGetLastError(), "hipSetDevice"); return -TM_ERR_HIP; }
+    hipEvent_t ev = e->up_ev[token % TM_UPLOAD_FENCES];
+    if (block) {
+        const hipError_t r = hipEventSynchronize(ev);
+        if (r != hipSuccess) { (void)hip_fail(r, "hipEventSynchronize"); return -TM_ERR_HIP; }
+        return 1;
+    }
+    const hipError_t r = hipEventQuery(ev);
+    if (r == hipSuccess) return 1;
+    if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    (void)hip_fail(r, "hipEventQuery");
+    return -TM_ERR_HIP;
 }
 
 int tm_engine_set_profiling(tm_engine *e, int on)

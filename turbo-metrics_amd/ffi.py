@@ -47,6 +47,8 @@ SYMBOLS = {
     "tm_engine_set_frame_rgb16": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
     "tm_engine_set_frame_rgbf32": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
     "tm_engine_set_frame_linear_f32": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
+    "tm_engine_upload_fence": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "tm_engine_upload_done": (_i, [_vp, C.c_uint64, _i]),
     "tm_engine_compute_async": (_i, [_vp, _u32]),
     "tm_engine_sync": (_i, [_vp]),
     "tm_engine_get_scores": (_i, [_vp, _u32, C.POINTER(FrameScoresC)]),

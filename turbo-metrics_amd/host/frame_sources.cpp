@@ -10,9 +10,14 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <fstream>
 #include <sstream>
+
+#include <sched.h>
 
 namespace tm_host {
 
@@ -263,7 +268,55 @@ bool ImageFrameSource::next_frame(HwFrame &out)
     return true;
 }
 
+// pread the whole range or fail
+static void pread_all(int fd, unsigned char *dst, size_t n, size_t off)
+{
+    while (n > 0) {
+        const ssize_t got = pread(fd, dst, n, (off_t)off);
+        if (got < 0) { if (errno == EINTR) continue; fail(std::string("read error: ") + strerror(errno)); }
+        if (got == 0) fail("truncated picture in the YUV stream");
+        dst += got; off += (size_t)got; n -= (size_t)got;
+    }
+}
+
+unsigned effective_cpus()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    // cgroup v2: "max 100000" or "<quota> <period>"; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us (-1 = no limit)
+    long long quota = -1, period = 0;
+    {
+        std::ifstream f("/sys/fs/cgroup/cpu.max");
+        std::string q;
+        if (f >> q >> period && q != "max") quota = atoll(q.c_str());
+    }
+    if (quota <= 0) {
+        std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+        if (!(fq >> quota) || !(fp >> period)) quota = -1;
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return n;
+}
+
 // ---- planar 4:2:0 streams ---------------------------------------------------------------------------------------------
+struct YuvStreamSource::ReadAhead {
+    struct Piece { size_t pic, off, len; unsigned char *dst; };
+    std::vector<std::thread> pool;
+    std::thread dispatcher;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done, cv_room;
+    std::deque<Piece> q;
+    std::vector<unsigned> left;   // [slot]: pieces of the picture in it that are still being read
+    std::vector<size_t> pic_of;   // [slot]: the picture the slot holds or is being filled with (SIZE_MAX: none yet)
+    size_t ahead = 1;
+    size_t entered = 0;           // next_frame calls started so far
+    size_t eof_pic = SIZE_MAX;    // index of the first picture that does not exist
+    size_t err_pic = SIZE_MAX;    // first picture that could not be read (err: why); pictures before it are still delivered
+    std::exception_ptr err;
+    std::atomic<bool> quit{false};
+};
+
 YuvStreamSource::YuvStreamSource(FILE *in, bool y4m, uint32_t w, uint32_t h, int bits, ColorCharacteristics cc, ColorRange cr,
                                  size_t frame_count, std::string codec)
     : in_(in), y4m_(y4m), w_(w), h_(h), bits_(bits), cc_(cc), cr_(cr), frame_count_(frame_count), codec_(std::move(codec))
@@ -346,14 +399,30 @@ void RowWorkers::run(size_t total, const std::function<void(size_t, size_t)> &fn
 
 YuvStreamSource::~YuvStreamSource()
 {
+    stop_readahead();
     if (ring_alloc_.joinable()) ring_alloc_.join();
     workers_.reset();
     if (in_ && in_ != stdin) fclose(in_);
-    for (unsigned char *p : ring_) {
-        if (!p) continue;
-        if (ring_pinned_) tm_host_free(p);
-        else free(p);
+    for (size_t i = 0; i < ring_.size(); ++i) {
+        if (!ring_[i]) continue;
+        if (ring_pinned_[i]) tm_host_free(ring_[i]);
+        else free(ring_[i]);
     }
+}
+
+void YuvStreamSource::stop_readahead()
+{
+    if (!ra_) return;
+    {
+        std::lock_guard<std::mutex> g(ra_->m);
+        ra_->quit = true;
+    }
+    ra_->cv_job.notify_all(); ra_->cv_room.notify_all(); ra_->cv_done.notify_all();
+    { std::lock_guard<std::mutex> g(ring_m_); } // (the dispatcher may be waiting for a ring slot: it looks at quit under this lock)
+    ring_cv_.notify_all();
+    if (ra_->dispatcher.joinable()) ra_->dispatcher.join();
+    for (auto &t : ra_->pool) t.join();
+    ra_.reset();
 }
 
 void YuvStreamSource::set_prefix(std::vector<unsigned char> bytes)
@@ -383,12 +452,27 @@ void YuvStreamSource::set_lookahead(size_t frames)
 void YuvStreamSource::ensure_ring()
 {
     if (!ring_.empty()) return;
-    const size_t n = lookahead_ + 1;
+    // reader threads per stream (the reference and the distorted stream are read at the same time): what the process may really use
+    // (effective_cpus: hardware threads, affinity mask, cgroup quota) less two for the main thread and the HIP runtime, halved; one
+    // thread per 384 KB of picture at most (3 MB at 1080p, 25 MB at 4K 10-bit), at most 16.  TM_READER_THREADS overrides; 1 = serial.
+    // Measured on a host of 256 hardware threads (rounds 2-3): 1080p 4.97 k pairs/s with 8 threads per stream, 4.45 k with 16; 4K
+    // 10-bit 640 / 822 / 536 pairs/s with 8 / 16 / 32 -- that host's container is limited to 16 CPUs of time, which is where the
+    // optimum and its instability from box to box came from.
+    const char *env = getenv("TM_READER_THREADS");
+    const unsigned cpus = effective_cpus();
+    const unsigned by_size = (unsigned)std::min<size_t>(16, std::max<size_t>(2, planar_bytes_ / (384u << 10)));
+    const unsigned want = env ? (unsigned)std::max(1, atoi(env)) : std::min(by_size, std::max(1u, (cpus > 2 ? cpus - 2 : 1) / 2));
+    const bool ra = readahead_ && fd_ >= 0 && h_ >= 64;
+    // read-ahead: enough pictures in flight to keep `want` readers busy with pieces of ~2 MB, at most 256 MB of them
+    const size_t pieces = std::max<size_t>(1, (planar_bytes_ + ((size_t)2 << 20) - 1) / ((size_t)2 << 20));
+    const size_t ahead = ra ? std::max<size_t>(2, std::min<size_t>((2 * want + pieces - 1) / pieces, std::max<size_t>(2, ((size_t)256 << 20) / planar_bytes_))) : 0;
+    const size_t n = lookahead_ + 1 + ahead;
     ring_.assign(n, nullptr);
-    // slot 0 here (it decides pinned / pageable for the whole ring: the engine copies pageable surfaces synchronously) ...
+    ring_pinned_.assign(n, 0);
+    // slot 0 here ...
     ring_[0] = (unsigned char *)tm_host_alloc(planar_bytes_);
-    ring_pinned_ = ring_[0] != nullptr;
-    if (!ring_pinned_) {
+    ring_pinned_[0] = ring_[0] != nullptr;
+    if (!ring_pinned_[0]) { // no page-locked memory at all: the whole ring is plain memory (the engine then copies synchronously)
         for (size_t i = 0; i < n; ++i) {
             ring_[i] = (unsigned char *)calloc(1, planar_bytes_);
             if (!ring_[i]) fail("out of memory for the frame ring");
@@ -396,35 +480,113 @@ void YuvStreamSource::ensure_ring()
         ring_ready_ = n;
     } else {
         ring_ready_ = 1;
-        // ... the others on a helper thread, in the order the reader will want them
+        // ... the others on a helper thread, in the order the readers will want them.  When page-locking fails part of the way
+        // (the page-lock limit: 4K 10-bit rings at a large --batch), the REST of the ring is plain memory -- a frame says per slot
+        // whether it is page-locked (HwFrame::pinned), and a pageable frame is copied synchronously by the engine
         ring_alloc_ = std::thread([this, n] {
+            bool pinned = true;
             for (size_t i = 1; i < n; ++i) {
-                unsigned char *p = (unsigned char *)tm_host_alloc(planar_bytes_);
+                unsigned char *p = pinned ? (unsigned char *)tm_host_alloc(planar_bytes_) : nullptr;
+                if (!p) { pinned = false; p = (unsigned char *)calloc(1, planar_bytes_); }
                 std::lock_guard<std::mutex> g(ring_m_);
-                if (!p) { ring_failed_ = true; ring_cv_.notify_all(); return; }
+                if (!p) { ring_failed_ = true; ring_cv_.notify_all(); return; } // out of plain memory too
                 ring_[i] = p;
+                ring_pinned_[i] = pinned;
                 ring_ready_ = i + 1;
                 ring_cv_.notify_all();
             }
         });
     }
-    // workers + the reader itself per stream for pictures worth splitting: an eighth of the host's threads, 2 .. 16
-    // (TM_READER_THREADS overrides; 1 keeps it serial): pread from the page cache moves 2-4 GB/s per thread
-    const char *env = getenv("TM_READER_THREADS");
-    const unsigned hw = std::thread::hardware_concurrency();
-    // measured on a 256-thread host (two streams reading at once): 1080p 8-bit (3 MB pictures) 4.97 k pairs/s with 8 threads per
-    // stream, 4.45 k with 16; 4K 10-bit (25 MB) 640 / 822 / 536 pairs/s with 8 / 16 / 32 -> one thread per 384 KB, at most 16
-    const unsigned by_size = (unsigned)std::min<size_t>(16, std::max<size_t>(2, planar_bytes_ / (384u << 10)));
-    const unsigned want = env ? (unsigned)atoi(env) : std::min(by_size, std::max(2u, hw / 4));
-    if (h_ >= 256 && want > 1) workers_ = std::make_unique<RowWorkers>(std::min(want, 32u) - 1);
+    if (ra) start_readahead(want, ahead);
+    else if (h_ >= 256 && want > 1 && fd_ >= 0) workers_ = std::make_unique<RowWorkers>(std::min(want, 32u) - 1);
 }
 
 unsigned char *YuvStreamSource::ring_slot(size_t i)
 {
     std::unique_lock<std::mutex> lk(ring_m_);
-    ring_cv_.wait(lk, [&] { return ring_ready_ > i || ring_failed_; });
-    if (ring_ready_ <= i) fail("out of page-locked memory for the frame ring");
+    ring_cv_.wait(lk, [&] { return ring_ready_ > i || ring_failed_ || (ra_ && ra_->quit); });
+    if (ring_ready_ <= i) fail("out of memory for the frame ring");
     return ring_[i];
+}
+
+// the FRAME line of a Y4M picture at file_pos_ (regular files); false at the end of the stream; throws on a malformed header
+bool YuvStreamSource::parse_frame_header()
+{
+    if (file_pos_ >= file_size_) return false;
+    if (y4m_) {
+        unsigned char head[256];
+        const size_t n = std::min<size_t>(file_size_ - file_pos_, sizeof head);
+        pread_all(fd_, head, n, file_pos_);
+        if (n < 6 || memcmp(head, "FRAME", 5)) fail("Y4M: expected a FRAME header");
+        const void *nl = memchr(head, '\n', n);
+        if (!nl) fail("Y4M: truncated FRAME header");
+        file_pos_ += (size_t)((const unsigned char *)nl - head) + 1;
+    }
+    if (file_size_ - file_pos_ < planar_bytes_) {
+        if (!y4m_) return false; // a trailing partial picture of a raw stream is ignored
+        fail("truncated picture in the YUV stream");
+    }
+    return true;
+}
+
+void YuvStreamSource::start_readahead(unsigned threads, size_t ahead)
+{
+    ra_ = std::make_unique<ReadAhead>();
+    ReadAhead &R = *ra_;
+    R.ahead = ahead;
+    R.left.assign(ring_.size(), 0);
+    R.pic_of.assign(ring_.size(), SIZE_MAX);
+    const size_t piece = (size_t)2 << 20;
+    R.dispatcher = std::thread([this, &R, piece] {
+        for (size_t p = 0;; ++p) {
+            {
+                std::unique_lock<std::mutex> lk(R.m);
+                R.cv_room.wait(lk, [&] { return R.quit || p < R.entered + R.ahead; });
+                if (R.quit) return;
+            }
+            const size_t slot = p % ring_.size();
+            unsigned char *dst = nullptr;
+            size_t at = 0;
+            bool more = false;
+            std::exception_ptr ex;
+            try {
+                dst = ring_slot(slot);
+                more = parse_frame_header();
+                at = file_pos_;
+                if (more) file_pos_ += planar_bytes_;
+            } catch (...) { ex = std::current_exception(); }
+            std::lock_guard<std::mutex> g(R.m);
+            if (R.quit) return;
+            if (ex) { if (p < R.err_pic) { R.err_pic = p; R.err = ex; } R.cv_done.notify_all(); return; }
+            if (!more) { R.eof_pic = p; R.cv_done.notify_all(); return; }
+            const size_t npieces = (planar_bytes_ + piece - 1) / piece;
+            R.pic_of[slot] = p;
+            R.left[slot] = (unsigned)npieces;
+            for (size_t i = 0; i < npieces; ++i) {
+                const size_t first = i * piece, len = std::min(piece, planar_bytes_ - first);
+                R.q.push_back(ReadAhead::Piece{p, at + first, len, dst + first});
+            }
+            R.cv_job.notify_all();
+        }
+    });
+    for (unsigned t = 0; t < std::max(1u, threads); ++t)
+        R.pool.emplace_back([this, &R] {
+            for (;;) {
+                ReadAhead::Piece pc;
+                {
+                    std::unique_lock<std::mutex> lk(R.m);
+                    R.cv_job.wait(lk, [&] { return R.quit || !R.q.empty(); });
+                    if (R.quit) return;
+                    pc = R.q.front();
+                    R.q.pop_front();
+                }
+                std::exception_ptr ex;
+                try { pread_all(fd_, pc.dst, pc.len, pc.off); } catch (...) { ex = std::current_exception(); }
+                std::lock_guard<std::mutex> g(R.m);
+                if (ex && pc.pic < R.err_pic) { R.err_pic = pc.pic; R.err = ex; }
+                if (--R.left[pc.pic % ring_.size()] == 0 || ex) R.cv_done.notify_all();
+            }
+        });
 }
 
 FormatIdentifier YuvStreamSource::format_id() const
@@ -432,35 +594,11 @@ FormatIdentifier YuvStreamSource::format_id() const
     return FormatIdentifier{y4m_ ? std::optional<std::string>("Y4M") : std::nullopt, codec_, "turbo-metrics-hip"};
 }
 
-// pread the whole range or fail
-static void pread_all(int fd, unsigned char *dst, size_t n, size_t off)
-{
-    while (n > 0) {
-        const ssize_t got = pread(fd, dst, n, (off_t)off);
-        if (got < 0) { if (errno == EINTR) continue; fail(std::string("read error: ") + strerror(errno)); }
-        if (got == 0) fail("truncated picture in the YUV stream");
-        dst += got; off += (size_t)got; n -= (size_t)got;
-    }
-}
-
 // next picture -> `surface` (planar_bytes_ bytes: Y, Cb, Cr planes back to back, as in the stream); nullptr: consume it only
 bool YuvStreamSource::read_picture(unsigned char *surface)
 {
     if (fd_ >= 0) { // regular file: positioned reads, split over the workers
-        if (file_pos_ >= file_size_) return false;
-        if (y4m_) {
-            unsigned char head[256];
-            const size_t n = std::min<size_t>(file_size_ - file_pos_, sizeof head);
-            pread_all(fd_, head, n, file_pos_);
-            if (n < 6 || memcmp(head, "FRAME", 5)) fail("Y4M: expected a FRAME header");
-            const void *nl = memchr(head, '\n', n);
-            if (!nl) fail("Y4M: truncated FRAME header");
-            file_pos_ += (size_t)((const unsigned char *)nl - head) + 1;
-        }
-        if (file_size_ - file_pos_ < planar_bytes_) {
-            if (!y4m_) return false; // a trailing partial picture of a raw stream is ignored
-            fail("truncated picture in the YUV stream");
-        }
+        if (!parse_frame_header()) return false;
         const size_t at = file_pos_;
         file_pos_ += planar_bytes_;
         if (!surface) return true;
@@ -493,6 +631,12 @@ bool YuvStreamSource::read_picture(unsigned char *surface)
     return true;
 }
 
+bool YuvStreamSource::skip_one()
+{
+    if (ra_) { HwFrame f; return next_frame(f); }
+    return read_picture(nullptr);
+}
+
 void YuvStreamSource::skip_frames(uint32_t n)
 {
     for (uint32_t i = 0; i < n; ++i)
@@ -502,9 +646,25 @@ void YuvStreamSource::skip_frames(uint32_t n)
 bool YuvStreamSource::next_frame(HwFrame &out)
 {
     ensure_ring();
-    unsigned char *surface = ring_slot(ring_pos_);
-    if (!read_picture(surface)) return false;
-    ring_pos_ = (ring_pos_ + 1) % ring_.size();
+    unsigned char *surface = nullptr;
+    size_t slot = ring_pos_;
+    if (ra_) { // the picture is (being) read by the pool: wait for it
+        ReadAhead &R = *ra_;
+        std::unique_lock<std::mutex> lk(R.m);
+        const size_t k = R.entered; // this call's picture
+        slot = k % ring_.size();
+        R.entered = k + 1;
+        R.cv_room.notify_all();
+        R.cv_done.wait(lk, [&] { return (R.pic_of[slot] == k && R.left[slot] == 0) || R.eof_pic <= k || R.err_pic <= k; });
+        if (R.err_pic <= k) std::rethrow_exception(R.err);
+        if (R.eof_pic <= k) return false;
+        lk.unlock();
+        surface = ring_slot(slot);
+    } else {
+        surface = ring_slot(slot);
+        if (!read_picture(surface)) return false;
+        ring_pos_ = (ring_pos_ + 1) % ring_.size();
+    }
     const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
     out = HwFrame{};
     out.kind = HwFrame::Planar420;
@@ -514,7 +674,7 @@ bool YuvStreamSource::next_frame(HwFrame &out)
     out.pitch = (size_t)w_ * bps;
     out.pitch_uv = cw * bps;
     out.bits = bits_;
-    out.pinned = ring_pinned_;
+    out.pinned = ring_pinned_[slot] != 0;
     return true;
 }
 

@@ -48,7 +48,7 @@ void usage(std::ostream &os)
           "      --skip-dis <SKIP_DIS>  Index of the first distorted frame, additive with `skip` [default: 0]\n"
           "      --frames <FRAMES>      Amount of frames to compute [default: 0]\n"
           "      --output <OUTPUT>      stdout format [possible values: default, json, json-lines, csv]\n"
-          "      --batch <N>            frame pairs per GPU launch [default: 8]\n"
+          "      --batch <N>            frame pairs per GPU launch [default: by picture size, 16 at 1080p, 4 at 4K]\n"
           "      --device <N>           GPU ordinal [default: 0]\n"
           "      --devices <N>          shard the frame pairs of two regular files over N GPUs (0 = all visible) [default: 1]\n"
           "      --no-pipeline          do not overlap reading/upload of the next batch with the current one\n"
@@ -92,6 +92,19 @@ void log_source(const char *target, const FrameSource &src)
 
 } // namespace
 
+// --batch not given: about 32 Mpx per launch, 2 .. 32 pairs (16 at 1080p, 4 at 4K, 32 at 720p and below).  Host-fed streams are
+// bound by the file reads and PCIe long before the engine (1080p: ~7.5 k pairs/s over PCIe against 12.7 k pairs/s of the engine at 16
+// pairs per launch; 4K: 1.1 k against 3.0 k at 4), and since round 4 the page-locked frame rings no longer grow with the batch
+// (upload fences), so the batch only has to be large enough for the kernels and small enough for the engines' memory
+// (two engines x batch x 0.24 GB at 1080p, x 0.95 GB at 4K).
+static uint32_t auto_batch(uint32_t w, uint32_t h)
+{
+    const double mpx = (double)w * (double)h / 1e6;
+    uint32_t b = 32;
+    while (b > 2 && (double)b * mpx > 36.0) b /= 2;
+    return b;
+}
+
 int main(int argc, char **argv)
 {
     if (const char *env = getenv("RUST_LOG")) {
@@ -104,7 +117,7 @@ int main(int argc, char **argv)
     Options opts;
     Output output = Output::Default;
     SourceHints hints;
-    uint32_t batch = 8, device = 0, devices = 1;
+    uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1;
     bool pipeline = true, full_sums = false;
 
     auto bad = [&](const std::string &m) {
@@ -231,6 +244,7 @@ int main(int argc, char **argv)
             log_source("reference", *source_ref);
             log_source("distorted", *source_dis);
             const uint32_t w = source_ref->width(), h = source_ref->height();
+            if (batch == 0) batch = auto_batch(w, h);
             source_ref.reset(); source_dis.reset(); // every shard opens its own
             if (known < 20000) tm_set_placement_candidates(1); // as below: the search pays off on long streams only
             struct Shard { std::vector<FrameScores> scores; uint32_t decoded = 0; std::string err; };
@@ -289,6 +303,7 @@ int main(int argc, char **argv)
         if (metrics.mask() == 0) throw std::runtime_error("no metric selected (-m psnr|ssim|msssim|ssimulacra2)");
         // a source that knows its length never needs more slots than it has pairs (a single image pair: one slot, one engine)
         const size_t known = std::min(source_ref->frame_count(), source_dis->frame_count());
+        if (batch == 0) batch = auto_batch(source_ref->width(), source_ref->height());
         if (known > 0 && known <= batch) { batch = (uint32_t)known; pipeline = false; }
         // the placement search of tm_engine_create (~10 ms per candidate and engine) pays off on long streams only
         if (known > 0 && known < 20000) tm_set_placement_candidates(1);

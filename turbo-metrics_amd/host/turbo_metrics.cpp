@@ -239,9 +239,19 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
 
     uint32_t decode_count = opts.decode_start;
     size_t compute_count = 0;
-    // a pinned frame is read by DMA until its batch has synced: with two engines that is up to 2 * batch frames later
-    frames_ref.set_lookahead((size_t)batch_ * (eng_[1] ? 2 : 1) + 1);
-    frames_dis.set_lookahead((size_t)batch_ * (eng_[1] ? 2 : 1) + 1);
+    // A page-locked frame is pulled into an engine-owned device surface by an asynchronous DMA; its bytes are free again when THAT
+    // copy is done (tm_engine_upload_fence / tm_engine_upload_done), not when its batch has been computed: a frame has to survive
+    // only UPLOADS_IN_FLIGHT further next_frame calls, whatever the batch size -- the sources' rings of page-locked surfaces stay
+    // small (round 3: 2 * batch + 1 surfaces per stream; page-locking them, at ~3 GB/s, was most of a short 4K run and the reason
+    // why --batch 16 was slower than --batch 8)
+    constexpr size_t UPLOADS_IN_FLIGHT = 4;
+    frames_ref.set_lookahead(UPLOADS_IN_FLIGHT);
+    frames_dis.set_lookahead(UPLOADS_IN_FLIGHT);
+    frames_ref.set_readahead(opts.every <= 1); // dropped pictures are consumed without being read: no reading ahead then
+    frames_dis.set_readahead(opts.every <= 1);
+    struct Fence { tm_engine *e = nullptr; uint64_t token = 0; };
+    Fence fences[UPLOADS_IN_FLIGHT + 1];
+    size_t kept = 0; // pairs handed to an engine so far
     frames_ref.skip_frames(opts.skip_ref + opts.skip + opts.decode_start);
     frames_dis.skip_frames(opts.skip_dis + opts.skip + opts.decode_start);
 
@@ -315,6 +325,11 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     };
     for (;;) {
         const bool dropped = opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0; // lib.rs:391-394
+        if (!dropped && kept > UPLOADS_IN_FLIGHT) { // the call below may overwrite the surfaces of pair kept - UPLOADS_IN_FLIGHT - 1
+            const Fence &f = fences[(kept - UPLOADS_IN_FLIGHT - 1) % (UPLOADS_IN_FLIGHT + 1)];
+            const int r = tm_engine_upload_done(f.e, f.token, 1);
+            if (r < 0) chk(-r, "tm_engine_upload_done");
+        }
         if (!next_pair(!dropped)) break;
         if (dropped) {
             ++decode_count;
@@ -324,6 +339,12 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
         ++decode_count;
         set_frame(eng_[cur], filled[cur], TM_SIDE_REF, fref, cref);
         set_frame(eng_[cur], filled[cur], TM_SIDE_DIS, fdis, cdis);
+        {
+            Fence &f = fences[kept % (UPLOADS_IN_FLIGHT + 1)];
+            f.e = eng_[cur];
+            chk(tm_engine_upload_fence(f.e, &f.token), "tm_engine_upload_fence");
+            ++kept;
+        }
         if (++filled[cur] == batch_) {
             submit(cur);
             if (eng_[1]) {

@@ -153,7 +153,16 @@ public:
     // How many further next_frame calls a returned frame must survive (the engine reads a pinned frame asynchronously until
     // its batch has synced).  Sources that hand out pinned memory size their ring from this; call before the first frame.
     virtual void set_lookahead(size_t frames) {}
+    // May the source read pictures AHEAD of the next_frame calls (regular planar files: a pool of readers fills a few ring slots
+    // beyond the one being asked for)?  compute_all switches it off when `--every` drops frames: dropped pictures are then
+    // consumed without being read at all.  Call before the first frame.
+    virtual void set_readahead(bool on) { (void)on; }
 };
+
+// CPUs this process may really use: the smallest of the hardware threads, the affinity mask and the cgroup CPU quota (a container
+// that sees 256 CPUs may be limited to 16 CPUs' worth of time -- the GPU boxes of rounds 1-4 are: cpu.max = "1600000 100000" --
+// and more busy threads than that only buy throttling: the whole group sleeps out the rest of every 100-ms period).
+unsigned effective_cpus();
 
 // compute_all selected no frame pair at all (the reference panics in Stats::compute: index out of bounds)
 class NoFramesSelected : public std::out_of_range {

@@ -92,6 +92,7 @@ public:
     bool next_frame(HwFrame &out) override { return inner_->next_frame(out); }
     bool skip_one() override { return inner_->skip_one(); }
     void set_lookahead(size_t frames) override { inner_->set_lookahead(frames); }
+    void set_readahead(bool on) override { inner_->set_readahead(on); }
     const StreamFormat &stream_format() const { return fmt_; }
 
 private:
