@@ -1,5 +1,6 @@
 // tests/host/tm_host_test.cpp -- TEST INFRASTRUCTURE: exposes the host-side pieces of turbo-metrics_amd/host that need no
 // GPU (number formatting, Stats, image / Y4M decoding, output layer) to the pytest tier through a tiny command line.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -104,6 +105,23 @@ int main(int argc, char **argv)
                     std::cout << (f.kind == HwFrame::Npp8 ? "rgb8 " : f.kind == HwFrame::Npp16 ? "rgb16 " : "rgbf32 ") << f.pitch << " " << w << "\n";
                 }
             }
+        } else if (cmd == "readbench") { // readbench PATH [lookahead]: next_frame over the whole stream, nothing else -> pictures/s and GB/s of the reader alone
+            SourceHints h;
+            auto src = create_source(argv[2], h);
+            if (argc > 3) src->set_lookahead((size_t)atoi(argv[3]));
+            HwFrame f;
+            size_t n = 0, bytes = 0;
+            unsigned long long sum = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (src->next_frame(f)) {
+                ++n;
+                const size_t crows = (src->height() + 1) / 2;
+                bytes += f.pitch * src->height() + 2 * f.pitch_uv * crows;
+                sum += ((const unsigned char *)f.data)[0];
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::cout << n << " pictures in " << dt << " s = " << (double)n / dt << " pictures/s, " << (double)bytes / dt / 1e9 << " GB/s, pinned " << (f.pinned ? 1 : 0)
+                      << " cpus " << effective_cpus() << " (" << sum << ")\n";
         } else if (cmd == "demux") { // demux PATH OUT: container codec frame_count, then OUT = [u32 len][bytes] of init() and of every demux() piece
             FILE *f = fopen(argv[2], "rb");
             if (!f) throw std::runtime_error("open");

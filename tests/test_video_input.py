@@ -295,6 +295,9 @@ def test_mkv_av1_mpeg2_lacing_and_probe_errors(helper, tmp_path):
 
 FAKE_DECODER = """#!%s
 import os, sys
+if sys.argv[1:] == ["-version"]:
+    print(os.environ.get("TM_FAKE_VERSION", "ffmpeg version 6.1.1 Copyright (c) 2000-2023 the FFmpeg developers"))
+    sys.exit(0)
 data = sys.stdin.buffer.read()
 open(os.environ["TM_FAKE_ES"], "wb").write(" ".join(sys.argv[1:]).encode() + b"\\n" + data)
 sys.stdout.buffer.write(open(os.environ["TM_FAKE_Y4M"], "rb").read())
@@ -326,6 +329,17 @@ def test_video_source_feeds_the_decoder_and_takes_colour_from_the_sequence_heade
     args, stream = es.split(b"\n", 1)
     assert args == b"-nostdin -v error -f h264 -i pipe:0 -fps_mode passthrough -f yuv4mpegpipe -strict -1 pipe:1"  # one picture out per picture decoded
     assert stream == b"".join(b"\x00\x00\x00\x01" + n for n in [sps, pps] + nals)
+    # ffmpeg before 5.1 (Ubuntu 22.04: 4.4, Debian 11: 4.3) has no -fps_mode: the decoder is asked for its version;
+    # TM_DECODER_ARGS replaces the option for decoders that are not ffmpeg
+    for version, extra_env, want_opt in (("ffmpeg version 4.4.2-0ubuntu0.22.04.1 Copyright (c) 2000-2021", {}, b"-vsync passthrough"),
+                                         ("ffmpeg version 5.0.1", {}, b"-vsync passthrough"), ("ffmpeg version 5.1.4-0+deb12u1", {}, b"-fps_mode passthrough"),
+                                         ("ffmpeg version n7.0.2", {}, b"-fps_mode passthrough"), ("ffmpeg version N-111111-gdeadbeef", {}, b"-fps_mode passthrough"),
+                                         ("something else 1.0", {}, b"-fps_mode passthrough"), ("ffmpeg version 4.4", {"TM_DECODER_ARGS": "-an  -sn"}, b"-an -sn"),
+                                         ("ffmpeg version 4.4", {"TM_DECODER_ARGS": ""}, b"")):
+        r = subprocess.run([helper, "source", p, out], capture_output=True, text=True, env=dict(env, TM_FAKE_VERSION=version, **extra_env))
+        assert len(r.stdout.strip().split("\n")) == 4, r.stdout
+        got = open(env["TM_FAKE_ES"], "rb").read().split(b"\n", 1)[0]
+        assert got == b" ".join(x for x in (b"-nostdin -v error -f h264 -i pipe:0", want_opt, b"-f yuv4mpegpipe -strict -1 pipe:1") if x), (version, got)
     # AV1 in IVF: packets re-wrapped as IVF for the decoder; size and colour from the sequence header OBU, frame count from the header
     seq = av1_sequence_header_obu(w, h, color=(1, 1, 1), full=1)
     pkts = [bytes([(2 << 3) | 2, 0]) + seq + bytes([6 << 3 | 2, 1, 7])] + [bytes([(2 << 3) | 2, 0, 6 << 3 | 2, 1, i]) for i in range(2)]

@@ -453,15 +453,19 @@ void YuvStreamSource::ensure_ring()
 {
     if (!ring_.empty()) return;
     // reader threads per stream (the reference and the distorted stream are read at the same time): what the process may really use
-    // (effective_cpus: hardware threads, affinity mask, cgroup quota) less two for the main thread and the HIP runtime, halved; one
-    // thread per 384 KB of picture at most (3 MB at 1080p, 25 MB at 4K 10-bit), at most 16.  TM_READER_THREADS overrides; 1 = serial.
+    // (effective_cpus: hardware threads, affinity mask, cgroup quota) less four for the main thread, helpers and the HIP runtime, a third
+    // of the rest (two streams, and head room under the quota); one thread per 384 KB of picture at most (3 MB at 1080p, 25 MB at 4K 10-bit), at most 16.  TM_READER_THREADS overrides; 1 = serial.
     // Measured on a host of 256 hardware threads (rounds 2-3): 1080p 4.97 k pairs/s with 8 threads per stream, 4.45 k with 16; 4K
     // 10-bit 640 / 822 / 536 pairs/s with 8 / 16 / 32 -- that host's container is limited to 16 CPUs of time, which is where the
     // optimum and its instability from box to box came from.
     const char *env = getenv("TM_READER_THREADS");
     const unsigned cpus = effective_cpus();
     const unsigned by_size = (unsigned)std::min<size_t>(16, std::max<size_t>(2, planar_bytes_ / (384u << 10)));
-    const unsigned want = env ? (unsigned)std::max(1, atoi(env)) : std::min(by_size, std::max(1u, (cpus > 2 ? cpus - 2 : 1) / 2));
+    // (round 4, reader alone on a box of this pool -- 16 CPUs of quota -- two streams at once, file in tmpfs -> page-locked ring: 1 / 2 / 4 / 7 /
+    // 12 / 16 threads per stream = 9 / 12 / 17 / 20 / 11 / 18 GB/s per stream at 1080p, 6 / 8 / 17 / 15 / 12 / 16 at 4K: a thread copies
+    // 6-9 GB/s, the pair of streams tops out at 35-40 GB/s, and more busy threads than the quota get the group throttled:
+    // profiles/r04h_read_probe.log) -> a third of the CPUs left after main thread, dispatchers, ring helper and the HIP runtime
+    const unsigned want = env ? (unsigned)std::max(1, atoi(env)) : std::min(by_size, std::max(1u, (cpus > 4 ? cpus - 4 : 1) / 3));
     const bool ra = readahead_ && fd_ >= 0 && h_ >= 64;
     // read-ahead: enough pictures in flight to keep `want` readers busy with pieces of ~2 MB, at most 256 MB of them
     const size_t pieces = std::max<size_t>(1, (planar_bytes_ + ((size_t)2 << 20) - 1) / ((size_t)2 << 20));

@@ -5,6 +5,7 @@
 #include <cerrno>
 #include <csignal>
 #include <cstring>
+#include <sstream>
 #include <fcntl.h>
 #include <stdexcept>
 #include <sys/types.h>
@@ -674,6 +675,37 @@ void put_le(std::vector<uint8_t> &v, uint64_t x, int bytes) { for (int i = 0; i 
 
 } // namespace
 
+// the decoder's option for "no frame-rate conversion": see the call site
+std::vector<std::string> decoder_sync_args(const std::string &prog)
+{
+    std::vector<std::string> out;
+    if (const char *env = getenv("TM_DECODER_ARGS")) {
+        std::istringstream ss(env);
+        for (std::string t; ss >> t;) out.push_back(t);
+        return out;
+    }
+    int major = -1, minor = 0;
+    bool safe = !prog.empty();
+    for (char c : prog) safe = safe && (isalnum((unsigned char)c) || strchr("/._-+", c)); // the name goes through a shell below
+    if (safe) {
+        if (FILE *p = popen((prog + " -version 2>/dev/null </dev/null").c_str(), "r")) {
+            char line[256];
+            if (fgets(line, sizeof line, p)) { // "ffmpeg version 4.4.2-0ubuntu0.22.04.1 Copyright ..." / "ffmpeg version n6.1.1" / "ffmpeg version N-110000-g..."
+                const char *v = strstr(line, "version ");
+                if (v) {
+                    v += 8;
+                    if (*v == 'n') ++v;
+                    if (isdigit((unsigned char)*v)) { major = atoi(v); const char *dot = strchr(v, '.'); minor = dot ? atoi(dot + 1) : 0; }
+                }
+            }
+            pclose(p);
+        }
+    }
+    if (major >= 0 && (major < 5 || (major == 5 && minor < 1))) out = {"-vsync", "passthrough"};
+    else out = {"-fps_mode", "passthrough"}; // 5.1 and later, git snapshots, and anything that does not say
+    return out;
+}
+
 VideoFrameSource::VideoFrameSource(std::unique_ptr<Demuxer> demuxer, const SourceHints &hints) : demuxer_(std::move(demuxer))
 {
     // sequence header: out-of-band data first, then packets until one carries it (what VideoFrameSource::new does with cuvid's
@@ -711,6 +743,10 @@ VideoFrameSource::VideoFrameSource(std::unique_ptr<Demuxer> demuxer, const Sourc
     const char *prog = getenv("TM_DECODER");
     decoder_name_ = prog && *prog ? prog : "ffmpeg";
     const char *in_fmt = codec == Codec::H264 ? "h264" : (codec == Codec::MPEG2 ? "mpegvideo" : "ivf"); // AV1 packets are re-wrapped as IVF
+    // "one picture out per picture decoded" is `-fps_mode passthrough` from ffmpeg 5.1 on and `-vsync passthrough` before (Ubuntu 22.04
+    // ships 4.4, Debian 11 4.3; 7.0 removed -vsync): the decoder is asked for its version first.  TM_DECODER_ARGS replaces
+    // the option altogether (whitespace-separated; may be empty) for decoders that are not ffmpeg.
+    const std::vector<std::string> sync_args = decoder_sync_args(decoder_name_);
     int to_child[2], from_child[2];
     if (pipe2(to_child, O_CLOEXEC) != 0 || pipe2(from_child, O_CLOEXEC) != 0) vfail(std::string("pipe: ") + strerror(errno));
     signal(SIGPIPE, SIG_IGN);
@@ -722,8 +758,11 @@ VideoFrameSource::VideoFrameSource(std::unique_ptr<Demuxer> demuxer, const Sourc
         // one output picture per decoded picture, whatever rate the muxer guesses (raw streams carry no timestamps): without
         // passthrough a constant-frame-rate muxer may duplicate or drop pictures and misalign the reference / distorted pairs
         // (the reference's NVDEC path emits exactly one picture per decode).  dup2 clears O_CLOEXEC on descriptors 0 and 1.
-        execlp(decoder_name_.c_str(), decoder_name_.c_str(), "-nostdin", "-v", "error", "-f", in_fmt, "-i", "pipe:0", "-fps_mode", "passthrough", "-f",
-               "yuv4mpegpipe", "-strict", "-1", "pipe:1", (char *)nullptr);
+        std::vector<const char *> argv = {decoder_name_.c_str(), "-nostdin", "-v", "error", "-f", in_fmt, "-i", "pipe:0"};
+        for (const std::string &a : sync_args) argv.push_back(a.c_str());
+        for (const char *a : {"-f", "yuv4mpegpipe", "-strict", "-1", "pipe:1"}) argv.push_back(a);
+        argv.push_back(nullptr);
+        execvp(decoder_name_.c_str(), (char *const *)argv.data());
         _exit(127);
     }
     child_ = (int)pid;

@@ -79,6 +79,10 @@ public:
 std::unique_ptr<Demuxer> probe_video(FILE *f, std::string &why);
 
 // == VideoFrameSource (input_video.rs:347-441) with the decoder behind a pipe
+// the decoder's arguments for "one picture out per picture decoded": `-fps_mode passthrough` (ffmpeg >= 5.1 or unknown), `-vsync passthrough` (older),
+// or the tokens of TM_DECODER_ARGS
+std::vector<std::string> decoder_sync_args(const std::string &prog);
+
 class VideoFrameSource : public FrameSource {
 public:
     VideoFrameSource(std::unique_ptr<Demuxer> demuxer, const SourceHints &hints);
