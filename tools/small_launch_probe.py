@@ -20,16 +20,18 @@ BIG = 1 << 40
 SEL = os.environ.get("PROBE_CONFIGS")  # comma list of config names (default: all)
 CONFIGS = [  # name, {param: value}, graph
     ("base", {}, False),
-    ("colw32", {F.TM_DBG_COL_WINDOW32_BELOW: BIG}, False),
-    ("w32", {F.TM_DBG_SPLIT_WINDOW: 32}, False),
-    ("colw32+w32", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32}, False),
-    ("colw32+w32+split5", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT5_ROWS_BELOW: BIG}, False),
-    ("colw32+w32+split8", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
-    ("colw32+w16+split8", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
+        ("w32", {F.TM_DBG_SPLIT_WINDOW: 32}, False),
+    ("colw32+w32", {F.TM_DBG_SPLIT_WINDOW: 32}, False),
+    ("colw32+w32+split5", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT5_ROWS_BELOW: BIG}, False),
+    ("colw32+w32+split8", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
+    ("colw32+w16+split8", {F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
     ("w32+split8", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
+    ("w32+split10", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT10_ROWS_BELOW: BIG}, False),
+    ("w16+split10", {F.TM_DBG_SPLIT_WINDOW: 16, F.TM_DBG_SPLIT10_ROWS_BELOW: BIG}, False),
+    ("w32+split10+graph", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT10_ROWS_BELOW: BIG}, True),
     ("w32+split8+forced", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG, "variant": F.TM_VARIANT_SPLIT_ROWS}, False),
     ("whole_rows", {"variant": F.TM_VARIANT_WHOLE_ROWS}, False),
-    ("colw32+w32+split8+graph", {F.TM_DBG_COL_WINDOW32_BELOW: BIG, F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, True),
+    ("colw32+w32+split8+graph", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, True),
 ]
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4,6,8,12,16").split(",")]:
     sc = None

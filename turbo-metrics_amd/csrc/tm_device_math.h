@@ -377,29 +377,46 @@ __device__ __forceinline__ float iir_step(Iir &s, float sum)
     return (o1 + o3) + o5;
 }
 
-// the edge-difference half of compute_error_maps (error_maps.rs:45-59): needs mu1, mu2 only
-__device__ __forceinline__ void edge_maps(float source, float distorted, float mu1, float mu2, float &artifact,
-                                          float &detail_loss)
+// the edge-difference half of compute_error_maps (error_maps.rs:45-59): needs mu1, mu2 only.  In two steps, so that a launch of a pair
+// or two can give each step to a wave of its own (k_blur_h_jobs_split<10>): d1 first, the two maps from it
+__device__ __forceinline__ float edge_d1(float source, float distorted, float mu1, float mu2)
 {
     const float denom = 1.0f / (1.0f + fabsf(source - mu1));
     const float numer = 1.0f + fabsf(distorted - mu2);
-    const float d1 = __builtin_fmaf(numer, denom, -1.0f);
+    return __builtin_fmaf(numer, denom, -1.0f);
+}
+__device__ __forceinline__ void edge_from_d1(float d1, float &artifact, float &detail_loss)
+{
     artifact = fmaxf(d1, 0.0f);
     detail_loss = fmaxf(-d1, 0.0f);
 }
+__device__ __forceinline__ void edge_maps(float source, float distorted, float mu1, float mu2, float &artifact,
+                                          float &detail_loss)
+{
+    edge_from_d1(edge_d1(source, distorted, mu1, mu2), artifact, detail_loss);
+}
 
-// compute_error_maps, ssimulacra2-cuda-kernel/src/error_maps.rs:5-60
-__device__ __forceinline__ void error_maps(float source, float distorted, float mu1, float mu2, float sigma11,
-                                           float sigma22, float sigma12, float &ssim, float &artifact,
-                                           float &detail_loss)
+// the ssim map of compute_error_maps (error_maps.rs:5-44), also in two steps: numerator and denominator, then the quotient
+__device__ __forceinline__ void ssim_terms(float mu1, float mu2, float sigma11, float sigma22, float sigma12, float &num, float &den)
 {
     const float C2 = 0.0009f;
     const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
     const float mu_diff = mu1 - mu2;
     const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
     const float num_s = __builtin_fmaf(2.0f, sigma12 - mu12, C2);
-    const float denom_s = (sigma11 - mu11) + (sigma22 - mu22) + C2;
-    ssim = fmaxf(1.0f - (num_m * num_s) / denom_s, 0.0f);
+    den = (sigma11 - mu11) + (sigma22 - mu22) + C2;
+    num = num_m * num_s;
+}
+__device__ __forceinline__ float ssim_from_terms(float num, float den) { return fmaxf(1.0f - num / den, 0.0f); }
+
+// compute_error_maps, ssimulacra2-cuda-kernel/src/error_maps.rs:5-60
+__device__ __forceinline__ void error_maps(float source, float distorted, float mu1, float mu2, float sigma11,
+                                           float sigma22, float sigma12, float &ssim, float &artifact,
+                                           float &detail_loss)
+{
+    float num, den;
+    ssim_terms(mu1, mu2, sigma11, sigma22, sigma12, num, den);
+    ssim = ssim_from_terms(num, den);
     edge_maps(source, distorted, mu1, mu2, artifact, detail_loss);
 }
 

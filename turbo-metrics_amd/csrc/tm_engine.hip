@@ -179,8 +179,8 @@ struct tm_engine {
     long long split8_rows_below = 1ll << 40; // ... and up to which it runs with eight waves (one recurrence per wave).  Round 4: wherever the multi-wave pass runs, eight
                                       // waves with 32-row producer windows beat five and three (1080p, pairs per launch 1 / 4 / 8 / 16 / 32: 3.03 k vs 2.80 k, 8.4 k vs 7.0 k, 11.0 k vs
                                       // 10.9 k, 12.7 k vs 11.7 k, 13.2 k vs 13.0 k pairs/s; 4K and 720p alike: profiles/r04e_split8_*.log) -- five / three remain selectable (tm_engine_debug_set_param)
+    long long split10_rows_below = 0;  // ... and with ten (each consumer cut in two waves; one workgroup per CU): launches of a pair or two
     int split_window = 32;            // register window of the multi-wave row pass' producers: 16 or 32 rows
-    long long col_window32_below = 0; // column-pass workgroups per launch up to which the pass runs with a 32-row register window (22 rows of loads in flight)
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (tm_engine_debug_set_ingest_rows)
 };
 
@@ -929,7 +929,6 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
-        else if (vgrid.y && (long long)n * vgrid.y <= e->col_window32_below) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 32>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         if (!e->use_graph) HIPCHK(hipEventRecord(e->ev_col_done, st));
@@ -947,7 +946,10 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             // (five waves: 3 1080p pairs = 324 blocks 0.35 -> 0.26 ms, 6 pairs = 648 blocks 0.36 -> 0.45; with the fused kernel beside, FULL jobs only: 6 pairs = 456 blocks
             // 0.45 -> 0.35, 8 pairs = 608 blocks 0.44 -> 0.40, 10 pairs = 760 blocks 0.44 -> 0.47)
             const bool w32 = e->split_window == 32;
-            if ((long long)n * hblocks <= e->split8_rows_below) {
+            if ((long long)n * hblocks <= e->split10_rows_below) {
+                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<10, 32>), hgrid, dim3(640), 0, st, g, jobs, XYB, V, PART);
+                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<10, 16>), hgrid, dim3(640), 0, st, g, jobs, XYB, V, PART);
+            } else if ((long long)n * hblocks <= e->split8_rows_below) {
                 if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<8, 32>), hgrid, dim3(512), 0, st, g, jobs, XYB, V, PART);
                 else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<8, 16>), hgrid, dim3(512), 0, st, g, jobs, XYB, V, PART);
             } else if ((long long)n * hblocks <= (beside && !e->split5_rows_env ? 700 : e->split5_rows_below)) {
@@ -1299,8 +1301,8 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     case TM_DBG_SPLIT5_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split5_rows_below = value; e->split5_rows_env = true; break;
     case TM_DBG_EF_FAULT: if (value < 0 || value > 3) return TM_ERR_INVALID_ARG; e->ef_fault = (int)value; break;
     case TM_DBG_SPLIT8_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split8_rows_below = value; break;
+    case TM_DBG_SPLIT10_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split10_rows_below = value; break;
     case TM_DBG_SPLIT_WINDOW: if (value != 16 && value != 32) return TM_ERR_INVALID_ARG; e->split_window = (int)value; break;
-    case TM_DBG_COL_WINDOW32_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->col_window32_below = value; break;
     default: return TM_ERR_INVALID_ARG;
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values
