@@ -1113,7 +1113,6 @@ __device__ __forceinline__ void blur_v_role(float *__restrict__ tile, const floa
         (void)tmdev::iir_step(f, product ? aold * bold + a * b : aold + a);
     }
     const int T = (h + U - 1) / U * U + 4;
-    const unsigned rowb = (unsigned)pitch * 4u; // bytes per input row
     for (int t0 = 4; t0 < T; t0 += U) {
         // Keep the five role-waves of the workgroup within one iteration of each other: they read the same
         // ref/dis rows (3 readers each), and only while they stay close do the 2nd and 3rd reader hit L1/L2
@@ -1141,21 +1140,10 @@ __device__ __forceinline__ void blur_v_role(float *__restrict__ tile, const floa
                 __builtin_amdgcn_wave_barrier();                                                                                     \
             }                                                                                                                        \
         }
-        if (t0 + (U - 1) + P < h) {
-            // every row this block of U steps loads exists (all blocks but the last one or two): the row address advances by one
-            // pitch per step (two scalar adds) and nothing is clamped or zeroed -- 6 scalar instructions and a select fewer per step
-            // than the general form below, a fifth of the step (round 4: one wave issues one instruction per ~7 cycles when it is alone
-            // on its SIMD, and a launch of one or two pairs is exactly that)
-            TM_GLOBAL_AS const char *rowp = (TM_GLOBAL_AS const char *)tm_uniform_ptr(in + (size_t)(t0 + P) * pitch);
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                if (PAIR) {
-                    TM_BLUR_V_STEP({ const tm_g2 v2 = *(TM_GLOBAL_AS const tm_g2 *)(rowp + x); wa[(j + 4 + P) % W] = v2.x; wb[(j + 4 + P) % W] = v2.y; rowp += rowb; })
-                } else {
-                    TM_BLUR_V_STEP({ wa[(j + 4 + P) % W] = *(TM_GLOBAL_AS const float *)(rowp + x); rowp += rowb; })
-                }
-            }
-        } else {
+        // (round 4: a second copy of the block without clamps and selects -- every row of an interior block exists -- with the row address
+        // advanced by two scalar adds per step was 21 instead of 30 instructions per step and SLOWER: one 1080p pair 0.101 -> 0.117 ms,
+        // one 4K pair 0.22 -> 0.27; the step is not bound by its instruction count: profiles/r04i_split10.log)
+        {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 if (PAIR) {
@@ -1560,24 +1548,7 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
                 for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[i]; tile[1][ph & 3][4 * i + lr][lc] = qb[i]; }
                 fetch_block(ph + 1);
             }
-            if (NP > 0 && 16 * ph + 15 + P < w) {
-                // every column this phase loads exists (all phases but the last two or three): a running pointer per plane instead of
-                // clamp, 64-bit multiply and select per load -- a third of a one-plane producer's step
-                const float *pk[NA];
-#pragma unroll
-                for (int k = 0; k < NP; ++k) pk[k] = v[k] + (size_t)(16 * ph + P) * pt;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int sl = 16 * sub + j;
-#pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        const float o = tmdev::iir_step(f[k], win[k][(sl + P) % WN] + win[k][sl]);
-                        win[k][(sl + P) % WN] = *pk[k];
-                        pk[k] += pt;
-                        ring[ph & 1][j][plane[k]][lane] = o;
-                    }
-                }
-            } else if (NP > 0) {
+            if (NP > 0) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int t = 16 * ph + j; // row t lives in slot t % WN = 16 sub + j (ph0 is a multiple of SUB), row t-10 in slot (. + P) % WN, which row t+P then takes over
@@ -1590,6 +1561,40 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
                     }
                 }
             }
+            TM_LDS_BARRIER();
+        }
+    }
+}
+
+// The ref / dis blocks of a row block when they have a wave to themselves (NW = 8, 10): block e is requested D phases before it is
+// written into its tile buffer.  With the one phase of look-ahead of the shared producer above, a phase could not be shorter than one
+// load from HBM takes on an idle chip -- and that, not any wave's instruction count, was what a launch of a pair or two measured:
+// ~1.3 us per phase of 16 steps whether a consumer ran 47, 37 or 21 instructions per step (profiles/r04i_split10.log).
+template <int D>
+__device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[4][64][17], const float *__restrict__ rdn, int y0, int h, int pitch, int nphases)
+{
+    const int lane = threadIdx.x & 63;
+    const int lr = lane >> 4, lc = lane & 15;
+    float qa[D][16], qb[D][16];
+    auto fetch_block = [&](int e, float (&a)[16], float (&b)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int x = 16 * e + lc, y = y0 + 4 * i + lr;
+            const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
+            const float2 val = *(const float2 *)(rdn + 2 * ((size_t)yc * pitch + xc));
+            a[i] = val.x; b[i] = val.y;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch_block(d, qa[d], qb[d]);
+    for (int ph0 = 0; ph0 < nphases; ph0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ph = ph0 + d;
+            if (ph >= nphases) break; // (the same for every wave of the workgroup: they all meet at the same barriers)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[d][i]; tile[1][ph & 3][4 * i + lr][lc] = qb[d][i]; }
+            fetch_block(ph + D, qa[d], qb[d]);
             TM_LDS_BARRIER();
         }
     }
@@ -1756,8 +1761,8 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
         } else if (wave < 5) { // mu1 | mu2
             const float *const pv[1] = {wave == 3 ? v3 : v4}; const int pl[1] = {wave};
             blur_h_split_producer<1, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL);
-        } else if (wave == 5) { // the ref / dis blocks
-            blur_h_split_producer<0, WN>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
+        } else if (wave == 5) { // the ref / dis blocks, two / three phases ahead (eight waves: two, so that the kernel stays at 128 registers and two workgroups per CU)
+            blur_h_split_fetcher<(NW == 10 ? 3 : 2)>(tile, rdn, y0, sg.h, sg.pitch, nphases);
         } else if (NW == 8) {
             if (wave == 6) { // the ssim map and its sums (FULL)
                 if (full) { blur_h_split_consumer<1>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 1; }
