@@ -322,22 +322,9 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
         const int vb = jobs.vstart[jobs.nfull], hb = jobs.hstart[jobs.nfull]; // the two passes run jobs [0, nfull)
-        // 0x400: multi-wave row pass, three waves -- with 0x2000 five, with 0x20000 eight --, 0x40000: its producers with a 32-row window
         launch_wave_lockstep(dim3(n, vb, 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
-        const bool w32 = (variant & 0x40000) != 0;
-        if ((variant & 0x400) && (variant & 0x80000)) { // ten waves: two-stage consumers
-            if (w32) launch_wg_lockstep(dim3(n, hb, 1), 640, [&] { tmk::k_blur_h_jobs_split<10, 32>(g, jobs, XYB, V, PART); });
-            else launch_wg_lockstep(dim3(n, hb, 1), 640, [&] { tmk::k_blur_h_jobs_split<10, 16>(g, jobs, XYB, V, PART); });
-        } else if ((variant & 0x400) && (variant & 0x20000)) {
-            if (w32) launch_wg_lockstep(dim3(n, hb, 1), 512, [&] { tmk::k_blur_h_jobs_split<8, 32>(g, jobs, XYB, V, PART); });
-            else launch_wg_lockstep(dim3(n, hb, 1), 512, [&] { tmk::k_blur_h_jobs_split<8, 16>(g, jobs, XYB, V, PART); });
-        } else if ((variant & 0x400) && (variant & 0x2000)) {
-            if (w32) launch_wg_lockstep(dim3(n, hb, 1), 320, [&] { tmk::k_blur_h_jobs_split<5, 32>(g, jobs, XYB, V, PART); });
-            else launch_wg_lockstep(dim3(n, hb, 1), 320, [&] { tmk::k_blur_h_jobs_split<5, 16>(g, jobs, XYB, V, PART); });
-        } else if (variant & 0x400) {
-            if (w32) launch_wg_lockstep(dim3(n, hb, 1), 192, [&] { tmk::k_blur_h_jobs_split<3, 32>(g, jobs, XYB, V, PART); });
-            else launch_wg_lockstep(dim3(n, hb, 1), 192, [&] { tmk::k_blur_h_jobs_split<3, 16>(g, jobs, XYB, V, PART); });
-        }
+        // 0x400: the eight-wave row pass of small launches (TM_VARIANT_SPLIT_ROWS)
+        if (variant & 0x400) launch_wg_lockstep(dim3(n, hb, 1), 64 * TM_SPLIT_WAVES, [&] { tmk::k_blur_h_jobs_split(g, jobs, XYB, V, PART); });
         else if (wide_rows) launch_wave_lockstep(dim3(n, hb, 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });
         else launch_wave_lockstep(dim3(n, hb, 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 32, 16>(g, jobs, XYB, V, PART); });
         if (jobs.n > jobs.nfull) { // the engine's buffers of the fused EDGE kernel, sized the same way

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""GPU box: launches of 1 .. 16 pairs of 1080p (the reference's compute_one is ONE pair per call) under the round-4 variants of
-the two passes: column pass with a 32-row window, multi-wave row pass with a 32-row producer window, eight waves per row block.
+"""GPU box: launches of 1 .. 16 pairs of 1080p (the reference's compute_one is ONE pair per call) : the default choice of kernels
+against the eight-wave row pass forced / forbidden, the EDGE jobs in the two passes, hipGraph replay.
 Per batch and configuration: wall ms per step (compute_async + sync), stage ms, pairs/s; scores must not change.
 usage: small_launch_probe.py [batches] [WxH]"""
 import json, os, sys, time
@@ -19,19 +19,11 @@ for n in range(4):
 BIG = 1 << 40
 SEL = os.environ.get("PROBE_CONFIGS")  # comma list of config names (default: all)
 CONFIGS = [  # name, {param: value}, graph
-    ("base", {}, False),
-        ("w32", {F.TM_DBG_SPLIT_WINDOW: 32}, False),
-    ("colw32+w32", {F.TM_DBG_SPLIT_WINDOW: 32}, False),
-    ("colw32+w32+split5", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT5_ROWS_BELOW: BIG}, False),
-    ("colw32+w32+split8", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
-    ("colw32+w16+split8", {F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
-    ("w32+split8", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, False),
-    ("w32+split10", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT10_ROWS_BELOW: BIG}, False),
-    ("w16+split10", {F.TM_DBG_SPLIT_WINDOW: 16, F.TM_DBG_SPLIT10_ROWS_BELOW: BIG}, False),
-    ("w32+split10+graph", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT10_ROWS_BELOW: BIG}, True),
-    ("w32+split8+forced", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG, "variant": F.TM_VARIANT_SPLIT_ROWS}, False),
+    ("default", {}, False),
+    ("split_forced", {"variant": F.TM_VARIANT_SPLIT_ROWS}, False),
     ("whole_rows", {"variant": F.TM_VARIANT_WHOLE_ROWS}, False),
-    ("colw32+w32+split8+graph", {F.TM_DBG_SPLIT_WINDOW: 32, F.TM_DBG_SPLIT8_ROWS_BELOW: BIG}, True),
+    ("two_pass_edge", {"variant": F.TM_VARIANT_TWO_PASS_EDGE}, False),
+    ("graph", {}, True),
 ]
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4,6,8,12,16").split(",")]:
     sc = None

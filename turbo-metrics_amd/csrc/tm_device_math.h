@@ -377,8 +377,7 @@ __device__ __forceinline__ float iir_step(Iir &s, float sum)
     return (o1 + o3) + o5;
 }
 
-// the edge-difference half of compute_error_maps (error_maps.rs:45-59): needs mu1, mu2 only.  In two steps, so that a launch of a pair
-// or two can give each step to a wave of its own (k_blur_h_jobs_split<10>): d1 first, the two maps from it
+// the edge-difference half of compute_error_maps (error_maps.rs:45-59): needs mu1, mu2 only (d1 first, the two maps from it)
 __device__ __forceinline__ float edge_d1(float source, float distorted, float mu1, float mu2)
 {
     const float denom = 1.0f / (1.0f + fabsf(source - mu1));
@@ -396,7 +395,7 @@ __device__ __forceinline__ void edge_maps(float source, float distorted, float m
     edge_from_d1(edge_d1(source, distorted, mu1, mu2), artifact, detail_loss);
 }
 
-// the ssim map of compute_error_maps (error_maps.rs:5-44), also in two steps: numerator and denominator, then the quotient
+// the ssim map of compute_error_maps (error_maps.rs:5-44): numerator and denominator, then the quotient
 __device__ __forceinline__ void ssim_terms(float mu1, float mu2, float sigma11, float sigma22, float sigma12, float &num, float &den)
 {
     const float C2 = 0.0009f;

@@ -173,14 +173,8 @@ struct tm_engine {
     uint32_t last_n = 0;
     bool in_flight = false, have_results = false;
     int variant = TM_VARIANT_DEFAULT;
-    long long split_rows_below = 1024; // row blocks per launch up to which the three-wave row pass runs: one per SIMD (measured at 1080p: 8 pairs = 864 blocks 0.43 vs 0.62 ms, 16 pairs = 1 728 blocks 0.76 vs 0.67 ms)
-    bool split_rows_env = false, split5_rows_env = false; // TM_DBG_SPLIT_ROWS_BELOW / TM_DBG_SPLIT5_ROWS_BELOW were set: used as they are
-    long long split5_rows_below = 400; // ... and up to which that pass runs with five instead of three waves per row block
-    long long split8_rows_below = 1ll << 40; // ... and up to which it runs with eight waves (one recurrence per wave).  Round 4: wherever the multi-wave pass runs, eight
-                                      // waves with 32-row producer windows beat five and three (1080p, pairs per launch 1 / 4 / 8 / 16 / 32: 3.03 k vs 2.80 k, 8.4 k vs 7.0 k, 11.0 k vs
-                                      // 10.9 k, 12.7 k vs 11.7 k, 13.2 k vs 13.0 k pairs/s; 4K and 720p alike: profiles/r04e_split8_*.log) -- five / three remain selectable (tm_engine_debug_set_param)
-    long long split10_rows_below = 0;  // ... and with ten (each consumer cut in two waves; one workgroup per CU): launches of a pair or two
-    int split_window = 32;            // register window of the multi-wave row pass' producers: 16 or 32 rows
+    long long split_rows_below = 1024; // row blocks per launch up to which the eight-wave row pass runs (2 600 beside the fused kernel, whose passes hold the FULL jobs only: see launch_batch)
+    bool split_rows_env = false; // TM_DBG_SPLIT_ROWS_BELOW was set: used as it is
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (tm_engine_debug_set_ingest_rows)
 };
 
@@ -936,29 +930,11 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         // ---- stage BLUR_H: row pass + error maps + reductions
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, jobs, XYBT, V, PART);
         else if (!hgrid.y) {}
-        // few row blocks (small batches): three waves per block -- a wave's own issue rate, not the chip, bounds this pass then
-        // (with the fused kernel beside it the three-wave pass pays up to twice as many row blocks: 16 1080p pairs = 1 216 blocks of FULL
-        // jobs 1.48 -> 1.36 ms, 20 pairs 1.74 -> 1.63, 32 pairs = 2 432 blocks the same either way)
-        // (round 4, eight waves: faster than the one-wave pass up to 32 1080p pairs beside the fused kernel = 2 432 row blocks of FULL jobs -- 13.2 k vs 13.0 k pairs/s --,
+        // few row blocks (small launches): eight waves per block -- what one CU can issue for one row block, not the chip, bounds this pass then
+        // (faster than the one-wave pass up to 32 1080p pairs beside the fused kernel = 2 432 row blocks of FULL jobs -- 13.2 k vs 13.0 k pairs/s --,
         // slower at 48 = 3 648 blocks: 13.6 k vs 13.75 k; profiles/r04e_split8_threshold.log)
         else if ((e->variant & TM_VARIANT_SPLIT_ROWS) || (!(e->variant & TM_VARIANT_WHOLE_ROWS) && (long long)n * hblocks <= (beside && !e->split_rows_env ? 2600 : e->split_rows_below))) {
-            // five waves per row block up to a quarter of a row block per SIMD (1-2 pairs of 1080p: 0.26 vs 0.35 ms), three above (8 pairs: 0.43 vs 0.58)
-            // (five waves: 3 1080p pairs = 324 blocks 0.35 -> 0.26 ms, 6 pairs = 648 blocks 0.36 -> 0.45; with the fused kernel beside, FULL jobs only: 6 pairs = 456 blocks
-            // 0.45 -> 0.35, 8 pairs = 608 blocks 0.44 -> 0.40, 10 pairs = 760 blocks 0.44 -> 0.47)
-            const bool w32 = e->split_window == 32;
-            if ((long long)n * hblocks <= e->split10_rows_below) {
-                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<10, 32>), hgrid, dim3(640), 0, st, g, jobs, XYB, V, PART);
-                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<10, 16>), hgrid, dim3(640), 0, st, g, jobs, XYB, V, PART);
-            } else if ((long long)n * hblocks <= e->split8_rows_below) {
-                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<8, 32>), hgrid, dim3(512), 0, st, g, jobs, XYB, V, PART);
-                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<8, 16>), hgrid, dim3(512), 0, st, g, jobs, XYB, V, PART);
-            } else if ((long long)n * hblocks <= (beside && !e->split5_rows_env ? 700 : e->split5_rows_below)) {
-                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5, 32>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
-                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<5, 16>), hgrid, dim3(320), 0, st, g, jobs, XYB, V, PART);
-            } else {
-                if (w32) hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3, 32>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
-                else hipLaunchKernelGGL((tmk::k_blur_h_jobs_split<3, 16>), hgrid, dim3(192), 0, st, g, jobs, XYB, V, PART);
-            }
+            hipLaunchKernelGGL(tmk::k_blur_h_jobs_split, hgrid, dim3(64 * TM_SPLIT_WAVES), 0, st, g, jobs, XYB, V, PART);
         }
         else if (g.s[0].w > 2560 || (e->variant & TM_VARIANT_WIDE_ROWS)) hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 16, 8>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
         else hipLaunchKernelGGL((tmk::k_blur_h_jobs_x<16, 8, 32, 16>), hgrid, dim3(64), 0, st, g, jobs, XYB, V, PART);
@@ -1298,11 +1274,7 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     case TM_DBG_EF_PERSIST_WGS: if (value < -1 || value > 65536) return TM_ERR_INVALID_ARG; e->ef_persist_wgs = (int)value; break;
     case TM_DBG_PASS_PRIO: if (value < 0 || value > 1) return TM_ERR_INVALID_ARG; e->ef_pass_prio = (int)value; break;
     case TM_DBG_SPLIT_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split_rows_below = value; e->split_rows_env = true; break;
-    case TM_DBG_SPLIT5_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split5_rows_below = value; e->split5_rows_env = true; break;
     case TM_DBG_EF_FAULT: if (value < 0 || value > 3) return TM_ERR_INVALID_ARG; e->ef_fault = (int)value; break;
-    case TM_DBG_SPLIT8_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split8_rows_below = value; break;
-    case TM_DBG_SPLIT10_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split10_rows_below = value; break;
-    case TM_DBG_SPLIT_WINDOW: if (value != 16 && value != 32) return TM_ERR_INVALID_ARG; e->split_window = (int)value; break;
     default: return TM_ERR_INVALID_ARG;
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values

@@ -1480,96 +1480,67 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row pass for SMALL batches ("split"): the same arithmetic and the same per-lane order of accumulation as k_blur_h_jobs_x --
-// its PART entries are bit-identical --, cut across THREE or FIVE waves per 64-row block.  Why: one wave issues at most one
-// instruction per four cycles, and a step of the FULL path is ~180 instructions (five recurrences, seven loads, the LDS
-// transposition, two IEEE divisions, six f64 accumulations), so the 1 924 steps of a 1080p row take 0.58 ms however idle the
-// chip is -- with fewer waves than SIMDs (8 pairs: 860 waves on 1 024 SIMDs) the pass sits at that latency.  Here
-//   NW = 3   wave 0  recurrences sigma11, sigma22 (FULL) + the ref / dis blocks: fetched in the normal orientation, parked transposed in LDS
-//            wave 1  recurrences sigma12, mu1, mu2 (FULL) / mu1, mu2 (EDGE)
-//            wave 2  the consumer: five (two) blurred values + ref, dis from LDS -> compute_error_maps -> f64 sums
-//   NW = 5   wave 0  sigma11, sigma22 (FULL; the ref / dis blocks of an EDGE job)     wave 1  sigma12 + the ref / dis blocks (FULL)
-//            wave 2  mu1, mu2          wave 3  the ssim map and its two sums (FULL)    wave 4  the two edge maps and their four sums
-// and the longest step body is ~70 (NW = 3) / ~45 (NW = 5) instructions: 0.35 / 0.26 ms per 1080p row block against 0.58.  Five waves
-// stop paying once a launch has more than a few hundred row blocks (8 pairs: 0.58 ms, three waves 0.43), so the engine picks by
-// size.  Steps run in phases of 16 with one LDS barrier per phase:
-// the producers fill half (phase & 1) of a two-phase ring [2][16][5][64] (40 KB) while the consumer empties the other half --
-// step t of the recurrences emits column t - 4, stored at ring position t --; ref / dis block b (columns 16 b .. + 15) is
-// loaded during phase b - 1, written during phase b, read during phases b + 1 and b + 2: four tile buffers (35 KB).
-// 75 KB of LDS per workgroup -> two workgroups per CU: for launches with fewer row blocks than the chip has wave slots only
-// (the engine switches by batch size; TM_VARIANT_SPLIT_ROWS forces it).  grid (slots, jobs.hstart[n]), block 64 * NW.
+// Row pass for SMALL launches ("split"): the same arithmetic and the same per-lane order of accumulation as k_blur_h_jobs_x -- its
+// PART entries are bit-identical --, cut across EIGHT waves per 64-row block.  Why: a launch of a few pairs leaves most of the chip
+// idle, and what its row pass takes is the time ONE row block needs to walk its w + 4 steps.  Round 3 gave a block three, then five
+// waves (0.58 -> 0.35 -> 0.26 ms per 1080p row); round 4 measured what bounds it (profiles/r04c_*_sq_summary.txt, r04d ... r04j):
+//   * a step of the FULL path is ~180 instructions over all its waves (five recurrences of ~20 with their loads and ring stores, ~10 for
+//     the ref / dis blocks, 37 for the ssim map and its sums, 32 for the edge maps and theirs), a SIMD issues one instruction per four
+//     cycles, and a workgroup lives on ONE CU: four SIMDs, waves i and i + 4 on the same one.  The time per step is the largest
+//     per-SIMD sum x 4 cycles (measured: 57 instructions -> 228 cycles predicted, 215-225 seen), not any single wave's count: a consumer
+//     cut into two waves of ~20 (ten waves per block, tried) changed nothing, nor did producers without clamps (13 instead of 20);
+//   * the consumers must not wait per step: an `if (valid)` around every step put each into its own exec-masked block, so that no LDS
+//     read of step j + 1 could be issued before the arithmetic of step j (~340 cycles per step: 0.26 -> 0.20 ms without it);
+//   * the ref / dis blocks need more than one phase of look-ahead: with one, a phase of 16 steps cannot be shorter than a load from
+//     HBM on an idle chip (8 pairs per launch: row pass 0.34 -> 0.28 ms with two).
+// Roles (wave: SIMD = wave % 4; the pairs are chosen so that the per-SIMD sums are 47 / 52 / 40 / 40 instructions per step):
+//   wave 0  the ssim map and its two sums (FULL)        wave 4  the ref / dis blocks: fetched in the normal orientation two phases ahead,
+//   wave 1  the two edge maps and their four sums                parked transposed in LDS (this replaces the reference's nppiTranspose)
+//   wave 2  sigma11 (FULL)     wave 6  sigma22 (FULL)   wave 5  mu2
+//   wave 3  sigma12 (FULL)     wave 7  mu1
+// Steps run in phases of 16 with one LDS barrier per phase: the producers fill half (phase & 1) of a two-phase ring [2][16][5][64]
+// (40 KB) while the consumers empty the other half -- step t of a recurrence emits column t - 4, stored at ring position t --; a
+// producer keeps a 32-row register window of its plane (22 rows of loads in flight); ref / dis block b (columns 16 b .. + 15) is
+// requested during phase b - 2, written during phase b, read during phases b + 1 and b + 2: four tile buffers (35 KB).  75 KB of LDS
+// and 112 registers: two workgroups per CU.  The engine runs it up to ~2 600 row blocks per launch (32 pairs of 1080p beside the fused
+// kernel; above, the one-wave pass has enough waves to hide its latencies); TM_VARIANT_SPLIT_ROWS / _WHOLE_ROWS force / forbid it.
+// Measured (1080p, pairs per launch, pairs/s; round 3 -> round 4): 1: 2.4 k -> 3.0 k, 4: 6.6 k -> 8.4 k, 8: 10.0 k -> 11.9 k,
+// 16: 11.7 k -> 12.8 k, 32: 12.5 k -> 13.5 k.  grid (slots, jobs.hstart[n]), block 512.
 // ------------------------------------------------------------------------------------------------
-// WN: register window of a producer's planes, 16 or 32 rows (rows t - 10 .. t + WN - 11 in registers or in flight).  A producer's
-// step is ~20 instructions per plane, so the 6 rows of look-ahead of WN = 16 are ~0.4 us of its own time -- less than a load from
-// HBM takes on an idle chip: with few waves in flight (the launches this kernel exists for) the producers wait for their loads.
-// WN = 32 looks 22 rows ahead (the one-wave pass is different: ~180 instructions per step, 6 rows = 1.8 us, and a deeper window
-// changed nothing there).
-template <int NP, int WN = 16, int NA = (NP > 0 ? NP : 1)> // NP: planes of this producer
-__device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)[16][5][64], const float *const (&v)[NA], const int (&plane)[NA],
-                                                      float (*__restrict__ tile)[4][64][17], const float *__restrict__ rdn, bool fetch_rd,
-                                                      int y0, int w, int h, int pitch, int pt, int nphases)
+#define TM_SPLIT_WAVES 8
+__device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)[16][5][64], const float *__restrict__ v, int plane, int w, int pt, int nphases)
 {
-    static_assert(WN == 16 || WN == 32, "window: one or two phases of 16 steps");
-    constexpr int P = WN - 10, SUB = WN / 16;
+    // v: this lane's row of a transposed blurred plane (column x at v[x * pt]); step t emits column t - 4 into ring[phase & 1][t & 15][plane]
+    constexpr int WN = 32, P = WN - 10;
     const int lane = threadIdx.x & 63;
-    const int lr = lane >> 4, lc = lane & 15;
-    auto ld_col = [&](const float *__restrict__ p, int x) { // column x of a transposed blurred plane, this lane's row; 0 outside
+    auto ld_col = [&](int x) { // column x, this lane's row; 0 outside
         const int rc = x < w ? x : w - 1;
-        const float val = p[(size_t)rc * pt];
+        const float val = v[(size_t)rc * pt];
         return x < w ? val : 0.0f;
     };
-    float win[NA][WN];
-    tmdev::Iir f[NA];
+    float win[WN];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        f[k] = tmdev::Iir{0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < WN; ++j) win[j] = j < P ? ld_col(j) : 0.0f;
+    tmdev::Iir f = {0, 0, 0, 0, 0, 0};
+    for (int ph0 = 0; ph0 < nphases; ph0 += 2) {
 #pragma unroll
-        for (int j = 0; j < WN; ++j) win[k][j] = j < P ? ld_col(v[k], j) : 0.0f;
-    }
-    // ref / dis block e: rows y0 + 4 * i + lr (i = 0 .. 15), columns 16 * e + lc: one 8-byte load per lane and row group
-    float qa[16], qb[16];
-    auto fetch_block = [&](int e) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int x = 16 * e + lc, y = y0 + 4 * i + lr;
-            const int yc = y < h ? y : h - 1, xc = x < pitch ? x : pitch - 1; // stay inside the plane; such samples are never used
-            const float2 val = *(const float2 *)(rdn + 2 * ((size_t)yc * pitch + xc));
-            qa[i] = val.x; qb[i] = val.y;
-        }
-    };
-    if (fetch_rd) fetch_block(0);
-    for (int ph0 = 0; ph0 < nphases; ph0 += SUB) {
-#pragma unroll
-        for (int sub = 0; sub < SUB; ++sub) {
+        for (int sub = 0; sub < 2; ++sub) {
             const int ph = ph0 + sub;
             if (ph >= nphases) break; // (the same for every wave of the workgroup: they all meet at the same barriers)
-            if (fetch_rd) { // block ph (in registers since the previous phase) -> its buffer; block ph + 1 requested
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[i]; tile[1][ph & 3][4 * i + lr][lc] = qb[i]; }
-                fetch_block(ph + 1);
-            }
-            if (NP > 0) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int t = 16 * ph + j; // row t lives in slot t % WN = 16 sub + j (ph0 is a multiple of SUB), row t-10 in slot (. + P) % WN, which row t+P then takes over
-                    const int sl = 16 * sub + j;
-#pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        const float o = tmdev::iir_step(f[k], win[k][(sl + P) % WN] + win[k][sl]);
-                        win[k][(sl + P) % WN] = ld_col(v[k], t + P);
-                        ring[ph & 1][j][plane[k]][lane] = o;
-                    }
-                }
+            for (int j = 0; j < 16; ++j) {
+                const int t = 16 * ph + j, sl = 16 * sub + j; // row t lives in slot t % 32 (ph0 is even), row t - 10 in slot (sl + P) % 32, which row t + P then takes over
+                const float o = tmdev::iir_step(f, win[(sl + P) % WN] + win[sl]);
+                win[(sl + P) % WN] = ld_col(t + P);
+                ring[ph & 1][j][plane][lane] = o;
             }
             TM_LDS_BARRIER();
         }
     }
 }
 
-// The ref / dis blocks of a row block when they have a wave to themselves (NW = 8, 10): block e is requested D phases before it is
-// written into its tile buffer.  With the one phase of look-ahead of the shared producer above, a phase could not be shorter than one
-// load from HBM takes on an idle chip -- and that, not any wave's instruction count, was what a launch of a pair or two measured:
-// ~1.3 us per phase of 16 steps whether a consumer ran 47, 37 or 21 instructions per step (profiles/r04i_split10.log).
+// the ref / dis blocks: block e = rows y0 + 4 i + (lane >> 4) (i = 0 .. 15), columns 16 e + (lane & 15) -- one 8-byte load per lane and
+// row group, a row of the block is one whole 128-B line --, requested D phases before it is written into its tile buffer
 template <int D>
 __device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[4][64][17], const float *__restrict__ rdn, int y0, int h, int pitch, int nphases)
 {
@@ -1591,7 +1562,7 @@ __device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int ph = ph0 + d;
-            if (ph >= nphases) break; // (the same for every wave of the workgroup: they all meet at the same barriers)
+            if (ph >= nphases) break;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[d][i]; tile[1][ph & 3][4 * i + lr][lc] = qb[d][i]; }
             fetch_block(ph + D, qa[d], qb[d]);
@@ -1600,79 +1571,54 @@ __device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[
     }
 }
 
-// WHAT (bits): 1 = the ssim map and its two sums (needs all five blurred values), 2 = the two edge maps and their four sums (mu1, mu2,
-// ref, dis); 3 = a FULL job in one wave, 2 alone also serves the EDGE jobs.  The per-lane order of accumulation is that of
-// k_blur_h_jobs_x either way.
-// STAGE 0: maps and sums in this wave.  STAGE 1 / 2 (k_blur_h_jobs_split<10>, WHAT = 1 or 2): the work of a consumer cut in two, one
-// wave each -- stage 1 reads the blurred values (and ref, dis) and leaves {numerator, denominator} of the ssim map, or d1 of the edge
-// maps, in `mid`; stage 2, one phase later, does the division / the maxima and the f64 sums.  The same f32 operations on the same
-// values in the same order (tmdev::ssim_terms + ssim_from_terms == error_maps), so the sums stay bit-identical.
-template <int WHAT, int STAGE = 0>
+// SSIM: the ssim map and its two sums (all five blurred values); otherwise the two edge maps and their four sums (mu1, mu2, ref, dis).
+// The per-lane order of accumulation is that of k_blur_h_jobs_x.  Runs one phase behind the producers.
+template <bool SSIM>
 __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__ ring)[16][5][64], const float (*__restrict__ tile)[4][64][17],
-                                                      float (*__restrict__ mid)[16][3][64], int w, bool valid, int nphases, double (&acc)[6])
+                                                      int w, bool valid, int nphases, double (&acc)[6])
 {
-    static_assert(STAGE == 0 || WHAT == 1 || WHAT == 2, "two-stage consumers handle one kind of map each");
     const int lane = threadIdx.x & 63;
     const int T = w + 4;
-    constexpr int LAG = STAGE == 2 ? 2 : 1; // phases behind the producers
-    // Lanes of rows below the image accumulate too (their inputs are the clamped last row's: finite) and are zeroed at the end -- a
-    // per-step `if (valid)` put every step into its own exec-masked block, so that no LDS read of step j + 1 could be issued before the
-    // arithmetic of step j: the consumer then took ~340 cycles per step (LDS latency + ~47 instructions) and the whole workgroup waited
-    // for it at every phase barrier (SQ counters, one 1080p pair: 58 % of the wave-cycles parked; 8 waves per row block instead of 5
-    // changed nothing).  The LDS reads of a block of eight steps are issued together, in front of its arithmetic.
+    // Lanes of rows below the image accumulate too (their inputs are the clamped last row's: finite) and are zeroed at the end; the LDS
+    // reads of a block of eight steps are issued together, in front of its arithmetic.
     struct In { float mu1, mu2, s11, s22, s12, src, dsv; };
     auto fetch = [&](int ph1, int j, int t) __attribute__((always_inline)) {
         const int u = t - 4; // the column whose maps are evaluated at step t
-        In v;
-        v.mu1 = v.mu2 = v.s11 = v.s22 = v.s12 = 0.0f; v.src = v.dsv = 0.0f;
-        if (STAGE == 2) { // what stage 1 left: {num, den} in s11, s22; d1 in src
-            const float (*m)[64] = mid[ph1 & 1][j];
-            if (WHAT & 1) { v.s11 = m[0][lane]; v.s22 = m[1][lane]; }
-            else v.src = m[2][lane];
-            return v;
-        }
         const float (*r)[64] = ring[ph1 & 1][j];
+        In v;
         v.mu1 = r[3][lane]; v.mu2 = r[4][lane];
-        if (WHAT & 1) { v.s11 = r[0][lane]; v.s22 = r[1][lane]; v.s12 = r[2][lane]; }
-        if (WHAT & 2) { v.src = tile[0][(u >> 4) & 3][lane][u & 15]; v.dsv = tile[1][(u >> 4) & 3][lane][u & 15]; }
+        v.s11 = v.s22 = v.s12 = 0.0f; v.src = v.dsv = 0.0f;
+        if (SSIM) { v.s11 = r[0][lane]; v.s22 = r[1][lane]; v.s12 = r[2][lane]; }
+        else { v.src = tile[0][(u >> 4) & 3][lane][u & 15]; v.dsv = tile[1][(u >> 4) & 3][lane][u & 15]; }
         return v;
     };
-    auto step = [&](const In &v, int ph1, int j) __attribute__((always_inline)) {
-        if (STAGE == 1) {
-            float (*m)[64] = mid[ph1 & 1][j];
-            if (WHAT & 1) { float num, den; tmdev::ssim_terms(v.mu1, v.mu2, v.s11, v.s22, v.s12, num, den); m[0][lane] = num; m[1][lane] = den; }
-            else m[2][lane] = tmdev::edge_d1(v.src, v.dsv, v.mu1, v.mu2);
-            return;
-        }
-        float ssim = 0.0f, art = 0.0f, det = 0.0f;
-        if (STAGE == 2) {
-            if (WHAT & 1) ssim = tmdev::ssim_from_terms(v.s11, v.s22);
-            else tmdev::edge_from_d1(v.src, art, det);
-        } else if (WHAT & 1) tmdev::error_maps(v.src, v.dsv, v.mu1, v.mu2, v.s11, v.s22, v.s12, ssim, art, det); // (the compiler drops the half whose results are not used)
-        else tmdev::edge_maps(v.src, v.dsv, v.mu1, v.mu2, art, det);
-        float q;
-        if (WHAT & 1) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
-        if (WHAT & 2) {
+    auto step = [&](const In &v) __attribute__((always_inline)) {
+        float ssim = 0.0f, art = 0.0f, det = 0.0f, q;
+        if (SSIM) { // (error_maps evaluates all three maps; the compiler drops the half whose results are not used)
+            tmdev::error_maps(v.src, v.dsv, v.mu1, v.mu2, v.s11, v.s22, v.s12, ssim, art, det);
+            acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q;
+        } else {
+            tmdev::edge_maps(v.src, v.dsv, v.mu1, v.mu2, art, det);
             acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
             acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
         }
     };
     for (int ph = 0; ph < nphases; ++ph) {
-        if (ph >= LAG) {
-            const int ph1 = ph - LAG, tb = 16 * ph1;
+        if (ph > 0) {
+            const int tb = 16 * (ph - 1);
             if (tb >= 4 && tb + 15 < T) { // every step of the phase emits a column (all phases but the first and the last one or two): straight-line code
 #pragma unroll
                 for (int j0 = 0; j0 < 16; j0 += 8) {
                     In v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fetch(ph1, j0 + j, tb + j0 + j);
+                    for (int j = 0; j < 8; ++j) v[j] = fetch(ph - 1, j0 + j, tb + j0 + j);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) step(v[j], ph1, j0 + j);
+                    for (int j = 0; j < 8; ++j) step(v[j]);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (tb + j >= 4 && tb + j < T) step(fetch(ph1, j, tb + j), ph1, j);
+                    if (tb + j >= 4 && tb + j < T) step(fetch(ph - 1, j, tb + j));
             }
         }
         TM_LDS_BARRIER();
@@ -1689,22 +1635,11 @@ __device__ __forceinline__ void blur_h_split_idle(int nphases)
     for (int ph = 0; ph < nphases; ++ph) TM_LDS_BARRIER();
 }
 
-// NW = 8 (launches of a pair or two: the reference's compute_one granularity): one recurrence per wave --
-//            wave 0 sigma11   wave 1 sigma22   wave 2 sigma12 (FULL only)   wave 3 mu1   wave 4 mu2   wave 5 the ref / dis blocks
-//            wave 6 the ssim map and its two sums (FULL)   wave 7 the two edge maps and their four sums
-// the longest step body is then a consumer's (~40 instructions); 512 threads, the same 75 KB of LDS.
-// NW = 10 (one or two pairs per launch): as NW = 8, with each consumer cut in two -- wave 6 numerator and denominator of the ssim map, wave 7 d1
-//            of the edge maps, waves 8 / 9 one phase later the division / the maxima and the f64 sums (a consumer's ~37 instructions per
-//            step were what every phase waited for once the producers had a wave per recurrence); 24 KB of LDS more (99 KB: one workgroup per CU).
-template <int NW, int WN = 16> // 3, 5, 8 or 10 waves per row block; WN: register window of the producers (16 or 32 rows)
-__global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, const float *__restrict__ V,
-                                                               double *__restrict__ PART)
+__global__ void __launch_bounds__(64 * TM_SPLIT_WAVES) k_blur_h_jobs_split(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, const float *__restrict__ V,
+                                                                           double *__restrict__ PART)
 {
-    static_assert(NW == 3 || NW == 5 || NW == 8 || NW == 10, "three, five, eight or ten waves per row block");
     __shared__ float ring[2][16][5][64];
     __shared__ float tile[2][4][64][17];
-    __shared__ typename std::conditional<NW == 10, float[2][16][3][64], float[1][1][1][1]>::type mid_s; // two-stage consumers only
-    float (*const mid)[16][3][64] = (float (*)[16][3][64])mid_s;
     const int b = blockIdx.y, slot = blockIdx.x;
     const int j = tm_find_job(jobs.hstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
@@ -1717,74 +1652,22 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
     const int yy = valid ? y : sg.h - 1;
     const size_t to = sg.off_t + c * sg.plane_t + (size_t)yy;
     const float *rdn = XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane);
-    const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to, *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to,
-                *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to, *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to,
-                *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
-    const int nphases = (sg.w + 4 + 15) / 16 + (NW == 10 ? 2 : 1); // the consumers run one phase behind the producers (their second stage: two)
+    const int nphases = (sg.w + 4 + 15) / 16 + 1; // the consumers run one phase behind the producers
     const bool full = mode == TM_MODE_FULL;
-    const float *const none[1] = {nullptr};
-    const int pl0[1] = {0};
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    int mine = 0; // bits: which maps' sums this wave holds at the end
-#define TM_SPLIT_TAIL y0, sg.w, sg.h, sg.pitch, sg.pitch_t, nphases
-    if (NW == 3) {
-        if (wave == 0) { // sigma11, sigma22 (FULL) + the ref / dis blocks
-            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
-            else blur_h_split_producer<0, WN>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
-        } else if (wave == 1) { // sigma12, mu1, mu2 (FULL) / mu1, mu2 (EDGE)
-            if (full) { const float *const pv[3] = {v2, v3, v4}; const int pl[3] = {2, 3, 4}; blur_h_split_producer<3, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
-            else { const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4}; blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
-        } else { // all maps and sums
-            if (full) { blur_h_split_consumer<3>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 3; }
-            else { blur_h_split_consumer<2>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 2; }
-        }
-    } else if (NW == 5) {
-        if (wave == 0) { // sigma11, sigma22 (FULL); the ref / dis blocks of an EDGE job
-            if (full) { const float *const pv[2] = {v0, v1}; const int pl[2] = {0, 1}; blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
-            else blur_h_split_producer<0, WN>(ring, none, pl0, tile, rdn, true, TM_SPLIT_TAIL);
-        } else if (wave == 1) { // sigma12 + the ref / dis blocks (FULL)
-            if (full) { const float *const pv[1] = {v2}; const int pl[1] = {2}; blur_h_split_producer<1, WN>(ring, pv, pl, tile, rdn, true, TM_SPLIT_TAIL); }
-            else blur_h_split_idle(nphases);
-        } else if (wave == 2) { // mu1, mu2
-            const float *const pv[2] = {v3, v4}; const int pl[2] = {3, 4};
-            blur_h_split_producer<2, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL);
-        } else if (wave == 3) { // the ssim map and its sums (FULL)
-            if (full) { blur_h_split_consumer<1>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 1; }
-            else blur_h_split_idle(nphases);
-        } else { // the edge maps and their sums
-            blur_h_split_consumer<2>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 2;
-        }
-    } else {
-        if (wave < 3) { // sigma11 | sigma22 | sigma12 (FULL)
-            if (full) { const float *const pv[1] = {wave == 0 ? v0 : (wave == 1 ? v1 : v2)}; const int pl[1] = {wave}; blur_h_split_producer<1, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL); }
-            else blur_h_split_idle(nphases);
-        } else if (wave < 5) { // mu1 | mu2
-            const float *const pv[1] = {wave == 3 ? v3 : v4}; const int pl[1] = {wave};
-            blur_h_split_producer<1, WN>(ring, pv, pl, tile, rdn, false, TM_SPLIT_TAIL);
-        } else if (wave == 5) { // the ref / dis blocks, two / three phases ahead (eight waves: two, so that the kernel stays at 128 registers and two workgroups per CU)
-            blur_h_split_fetcher<(NW == 10 ? 3 : 2)>(tile, rdn, y0, sg.h, sg.pitch, nphases);
-        } else if (NW == 8) {
-            if (wave == 6) { // the ssim map and its sums (FULL)
-                if (full) { blur_h_split_consumer<1>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 1; }
-                else blur_h_split_idle(nphases);
-            } else { // the edge maps and their sums
-                blur_h_split_consumer<2>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 2;
-            }
-        } else { // NW == 10: two-stage consumers
-            if (wave == 6) { // ssim map, first half (FULL)
-                if (full) blur_h_split_consumer<1, 1>(ring, tile, mid, sg.w, valid, nphases, acc);
-                else blur_h_split_idle(nphases);
-            } else if (wave == 7) { // edge maps, first half
-                blur_h_split_consumer<2, 1>(ring, tile, mid, sg.w, valid, nphases, acc);
-            } else if (wave == 8) { // ssim map, second half + its sums (FULL)
-                if (full) { blur_h_split_consumer<1, 2>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 1; }
-                else blur_h_split_idle(nphases);
-            } else { // edge maps, second half + their sums
-                blur_h_split_consumer<2, 2>(ring, tile, mid, sg.w, valid, nphases, acc); mine = 2;
-            }
-        }
-    }
-#undef TM_SPLIT_TAIL
+    int mine = 0; // bits: which maps' sums this wave holds at the end (1 ssim, 2 edge)
+    // which blurred plane a producer wave runs: waves 2, 6, 3 = sigma11, sigma22, sigma12 (FULL jobs only); 7, 5 = mu1, mu2
+    const int plane = wave == 2 ? 0 : (wave == 6 ? 1 : (wave == 3 ? 2 : (wave == 7 ? 3 : 4)));
+    if (wave == 0) { // the ssim map and its sums (FULL)
+        if (full) { blur_h_split_consumer<true>(ring, tile, sg.w, valid, nphases, acc); mine = 1; }
+        else blur_h_split_idle(nphases);
+    } else if (wave == 1) { // the edge maps and their sums
+        blur_h_split_consumer<false>(ring, tile, sg.w, valid, nphases, acc); mine = 2;
+    } else if (wave == 4) { // the ref / dis blocks, two phases ahead (three would cost the second workgroup per CU: 138 registers)
+        blur_h_split_fetcher<2>(tile, rdn, y0, sg.h, sg.pitch, nphases);
+    } else if (plane >= 3 || full) {
+        blur_h_split_producer(ring, V + (size_t)(slot * 5 + plane) * g.pyr_t + to, plane, sg.w, sg.pitch_t, nphases);
+    } else blur_h_split_idle(nphases); // the sigma producers of an EDGE job
     if (mine == 0) return;
     // a consumer holds some of the six sums of the row block (zeros elsewhere); the shuffle tree adds every entry in the order
     // k_blur_h_jobs_x adds it, so the entries come out bit-identical.  An EDGE job has no ssim sums: zeros, as k_blur_h_jobs_x writes
@@ -1792,7 +1675,7 @@ __global__ void __launch_bounds__(64 * NW) k_blur_h_jobs_split(TmGeom g, TmJobs 
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent fibers: sum through memory, in lane order like the shuffle tree's result
         __shared__ double redl[2][6][64];
-        const int slotw = wave == NW - 1 ? 1 : 0;
+        const int slotw = wave; // waves 0 and 1
         for (int k = 0; k < 6; ++k) redl[slotw][k][lane] = acc[k];
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
