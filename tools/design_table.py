@@ -5,10 +5,9 @@ import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T = sys.argv[1]
 P = lambda n: os.path.join(ROOT, "profiles", n)
-line = [l for l in open(P(f"{T}_bench.json")) if l.startswith('{"metric"')][0]
 wall = [l for l in open(P(f"{T}_bench.json")) if l.startswith("real")]
-d = json.loads(line)
-prof = json.loads(open(P(f"{T}_prof_bench_1080p.json")).read())
+d = json.load(open(P(f"{T}_bench_detail.json")))  # the full record of the default run (the stdout line is the compact one)
+prof = json.load(open(P(f"{T}_prof_bench_1080p_detail.json")))
 def stats(name):
     out = {}
     for r in csv.DictReader(open(P(name))):
@@ -33,15 +32,15 @@ def row(label, x, bold=True, r01=None):
 c = d["compare"]
 w = d["workloads"]
 rows = [
-    f"| workload (1 GPU, inputs resident in HBM), `{T}_bench.json`; in brackets: every kernel alone on the chip (`kernels_alone`) | pairs/s | ms/step | ingest | column pass (FULL jobs) | row pass (FULL jobs) | fused kernel of the EDGE jobs, beside the passes | SSIM stage | column-pass frac of 8 TB/s | blur+reduce stage frac (= `roofline.frac`: the three kernels as one concurrent group) |",
+    f"| workload (1 GPU, inputs resident in HBM), `{T}_bench_detail.json`; in brackets: every kernel alone on the chip (`kernels_alone`) | pairs/s | ms/step | ingest | column pass (FULL jobs) | row pass (FULL jobs) | fused kernel of the EDGE jobs, beside the passes | SSIM stage | column-pass frac of 8 TB/s | blur+reduce stage frac (= `roofline.frac`: the three kernels as one concurrent group) |",
     "|---|---|---|---|---|---|---|---|---|---|",
-    row("1080p NV12, SSIMULACRA2, 64 pairs/step (headline; r01 driver: 11 384, r02 driver: 11 033; this round before the fused kernel: 11 747)", d),
-    row(f"— the same command under rocprofv3, `{T}_prof_bench_1080p.json`", prof),
+    row("1080p NV12, SSIMULACRA2, 64 pairs/step (headline; drivers' runs: r01 11 384, r02 11 033, r03 13 911)", d),
+    row(f"— the same command under rocprofv3, `{T}_prof_bench_1080p_detail.json`", prof),
     f"| — with all 108 sums (`compare`: every job FULL, no fused kernel) | {fmt(c['value'])} | {c['ms_per_step']:.2f} | {c['stage_ms']['ingest']:.2f} | {c['stage_ms']['blur_v']:.2f} | {c['stage_ms']['blur_h']:.2f} | — | — | "
     f"{14858e6 * 64 / 64 / c['stage_ms']['blur_v'] / 8e9 * 1e3 / 1e3:.2f} | {c['blur_reduce_stage_frac']:.3f} |",
-    row("4K P016, SSIMULACRA2, 24 pairs/step (r02 driver: 2 822; before the fused kernel: 3 010)", w["4k_p016"]),
-    row("1080p PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["1080p_nv12_fused"], r01="6 545, r02: 8 292, before the fused kernel: 8 725"),
-    row("4K PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["4k_p016_fused"], r01="1 633, r02: 2 059, before the fused kernel: 2 188"),
+    row("4K P016, SSIMULACRA2, 24 pairs/step (r02 driver: 2 822; r03: 3 500)", w["4k_p016"]),
+    row("1080p PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["1080p_nv12_fused"], r01="6 545, r02: 8 292, r03: 9 770"),
+    row("4K PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["4k_p016_fused"], r01="1 633, r02: 2 059, r03: 2 453"),
 ]
 s1, sf, s4f = stats(f"{T}_kernel_stats_1080p_b64.csv"), stats(f"{T}_kernel_stats_1080p_b64_fused.csv"), stats(f"{T}_kernel_stats_4k_b24_fused.csv")
 pk = prof["kernels"]
@@ -54,10 +53,10 @@ efk = [k for k in s1 if "k_blur_edge_fused" in k][0]
 text = "\n".join(rows) + f"""
 
 (`python bench.py`, {wall[0].split()[1] if wall else '?'} wall; `fixed_stream` {fmt(fx['value'])} pairs/s over 2 048 pairs, {fmt(fx['long']['value'])} over 16 384; `host_fed` {fmt(hf['1080p_nv12']['value'])} pairs/s at 1080p =
-{hf['1080p_nv12']['h2d_GBs_per_gpu']:.1f} GB/s over PCIe, {fmt(hf['4k_p016']['value'])} at 4K = {hf['4k_p016']['h2d_GBs_per_gpu']:.1f} GB/s (40 steps each); `cpu_baseline` {cb['value']:.2f} pairs/s on one core, {cb['all_cores']['value']:.1f} on {cb['all_cores']['cores']} threads.)
+{hf['1080p_nv12']['h2d_GBs_per_gpu']:.1f} GB/s over PCIe, {fmt(hf['4k_p016']['value'])} at 4K = {hf['4k_p016']['h2d_GBs_per_gpu']:.1f} GB/s (40 steps each); `cpu_baseline` {cb['value']:.2f} pairs/s on one core, {cb['all_cores']['value']:.1f} on the {cb['all_cores']['cores']} CPUs the container may use ({cb['host_cpus']} visible).)
 `batch_curve` (1080p, pairs per launch: pairs/s (ms per step, engine memory)): {curve}.
-`cli_end_to_end` (the C++ binary on Y4M clips in tmpfs, its own "Processed" figure): 1080p 8-bit {fmt(cli['1080p_yuv420p']['default']['pairs_per_s'])} pairs/s with the defaults and {fmt(cli['1080p_yuv420p']['batch16']['pairs_per_s'])} with `--batch 16`;
-4K 10-bit {fmt(cli['4k_yuv420p10']['default']['pairs_per_s'])} / {fmt(cli['4k_yuv420p10']['batch16']['pairs_per_s'])}.
+`cli_end_to_end` (the C++ binary on Y4M clips in tmpfs, its own "Processed" figure): 1080p 8-bit {fmt(cli['1080p_yuv420p']['default']['pairs_per_s'])} pairs/s with the defaults (`--batch` by picture size: 16) and {fmt(cli['1080p_yuv420p']['batch16']['pairs_per_s'])} with `--batch 16`;
+4K 10-bit {fmt(cli['4k_yuv420p10']['default']['pairs_per_s'])} (batch 4) / {fmt(cli['4k_yuv420p10']['batch16']['pairs_per_s'])}.
 rocprofv3 of the same command (`profiles/{T}_kernel_stats_1080p_b64.csv`): `k_blur_v_jobs<32,16,0>` {s1['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms average over {s1['tmk::k_blur_v_jobs<32, 16, 0>'][0]}
 launches vs {pk['k_blur_v_jobs']['avg_launch_ms']:.3f} ms from the HIP events of the timed steps of that run; row pass {s1['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} vs {pk['k_blur_h_jobs_x']['avg_launch_ms']:.3f}; `k_ingest_rows` {s1[ing][1]:.3f} +
 `k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_rows']['avg_launch_ms']:.3f} for the stage; `{efk.replace('tmk::', '')}` {s1[efk][1]:.3f} vs {pk['k_blur_edge_fused']['avg_launch_ms']:.3f} (+ `k_finish_edge`

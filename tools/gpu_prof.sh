@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-compare --no-extras "$@" > $R/gpurun_out/${TAG}_prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-compare --no-extras --detail-file $R/gpurun_out/${TAG}_prof_detail.json "$@" > $R/gpurun_out/${TAG}_prof.log 2>&1
 cd $R
 grep '^{"metric"' gpurun_out/${TAG}_prof.log | tail -1 | python3 -c "
 import json,sys

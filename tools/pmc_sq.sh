@@ -6,7 +6,7 @@ shift
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-timeout 600 rocprofv3 --pmc ${TM_SQ_COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU} --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-extras "$@" > $R/gpurun_out/${TAG}_sq.log 2>&1
+timeout 600 rocprofv3 --pmc ${TM_SQ_COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU} --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-extras --detail-file /tmp/tm_sq_detail.json "$@" > $R/gpurun_out/${TAG}_sq.log 2>&1
 cd $R
 python3 - <<PY | tee gpurun_out/${TAG}_sq_summary.txt
 import csv, glob, collections

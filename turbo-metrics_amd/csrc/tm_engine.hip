@@ -445,6 +445,15 @@ int tm_device_count(void)
     return n;
 }
 
+int tm_device_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return TM_OK;
+}
+
 int tm_init(int device)
 {
     int n = 0;

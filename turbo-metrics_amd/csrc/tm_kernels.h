@@ -1486,18 +1486,21 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
 // waves (0.58 -> 0.35 -> 0.26 ms per 1080p row); round 4 measured what bounds it (profiles/r04c_*_sq_summary.txt, r04d ... r04j):
 //   * a step of the FULL path is ~180 instructions over all its waves (five recurrences of ~20 with their loads and ring stores, ~10 for
 //     the ref / dis blocks, 37 for the ssim map and its sums, 32 for the edge maps and theirs), a SIMD issues one instruction per four
-//     cycles, and a workgroup lives on ONE CU: four SIMDs, waves i and i + 4 on the same one.  The time per step is the largest
-//     per-SIMD sum x 4 cycles (measured: 57 instructions -> 228 cycles predicted, 215-225 seen), not any single wave's count: a consumer
-//     cut into two waves of ~20 (ten waves per block, tried) changed nothing, nor did producers without clamps (13 instead of 20);
+//     cycles, and a workgroup lives on ONE CU with its four SIMDs: 180 instructions / 4 SIMDs x 4 cycles = 180 cycles per step if the
+//     waves were spread evenly, 215-225 measured (1 924 steps of a 1080p row: 0.175 ms) -- the time per step is what the CU can issue
+//     for the block, not any single wave's count: a consumer cut into two waves of ~20 (ten waves per block, tried) changed nothing,
+//     nor did producers without clamps (13 instead of 20);
 //   * the consumers must not wait per step: an `if (valid)` around every step put each into its own exec-masked block, so that no LDS
 //     read of step j + 1 could be issued before the arithmetic of step j (~340 cycles per step: 0.26 -> 0.20 ms without it);
 //   * the ref / dis blocks need more than one phase of look-ahead: with one, a phase of 16 steps cannot be shorter than a load from
 //     HBM on an idle chip (8 pairs per launch: row pass 0.34 -> 0.28 ms with two).
-// Roles (wave: SIMD = wave % 4; the pairs are chosen so that the per-SIMD sums are 47 / 52 / 40 / 40 instructions per step):
-//   wave 0  the ssim map and its two sums (FULL)        wave 4  the ref / dis blocks: fetched in the normal orientation two phases ahead,
-//   wave 1  the two edge maps and their four sums                parked transposed in LDS (this replaces the reference's nppiTranspose)
-//   wave 2  sigma11 (FULL)     wave 6  sigma22 (FULL)   wave 5  mu2
-//   wave 3  sigma12 (FULL)     wave 7  mu1
+// Roles:  waves 0, 1, 2  sigma11, sigma22, sigma12 (FULL jobs)     waves 3, 4  mu1, mu2
+//         wave 5  the ref / dis blocks: fetched in the normal orientation two phases ahead, parked transposed in LDS (this replaces the
+//                 reference's nppiTranspose)
+//         wave 6  the ssim map and its two sums (FULL)              wave 7  the two edge maps and their four sums
+// (an order that pairs the heavy consumers with the light waves under "wave i runs on SIMD i % 4" -- 47 / 52 / 40 / 40 instead of 40 / 30 /
+// 57 / 52 instructions per step and SIMD -- measured SLOWER: one pair 0.175 -> 0.196 ms, eight pairs 0.285 -> 0.298; the placement of a
+// workgroup's waves is not that simple, and this order is the measured best)
 // Steps run in phases of 16 with one LDS barrier per phase: the producers fill half (phase & 1) of a two-phase ring [2][16][5][64]
 // (40 KB) while the consumers empty the other half -- step t of a recurrence emits column t - 4, stored at ring position t --; a
 // producer keeps a 32-row register window of its plane (22 rows of loads in flight); ref / dis block b (columns 16 b .. + 15) is
@@ -1656,17 +1659,15 @@ __global__ void __launch_bounds__(64 * TM_SPLIT_WAVES) k_blur_h_jobs_split(TmGeo
     const bool full = mode == TM_MODE_FULL;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     int mine = 0; // bits: which maps' sums this wave holds at the end (1 ssim, 2 edge)
-    // which blurred plane a producer wave runs: waves 2, 6, 3 = sigma11, sigma22, sigma12 (FULL jobs only); 7, 5 = mu1, mu2
-    const int plane = wave == 2 ? 0 : (wave == 6 ? 1 : (wave == 3 ? 2 : (wave == 7 ? 3 : 4)));
-    if (wave == 0) { // the ssim map and its sums (FULL)
+    if (wave == 6) { // the ssim map and its sums (FULL)
         if (full) { blur_h_split_consumer<true>(ring, tile, sg.w, valid, nphases, acc); mine = 1; }
         else blur_h_split_idle(nphases);
-    } else if (wave == 1) { // the edge maps and their sums
+    } else if (wave == 7) { // the edge maps and their sums
         blur_h_split_consumer<false>(ring, tile, sg.w, valid, nphases, acc); mine = 2;
-    } else if (wave == 4) { // the ref / dis blocks, two phases ahead (three would cost the second workgroup per CU: 138 registers)
+    } else if (wave == 5) { // the ref / dis blocks, two phases ahead (three would cost the second workgroup per CU: 138 registers)
         blur_h_split_fetcher<2>(tile, rdn, y0, sg.h, sg.pitch, nphases);
-    } else if (plane >= 3 || full) {
-        blur_h_split_producer(ring, V + (size_t)(slot * 5 + plane) * g.pyr_t + to, plane, sg.w, sg.pitch_t, nphases);
+    } else if (wave >= 3 || full) { // producer of plane `wave`
+        blur_h_split_producer(ring, V + (size_t)(slot * 5 + wave) * g.pyr_t + to, wave, sg.w, sg.pitch_t, nphases);
     } else blur_h_split_idle(nphases); // the sigma producers of an EDGE job
     if (mine == 0) return;
     // a consumer holds some of the six sums of the row block (zeros elsewhere); the shuffle tree adds every entry in the order
@@ -1675,7 +1676,7 @@ __global__ void __launch_bounds__(64 * TM_SPLIT_WAVES) k_blur_h_jobs_split(TmGeo
 #ifdef TM_EMULATE
     { // the lockstep emulator runs the lanes as concurrent fibers: sum through memory, in lane order like the shuffle tree's result
         __shared__ double redl[2][6][64];
-        const int slotw = wave; // waves 0 and 1
+        const int slotw = wave - 6; // waves 6 and 7
         for (int k = 0; k < 6; ++k) redl[slotw][k][lane] = acc[k];
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {

@@ -30,6 +30,7 @@ _vp, _u32, _i, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
 SYMBOLS = {
     "tm_init": (_i, [_i]),
     "tm_device_count": (_i, []),
+    "tm_device_mem_info": (_i, [C.POINTER(_sz), C.POINTER(_sz)]),
     "tm_host_alloc": (_vp, [_sz]),
     "tm_host_free": (None, [_vp]),
     "tm_set_placement_candidates": (None, [_i]),
