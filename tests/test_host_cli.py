@@ -210,6 +210,60 @@ def test_png_sources_decode_to_packed_rgb(helper, tmp_path):
     assert "detected as JPEG but no decoder is available" in run(helper, "source", p, str(tmp_path / "j.bin"))
 
 
+@pytest.mark.parametrize("bits16", [False, True])
+def test_animated_png_yields_every_frame_composed_onto_the_canvas(helper, tmp_path, bits16):
+    """every frame of a decoded image becomes a frame of the stream (input_image.rs:115-128): an animated PNG (acTL / fcTL / fdAT) --
+    sub-rectangle frames, all three dispose operations -- against Pillow's own APNG decoder; a plain PNG still has one frame"""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    w, h, n = 61, 47, 6
+    base = (rng.random((h, w, 3)) * 255).astype(np.uint8)
+    frames = [base.copy()]
+    for k in range(1, n):  # local changes: Pillow stores the bounding box of the difference only
+        f = frames[-1].copy()
+        y0, x0 = 3 + 5 * k, 2 + 7 * k
+        f[y0:y0 + 9, x0:x0 + 11] = (rng.random((9, 11, 3)) * 255).astype(np.uint8)
+        frames.append(f)
+    p = str(tmp_path / "a.png")
+    for disposal in (0, 1, 2, [0, 1, 2, 1, 0, 2]):
+        Image.fromarray(frames[0]).save(p, save_all=True, append_images=[Image.fromarray(f) for f in frames[1:]], disposal=disposal, blend=0)
+        im = Image.open(p)
+        assert getattr(im, "n_frames", 1) == n
+        want = []
+        for k in range(n):
+            im.seek(k)
+            want.append(np.asarray(im.convert("RGB")).copy())
+        head, fr, data = read_dump(helper, p, str(tmp_path / "a.bin"))
+        assert head[0] == "PNG/turbo-metrics-hip" and head[7] == str(n) and len(fr) == n, (head, len(fr))
+        got = data.reshape(n, h, w, 3)
+        for k in range(n):
+            assert np.array_equal(got[k], want[k]), (disposal, k)
+        assert len(read_dump(helper, p, str(tmp_path / "b.bin"), "--skip", 4)[1]) == n - 4
+    if bits16:  # 16-bit samples: a hand-made APNG (Pillow writes 8-bit RGB only) -- IHDR, acTL, fcTL, IDAT, fcTL, fdAT, IEND
+        import struct, zlib
+        a = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16)
+        patch = rng.integers(0, 65536, (8, 10, 3), dtype=np.uint16)
+
+        def chunk(t, body):
+            return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+
+        def zimg(arr):
+            return zlib.compress(b"".join(b"\x00" + row.astype(">u2").tobytes() for row in arr))
+        blob = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) + chunk(b"acTL", struct.pack(">II", 2, 0))
+                + chunk(b"fcTL", struct.pack(">IIIIIHHBB", 0, w, h, 0, 0, 1, 10, 0, 0)) + chunk(b"IDAT", zimg(a))
+                + chunk(b"fcTL", struct.pack(">IIIIIHHBB", 1, 10, 8, 5, 7, 1, 10, 0, 0)) + chunk(b"fdAT", struct.pack(">I", 2) + zimg(patch)) + chunk(b"IEND", b""))
+        open(p, "wb").write(blob)
+        head, fr, data = read_dump(helper, p, str(tmp_path / "c.bin"))
+        assert len(fr) == 2 and fr[0][0] == "rgb16"
+        got = data.view(np.uint16).reshape(2, h, w, 3)
+        b = a.copy(); b[7:15, 5:15] = patch
+        assert np.array_equal(got[0], a) and np.array_equal(got[1], b)
+        # a frame that sticks out of the canvas, an fdAT without its fcTL: errors, not crashes
+        bad = blob.replace(struct.pack(">IIIIIHHBB", 1, 10, 8, 5, 7, 1, 10, 0, 0), struct.pack(">IIIIIHHBB", 1, 10, 8, 55, 7, 1, 10, 0, 0))
+        open(p, "wb").write(bad)
+        assert "outside the canvas" in run(helper, "source", p, str(tmp_path / "d.bin"))
+
+
 def test_ppm_and_pfm_sources(helper, tmp_path):
     rng = np.random.default_rng(2)
     a8 = (rng.random((9, 31, 3)) * 255).astype(np.uint8)

@@ -29,8 +29,23 @@ def png(w, h, depth, interlace):
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 2, 0, 0, interlace)) + chunk(b"IDAT", zlib.compress(data)) + chunk(b"IEND", b"")
 
 
+def apng(w, h, depth, n):
+    """animated PNG: a full first frame (IDAT) and n - 1 sub-rectangle frames (fdAT) with the three dispose operations"""
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    bpp = 3 * depth // 8
+    def z(ww, hh): return zlib.compress(b"".join(b"\0" + nrng.integers(0, 256, ww * bpp, dtype=np.uint8).tobytes() for _ in range(hh)))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 2, 0, 0, 0)) + chunk(b"acTL", struct.pack(">II", n, 0))
+    out += chunk(b"fcTL", struct.pack(">IIIIIHHBB", 0, w, h, 0, 0, 1, 10, 0, 0)) + chunk(b"IDAT", z(w, h))
+    seq = 1
+    for k in range(1, n):
+        fw, fh, x, y = max(1, w // 2), max(1, h // 3), k % max(1, w // 2), k % max(1, h // 2)
+        out += chunk(b"fcTL", struct.pack(">IIIIIHHBB", seq, fw, fh, x, y, 1, 10, k % 3, k % 2)) + chunk(b"fdAT", struct.pack(">I", seq + 1) + z(fw, fh))
+        seq += 2
+    return out + chunk(b"IEND", b"")
+
+
 seeds = {
-    "a.png": png(37, 23, 8, 0), "b.png": png(19, 11, 16, 0), "c.png": png(21, 13, 8, 1),
+    "a.png": png(37, 23, 8, 0), "b.png": png(19, 11, 16, 0), "c.png": png(21, 13, 8, 1), "m.png": apng(29, 17, 8, 5), "n.png": apng(13, 9, 16, 3),
     "d.ppm": b"P6\n17 9\n255\n" + nrng.integers(0, 256, 17 * 9 * 3, dtype=np.uint8).tobytes(),
     "e.ppm": b"P6\n# c\n9 5 65535\n" + nrng.integers(0, 256, 9 * 5 * 6, dtype=np.uint8).tobytes(),
     "f.pfm": b"PF\n8 6\n-1.0\n" + nrng.random(8 * 6 * 3, dtype=np.float32).tobytes(),

@@ -102,14 +102,75 @@ void unfilter(const unsigned char *raw, size_t rows, size_t stride, size_t bpp, 
 
 } // namespace
 
-CpuImg decode_png(const unsigned char *d, size_t len)
+namespace {
+
+// one PNG (sub)image: zlib stream -> unfiltered, de-interlaced packed RGB rows of fw x fh pixels (samples in network order)
+std::vector<unsigned char> png_inflate_image(const std::vector<unsigned char> &zdata, uint32_t fw, uint32_t fh, size_t bpp, int interlace)
+{
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole[1] = {{0, 0, 1, 1}};
+    const Pass *passes = interlace ? adam7 : whole;
+    const int npass = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int p = 0; p < npass; ++p) {
+        const size_t pw = (fw > passes[p].x0) ? (fw - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+        const size_t ph = (fh > passes[p].y0) ? (fh - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+        if (pw && ph) raw_size += ph * (1 + pw * bpp);
+    }
+    // deflate expands at most ~1032:1: a header that promises more than the compressed bytes can hold is corrupt (checked BEFORE
+    // the allocation)
+    if (raw_size / 1032 > zdata.size() + 1) fail("PNG: corrupt image data");
+    std::vector<unsigned char> raw(raw_size);
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) fail("PNG: inflateInit failed");
+        zs.next_in = const_cast<unsigned char *>(zdata.data()); zs.avail_in = (uInt)zdata.size();
+        zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
+        if (zdata.size() > 0xFFFFFFFFu || raw.size() > 0xFFFFFFFFu) { inflateEnd(&zs); fail("PNG: image too large"); }
+        const int rc = inflate(&zs, Z_FINISH);
+        const size_t got = raw.size() - zs.avail_out;
+        inflateEnd(&zs);
+        if ((rc != Z_STREAM_END && rc != Z_BUF_ERROR && rc != Z_OK) || got != raw.size()) fail("PNG: corrupt image data");
+    }
+    std::vector<unsigned char> out((size_t)fw * fh * bpp, 0);
+    size_t off = 0;
+    std::vector<unsigned char> rows;
+    for (int p = 0; p < npass; ++p) {
+        const size_t pw = (fw > passes[p].x0) ? (fw - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+        const size_t ph = (fh > passes[p].y0) ? (fh - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+        if (!pw || !ph) continue;
+        unfilter(raw.data() + off, ph, pw * bpp, bpp, rows);
+        off += ph * (1 + pw * bpp);
+        for (size_t y = 0; y < ph; ++y)
+            for (size_t x = 0; x < pw; ++x)
+                memcpy(out.data() + (((size_t)passes[p].y0 + y * passes[p].dy) * fw + passes[p].x0 + x * passes[p].dx) * bpp,
+                       rows.data() + (y * pw + x) * bpp, bpp);
+    }
+    return out;
+}
+
+} // namespace
+
+// Every frame of a PNG.  A plain PNG has one; an animated PNG (acTL / fcTL / fdAT, APNG 1.0) has the frames of its animation -- the
+// reference hands every frame of a decoded image to the metric as a frame of the stream (input_image.rs:115-128: img.frames_ref()) --,
+// each composed onto the canvas as the specification says: the frame's region is drawn at its offset (RGB has no alpha: blend_op OVER is
+// SOURCE), the canvas after drawing is the frame handed out, and dispose_op tells what the region holds for the NEXT frame (NONE: this
+// frame, BACKGROUND: zeros, PREVIOUS: what it held before; PREVIOUS on the first frame counts as BACKGROUND).  A default image that is not
+// part of the animation (IDAT before the first fcTL) is skipped, as viewers of animated PNGs do.
+std::vector<CpuImg> decode_png_frames(const unsigned char *d, size_t len)
 {
     if (len < 8 + 25) fail("PNG: truncated");
     size_t pos = 8;
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = -1, interlace = 0;
+    struct Frame { uint32_t w, h, x, y; int dispose, blend; bool is_default; std::vector<unsigned char> z; };
+    std::vector<Frame> frames;
     std::vector<unsigned char> idat;
-    bool end = false;
+    bool animated = false, seen_idat = false, fctl_before_idat = false, end = false;
+    uint32_t declared_frames = 0;
+    Frame *cur = nullptr; // the frame that fdAT chunks (or IDAT, for a first frame that is the default image) add to
     while (!end && pos + 12 <= len) {
         const uint32_t clen = be32(d + pos);
         const unsigned char *type = d + pos + 4, *body = d + pos + 8;
@@ -118,69 +179,68 @@ CpuImg decode_png(const unsigned char *d, size_t len)
             if (clen != 13) fail("PNG: bad IHDR");
             w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
             if (body[10] != 0 || body[11] != 0) fail("PNG: unknown compression/filter method");
+            check_dims("PNG", w, h);
+        } else if (!memcmp(type, "acTL", 4) && !seen_idat) {
+            if (clen != 8) fail("PNG: bad acTL");
+            declared_frames = be32(body);
+            if (declared_frames == 0 || declared_frames > (1u << 20)) fail("PNG: implausible number of animation frames");
+            animated = true;
+        } else if (!memcmp(type, "fcTL", 4) && animated) {
+            if (clen != 26) fail("PNG: bad fcTL");
+            if (ctype < 0) fail("PNG: fcTL before IHDR");
+            Frame f{be32(body + 4), be32(body + 8), be32(body + 12), be32(body + 16), body[24], body[25], !seen_idat, {}};
+            if (f.w == 0 || f.h == 0 || (uint64_t)f.x + f.w > w || (uint64_t)f.y + f.h > h) fail("PNG: animation frame outside the canvas");
+            if (f.dispose > 2 || f.blend > 1) fail("PNG: unknown dispose / blend operation");
+            if (!seen_idat) { if (fctl_before_idat) fail("PNG: two fcTL chunks before IDAT"); fctl_before_idat = true; if (f.w != w || f.h != h || f.x || f.y) fail("PNG: the first frame must cover the canvas"); }
+            if (frames.size() >= declared_frames) fail("PNG: more animation frames than acTL declares");
+            frames.push_back(std::move(f));
+            cur = &frames.back();
         } else if (!memcmp(type, "IDAT", 4)) {
+            seen_idat = true;
             idat.insert(idat.end(), body, body + clen);
+        } else if (!memcmp(type, "fdAT", 4) && animated) {
+            if (clen < 4 || !cur || cur->is_default) fail("PNG: fdAT without its fcTL");
+            cur->z.insert(cur->z.end(), body + 4, body + clen);
         } else if (!memcmp(type, "IEND", 4)) {
             end = true;
         }
         pos += 12 + (size_t)clen;
     }
     if (ctype < 0 || w == 0 || h == 0) fail("PNG: no IHDR");
-    check_dims("PNG", w, h);
     // the reference accepts RGB sample layouts only (turbo-metrics/src/img.rs:17-37: anything else is todo!())
     if (ctype != 2) fail("not implemented: PNG colour type " + std::to_string(ctype) + " (only RGB is supported, as in the reference)");
     if (depth != 8 && depth != 16) fail("PNG: RGB must be 8 or 16 bits per sample");
     if (interlace > 1) fail("PNG: unknown interlace method");
     const size_t bpp = 3 * (size_t)depth / 8;
-
-    struct Pass { uint32_t x0, y0, dx, dy; };
-    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
-    static const Pass whole[1] = {{0, 0, 1, 1}};
-    const Pass *passes = interlace ? adam7 : whole;
-    const int npass = interlace ? 7 : 1;
-    size_t raw_size = 0;
-    for (int p = 0; p < npass; ++p) {
-        const size_t pw = (w > passes[p].x0) ? (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
-        const size_t ph = (h > passes[p].y0) ? (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
-        if (pw && ph) raw_size += ph * (1 + pw * bpp);
+    if (!animated || frames.empty()) { // a plain PNG (or an acTL without any frame: the default image)
+        frames.clear();
+        frames.push_back(Frame{w, h, 0, 0, 0, 0, true, {}});
     }
-    // deflate expands at most ~1032:1: a header that promises more than the IDAT bytes can hold is corrupt (checked BEFORE
-    // the allocation)
-    if (raw_size / 1032 > idat.size() + 1) fail("PNG: corrupt image data");
-    std::vector<unsigned char> raw(raw_size);
-    {
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit(&zs) != Z_OK) fail("PNG: inflateInit failed");
-        zs.next_in = idat.data(); zs.avail_in = (uInt)idat.size();
-        zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
-        if (idat.size() > 0xFFFFFFFFu || raw.size() > 0xFFFFFFFFu) { inflateEnd(&zs); fail("PNG: image too large"); }
-        const int rc = inflate(&zs, Z_FINISH);
-        const size_t got = raw.size() - zs.avail_out;
-        inflateEnd(&zs);
-        if ((rc != Z_STREAM_END && rc != Z_BUF_ERROR && rc != Z_OK) || got != raw.size()) fail("PNG: corrupt image data");
+    if ((uint64_t)w * h * bpp * frames.size() > ((uint64_t)1 << 34)) fail("PNG: animation too large");
+    std::vector<CpuImg> out;
+    std::vector<unsigned char> canvas((size_t)w * h * bpp, 0), before;
+    for (size_t k = 0; k < frames.size(); ++k) {
+        const Frame &f = frames[k];
+        const std::vector<unsigned char> px = png_inflate_image(f.is_default ? idat : f.z, f.w, f.h, bpp, interlace);
+        const int dispose = (k == 0 && f.dispose == 2) ? 1 : f.dispose;
+        if (dispose == 2) before = canvas;
+        for (uint32_t y = 0; y < f.h; ++y)
+            memcpy(canvas.data() + (((size_t)f.y + y) * w + f.x) * bpp, px.data() + (size_t)y * f.w * bpp, (size_t)f.w * bpp);
+        CpuImg img;
+        img.width = w; img.height = h;
+        img.sample_type = depth == 8 ? CpuImg::U8 : CpuImg::U16;
+        img.data = canvas;
+        if (depth == 16) // network order -> host order
+            for (size_t i = 0; i + 1 < img.data.size(); i += 2) std::swap(img.data[i], img.data[i + 1]);
+        out.push_back(std::move(img));
+        if (dispose == 1)
+            for (uint32_t y = 0; y < f.h; ++y) memset(canvas.data() + (((size_t)f.y + y) * w + f.x) * bpp, 0, (size_t)f.w * bpp);
+        else if (dispose == 2) canvas = before;
     }
-    CpuImg img;
-    img.width = w; img.height = h;
-    img.sample_type = depth == 8 ? CpuImg::U8 : CpuImg::U16;
-    img.data.assign((size_t)w * h * bpp, 0);
-    size_t off = 0;
-    std::vector<unsigned char> rows;
-    for (int p = 0; p < npass; ++p) {
-        const size_t pw = (w > passes[p].x0) ? (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
-        const size_t ph = (h > passes[p].y0) ? (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
-        if (!pw || !ph) continue;
-        unfilter(raw.data() + off, ph, pw * bpp, bpp, rows);
-        off += ph * (1 + pw * bpp);
-        for (size_t y = 0; y < ph; ++y)
-            for (size_t x = 0; x < pw; ++x)
-                memcpy(img.data.data() + (((size_t)passes[p].y0 + y * passes[p].dy) * w + passes[p].x0 + x * passes[p].dx) * bpp,
-                       rows.data() + (y * pw + x) * bpp, bpp);
-    }
-    if (depth == 16) // network order -> host order
-        for (size_t i = 0; i + 1 < img.data.size(); i += 2) std::swap(img.data[i], img.data[i + 1]);
-    return img;
+    return out;
 }
+
+CpuImg decode_png(const unsigned char *d, size_t len) { return std::move(decode_png_frames(d, len).front()); }
 
 // ---- PPM (P6) / PFM (PF) --------------------------------------------------------------------------------------------
 CpuImg decode_pnm(const unsigned char *d, size_t len)
@@ -235,9 +295,10 @@ CpuImg decode_pnm(const unsigned char *d, size_t len)
 // ---- ImageFrameSource ------------------------------------------------------------------------------------------------
 ImageFrameSource::ImageFrameSource(std::vector<unsigned char> file, ImageFormat f) : format_(f)
 {
-    CpuImg img = f == ImageFormat::PNG ? decode_png(file.data(), file.size()) : decode_pnm(file.data(), file.size());
-    width_ = img.width; height_ = img.height;
-    frames_.push_back(std::move(img));
+    // every frame of the decoded image becomes a frame of the stream (input_image.rs:115-128); PPM / PFM hold one
+    if (f == ImageFormat::PNG) { for (CpuImg &img : decode_png_frames(file.data(), file.size())) frames_.push_back(std::move(img)); }
+    else frames_.push_back(decode_pnm(file.data(), file.size()));
+    width_ = frames_.front().width; height_ = frames_.front().height;
 }
 
 FormatIdentifier ImageFrameSource::format_id() const { return FormatIdentifier{std::nullopt, to_string(format_), "turbo-metrics-hip"}; }

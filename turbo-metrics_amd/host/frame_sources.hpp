@@ -41,7 +41,8 @@ struct CpuImg { // img.rs:40-48
 };
 
 // decoders (throw std::runtime_error with the reason)
-CpuImg decode_png(const unsigned char *data, size_t len);
+CpuImg decode_png(const unsigned char *data, size_t len);                      // the first frame
+std::vector<CpuImg> decode_png_frames(const unsigned char *data, size_t len); // every frame (animated PNG: composed onto the canvas)
 CpuImg decode_pnm(const unsigned char *data, size_t len);
 
 class ImageFrameSource : public FrameSource {
