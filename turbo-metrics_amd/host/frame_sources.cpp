@@ -340,6 +340,9 @@ static void pread_all(int fd, unsigned char *dst, size_t n, size_t off)
     }
 }
 
+static std::atomic<unsigned> g_concurrent_streams{2};
+void set_concurrent_streams(unsigned n) { g_concurrent_streams.store(n < 1 ? 1 : n); }
+
 unsigned effective_cpus()
 {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
@@ -526,7 +529,9 @@ void YuvStreamSource::ensure_ring()
     // 12 / 16 threads per stream = 9 / 12 / 17 / 20 / 11 / 18 GB/s per stream at 1080p, 6 / 8 / 17 / 15 / 12 / 16 at 4K: a thread copies
     // 6-9 GB/s, the pair of streams tops out at 35-40 GB/s, and more busy threads than the quota get the group throttled:
     // profiles/r04h_read_probe.log) -> a third of the CPUs left after main thread, dispatchers, ring helper and the HIP runtime
-    const unsigned want = env ? (unsigned)std::max(1, atoi(env)) : std::min(by_size, std::max(1u, (cpus > 4 ? cpus - 4 : 1) / 3));
+    // (streams: how many sources this process reads at the same time -- two, or two per device with `--devices N`)
+    const unsigned streams = g_concurrent_streams.load();
+    const unsigned want = env ? (unsigned)std::max(1, atoi(env)) : std::min(by_size, std::max(1u, (cpus > 4 ? cpus - 4 : 1) / (streams + 1)));
     const bool ra = readahead_ && fd_ >= 0 && h_ >= 64;
     // read-ahead: enough pictures in flight to keep `want` readers busy with pieces of ~2 MB, at most 256 MB of them
     const size_t pieces = std::max<size_t>(1, (planar_bytes_ + ((size_t)2 << 20) - 1) / ((size_t)2 << 20));

@@ -245,6 +245,7 @@ int main(int argc, char **argv)
             log_source("distorted", *source_dis);
             const uint32_t w = source_ref->width(), h = source_ref->height();
             if (batch == 0) batch = auto_batch(w, h);
+            set_concurrent_streams(2 * want); // every shard reads its own pair of streams: the reader threads share the usable CPUs
             source_ref.reset(); source_dis.reset(); // every shard opens its own
             if (known < 20000) tm_set_placement_candidates(1); // as below: the search pays off on long streams only
             struct Shard { std::vector<FrameScores> scores; uint32_t decoded = 0; std::string err; };

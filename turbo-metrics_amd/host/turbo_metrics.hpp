@@ -163,6 +163,9 @@ public:
 // that sees 256 CPUs may be limited to 16 CPUs' worth of time -- the GPU boxes of rounds 1-4 are: cpu.max = "1600000 100000" --
 // and more busy threads than that only buy throttling: the whole group sleeps out the rest of every 100-ms period).
 unsigned effective_cpus();
+// how many frame sources this process reads at the same time (default 2: reference and distorted; 2 per device with `--devices N`):
+// the sources share the usable CPUs between their reader threads
+void set_concurrent_streams(unsigned n);
 
 // compute_all selected no frame pair at all (the reference panics in Stats::compute: index out of bounds)
 class NoFramesSelected : public std::out_of_range {
