@@ -570,6 +570,9 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     e->w = width; e->h = height; e->mask = metrics_mask; e->cap = batch_capacity;
     tm_make_geom(&e->g, (int)width, (int)height);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cus = prop.multiProcessorCount; }
+    // the kernels' code object is loaded HERE, not by the first launch (the reference loads its PTX modules in Ssimulacra2::new:
+    // cuModuleLoadData, ssimulacra2-cuda/src/kernel.rs): asking for a kernel's attributes makes the runtime load the module of this library
+    { hipFuncAttributes fa; if (hipFuncGetAttributes(&fa, (const void *)tmk::k_finish_jobs) != hipSuccess) (void)hipGetLastError(); }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));

@@ -513,7 +513,23 @@ void YuvStreamSource::set_lookahead(size_t frames)
     if (ring_.empty()) lookahead_ = frames ? frames : 1;
 }
 
+void YuvStreamSource::prepare()
+{
+    alloc_ring();
+    if (ring_alloc_.joinable()) ring_alloc_.join(); // every slot page-locked (or known not to be) before the caller's clock starts
+}
+
 void YuvStreamSource::ensure_ring()
+{
+    alloc_ring();
+    if (readers_started_) return;
+    readers_started_ = true;
+    // the readers start with the first frame that is asked for: skip_frames (sequential, before) has moved the file position by then
+    if (ahead_ > 0) start_readahead(reader_threads_, ahead_);
+    else if (h_ >= 256 && reader_threads_ > 1 && fd_ >= 0) workers_ = std::make_unique<RowWorkers>(std::min(reader_threads_, 32u) - 1);
+}
+
+void YuvStreamSource::alloc_ring()
 {
     if (!ring_.empty()) return;
     // reader threads per stream (the reference and the distorted stream are read at the same time): what the process may really use
@@ -567,8 +583,8 @@ void YuvStreamSource::ensure_ring()
             }
         });
     }
-    if (ra) start_readahead(want, ahead);
-    else if (h_ >= 256 && want > 1 && fd_ >= 0) workers_ = std::make_unique<RowWorkers>(std::min(want, 32u) - 1);
+    reader_threads_ = want;
+    ahead_ = ahead;
 }
 
 unsigned char *YuvStreamSource::ring_slot(size_t i)

@@ -105,6 +105,7 @@ public:
     bool shardable() const override { return fd_ >= 0; }
     void set_lookahead(size_t frames) override;
     void set_readahead(bool on) override { if (ring_.empty()) readahead_ = on; }
+    void prepare() override; // the whole ring, page-locked, before the first frame is asked for
     // bytes that were read from the stream before this source took it over (the format probe of a pipe)
     void set_prefix(std::vector<unsigned char> bytes);
 
@@ -137,7 +138,11 @@ private:
     std::mutex ring_m_;
     std::condition_variable ring_cv_;
     std::thread ring_alloc_;
-    void ensure_ring();
+    void ensure_ring();                   // ring (alloc_ring) + readers
+    void alloc_ring();
+    unsigned reader_threads_ = 1;
+    size_t ahead_ = 0;
+    bool readers_started_ = false;
     unsigned char *ring_slot(size_t i);
     std::unique_ptr<RowWorkers> workers_; // created with the ring (pictures of 256 rows and more; synchronous mode)
     bool parse_frame_header();            // regular files: the FRAME line at file_pos_ (Y4M); false at the end of the stream

@@ -317,6 +317,10 @@ int main(int argc, char **argv)
 
     log_source("reference", *source_ref);
     log_source("distorted", *source_dis);
+    // the sources' frame rings are page-locked here, before the clock starts: the counterpart of the surface pool the reference's decoder
+    // allocates when it is created (its clock, main.rs:252, starts after decoders and engine exist too)
+    try { TurboMetrics::prepare_sources(*source_ref, *source_dis, opts); }
+    catch (const std::exception &e) { log_line(L_ERROR, kTarget, std::string("Could not initialize the sources : ") + e.what()); return EXIT_FAILURE; }
     log_line(L_DEBUG, kTarget, "Initialized, now processing ...");
 
     const auto start = std::chrono::steady_clock::now();

@@ -224,6 +224,22 @@ MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Me
     return res;
 }
 
+// A page-locked frame is pulled into an engine-owned device surface by an asynchronous DMA; its bytes are free again when THAT
+// copy is done (tm_engine_upload_fence / tm_engine_upload_done), not when its batch has been computed: a frame has to survive
+// only UPLOADS_IN_FLIGHT further next_frame calls, whatever the batch size -- the sources' rings of page-locked surfaces stay
+// small (round 3: 2 * batch + 1 surfaces per stream; page-locking them, at ~3 GB/s, was most of a short 4K run and the reason
+// why --batch 16 was slower than --batch 8)
+static constexpr size_t UPLOADS_IN_FLIGHT = 4;
+
+void TurboMetrics::prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts)
+{
+    for (FrameSource *s : {&frames_ref, &frames_dis}) {
+        s->set_lookahead(UPLOADS_IN_FLIGHT);
+        s->set_readahead(opts.every <= 1); // dropped pictures are consumed without being read: no reading ahead then
+        s->prepare();
+    }
+}
+
 MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts,
                                          const std::function<void(const FrameScores &)> &on_frame, uint32_t *decode_count_out)
 {
@@ -239,16 +255,7 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
 
     uint32_t decode_count = opts.decode_start;
     size_t compute_count = 0;
-    // A page-locked frame is pulled into an engine-owned device surface by an asynchronous DMA; its bytes are free again when THAT
-    // copy is done (tm_engine_upload_fence / tm_engine_upload_done), not when its batch has been computed: a frame has to survive
-    // only UPLOADS_IN_FLIGHT further next_frame calls, whatever the batch size -- the sources' rings of page-locked surfaces stay
-    // small (round 3: 2 * batch + 1 surfaces per stream; page-locking them, at ~3 GB/s, was most of a short 4K run and the reason
-    // why --batch 16 was slower than --batch 8)
-    constexpr size_t UPLOADS_IN_FLIGHT = 4;
-    frames_ref.set_lookahead(UPLOADS_IN_FLIGHT);
-    frames_dis.set_lookahead(UPLOADS_IN_FLIGHT);
-    frames_ref.set_readahead(opts.every <= 1); // dropped pictures are consumed without being read: no reading ahead then
-    frames_dis.set_readahead(opts.every <= 1);
+    prepare_sources(frames_ref, frames_dis, opts); // (no-ops when the caller has done it already)
     struct Fence { tm_engine *e = nullptr; uint64_t token = 0; };
     Fence fences[UPLOADS_IN_FLIGHT + 1];
     size_t kept = 0; // pairs handed to an engine so far

@@ -157,6 +157,10 @@ public:
     // beyond the one being asked for)?  compute_all switches it off when `--every` drops frames: dropped pictures are then
     // consumed without being read at all.  Call before the first frame.
     virtual void set_readahead(bool on) { (void)on; }
+    // Allocate what the source needs to hand out frames -- for planar streams the ring of page-locked surfaces, the counterpart of the
+    // surface pool the reference's decoder allocates when it is CREATED (cudarse-video/src/dec_simple.rs), i.e. before the CLI's clock
+    // starts (turbo-metrics-cli/src/main.rs:252).  Call after set_lookahead / set_readahead; next_frame does it itself otherwise.
+    virtual void prepare() {}
 };
 
 // CPUs this process may really use: the smallest of the hardware threads, the affinity mask and the cgroup CPU quota (a container
@@ -207,6 +211,9 @@ public:
     // in stream order (the CLI's output_single_score).  Returns the number of frames decoded (for the CLI's log line).
     MetricsResults compute_all(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts,
                                const std::function<void(const FrameScores &)> &on_frame = nullptr, uint32_t *decode_count = nullptr);
+    // what compute_all asks of its sources (how long a frame must stay valid, whether they may read ahead) + FrameSource::prepare():
+    // a caller that times compute_all like the reference's CLI (clock started after the decoders exist) calls this first
+    static void prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts);
 
 private:
     void set_frame(tm_engine *e, uint32_t slot, int side, const HwFrame &f, const ColorInfo &c);

@@ -97,6 +97,7 @@ public:
     bool skip_one() override { return inner_->skip_one(); }
     void set_lookahead(size_t frames) override { inner_->set_lookahead(frames); }
     void set_readahead(bool on) override { inner_->set_readahead(on); }
+    void prepare() override { inner_->prepare(); }
     const StreamFormat &stream_format() const { return fmt_; }
 
 private:
