@@ -106,7 +106,6 @@ public:
     void set_lookahead(size_t frames) override;
     void set_readahead(bool on) override { if (ring_.empty()) readahead_ = on; }
     void prepare() override; // the whole ring, page-locked, before the first frame is asked for
-    bool reads_ahead() const override { return ahead_ > 0; }
     // bytes that were read from the stream before this source took it over (the format probe of a pipe)
     void set_prefix(std::vector<unsigned char> bytes);
 

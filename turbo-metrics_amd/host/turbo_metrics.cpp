@@ -318,13 +318,7 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     // keep = false: the pair is consumed but not handed out (dropped by `every`): no upload preparation, and the sources' rings of
     // page-locked surfaces do not advance -- a surface is only reused after `lookahead` KEPT frames, which is what the engines'
     // asynchronous DMA relies on
-    const bool both_ahead = frames_ref.reads_ahead() && frames_dis.reads_ahead(); // both only wait for pictures their reader pools fetch: no helper round trip per pair
     auto next_pair = [&](bool keep) {
-        if (both_ahead) {
-            const bool ok_ref = keep ? frames_ref.next_frame(fref) : frames_ref.skip_one();
-            const bool ok_dis = keep ? frames_dis.next_frame(fdis) : frames_dis.skip_one();
-            return ok_ref && ok_dis;
-        }
         { std::lock_guard<std::mutex> g(fx.m); fx.want = true; fx.done = false; fx.keep = keep; }
         fx.cv.notify_all();
         bool ok_dis = false;

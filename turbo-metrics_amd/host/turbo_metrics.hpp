@@ -161,9 +161,6 @@ public:
     // surface pool the reference's decoder allocates when it is CREATED (cudarse-video/src/dec_simple.rs), i.e. before the CLI's clock
     // starts (turbo-metrics-cli/src/main.rs:252).  Call after set_lookahead / set_readahead; next_frame does it itself otherwise.
     virtual void prepare() {}
-    // after prepare(): does next_frame only wait for a picture that a pool of readers has fetched ahead?  (compute_all then asks the two
-    // sources one after the other on its own thread instead of handing one of them to a helper thread for every pair)
-    virtual bool reads_ahead() const { return false; }
 };
 
 // CPUs this process may really use: the smallest of the hardware threads, the affinity mask and the cgroup CPU quota (a container

@@ -98,7 +98,6 @@ public:
     void set_lookahead(size_t frames) override { inner_->set_lookahead(frames); }
     void set_readahead(bool on) override { inner_->set_readahead(on); }
     void prepare() override { inner_->prepare(); }
-    bool reads_ahead() const override { return inner_->reads_ahead(); }
     const StreamFormat &stream_format() const { return fmt_; }
 
 private:
