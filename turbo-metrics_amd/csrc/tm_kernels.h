@@ -2,7 +2,7 @@
 //
 // Two pipelines live here:
 //   default    k_ingest_rows<KIND> (4:2:0 kinds; k_ingest_wave<KIND> for the RGB kinds and mixed launches) + k_ingest_upper_rd
-//              -> k_blur_v_jobs<32, 16> -> k_blur_h_jobs_x (k_blur_h_jobs_split<3 | 5> for small launches) -> k_finish_jobs
+//              -> k_blur_v_jobs<32, 16> -> k_blur_h_jobs_x (k_blur_h_jobs_split, eight waves per row block, for small launches) -> k_finish_jobs
 //              over the ref/dis-interleaved XYB pyramid, job-table driven, slot-major grids (x = slot); larger launches send the
 //              edge-only jobs through k_blur_edge_fused + k_finish_edge (one kernel, no pass-1 planes) beside the two passes
 //   reference  k_ingest + k_downscale + k_xyb -> k_blur_v -> k_blur_h_jobs -> k_finish_jobs: straight-line, LDS-free kernels
@@ -15,7 +15,7 @@
 //   k_ingest_upper_rd grid (ceil(w2/32), ceil(h2/32), slots)         block 256   pyramid levels 2..5
 //   k_blur_v_jobs     grid (slots, jobs.vstart[n])                   block 320   column pass, five role-waves per 64 columns
 //   k_blur_h_jobs_x   grid (slots, jobs.hstart[n])                   block 64    row pass + error maps + sums, lane = image row
-//   k_blur_h_jobs_split<NW>  grid (slots, jobs.hstart[n])            block 64 NW the same row pass over NW = 3 or 5 waves per row block (small launches)
+//   k_blur_h_jobs_split grid (slots, jobs.hstart[n])                 block 512   the same row pass over eight waves per row block (small launches)
 //   k_finish_jobs     grid (slots)                                   block 128
 //   k_blur_edge_fused<4, grouped>  grid (tickets = slots * edge jobs * ceil(bands of 32 rows / 4), or fewer: persistent)  block 256   four waves = four adjacent bands of one (slot, job) per ticket
 //   k_finish_edge     grid (slots * edge jobs)                       block 64
