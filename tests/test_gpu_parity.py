@@ -988,3 +988,36 @@ def test_toggling_full_sums_does_not_grow_the_engine():
     eng.set_variant(F.TM_VARIANT_FUSED_EDGE)
     assert eng.uses_fused_edge()
     eng.close()
+
+
+def test_upload_fences_say_when_a_page_locked_frame_may_be_overwritten():
+    """tm_engine_upload_fence / tm_engine_upload_done: a TM_MEM_HOST_PINNED frame is the caller's again as soon as its DMA into the
+    engine's device surface is done -- the host buffer is overwritten right after the fence has been waited for, BEFORE compute_async,
+    and the scores are those of the bytes that were there at set_frame time (what lets the CLI recycle a ring of five page-locked
+    pictures per stream whatever the batch size)"""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    w, h = 640, 360
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2)
+    (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, 4)
+    eng.set_pair(0, tm.HwFrame.nv12(rs, rp, rch), tm.HwFrame.nv12(ds, dp, dch))  # pageable reference run
+    eng.compute_async(1); eng.sync()
+    want = eng.raw_sums(0).copy(); want_sse = eng.sse(0)
+    pr, pd = torch.from_numpy(np.asarray(rs).copy()).pin_memory(), torch.from_numpy(np.asarray(ds).copy()).pin_memory()
+    L, hnd = eng._L, eng._h
+    tok = C.c_uint64()
+    assert L.tm_engine_upload_done(hnd, 0, 0) < 0  # no fence taken yet: invalid token
+    for slot in range(2):
+        eng.set_pair(slot, tm.HwFrame.nv12(pr, rp, rch), tm.HwFrame.nv12(pd, dp, dch))
+        assert L.tm_engine_upload_fence(hnd, C.byref(tok)) == 0 and tok.value == slot
+        assert L.tm_engine_upload_done(hnd, tok.value, 1) == 1  # blocks until the two copies have left host memory
+        assert L.tm_engine_upload_done(hnd, tok.value, 0) == 1
+        pr.fill_(0); pd.fill_(255)                               # the host buffers are ours again ...
+        if slot == 0:
+            pr.copy_(torch.from_numpy(np.asarray(rs))); pd.copy_(torch.from_numpy(np.asarray(ds)))  # ... refilled for the next slot
+    eng.compute_async(2); eng.sync()
+    for slot in range(2):
+        assert np.array_equal(eng.raw_sums(slot), want) and eng.sse(slot) == want_sse, slot
+    free, total = C.c_size_t(), C.c_size_t()
+    assert L.tm_device_mem_info(C.byref(free), C.byref(total)) == 0 and 0 < free.value <= total.value and total.value > (64 << 30)
+    eng.close()
