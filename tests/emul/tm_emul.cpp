@@ -322,7 +322,9 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
         const int vb = jobs.vstart[jobs.nfull], hb = jobs.hstart[jobs.nfull]; // the two passes run jobs [0, nfull)
-        launch_wave_lockstep(dim3(n, vb, 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
+        // 0x10000: the column pass with every role-wave as a workgroup of its own (launches of a pair or two)
+        if (variant & 0x10000) launch_wave_lockstep(dim3(n, vb, 5), [&] { tmk::k_blur_v_jobs<32, 16, 0, true>(g, jobs, XYB, V); });
+        else launch_wave_lockstep(dim3(n, vb, 1), [&] { tmk::k_blur_v_jobs<32, 16>(g, jobs, XYB, V); }, 5);
         // 0x400: the eight-wave row pass of small launches (TM_VARIANT_SPLIT_ROWS)
         if (variant & 0x400) launch_wg_lockstep(dim3(n, hb, 1), 64 * TM_SPLIT_WAVES, [&] { tmk::k_blur_h_jobs_split(g, jobs, XYB, V, PART); });
         else if (wide_rows) launch_wave_lockstep(dim3(n, hb, 1), [&] { tmk::k_blur_h_jobs_x<16, 8, 16, 8>(g, jobs, XYB, V, PART); });

@@ -255,6 +255,9 @@ def test_multi_wave_row_pass_writes_the_same_partial_sums(w, h):
         assert np.array_equal(em.SUMS, one.SUMS) and np.array_equal(em.PART, one.PART)
         if full:
             check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)
+        # the column pass of small launches: every role-wave a workgroup of its own -- the same pass-1 planes, bit for bit
+        solo = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=SPLIT_ROWS | 0x10000, weights=O.weights(), full_sums=full)
+        assert np.array_equal(solo.V.view(np.uint32), one.V.view(np.uint32)) and np.array_equal(solo.PART, one.PART)
 
 
 FUSED_EDGE = 0x4000

@@ -20,6 +20,8 @@ BIG = 1 << 40
 SEL = os.environ.get("PROBE_CONFIGS")  # comma list of config names (default: all)
 CONFIGS = [  # name, {param: value}, graph
     ("default", {}, False),
+    ("solo_col", {F.TM_DBG_SOLO_COL_BELOW: BIG}, False),
+    ("solo_col+graph", {F.TM_DBG_SOLO_COL_BELOW: BIG}, True),
     ("split_forced", {"variant": F.TM_VARIANT_SPLIT_ROWS}, False),
     ("whole_rows", {"variant": F.TM_VARIANT_WHOLE_ROWS}, False),
     ("two_pass_edge", {"variant": F.TM_VARIANT_TWO_PASS_EDGE}, False),

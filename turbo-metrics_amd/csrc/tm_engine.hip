@@ -175,6 +175,7 @@ struct tm_engine {
     int variant = TM_VARIANT_DEFAULT;
     long long split_rows_below = 1024; // row blocks per launch up to which the eight-wave row pass runs (2 600 beside the fused kernel, whose passes hold the FULL jobs only: see launch_batch)
     bool split_rows_env = false; // TM_DBG_SPLIT_ROWS_BELOW was set: used as it is
+    long long solo_col_below = 0; // role-waves of the column pass per launch (5 per column block) up to which each runs as its own workgroup
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (tm_engine_debug_set_ingest_rows)
 };
 
@@ -935,6 +936,8 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
+        // few column blocks (a pair or two per launch): every role-wave as a workgroup of its own, a SIMD each (tm_kernels.h)
+        else if (vgrid.y && 5ll * n * vgrid.y <= e->solo_col_below) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 0, true>), dim3(vgrid.x, vgrid.y, 5), dim3(64), 0, st, g, jobs, XYB, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         if (!e->use_graph) HIPCHK(hipEventRecord(e->ev_col_done, st));
@@ -1287,6 +1290,7 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     case TM_DBG_PASS_PRIO: if (value < 0 || value > 1) return TM_ERR_INVALID_ARG; e->ef_pass_prio = (int)value; break;
     case TM_DBG_SPLIT_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split_rows_below = value; e->split_rows_env = true; break;
     case TM_DBG_EF_FAULT: if (value < 0 || value > 3) return TM_ERR_INVALID_ARG; e->ef_fault = (int)value; break;
+    case TM_DBG_SOLO_COL_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->solo_col_below = value; break;
     default: return TM_ERR_INVALID_ARG;
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values
@@ -1300,6 +1304,16 @@ int tm_engine_debug_chain(tm_engine *e, tm_engine *peer)
     e->chain_peer = peer;
     return TM_OK;
 }
+
+#ifdef TM_SPLIT_TIMING
+// lab build only: {work cycles, phases, total cycles, -} per wave of the first row block of slot 0 of the last k_blur_h_jobs_split launch
+extern "C" int tm_debug_read_split_timing(unsigned long long out[TM_SPLIT_WAVES * 4])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmk::tm_split_timing), sizeof(unsigned long long) * TM_SPLIT_WAVES * 4));
+    return TM_OK;
+}
+#endif
 
 int tm_engine_debug_set_ingest_rows(tm_engine *e, int rows)
 {

@@ -1176,11 +1176,15 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
 // launches (cold caches, zeros) apart from the batch launches
 // (W = 32 -- 22 rows of loads in flight instead of 6 -- was measured in round 4 for launches that leave most of the chip idle: one 1080p pair
 // 0.104 -> 0.101 ms, two pairs slower; large launches are bound by their write stream anyway, DESIGN.md 5.1: not kept)
-template <int R, int W, int PROBE = 0>
-__global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V)
+// SOLO (launches of a pair or two): the five role-waves of a column block as five single-wave workgroups (grid z = role) -- on an idle
+// chip every wave then has a SIMD to itself, while the five waves of one workgroup share the four SIMDs of one CU and the pair that
+// shares a SIMD sets the pace of all five (they meet at the barrier): one 1080p pair 0.102 -> 0.06 ms.  No barrier, so the 2nd and 3rd
+// reader of a ref / dis row miss the caches more often: only where bandwidth is not what bounds the launch.
+template <int R, int W, int PROBE = 0, bool SOLO = false>
+__global__ void __launch_bounds__(SOLO ? 64 : 320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V)
 {
     using TT = BlurVTile<R>;
-    __shared__ float tiles[5 * R * TT::S];
+    __shared__ float tiles[(SOLO ? 1 : 5) * R * TT::S];
 #ifndef TM_EMULATE
     // the fused kernel of the EDGE jobs runs beside this pass (k_blur_edge_fused, second stream): its waves are the oldest on their
     // SIMDs and would win every issue arbitration; this pass needs few issue slots but needs them promptly to keep HBM busy
@@ -1190,9 +1194,9 @@ __global__ void __launch_bounds__(320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, c
     const int j = tm_find_job(jobs.vstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
     const TmScaleGeom sg = g.s[s];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
+    const int wave = SOLO ? (int)blockIdx.z : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
     const int lane = threadIdx.x & 63;
-    float *tile = tiles + wave * R * TT::S;
+    float *tile = tiles + (SOLO ? 0 : wave) * R * TT::S;
     const float *in = XYB + (size_t)slot * 2 * g.pyr + 2 * (sg.off + c * sg.plane);
     int blk = b - jobs.vstart[j], half, role;
     if (mode == TM_MODE_FULL) { role = wave == 2 ? 2 : (wave < 2 ? 0 : 3); half = wave == 2 ? 0 : (wave < 2 ? wave : wave - 3); }
@@ -1511,6 +1515,19 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
 // 16: 11.7 k -> 12.8 k, 32: 12.5 k -> 13.5 k.  grid (slots, jobs.hstart[n]), block 512.
 // ------------------------------------------------------------------------------------------------
 #define TM_SPLIT_WAVES 8
+// Lab build only (make -C csrc exp: -DTM_SPLIT_TIMING, tools/split_timing_probe.py): every wave of the first row block of slot 0 adds
+// up the shader cycles it spends between leaving a phase barrier and arriving at the next one (its WORK per phase; the rest of a
+// phase it waits for the slowest wave) -> tm_split_timing[wave] = {work cycles, phases, total cycles}.  Not in the shipped library.
+#ifdef TM_SPLIT_TIMING
+__device__ unsigned long long tm_split_timing[TM_SPLIT_WAVES][4];
+#define TM_SPLIT_T0() const unsigned long long tm_t_begin = __builtin_amdgcn_s_memtime(); unsigned long long tm_t_mark = tm_t_begin, tm_t_work = 0, tm_t_n = 0; const bool tm_t_on = blockIdx.x == 0 && blockIdx.y == 0
+#define TM_SPLIT_BARRIER() do { if (tm_t_on) { tm_t_work += __builtin_amdgcn_s_memtime() - tm_t_mark; ++tm_t_n; } TM_LDS_BARRIER(); if (tm_t_on) tm_t_mark = __builtin_amdgcn_s_memtime(); } while (0)
+#define TM_SPLIT_T1() do { if (tm_t_on && (threadIdx.x & 63) == 0) { unsigned long long *o = tm_split_timing[threadIdx.x >> 6]; o[0] = tm_t_work; o[1] = tm_t_n; o[2] = __builtin_amdgcn_s_memtime() - tm_t_begin; } } while (0)
+#else
+#define TM_SPLIT_T0() do {} while (0)
+#define TM_SPLIT_BARRIER() TM_LDS_BARRIER()
+#define TM_SPLIT_T1() do {} while (0)
+#endif
 __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)[16][5][64], const float *__restrict__ v, int plane, int w, int pt, int nphases)
 {
     // v: this lane's row of a transposed blurred plane (column x at v[x * pt]); step t emits column t - 4 into ring[phase & 1][t & 15][plane]
@@ -1525,21 +1542,39 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
 #pragma unroll
     for (int j = 0; j < WN; ++j) win[j] = j < P ? ld_col(j) : 0.0f;
     tmdev::Iir f = {0, 0, 0, 0, 0, 0};
+    TM_SPLIT_T0();
     for (int ph0 = 0; ph0 < nphases; ph0 += 2) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int ph = ph0 + sub;
             if (ph >= nphases) break; // (the same for every wave of the workgroup: they all meet at the same barriers)
+            if (16 * ph + 15 + P < w) {
+                // every column this phase loads exists (all phases but the last two): a running pointer instead of clamp, 64-bit multiply and
+                // select per load -- 14 instead of 20 instructions per step.  (Measured in the lab build, profiles/r04r_split_timing.log:
+                // the five producers work ~100 cycles per step, the two consumers ~205, and the CU's four SIMDs issue for all eight waves:
+                // every instruction less in ANY wave shortens the step.)
+                const float *pk = v + (size_t)(16 * ph + P) * pt;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int t = 16 * ph + j, sl = 16 * sub + j; // row t lives in slot t % 32 (ph0 is even), row t - 10 in slot (sl + P) % 32, which row t + P then takes over
-                const float o = tmdev::iir_step(f, win[(sl + P) % WN] + win[sl]);
-                win[(sl + P) % WN] = ld_col(t + P);
-                ring[ph & 1][j][plane][lane] = o;
+                for (int j = 0; j < 16; ++j) {
+                    const int sl = 16 * sub + j;
+                    const float o = tmdev::iir_step(f, win[(sl + P) % WN] + win[sl]);
+                    win[(sl + P) % WN] = *pk;
+                    pk += pt;
+                    ring[ph & 1][j][plane][lane] = o;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int t = 16 * ph + j, sl = 16 * sub + j; // row t lives in slot t % 32 (ph0 is even), row t - 10 in slot (sl + P) % 32, which row t + P then takes over
+                    const float o = tmdev::iir_step(f, win[(sl + P) % WN] + win[sl]);
+                    win[(sl + P) % WN] = ld_col(t + P);
+                    ring[ph & 1][j][plane][lane] = o;
+                }
             }
-            TM_LDS_BARRIER();
+            TM_SPLIT_BARRIER();
         }
     }
+    TM_SPLIT_T1();
 }
 
 // the ref / dis blocks: block e = rows y0 + 4 i + (lane >> 4) (i = 0 .. 15), columns 16 e + (lane & 15) -- one 8-byte load per lane and
@@ -1561,6 +1596,7 @@ __device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch_block(d, qa[d], qb[d]);
+    TM_SPLIT_T0();
     for (int ph0 = 0; ph0 < nphases; ph0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -1569,9 +1605,10 @@ __device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[
 #pragma unroll
             for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[d][i]; tile[1][ph & 3][4 * i + lr][lc] = qb[d][i]; }
             fetch_block(ph + D, qa[d], qb[d]);
-            TM_LDS_BARRIER();
+            TM_SPLIT_BARRIER();
         }
     }
+    TM_SPLIT_T1();
 }
 
 // SSIM: the ssim map and its two sums (all five blurred values); otherwise the two edge maps and their four sums (mu1, mu2, ref, dis).
@@ -1606,6 +1643,7 @@ __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__
             acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
         }
     };
+    TM_SPLIT_T0();
     for (int ph = 0; ph < nphases; ++ph) {
         if (ph > 0) {
             const int tb = 16 * (ph - 1);
@@ -1624,8 +1662,9 @@ __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__
                     if (tb + j >= 4 && tb + j < T) step(fetch(ph - 1, j, tb + j));
             }
         }
-        TM_LDS_BARRIER();
+        TM_SPLIT_BARRIER();
     }
+    TM_SPLIT_T1();
     if (!valid) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[k] = 0.0;
