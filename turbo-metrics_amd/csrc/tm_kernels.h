@@ -1178,8 +1178,9 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
 // 0.104 -> 0.101 ms, two pairs slower; large launches are bound by their write stream anyway, DESIGN.md 5.1: not kept)
 // SOLO (launches of a pair or two): the five role-waves of a column block as five single-wave workgroups (grid z = role) -- on an idle
 // chip every wave then has a SIMD to itself, while the five waves of one workgroup share the four SIMDs of one CU and the pair that
-// shares a SIMD sets the pace of all five (they meet at the barrier): one 1080p pair 0.102 -> 0.06 ms.  No barrier, so the 2nd and 3rd
-// reader of a ref / dis row miss the caches more often: only where bandwidth is not what bounds the launch.
+// shares a SIMD sets the pace of all five (they meet at the barrier): one 1080p pair 0.105 -> 0.094 ms, 2.94 k -> 3.05 k pairs/s (a lone wave
+// still takes ~7 cycles per instruction: the gain is the pair that no longer shares).  No barrier, so the 2nd and 3rd reader of a ref / dis
+// row miss the caches more often: from two pairs per launch on the five-wave workgroups win again (profiles/r04s_solo_col.log).
 template <int R, int W, int PROBE = 0, bool SOLO = false>
 __global__ void __launch_bounds__(SOLO ? 64 : 320, 4) k_blur_v_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYB, float *__restrict__ V)
 {
@@ -1548,28 +1549,15 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
         for (int sub = 0; sub < 2; ++sub) {
             const int ph = ph0 + sub;
             if (ph >= nphases) break; // (the same for every wave of the workgroup: they all meet at the same barriers)
-            if (16 * ph + 15 + P < w) {
-                // every column this phase loads exists (all phases but the last two): a running pointer instead of clamp, 64-bit multiply and
-                // select per load -- 14 instead of 20 instructions per step.  (Measured in the lab build, profiles/r04r_split_timing.log:
-                // the five producers work ~100 cycles per step, the two consumers ~205, and the CU's four SIMDs issue for all eight waves:
-                // every instruction less in ANY wave shortens the step.)
-                const float *pk = v + (size_t)(16 * ph + P) * pt;
+            // (a second copy of this loop without clamp, 64-bit multiply and select for interior phases -- 14 instead of 20 instructions per
+            // step -- was measured twice: the producers' work went from 97 to 90 cycles per step and the pass did not move, 0.175 -> 0.18 ms: it is
+            // the consumers that every phase waits for, profiles/r04s_split_timing.log)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int sl = 16 * sub + j;
-                    const float o = tmdev::iir_step(f, win[(sl + P) % WN] + win[sl]);
-                    win[(sl + P) % WN] = *pk;
-                    pk += pt;
-                    ring[ph & 1][j][plane][lane] = o;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int t = 16 * ph + j, sl = 16 * sub + j; // row t lives in slot t % 32 (ph0 is even), row t - 10 in slot (sl + P) % 32, which row t + P then takes over
-                    const float o = tmdev::iir_step(f, win[(sl + P) % WN] + win[sl]);
-                    win[(sl + P) % WN] = ld_col(t + P);
-                    ring[ph & 1][j][plane][lane] = o;
-                }
+            for (int j = 0; j < 16; ++j) {
+                const int t = 16 * ph + j, sl = 16 * sub + j; // row t lives in slot t % 32 (ph0 is even), row t - 10 in slot (sl + P) % 32, which row t + P then takes over
+                const float o = tmdev::iir_step(f, win[(sl + P) % WN] + win[sl]);
+                win[(sl + P) % WN] = ld_col(t + P);
+                ring[ph & 1][j][plane][lane] = o;
             }
             TM_SPLIT_BARRIER();
         }
