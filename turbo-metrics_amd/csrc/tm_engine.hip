@@ -175,7 +175,7 @@ struct tm_engine {
     int variant = TM_VARIANT_DEFAULT;
     long long split_rows_below = 1024; // row blocks per launch up to which the eight-wave row pass runs (2 600 beside the fused kernel, whose passes hold the FULL jobs only: see launch_batch)
     bool split_rows_env = false; // TM_DBG_SPLIT_ROWS_BELOW was set: used as it is
-    long long solo_col_below = 700; // role-waves of the column pass per launch (5 per column block) up to which each runs as its own workgroup: one 1080p pair (600; two pairs lose)
+    long long solo_col_below = 800; // role-waves of the column pass per launch (5 per column block) up to which each runs as its own workgroup: one 1080p pair (745; two pairs lose)
     int ingest_rows = 0; // quad rows per wave of k_ingest_rows; 0 = chosen per launch (tm_engine_debug_set_ingest_rows)
 };
 
