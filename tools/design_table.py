@@ -8,8 +8,16 @@ P = lambda n: os.path.join(ROOT, "profiles", n)
 wall = [l for l in open(P(f"{T}_bench.json")) if l.startswith("real")]
 d = json.load(open(P(f"{T}_bench_detail.json")))  # the full record of the default run (the stdout line is the compact one)
 prof = json.load(open(P(f"{T}_prof_bench_1080p_detail.json")))
+class Stats(dict):
+    """kernel name -> (calls, average ms); a name that is not there is looked up by prefix (template arguments added by later rounds)"""
+    def __missing__(self, key):
+        stem = key.rstrip(">")
+        hits = [k for k in self if k.startswith(stem)]
+        if not hits:
+            raise KeyError(key)
+        return self[sorted(hits, key=len)[0]]
 def stats(name):
-    out = {}
+    out = Stats()
     for r in csv.DictReader(open(P(name))):
         out[r["Name"].replace("void ", "").split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
     return out
