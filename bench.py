@@ -280,7 +280,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     # pass -- `job_bytes` is what THIS configuration must move.  Ingest reads the two surfaces and writes the planar XYB
     # pyramid once (24 B/px for the two sides).  The SSIM / MS-SSIM stage reads the u8-quantised planes (6 B/px per pair) and,
     # for MS-SSIM, builds and reads back the dyadic pyramid of box sums (u16, scales 1-4: 2 x 0.332 x 2 B per sample).
-    # Launches of >= 340 bands of EDGE planes (5 pairs of 1080p, 3 of 4K) run the edge-only jobs in ONE kernel (k_blur_edge_fused) that reads the {ref, dis} plane
+    # Launches of >= 400 bands of EDGE planes (6 pairs of 1080p, 3 of 4K) run the edge-only jobs in ONE kernel (k_blur_edge_fused) that reads the {ref, dis} plane
     # once (2 f32 per pixel) and writes nothing: the two passes then move the bytes of the FULL jobs only.
     units = {0: 0, 1: 4, 2: 7}
     fused_edge = bool(has_s2 and eng.uses_fused_edge(B))

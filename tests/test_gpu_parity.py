@@ -202,7 +202,7 @@ def test_fused_edge_kernel_is_bit_identical_with_the_two_passes(w, h, batch):
     for name, variant in (("two_pass", F.TM_VARIANT_TWO_PASS_EDGE), ("fused", F.TM_VARIANT_FUSED_EDGE), ("fused_again", F.TM_VARIANT_FUSED_EDGE),
                           ("fused_split_rows", F.TM_VARIANT_FUSED_EDGE | F.TM_VARIANT_SPLIT_ROWS), ("default", F.TM_VARIANT_DEFAULT)):
         eng.set_variant(variant)
-        assert eng.uses_fused_edge() == (name.startswith("fused") or (name == "default" and 2 * ((h + 31) // 32) * batch >= 340))
+        assert eng.uses_fused_edge() == (name.startswith("fused") or (name == "default" and 2 * ((h + 31) // 32) * batch >= 400))
         eng.compute_async()
         eng.sync()
         got[name] = [eng.raw_sums(i).copy() for i in range(batch)]

@@ -25,6 +25,7 @@ CONFIGS = [  # name, {param: value}, graph
     ("split_forced", {"variant": F.TM_VARIANT_SPLIT_ROWS}, False),
     ("whole_rows", {"variant": F.TM_VARIANT_WHOLE_ROWS}, False),
     ("two_pass_edge", {"variant": F.TM_VARIANT_TWO_PASS_EDGE}, False),
+    ("fused_edge", {"variant": F.TM_VARIANT_FUSED_EDGE}, False),
     ("graph", {}, True),
 ]
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4,6,8,12,16").split(",")]:

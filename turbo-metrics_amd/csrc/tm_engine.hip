@@ -128,8 +128,9 @@ struct tm_engine {
     unsigned ef_epoch_host = 1;      // host mirror of d_epoch[0] (one step per fused launch): HS is cleared when the 24-bit tag epoch wraps
     // The tuning values below are fixed in a release build's behaviour: no environment variable reaches them.  tools/ and tests move
     // them through tm_engine_debug_set_param (TM_DBG_*), per engine.
-    long long fused_edge_from = 340; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 5 pairs of
-                                     // 1080p, 3 of 4K, 4 of 1440p, 8 of 720p (below, the launch is bound by the latency of one wave walking its band and of the chain of bands)
+    long long fused_edge_from = 400; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 6 pairs of
+                                     // 1080p, 3 of 4K, 9 of 720p (below, the launch is bound by the latency of one wave walking its band and of the chain of bands; round 3: 340 --
+                                     // with round 4's eight-wave row pass the two passes win at 5 pairs of 1080p, 9.4 k vs 8.4 k pairs/s: profiles/r04v_fused_threshold.log)
     int ef_beside = 1;  // the fused kernel runs on stream2 beside the two blur passes: 1 = enqueued before the column pass, 2 = after it, 0 = behind the row pass on the engine's stream
     int ef_waves = 4;   // waves per workgroup of the fused kernel
     int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket
