@@ -694,6 +694,8 @@ def compact_line(d):
     pl = d.get("pipeline")
     if pl:
         sm["pipeline"] = {k: _r(v) for k, v in pl.items() if not isinstance(v, (dict, list))}
+    if d.get("leg_errors"):
+        sm["leg_errors"] = {k: str(v)[:80] for k, v in list(d["leg_errors"].items())[:4]}
     if d.get("score_mean") is not None:
         sm["score_mean"] = _r(d["score_mean"], 6)
     sm["detail"] = d.get("detail_file")
@@ -747,21 +749,41 @@ def run_rank(args):
             if fixed is not None and longer is not None:
                 fixed["long"] = {k: longer[k] for k in ("total_pairs", "seconds_first_submit_to_scores_on_rank0", "value", "pairs_per_rank", "scores_periodic_bit_identical", "scores_sha256_16")}
     eng.close()
-    workloads, host_fed = {}, None
+    # The legs below describe the machine around the headline (other workloads, PCIe, call granularity, the CLI): a failure in one of
+    # them -- a box out of memory, no room in tmpfs -- is recorded on the line and never takes the headline down with it.
+    workloads, host_fed, leg_errors = {}, None, {}
+
+    def leg(name, fn):
+        try:
+            return fn()
+        except Exception as ex:  # noqa: BLE001
+            leg_errors[name] = repr(ex)[:200]
+            try:
+                ctx.torch.cuda.synchronize()
+            except Exception:
+                pass
+            return None
+
     if extras:
         ks, kw = max(2, min(args.steps, 10)), min(args.warmup, 2)
         for wl, m in EXTRAS:
-            r, _, _ = run_workload(ctx, args, wl, set(m.split(",")), WORKLOADS[wl][3], ks, kw, 150.0, compare=False)
-            for drop in ("unit",):
-                r.pop(drop, None)
-            workloads[wl + ("_fused" if m == FUSED else "")] = r
+            tag = wl + ("_fused" if m == FUSED else "")
+            got = leg(tag, lambda: run_workload(ctx, args, wl, set(m.split(",")), WORKLOADS[wl][3], ks, kw, 150.0, compare=False))
+            if got is not None:
+                r = got[0]
+                r.pop("unit", None)
+                workloads[tag] = r
         if ctx.world == 1:  # a per-GPU PCIe figure: measured on one GPU only (>= 40 steps: 8 pairs x 10 steps was too short to be stable)
-            host_fed = {wl: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, max(ks, 40), kw) for wl in ("1080p_nv12", "4k_p016")}
+            host_fed = {}
+            for wl in ("1080p_nv12", "4k_p016"):
+                got = leg("host_fed_" + wl, lambda: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, max(ks, 40), kw))
+                if got is not None:
+                    host_fed[wl] = got
     batch_curve = cli = None
     if extras and ctx.world == 1 and head_name == "1080p_nv12":
-        batch_curve = run_batch_curve(ctx, args, head_name, B, res)
+        batch_curve = leg("batch_curve", lambda: run_batch_curve(ctx, args, head_name, B, res))
         if not args.no_cli:
-            cli = run_cli_end_to_end(ctx)
+            cli = leg("cli_end_to_end", lambda: run_cli_end_to_end(ctx))
     if ctx.rank == 0:
         out = {
             "metric": "ssimulacra2_frame_pairs_per_sec" if "ssimulacra2" in mets else "frame_pairs_per_sec",
@@ -781,6 +803,8 @@ def run_rank(args):
         for k in ("config", "roofline", "kernels", "kernels_alone", "stages", "score_mean", "compare"):
             if k in res:
                 out[k] = res[k]
+        if leg_errors:
+            out["leg_errors"] = leg_errors
         if workloads:
             out["workloads"] = workloads
         if fixed is not None:
