@@ -1009,9 +1009,10 @@ def test_upload_fences_say_when_a_page_locked_frame_may_be_overwritten():
     assert L.tm_engine_upload_done(hnd, 0, 0) < 0  # no fence taken yet: invalid token
     for slot in range(2):
         eng.set_pair(slot, tm.HwFrame.nv12(pr, rp, rch), tm.HwFrame.nv12(pd, dp, dch))
-        assert L.tm_engine_upload_fence(hnd, C.byref(tok)) == 0 and tok.value == slot
+        assert L.tm_engine_upload_fence(hnd, C.byref(tok)) == 0 and tok.value == 2 * slot
         assert L.tm_engine_upload_done(hnd, tok.value, 1) == 1  # blocks until the two copies have left host memory
         assert L.tm_engine_upload_done(hnd, tok.value, 0) == 1
+        assert eng.upload_done(eng.upload_fence(), block=True)  # the Python mirror of the same two calls
         pr.fill_(0); pd.fill_(255)                               # the host buffers are ours again ...
         if slot == 0:
             pr.copy_(torch.from_numpy(np.asarray(rs))); pd.copy_(torch.from_numpy(np.asarray(ds)))  # ... refilled for the next slot

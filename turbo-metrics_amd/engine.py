@@ -221,6 +221,18 @@ class TurboMetrics:
     def sync(self):
         _chk(self._L.tm_engine_sync(self._h), "tm_engine_sync")
 
+    def upload_fence(self) -> int:
+        """token for "every frame upload enqueued on this engine so far" (page-locked host frames: see the header)"""
+        t = C.c_uint64()
+        _chk(self._L.tm_engine_upload_fence(self._h, C.byref(t)), "tm_engine_upload_fence")
+        return int(t.value)
+
+    def upload_done(self, token: int, block: bool = False) -> bool:
+        """have the uploads in front of `token` left host memory?  block=True waits for them"""
+        r = self._L.tm_engine_upload_done(self._h, int(token), int(bool(block)))
+        _chk(-r if r < 0 else ffi.TM_OK, "tm_engine_upload_done")
+        return r > 0
+
     def scores(self, slot: int) -> FrameScores:
         s = ffi.FrameScoresC()
         _chk(self._L.tm_engine_get_scores(self._h, slot, C.byref(s)), "tm_engine_get_scores")
