@@ -178,6 +178,16 @@ def test_multi_wave_row_pass_is_bit_identical_with_the_one_wave_row_pass(w, h, b
     eng.set_variant(F.TM_VARIANT_DEFAULT)
     eng.compute_async(); eng.sync()
     assert all(np.array_equal(eng.raw_sums(i), got["whole"][i]) for i in range(batch))
+    # the column pass of a launch this small runs every role-wave as a workgroup of its own (one 1080p pair: 745 role-waves <= 800);
+    # forbidden and forced, the pass-1 planes and the sums are the same bits
+    planes = {}
+    for name, below in (("five_wave_workgroups", 0), ("solo", 1 << 40)):
+        eng.debug_set_param(F.TM_DBG_SOLO_COL_BELOW, below)
+        eng.compute_async(); eng.sync()
+        assert all(np.array_equal(eng.raw_sums(i), got["whole"][i]) for i in range(batch)), name
+        planes[name] = [eng.read_plane(batch - 1, F.TM_PLANE_PASS1_T, s_, p_, 1) for s_ in (0, 2) for p_ in range(5)]
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(planes["solo"], planes["five_wave_workgroups"]))
+    eng.debug_set_param(F.TM_DBG_SOLO_COL_BELOW, 800)
     if w * h <= 333 * 203:
         eng.set_variant(F.TM_VARIANT_SPLIT_ROWS)
         eng.compute_async()
