@@ -1032,3 +1032,53 @@ def test_upload_fences_say_when_a_page_locked_frame_may_be_overwritten():
     free, total = C.c_size_t(), C.c_size_t()
     assert L.tm_device_mem_info(C.byref(free), C.byref(total)) == 0 and 0 < free.value <= total.value and total.value > (64 << 30)
     eng.close()
+
+
+@pytest.mark.parametrize("w,h", [(16384, 40), (40, 16384)])
+def test_maximum_width_and_height_against_the_oracle(w, h):
+    """the largest picture sides tm_engine_create accepts (16 384): 512 tiles / 512 bands in the fused kernel, 256 column blocks / 256 row
+    blocks in the two passes, byte offsets close to 2^32 inside a plane -- every weighted sum against the oracle, default kernels, the
+    fused kernel forced, and the two-pass kernels, bit for bit among themselves"""
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2)
+    fr, fd = nv12_frames(w, h, 9)
+    eng.set_pair(0, fr, fd); eng.set_pair(1, fd, fr)
+    got = {}
+    for name, variant in (("default", F.TM_VARIANT_DEFAULT), ("fused", F.TM_VARIANT_FUSED_EDGE), ("two_pass", F.TM_VARIANT_TWO_PASS_EDGE),
+                          ("whole_rows", F.TM_VARIANT_WHOLE_ROWS | F.TM_VARIANT_TWO_PASS_EDGE)):
+        eng.set_variant(variant)
+        eng.compute_async(); eng.sync()
+        got[name] = [eng.raw_sums(i).copy() for i in range(2)]
+    for name in got:
+        assert all(np.array_equal(got[name][i], got["two_pass"][i]) for i in range(2)), name
+    lin = [oracle_linear(fr, w, h), oracle_linear(fd, w, h)]
+    want, sums = O.ssimulacra2_from_linear(lin[0], lin[1])
+    m = weight_mask()
+    np.testing.assert_allclose(got["default"][0][m], np.asarray(sums).reshape(6, 6, 3)[m], rtol=1e-12, atol=1e-300)
+    assert abs(eng.scores(0).ssimulacra2 - want) <= 1e-9
+    sse, psnr = O.psnr(lin[0], lin[1])
+    assert eng.sse(0) == sse == eng.sse(1) and eng.scores(0).psnr == psnr
+    eng.close()
+    with pytest.raises(tm.TmError):
+        tm.TurboMetrics(16385, 16, tm.Metrics(ssimulacra2=True), batch=1)
+
+
+def test_many_slots_of_small_frames():
+    """256 slots of 96 x 64 frames in one launch (slot-major grids of 256 x jobs workgroups, 512 planes for the fused kernel): every slot's
+    sums equal those of the same pair computed alone"""
+    w, h, B = 96, 64, 256
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B)
+    one = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)
+    frames = [nv12_frames(w, h, n) for n in range(5)]
+    for slot in range(B):
+        eng.set_pair(slot, *frames[slot % 5])
+    alone = []
+    for fr, fd in frames:
+        one.compute_one(fr, fd)
+        alone.append(one.raw_sums(0).copy())
+    for variant in (F.TM_VARIANT_DEFAULT, F.TM_VARIANT_FUSED_EDGE):
+        eng.set_variant(variant)
+        eng.compute_async(B); eng.sync()
+        assert eng.uses_fused_edge(B)
+        for slot in range(B):
+            assert np.array_equal(eng.raw_sums(slot), alone[slot % 5]), (variant, slot)
+    eng.close(); one.close()
