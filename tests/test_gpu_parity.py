@@ -1082,3 +1082,101 @@ def test_many_slots_of_small_frames():
         for slot in range(B):
             assert np.array_equal(eng.raw_sums(slot), alone[slot % 5]), (variant, slot)
     eng.close(); one.close()
+
+
+@pytest.mark.parametrize("bits,w,h", [(8, 1920, 1080), (10, 640, 360), (8, 328, 201), (8, 70, 38), (10, 333, 203), (12, 136, 22)])
+def test_a_tight_planar_picture_goes_up_as_one_copy_with_the_same_results(bits, w, h):
+    """a picture as it lies in a Y4M / raw planar file -- rows without padding, Cb behind Y, Cr behind Cb -- in host memory: ONE linear copy,
+    read by the kernels with the file's own pitches (chroma rows of 4n bytes; the others take the 2-D copies), against the same three
+    planes from separate arrays (2-D copies into padded rows) and with TM_DBG_LINEAR_UPLOAD = 0: raw sums, SSE and scores bit for bit;
+    pageable and page-locked memory"""
+    import torch
+    dt = np.uint8 if bits == 8 else np.uint16
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    pairs = []
+    for n in range(2):
+        ref, dis = tm.synth.yuv420_pair(w, h, n + 3, 8 if bits == 8 else 10)
+        if bits == 12:
+            ref, dis = tuple(p * 4 + 3 for p in ref), tuple(p * 4 + 1 for p in dis)
+        pairs.append((ref, dis))
+
+    def tight(planes, pinned):
+        flat = np.concatenate([np.ascontiguousarray(p.astype(dt)).reshape(-1) for p in planes])
+        if pinned:
+            t = torch.from_numpy(flat).pin_memory()
+            return t[:w * h].view(h, w), t[w * h:w * h + cw * ch].view(ch, cw), t[w * h + cw * ch:].view(ch, cw)
+        return flat[:w * h].reshape(h, w), flat[w * h:w * h + cw * ch].reshape(ch, cw), flat[w * h + cw * ch:].reshape(ch, cw)
+
+    got = {}
+    for name, linear, make in (("separate", 1, lambda pl, slot: [np.ascontiguousarray(p.astype(dt)) for p in pl]),
+                               ("tight", 1, lambda pl, slot: tight(pl, slot == 1)),
+                               ("tight_2d", 0, lambda pl, slot: tight(pl, slot == 1)),
+                               ("tight_one_stream", 2, lambda pl, slot: tight(pl, slot == 1))):
+        eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=2, full_sums=True)
+        eng.debug_set_param(F.TM_DBG_LINEAR_UPLOAD, 1 if linear else 0)
+        eng.debug_set_param(F.TM_DBG_UPLOAD_STREAMS, 1 if linear == 2 else 2)
+        for rep in range(2):  # the second round over the same staging surfaces
+            for slot, (ref, dis) in enumerate(pairs):
+                for side, planes in enumerate((ref, dis) if rep == 0 else (dis, ref)):
+                    pl = make(planes, slot)
+                    eng.set_frame(slot, side, tm.HwFrame.i420(pl[0], pl[1], pl[2], bits=bits))
+            eng.compute_async(); eng.sync()
+            got[(name, rep)] = [(eng.raw_sums(s).copy(), eng.sse(s), eng.scores(s)) for s in range(2)]
+        eng.close()
+    for rep in range(2):
+        for name in ("tight", "tight_2d", "tight_one_stream"):
+            for s in range(2):
+                a, b = got[(name, rep)][s], got[("separate", rep)][s]
+                assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], (name, rep, s)
+    assert not np.array_equal(got[("tight", 0)][0][0], got[("tight", 0)][1][0])
+
+
+@pytest.mark.parametrize("streams", [2, 1])
+def test_page_locked_frames_on_two_upload_streams_keep_their_order_with_the_launches(streams):
+    """page-locked frames of the distorted side go up on the device's second upload stream: 40 launches on two engines that take turns
+    (the CLI's ping-pong), every launch with other frames in the same staging surfaces and no host synchronisation between handing the
+    frames over and launching -- a copy that overtook the launch before it, or a launch that did not wait for its copies, shows up as the
+    sums of the wrong frames.  Fences: a frame's bytes may be overwritten once its fence is done, and the results still come out right."""
+    import torch
+    w, h, B = 640, 360, 4
+    engs = [tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=B) for _ in range(2)]
+    for e in engs:
+        e.debug_set_param(F.TM_DBG_UPLOAD_STREAMS, streams)
+    one = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=1)
+    src = []  # six different pairs, as NV12 surfaces and as tight planar pictures
+    want = []
+    for n in range(6):
+        (rs, rp, rch), (ds, dp, dch) = tm.synth.nv12_pair(w, h, n)
+        one.compute_one(tm.HwFrame.nv12(rs, rp, rch), tm.HwFrame.nv12(ds, dp, dch))
+        want.append((one.raw_sums(0).copy(), one.sse(0)))
+        src.append(((rs, rp, rch), (ds, dp, dch)))
+    ring = [[torch.empty_like(torch.from_numpy(src[0][side][0])).pin_memory() for side in range(2)] for _ in range(2 * B + 2)]
+    fences = [None] * len(ring)
+    k = 0
+    pending = [None, None]
+
+    def check(i):
+        if pending[i] is None:
+            return
+        engs[i].sync()
+        for slot, n in enumerate(pending[i]):
+            assert np.array_equal(engs[i].raw_sums(slot), want[n][0]) and engs[i].sse(slot) == want[n][1], (streams, i, slot, n)
+        pending[i] = None
+
+    for launch in range(40):
+        i = launch & 1
+        check(i)
+        picks = [(launch * 5 + slot * 7) % 6 for slot in range(B)]
+        for slot, n in enumerate(picks):
+            r = k % len(ring); k += 1
+            if fences[r] is not None:
+                assert fences[r][0].upload_done(fences[r][1], block=True)
+            for side in range(2):
+                ring[r][side].copy_(torch.from_numpy(src[n][side][0]))
+            engs[i].set_pair(slot, tm.HwFrame.nv12(ring[r][0], src[n][0][1], src[n][0][2]), tm.HwFrame.nv12(ring[r][1], src[n][1][1], src[n][1][2]))
+            fences[r] = (engs[i], engs[i].upload_fence())
+        engs[i].compute_async(B)
+        pending[i] = picks
+    check(0); check(1)
+    for e in engs + [one]:
+        e.close()

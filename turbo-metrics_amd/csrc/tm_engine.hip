@@ -65,6 +65,27 @@ void side_stream_release(int device)
     if (--g_side_users[device] == 0 && g_side_stream[device]) { (void)hipStreamSynchronize(g_side_stream[device]); (void)hipStreamDestroy(g_side_stream[device]); g_side_stream[device] = nullptr; }
 }
 
+// The same for a second UPLOAD stream: page-locked frames of the distorted side go up on it while those of the reference side go up
+// on the engine's own stream -- copies that follow each other on one stream leave the link idle between them (3-MB copies with a
+// fence per pair: 40 GB/s on one stream, 48-52 on two; tools/microbench/dma_depth_probe.hip, profiles/r04y_dma_depth_probe.log).
+// One per device for the same reason as above: two engines + the side stream + this one = the four hardware queues.
+hipStream_t g_up_stream[64] = {};
+int g_up_users[64] = {};
+hipStream_t up_stream_acquire(int device)
+{
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    if (device < 0 || device >= 64) return nullptr;
+    if (!g_up_stream[device] && hipStreamCreateWithFlags(&g_up_stream[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_up_stream[device] = nullptr; return nullptr; }
+    ++g_up_users[device];
+    return g_up_stream[device];
+}
+void up_stream_release(int device)
+{
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    if (device < 0 || device >= 64 || g_up_users[device] <= 0) return;
+    if (--g_up_users[device] == 0 && g_up_stream[device]) { (void)hipStreamSynchronize(g_up_stream[device]); (void)hipStreamDestroy(g_up_stream[device]); g_up_stream[device] = nullptr; }
+}
+
 const uint32_t k_lut_bits[256] = {TM_SRGB_LUT_BITS};
 const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
 // the math table buffer of tm_device_math.h (TM_TAB_DOUBLES): pow_pos tables, then the binary64 transfer-function cubics
@@ -136,6 +157,7 @@ struct tm_engine {
     int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket
     int ef_pass_prio = 1;   // the two passes raise their waves' issue priority while the fused kernel runs beside them
     int n_cus = 256;
+    int dbg_no_linear_upload = 0; // TM_DBG_LINEAR_UPLOAD 0: tight planar host pictures as 2-D copies into padded rows, like any other
     int ef_fault = 0;   // fault injection (TM_DBG_EF_FAULT): 1 = do not wait for the band above, 2 = do not publish the state (the hand-off then times out: TM_ERR_HIP from tm_engine_sync)
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
@@ -162,6 +184,14 @@ struct tm_engine {
     float *d_lut = nullptr, *d_coef = nullptr;
     double *d_powtab = nullptr;
     std::vector<hipEvent_t> up_ev;    // upload fences (tm_engine_upload_fence): a small ring of events on the engine's stream
+    std::vector<hipEvent_t> up_ev2;   // ... and on the second upload stream, for the fences that had copies on it (up_has2)
+    std::vector<char> up_has2;
+    hipStream_t up_stream = nullptr;  // the device's second upload stream (page-locked frames of the distorted side)
+    hipEvent_t ev_up_join = nullptr, ev_stage_free = nullptr;
+    bool up_pending = false;          // copies on up_stream that the engine's stream has not been made to wait for yet
+    bool up_since_fence = false;      // copies on up_stream since the last fence
+    bool stage_busy = false;          // a launch may still be reading the staging surfaces: up_stream waits for ev_stage_free first
+    int upload_streams = 2;           // TM_DBG_UPLOAD_STREAMS
     uint64_t up_next = 0;             // tokens handed out so far (token t lives in up_ev[t % size] until token t + size is taken)
     std::vector<void *> staging;      // [slot*2+side], lazily allocated
     std::vector<size_t> staging_size;
@@ -204,10 +234,26 @@ int check_slot_side(const tm_engine *e, uint32_t slot, int side)
 }
 
 // copy `rows` rows of `row_bytes` from host memory (pitch `src_pitch`) into the staging surface
-int stage_rows(tm_engine *e, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, size_t rows)
+int stage_rows(tm_engine *e, hipStream_t st, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, size_t rows)
 {
     if (rows == 0 || row_bytes == 0) return TM_OK;
-    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, st));
+    return TM_OK;
+}
+
+// the stream a host frame goes up on: the engine's own, or -- page-locked frames of the distorted side -- the device's second upload
+// stream, which first waits for the last launch that read the staging surfaces; tm_engine_compute_async makes the engine's stream wait
+// for these copies, fences and tm_engine_sync cover both streams
+int upload_stream(tm_engine *e, int side, int mem, hipStream_t *out)
+{
+    *out = e->stream;
+    if (mem != TM_MEM_HOST_PINNED || side != TM_SIDE_DIS || !e->up_stream || e->upload_streams < 2) return TM_OK;
+    if (e->stage_busy) {
+        HIPCHK(hipStreamWaitEvent(e->up_stream, e->ev_stage_free, 0));
+        e->stage_busy = false;
+    }
+    e->up_pending = e->up_since_fence = true;
+    *out = e->up_stream;
     return TM_OK;
 }
 
@@ -216,6 +262,7 @@ int ensure_staging(tm_engine *e, size_t idx, size_t bytes)
     if (e->staging_size[idx] >= bytes) return TM_OK;
     if (e->staging[idx]) {
         HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->up_pending) HIPCHK(hipStreamSynchronize(e->up_stream));
         HIPCHK(hipFree(e->staging[idx]));
         e->mem_bytes -= e->staging_size[idx];
         e->staging[idx] = nullptr; e->staging_size[idx] = 0;
@@ -257,6 +304,8 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         const size_t need = yuv ? spitch * ((coded_rows > e->h ? coded_rows : e->h) + chroma_rows) : spitch * e->h; // room for a declared surface's padding rows (below)
         rc = ensure_staging(e, idx, need);
         if (rc) return rc;
+        hipStream_t us;
+        if ((rc = upload_stream(e, side, mem, &us))) return rc;
         char *s = (char *)e->staging[idx];
         const size_t uv_bytes = yuv ? (size_t)((e->w + 1) / 2) * 2 * bps : 0, uv_row = uv_bytes <= pitch ? uv_bytes : pitch;
         // ONE 2-D copy of all rows instead of two (the per-copy cost is what limits small frames: DESIGN.md section 5, host-fed) in
@@ -267,14 +316,14 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         const size_t gap = yuv && (const char *)p1 >= (const char *)p0 ? (size_t)((const char *)p1 - (const char *)p0) : 0;
         const size_t luma_rows = coded_rows ? coded_rows : (yuv && gap == pitch * (size_t)e->h ? (size_t)e->h : 0);
         if (luma_rows >= e->h) {
-            rc = stage_rows(e, s, spitch, p0, pitch, row_bytes > uv_row ? row_bytes : uv_row, luma_rows + chroma_rows);
+            rc = stage_rows(e, us, s, spitch, p0, pitch, row_bytes > uv_row ? row_bytes : uv_row, luma_rows + chroma_rows);
             if (rc) return rc;
             d.p1 = s + spitch * luma_rows;
         } else {
-            rc = stage_rows(e, s, spitch, p0, pitch, row_bytes, e->h);
+            rc = stage_rows(e, us, s, spitch, p0, pitch, row_bytes, e->h);
             if (rc) return rc;
             if (yuv) {
-                rc = stage_rows(e, s + spitch * e->h, spitch, p1, pitch, uv_row, chroma_rows);
+                rc = stage_rows(e, us, s + spitch * e->h, spitch, p1, pitch, uv_row, chroma_rows);
                 if (rc) return rc;
                 d.p1 = s + spitch * e->h;
             } else d.p1 = nullptr;
@@ -315,14 +364,29 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
         const size_t sp_y = (row_y + 255) / 256 * 256, sp_c = (row_c + 255) / 256 * 256;
         rc = ensure_staging(e, idx, sp_y * e->h + 2 * sp_c * ch);
         if (rc) return rc;
+        hipStream_t us;
+        if ((rc = upload_stream(e, side, mem, &us))) return rc;
         char *s = (char *)e->staging[idx];
+        // a TIGHT picture (rows without padding, Cb behind Y, Cr behind Cb: a picture of a Y4M / raw planar file as it lies in the file)
+        // goes up as ONE linear copy and is read with its own pitches: what bounds the CLI at 1080p is the number of copies the
+        // main thread submits per pair (four 2-D copies: 5.0-5.7 k pairs/s whatever the readers deliver; two linear ones: DESIGN.md 5)
+        if (pitch_y == row_y && pitch_uv == row_c && (const char *)u == (const char *)y + row_y * e->h && (const char *)v == (const char *)u + row_c * ch &&
+            row_c % 4 == 0 && !e->dbg_no_linear_upload) {
+            HIPCHK(hipMemcpyAsync(s, y, row_y * e->h + 2 * row_c * ch, hipMemcpyHostToDevice, us));
+            if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+            d.p0 = s; d.p1 = s + row_y * e->h; d.p2 = s + row_y * e->h + row_c * ch; d.pitch = row_y; d.pitch2 = row_c;
+            d.kind = bits == 8 ? TM_KIND_I420_8 : TM_KIND_I420_16;
+            d.matrix = matrix;
+            d.shift = bits == 8 ? 0 : 16 - bits;
+            return TM_OK;
+        }
         char *su = s + sp_y * e->h, *sv = su + sp_c * ch;
-        if ((rc = stage_rows(e, s, sp_y, y, pitch_y, row_y, e->h))) return rc;
+        if ((rc = stage_rows(e, us, s, sp_y, y, pitch_y, row_y, e->h))) return rc;
         if ((const char *)v == (const char *)u + pitch_uv * ch) { // Cr follows Cb (a picture of a planar file): one copy for both
-            if ((rc = stage_rows(e, su, sp_c, u, pitch_uv, row_c, 2 * ch))) return rc;
+            if ((rc = stage_rows(e, us, su, sp_c, u, pitch_uv, row_c, 2 * ch))) return rc;
         } else {
-            if ((rc = stage_rows(e, su, sp_c, u, pitch_uv, row_c, ch))) return rc;
-            if ((rc = stage_rows(e, sv, sp_c, v, pitch_uv, row_c, ch))) return rc;
+            if ((rc = stage_rows(e, us, su, sp_c, u, pitch_uv, row_c, ch))) return rc;
+            if ((rc = stage_rows(e, us, sv, sp_c, v, pitch_uv, row_c, ch))) return rc;
         }
         if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
         d.p0 = s; d.p1 = su; d.p2 = sv; d.pitch = sp_y; d.pitch2 = sp_c;
@@ -579,6 +643,8 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     (void)he;
     if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
     if (!(e->stream2 = side_stream_acquire(e->device))) return fail(hip_fail(hipErrorOutOfMemory, "hipStreamCreate (side stream)"));
+    if (!(e->up_stream = up_stream_acquire(e->device))) return fail(hip_fail(hipErrorOutOfMemory, "hipStreamCreate (upload stream)"));
+    if ((he = hipEventCreateWithFlags(&e->ev_up_join, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_stage_free, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     if ((he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     if ((he = hipEventCreateWithFlags(&e->ev_col_done, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_row_done, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     const size_t B = batch_capacity;
@@ -632,6 +698,7 @@ void tm_engine_destroy(tm_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    if (e->up_stream) (void)hipStreamSynchronize(e->up_stream); // (copies into the staging surfaces that no launch has waited for)
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     for (void *p : e->staging) if (p) (void)hipFree(p);
     (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V_alloc);
@@ -646,6 +713,10 @@ void tm_engine_destroy(tm_engine *e)
     if (e->h_sse) (void)hipHostFree(e->h_sse);
     for (int i = 0; i < 7; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (hipEvent_t ev : e->up_ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->up_ev2) if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_up_join) (void)hipEventDestroy(e->ev_up_join);
+    if (e->ev_stage_free) (void)hipEventDestroy(e->ev_stage_free);
+    if (e->up_stream) up_stream_release(e->device);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->ev_col_done) (void)hipEventDestroy(e->ev_col_done);
@@ -731,10 +802,20 @@ int tm_engine_upload_fence(tm_engine *e, uint64_t *token)
     TM_BIND(e);
     if (e->up_ev.empty()) {
         e->up_ev.assign(TM_UPLOAD_FENCES, nullptr);
+        e->up_ev2.assign(TM_UPLOAD_FENCES, nullptr);
+        e->up_has2.assign(TM_UPLOAD_FENCES, 0);
         for (hipEvent_t &ev : e->up_ev)
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventCreate");
+        for (hipEvent_t &ev : e->up_ev2)
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventCreate");
     }
-    HIPCHK(hipEventRecord(e->up_ev[e->up_next % TM_UPLOAD_FENCES], e->stream));
+    const size_t i = e->up_next % TM_UPLOAD_FENCES;
+    HIPCHK(hipEventRecord(e->up_ev[i], e->stream));
+    e->up_has2[i] = e->up_since_fence;
+    if (e->up_since_fence) { // the copies of this fence that went up on the second upload stream
+        HIPCHK(hipEventRecord(e->up_ev2[i], e->up_stream));
+        e->up_since_fence = false;
+    }
     *token = e->up_next++;
     return TM_OK;
 }
@@ -747,17 +828,21 @@ int tm_engine_upload_done(tm_engine *e, uint64_t token, int block)
     if (!e || token >= e->up_next) return -TM_ERR_INVALID_ARG;
     if (e->up_next - token > TM_UPLOAD_FENCES) return 1;
     if (hipSetDevice(e->device) != hipSuccess) { (void)hip_fail(hipGetLastError(), "hipSetDevice"); return -TM_ERR_HIP; }
-    hipEvent_t ev = e->up_ev[token % TM_UPLOAD_FENCES];
-    if (block) {
-        const hipError_t r = hipEventSynchronize(ev);
-        if (r != hipSuccess) { (void)hip_fail(r, "hipEventSynchronize"); return -TM_ERR_HIP; }
-        return 1;
+    hipEvent_t evs[2] = {e->up_ev[token % TM_UPLOAD_FENCES], e->up_has2[token % TM_UPLOAD_FENCES] ? e->up_ev2[token % TM_UPLOAD_FENCES] : nullptr};
+    for (hipEvent_t ev : evs) {
+        if (!ev) continue;
+        if (block) {
+            const hipError_t r = hipEventSynchronize(ev);
+            if (r != hipSuccess) { (void)hip_fail(r, "hipEventSynchronize"); return -TM_ERR_HIP; }
+            continue;
+        }
+        const hipError_t r = hipEventQuery(ev);
+        if (r == hipSuccess) continue;
+        if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+        (void)hip_fail(r, "hipEventQuery");
+        return -TM_ERR_HIP;
     }
-    const hipError_t r = hipEventQuery(ev);
-    if (r == hipSuccess) return 1;
-    if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
-    (void)hip_fail(r, "hipEventQuery");
-    return -TM_ERR_HIP;
+    return 1;
 }
 
 int tm_engine_set_profiling(tm_engine *e, int on)
@@ -983,6 +1068,11 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     hipStream_t st = e->stream;
     const int n = (int)n_slots;
     const int want_sse = (e->mask & TM_METRIC_PSNR) ? 1 : 0;
+    if (e->up_pending) { // frames that went up on the second upload stream: the launch waits for them
+        HIPCHK(hipEventRecord(e->ev_up_join, e->up_stream));
+        HIPCHK(hipStreamWaitEvent(st, e->ev_up_join, 0));
+        e->up_pending = false;
+    }
     // everything one batch enqueues: descriptor upload, accumulator reset, the kernels, result download
     auto enqueue_all = [&]() -> int {
         HIPCHK(hipMemcpyAsync(e->d_desc, e->h_desc, (size_t)n * 2 * sizeof(TmFrameDesc), hipMemcpyHostToDevice, st));
@@ -1037,6 +1127,10 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
         if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
+    if (e->up_stream && e->upload_streams >= 2) { // the next frame that goes up on the second upload stream must not overtake this launch
+        HIPCHK(hipEventRecord(e->ev_stage_free, st));
+        e->stage_busy = true;
+    }
     e->ev_pending = e->profiling;
     e->last_n = n_slots;
     e->in_flight = true;
@@ -1049,6 +1143,10 @@ int tm_engine_sync(tm_engine *e)
     if (!e) return TM_ERR_INVALID_ARG;
     TM_BIND(e);
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->up_pending) { // frames handed over since the last launch: "valid until tm_engine_sync" holds for them too
+        HIPCHK(hipStreamSynchronize(e->up_stream));
+        e->up_pending = false;
+    }
     if (e->ev_pending) {
         // TM_STAGE_INGEST, BLUR_V, BLUR_H, SSIM: consecutive events on the engine's stream (SSIM: finisher + SSIM kernels, and the wait
         // for the fused kernel if it is still running beside); TM_STAGE_EDGE: the fused kernel's own pair, on the stream it ran on
@@ -1292,6 +1390,8 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     case TM_DBG_SPLIT_ROWS_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->split_rows_below = value; e->split_rows_env = true; break;
     case TM_DBG_EF_FAULT: if (value < 0 || value > 3) return TM_ERR_INVALID_ARG; e->ef_fault = (int)value; break;
     case TM_DBG_SOLO_COL_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->solo_col_below = value; break;
+    case TM_DBG_UPLOAD_STREAMS: if (value < 1 || value > 2) return TM_ERR_INVALID_ARG; if (e->up_pending) { HIPCHK(hipStreamSynchronize(e->up_stream)); e->up_pending = false; } e->upload_streams = (int)value; break;
+    case TM_DBG_LINEAR_UPLOAD: if (value < 0 || value > 1) return TM_ERR_INVALID_ARG; e->dbg_no_linear_upload = value ? 0 : 1; break;
     default: return TM_ERR_INVALID_ARG;
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values

@@ -119,6 +119,7 @@ int main(int argc, char **argv)
     SourceHints hints;
     uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1;
     bool pipeline = true, full_sums = false;
+    std::vector<std::pair<int, long long>> tune;
 
     auto bad = [&](const std::string &m) {
         std::cerr << "error: " << m << "\n\nFor more information, try '--help'.\n";
@@ -167,6 +168,10 @@ int main(int argc, char **argv)
         else if (a == "--devices") { if (!u32(devices)) return bad("invalid value for '--devices <N>'"); }
         else if (a == "--no-pipeline") pipeline = false;
         else if (a == "--full-sums") full_sums = true;
+        else if (a == "--tune") { // --tune <param>=<value>: tm_engine_debug_set_param (measurements; not in the usage text)
+            std::string kv; if (!value(kv) || kv.find('=') == std::string::npos) return bad("invalid value for '--tune <param>=<value>'");
+            tune.emplace_back(atoi(kv.c_str()), atoll(kv.c_str() + kv.find('=') + 1));
+        }
         else if (a == "--width") { if (!u32(hints.width)) return bad("invalid value for '--width <W>'"); }
         else if (a == "--height") { if (!u32(hints.height)) return bad("invalid value for '--height <H>'"); }
         else if (a == "--bits") { uint32_t b; if (!u32(b) || (b != 8 && b != 10 && b != 12 && b != 16)) return bad("invalid value for '--bits'"); hints.bits = (int)b; }
@@ -263,6 +268,7 @@ int main(int argc, char **argv)
                         uint32_t b = std::min(batch, hi - lo);
                         TurboMetrics tmx(w, h, metrics, b, pipeline && hi - lo > b);
                         if (full_sums) tmx.set_full_sums(true);
+                        for (auto &t : tune) tmx.debug_set_param(t.first, t.second);
                         Options o = opts;
                         o.decode_start = lo;
                         o.frames = hi; // absolute decode index at which this shard stops (lib.rs:396-398)
@@ -310,6 +316,7 @@ int main(int argc, char **argv)
         if (known > 0 && known < 20000) tm_set_placement_candidates(1);
         turbo = std::make_unique<TurboMetrics>(source_ref->width(), source_ref->height(), metrics, batch, pipeline);
         if (full_sums) turbo->set_full_sums(true);
+        for (auto &t : tune) turbo->debug_set_param(t.first, t.second);
     } catch (const std::exception &e) {
         log_line(L_ERROR, kTarget, std::string("Could not initialize engine : ") + e.what());
         return EXIT_FAILURE;
@@ -343,6 +350,13 @@ int main(int argc, char **argv)
     snprintf(perf_s, sizeof perf_s, "%.3f", perf);
     log_line(L_INFO, kTarget, "Processed: " + std::to_string(results.frame_count) + " (decoded: ~" + std::to_string(decode_count + opts.skip) +
                                   ") frame pairs in " + format_duration(ms) + " (" + std::to_string(fps) + " fps) (Mpx/s: " + perf_s + ")");
+    {
+        const TurboMetrics::LoopTiming &t = turbo->loop_timing();
+        char b[256];
+        snprintf(b, sizeof b, "main thread: %.0f ms waiting for an upload slot, %.0f ms for the sources, %.0f ms handing frames to the engine, %.0f ms submitting, %.0f ms waiting for results + output",
+                 t.wait_upload * 1e3, t.wait_frames * 1e3, t.set_frames * 1e3, t.submit * 1e3, t.drain * 1e3);
+        log_line(L_DEBUG, kTarget, b);
+    }
     output_results(output, results, std::cout);
     std::cout.flush();
     return EXIT_SUCCESS;

@@ -1,6 +1,7 @@
 // turbo_metrics.cpp -- see turbo_metrics.hpp.  Host orchestration only: frame selection, batching over the engine's
 // slots, ping-pong pipelining of two engines; every number comes out of libturbometrics_hip.so.
 #include "turbo_metrics.hpp"
+#include <chrono>
 
 #include <condition_variable>
 #include <cstring>
@@ -146,6 +147,12 @@ size_t TurboMetrics::mem_usage() const
     return tm_engine_mem_usage(eng_[0]) + (eng_[1] ? tm_engine_mem_usage(eng_[1]) : 0);
 }
 
+void TurboMetrics::debug_set_param(int param, long long value)
+{
+    for (tm_engine *e : eng_)
+        if (e) chk(tm_engine_debug_set_param(e, param, value), "tm_engine_debug_set_param");
+}
+
 void TurboMetrics::set_full_sums(bool on)
 {
     for (tm_engine *e : eng_)
@@ -255,6 +262,9 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
 
     uint32_t decode_count = opts.decode_start;
     size_t compute_count = 0;
+    timing_ = LoopTiming{};
+    const auto tick = [] { return std::chrono::steady_clock::now(); };
+    const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     prepare_sources(frames_ref, frames_dis, opts); // (no-ops when the caller has done it already)
     struct Fence { tm_engine *e = nullptr; uint64_t token = 0; };
     Fence fences[UPLOADS_IN_FLIGHT + 1];
@@ -332,18 +342,24 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     };
     for (;;) {
         const bool dropped = opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0; // lib.rs:391-394
+        auto t0 = tick();
         if (!dropped && kept > UPLOADS_IN_FLIGHT) { // the call below may overwrite the surfaces of pair kept - UPLOADS_IN_FLIGHT - 1
             const Fence &f = fences[(kept - UPLOADS_IN_FLIGHT - 1) % (UPLOADS_IN_FLIGHT + 1)];
             const int r = tm_engine_upload_done(f.e, f.token, 1);
             if (r < 0) chk(-r, "tm_engine_upload_done");
         }
-        if (!next_pair(!dropped)) break;
+        timing_.wait_upload += since(t0);
+        t0 = tick();
+        const bool more = next_pair(!dropped);
+        timing_.wait_frames += since(t0);
+        if (!more) break;
         if (dropped) {
             ++decode_count;
             continue;
         }
         if (opts.frames > 0 && decode_count >= opts.frames) break; // lib.rs:396-398
         ++decode_count;
+        t0 = tick();
         set_frame(eng_[cur], filled[cur], TM_SIDE_REF, fref, cref);
         set_frame(eng_[cur], filled[cur], TM_SIDE_DIS, fdis, cdis);
         {
@@ -352,14 +368,19 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
             chk(tm_engine_upload_fence(f.e, &f.token), "tm_engine_upload_fence");
             ++kept;
         }
+        timing_.set_frames += since(t0);
         if (++filled[cur] == batch_) {
+            t0 = tick();
             submit(cur);
+            timing_.submit += since(t0);
+            t0 = tick();
             if (eng_[1]) {
                 cur ^= 1;
                 drain(cur); // the batch submitted before this one: done (or nearly) while we were reading
             } else {
                 drain(cur);
             }
+            timing_.drain += since(t0);
         }
     }
     submit(cur);

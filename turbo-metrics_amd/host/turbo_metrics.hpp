@@ -199,9 +199,15 @@ public:
     uint32_t width() const { return w_; }
     uint32_t height() const { return h_; }
     uint32_t batch() const { return batch_; }
+    // where the calling thread spent the last compute_all (seconds): waiting for an upload slot, waiting for the two sources, handing
+    // frames to the engine (the copies' submission), submitting batches, waiting for results + the per-frame callback
+    struct LoopTiming { double wait_upload = 0, wait_frames = 0, set_frames = 0, submit = 0, drain = 0; };
+    const LoopTiming &loop_timing() const { return timing_; }
     size_t mem_usage() const;
     // also compute the 56 SSIMULACRA2 sums whose weight is 0.0 (see tm_engine_set_full_sums); the scores do not change
     void set_full_sums(bool on);
+    // tuning / measurement (tm_engine_debug_set_param): the results never depend on it
+    void debug_set_param(int param, long long value);
 
     using ColorInfo = std::pair<ColorCharacteristics, ColorRange>;
     // == compute_one (lib.rs:268-360): convert both frames, compute every selected metric, block, return the scores
@@ -221,6 +227,7 @@ private:
     uint32_t w_, h_, batch_;
     Metrics metrics_;
     tm_engine *eng_[2] = {nullptr, nullptr};
+    LoopTiming timing_;
 };
 
 } // namespace tm_host
