@@ -16,7 +16,8 @@ for side, s in enumerate(("ref", "dis")):
         for i in range(frames):
             f.write(blobs[i % 4])
 PY
-run() { RUST_LOG=debug turbo-metrics_amd/bin/turbo-metrics /dev/shm/tm_cli_${size}_ref.y4m /dev/shm/tm_cli_${size}_dis.y4m -m ssimulacra2 --output json-lines $1 2>&1 >/dev/null | grep -E "Processed|main thread" | sed -e 's/.*Processed: [0-9]* (decoded: ~[0-9]*) frame pairs in //' -e 's/.*main thread: /   /' | tr '\n' ' '; echo; }
+# a variant's words of the form TM_...=value go into the environment, the others onto the command line
+run() { local envs=() args=(); for t in $1; do if [[ $t == TM_*=* ]]; then envs+=("$t"); else args+=("$t"); fi; done; set -- "${args[*]}"; env RUST_LOG=debug "${envs[@]}" turbo-metrics_amd/bin/turbo-metrics /dev/shm/tm_cli_${size}_ref.y4m /dev/shm/tm_cli_${size}_dis.y4m -m ssimulacra2 --output json-lines $1 2>&1 >/dev/null | grep -E "Processed|main thread" | sed -e 's/.*Processed: [0-9]* (decoded: ~[0-9]*) frame pairs in //' -e 's/.*main thread: /   /' | tr '\n' ' '; echo; }
 run "" > /dev/null   # first pass over the fresh files
 for r in $(seq "$rounds"); do
   for v in "$@"; do printf '%-40s | ' "[$v]"; run "$v"; done

@@ -268,7 +268,7 @@ int main(int argc, char **argv)
                         uint32_t b = std::min(batch, hi - lo);
                         TurboMetrics tmx(w, h, metrics, b, pipeline && hi - lo > b);
                         if (full_sums) tmx.set_full_sums(true);
-                        for (auto &t : tune) tmx.debug_set_param(t.first, t.second);
+                        for (auto &t : tune) if (t.first < 100) tmx.debug_set_param(t.first, t.second);
                         Options o = opts;
                         o.decode_start = lo;
                         o.frames = hi; // absolute decode index at which this shard stops (lib.rs:396-398)
@@ -316,7 +316,7 @@ int main(int argc, char **argv)
         if (known > 0 && known < 20000) tm_set_placement_candidates(1);
         turbo = std::make_unique<TurboMetrics>(source_ref->width(), source_ref->height(), metrics, batch, pipeline);
         if (full_sums) turbo->set_full_sums(true);
-        for (auto &t : tune) turbo->debug_set_param(t.first, t.second);
+        for (auto &t : tune) if (t.first < 100) turbo->debug_set_param(t.first, t.second);
     } catch (const std::exception &e) {
         log_line(L_ERROR, kTarget, std::string("Could not initialize engine : ") + e.what());
         return EXIT_FAILURE;
@@ -326,6 +326,11 @@ int main(int argc, char **argv)
     log_source("distorted", *source_dis);
     // the sources' frame rings are page-locked here, before the clock starts: the counterpart of the surface pool the reference's decoder
     // allocates when it is created (its clock, main.rs:252, starts after decoders and engine exist too)
+    {   // --tune 100=<pairs in flight> / 101=<pairs per fence>: host-side upload tuning (the rest goes to the engines)
+        size_t in_flight = 4, fence_every = 1;
+        for (auto &t : tune) { if (t.first == 100) in_flight = (size_t)t.second; if (t.first == 101) fence_every = (size_t)t.second; }
+        TurboMetrics::set_upload_tuning(in_flight, fence_every);
+    }
     try { TurboMetrics::prepare_sources(*source_ref, *source_dis, opts); }
     catch (const std::exception &e) { log_line(L_ERROR, kTarget, std::string("Could not initialize the sources : ") + e.what()); return EXIT_FAILURE; }
     log_line(L_DEBUG, kTarget, "Initialized, now processing ...");

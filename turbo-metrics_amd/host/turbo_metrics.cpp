@@ -236,7 +236,16 @@ MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Me
 // only UPLOADS_IN_FLIGHT further next_frame calls, whatever the batch size -- the sources' rings of page-locked surfaces stay
 // small (round 3: 2 * batch + 1 surfaces per stream; page-locking them, at ~3 GB/s, was most of a short 4K run and the reason
 // why --batch 16 was slower than --batch 8)
-static constexpr size_t UPLOADS_IN_FLIGHT = 4;
+// (Up to 16 pairs in flight with a fence per 4 was measured too -- TurboMetrics::set_upload_tuning, `--tune 100=16 --tune 101=4`: the loop
+// then waits for the readers instead of the uploads and ends within the run-to-run spread of the default, 7.06 k vs 6.69 k pairs/s on one
+// box, 5.87 k vs 6.04 k on another; profiles/r04y_cli_ab2.log, r04y_cli_ab3.log -- the small ring kept.)
+static size_t UPLOADS_IN_FLIGHT = 4; // pairs whose uploads may be in flight behind the one being read (the sources' lookahead)
+static size_t FENCE_EVERY = 1;       // pairs per fence
+void TurboMetrics::set_upload_tuning(size_t in_flight, size_t fence_every)
+{
+    FENCE_EVERY = std::max<size_t>(1, fence_every);
+    UPLOADS_IN_FLIGHT = std::max(std::max<size_t>(in_flight ? 1 : 4, in_flight), FENCE_EVERY);
+}
 
 void TurboMetrics::prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts)
 {
@@ -267,7 +276,8 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     prepare_sources(frames_ref, frames_dis, opts); // (no-ops when the caller has done it already)
     struct Fence { tm_engine *e = nullptr; uint64_t token = 0; };
-    Fence fences[UPLOADS_IN_FLIGHT + 1];
+    std::vector<Fence> fences(UPLOADS_IN_FLIGHT + FENCE_EVERY + 2); // [pair % size]: the fence that covers the pair's uploads
+    size_t first_unfenced = 0;                                      // pairs [first_unfenced, kept) have no fence yet (fewer than FENCE_EVERY, all on eng_[cur])
     size_t kept = 0; // pairs handed to an engine so far
     frames_ref.skip_frames(opts.skip_ref + opts.skip + opts.decode_start);
     frames_dis.skip_frames(opts.skip_dis + opts.skip + opts.decode_start);
@@ -344,7 +354,7 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
         const bool dropped = opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0; // lib.rs:391-394
         auto t0 = tick();
         if (!dropped && kept > UPLOADS_IN_FLIGHT) { // the call below may overwrite the surfaces of pair kept - UPLOADS_IN_FLIGHT - 1
-            const Fence &f = fences[(kept - UPLOADS_IN_FLIGHT - 1) % (UPLOADS_IN_FLIGHT + 1)];
+            const Fence &f = fences[(kept - UPLOADS_IN_FLIGHT - 1) % fences.size()]; // (it has one: UPLOADS_IN_FLIGHT >= FENCE_EVERY)
             const int r = tm_engine_upload_done(f.e, f.token, 1);
             if (r < 0) chk(-r, "tm_engine_upload_done");
         }
@@ -362,11 +372,12 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
         t0 = tick();
         set_frame(eng_[cur], filled[cur], TM_SIDE_REF, fref, cref);
         set_frame(eng_[cur], filled[cur], TM_SIDE_DIS, fdis, cdis);
-        {
-            Fence &f = fences[kept % (UPLOADS_IN_FLIGHT + 1)];
+        ++kept;
+        if (kept - first_unfenced >= FENCE_EVERY || filled[cur] + 1 == batch_) { // (a fence covers one engine's uploads: never across a batch)
+            Fence f;
             f.e = eng_[cur];
             chk(tm_engine_upload_fence(f.e, &f.token), "tm_engine_upload_fence");
-            ++kept;
+            for (; first_unfenced < kept; ++first_unfenced) fences[first_unfenced % fences.size()] = f;
         }
         timing_.set_frames += since(t0);
         if (++filled[cur] == batch_) {

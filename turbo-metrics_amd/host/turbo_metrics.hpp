@@ -208,6 +208,8 @@ public:
     void set_full_sums(bool on);
     // tuning / measurement (tm_engine_debug_set_param): the results never depend on it
     void debug_set_param(int param, long long value);
+    // measurement: how many pairs' uploads may be in flight behind the one being read (4) and how many pairs share a fence (1)
+    static void set_upload_tuning(size_t in_flight, size_t fence_every);
 
     using ColorInfo = std::pair<ColorCharacteristics, ColorRange>;
     // == compute_one (lib.rs:268-360): convert both frames, compute every selected metric, block, return the scores
