@@ -157,7 +157,7 @@ struct tm_engine {
     int ef_persist_wgs = 0; // workgroups of the fused kernel when it runs beside the passes: 0 = 7/8 per CU, > 0 = that many, < 0 = one per ticket
     int ef_pass_prio = 1;   // the two passes raise their waves' issue priority while the fused kernel runs beside them
     int n_cus = 256;
-    int dbg_no_linear_upload = 0; // TM_DBG_LINEAR_UPLOAD 0: tight planar host pictures as 2-D copies into padded rows, like any other
+    int dbg_no_linear_upload = 1; // TM_DBG_LINEAR_UPLOAD 0 (default): tight planar host pictures as 2-D copies into padded rows, like any other; 1: one linear copy
     int ef_fault = 0;   // fault injection (TM_DBG_EF_FAULT): 1 = do not wait for the band above, 2 = do not publish the state (the hand-off then times out: TM_ERR_HIP from tm_engine_sync)
     bool full_sums = false;
     int channel_mode = TM_CHANNELS_POOLED;
@@ -368,8 +368,10 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
         if ((rc = upload_stream(e, side, mem, &us))) return rc;
         char *s = (char *)e->staging[idx];
         // a TIGHT picture (rows without padding, Cb behind Y, Cr behind Cb: a picture of a Y4M / raw planar file as it lies in the file)
-        // goes up as ONE linear copy and is read with its own pitches: what bounds the CLI at 1080p is the number of copies the
-        // main thread submits per pair (four 2-D copies: 5.0-5.7 k pairs/s whatever the readers deliver; two linear ones: DESIGN.md 5)
+        // can go up as ONE linear copy and be read with its own pitches (TM_DBG_LINEAR_UPLOAD = 1).  Which way is faster depends on how the
+        // caller submits: pictures handed over one by one as they arrive, with a fence per pair (the CLI) -- linear 7.1-7.7 k pairs/s of 1080p
+        // against 5.3-6.1 k with the 2-D copies; a whole batch queued at once (bench.py's host_fed loop) -- 2-D 6.6 k against 5.3 k linear
+        // (tools/cli_ab.sh, tools/host_fed_ab.py).  The CLI's host layer switches it on; the default is the 2-D path.
         if (pitch_y == row_y && pitch_uv == row_c && (const char *)u == (const char *)y + row_y * e->h && (const char *)v == (const char *)u + row_c * ch &&
             row_c % 4 == 0 && !e->dbg_no_linear_upload) {
             HIPCHK(hipMemcpyAsync(s, y, row_y * e->h + 2 * row_c * ch, hipMemcpyHostToDevice, us));

@@ -134,6 +134,10 @@ TurboMetrics::TurboMetrics(uint32_t width, uint32_t height, const Metrics &metri
             throw TmError(rc, "tm_engine_create (second engine of the pipeline)");
         }
     }
+    // compute_all hands pictures over one by one, as they arrive, with a fence per pair: for that pattern a picture of a planar file is
+    // fastest as one linear copy (the library's default suits callers that queue whole batches; tm_engine.hip, set_frame_planar)
+    for (tm_engine *e : eng_)
+        if (e) (void)tm_engine_debug_set_param(e, TM_DBG_LINEAR_UPLOAD, 1);
 }
 
 TurboMetrics::~TurboMetrics()
