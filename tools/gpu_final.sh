@@ -26,4 +26,6 @@ for a in "1080p_nv12 64 60" "1080p_nv12 32 100" "4k_p016 24 40" "1080p_nv12 64 4
 timeout 300 python tools/soak_create_destroy.py 200 > gpurun_out/${TAG}_soak_create_destroy.log 2>&1
 timeout 300 python tools/cli_bench.py --size 1080p 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_cli_1080p.log
 timeout 300 python tools/cli_bench.py --size 4k 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_cli_4k.log
+(bash tools/cli_ab.sh 1080p 3 "" "--tune 7=0" "--tune 7=0 --tune 8=1"; bash tools/cli_ab.sh 4k 3 "" "--tune 7=0" "--tune 7=0 --tune 8=1") 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_cli_ab.log
+(timeout 300 python3 tools/host_fed_ab.py 1080p 2; timeout 300 python3 tools/host_fed_ab.py 4k 2) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_host_fed_ab.log
 ls gpurun_out | grep $TAG | head -60
