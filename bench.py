@@ -537,8 +537,9 @@ def run_cli_end_to_end(ctx):
                     for i in range(frames):
                         f.write(blobs[i % len(blobs)])
             res = {"pairs": frames, "clip_GB_each": round(os.path.getsize(paths[0]) / 1e9, 2), "clips_in": base}
-            # the first pass over a freshly written clip runs at about half the rate of the later ones whatever its arguments (first
-            # touch of the tmpfs pages by a reader, code-object load, first page-locking): reported apart as `first_pass`
+            # the first pass over a freshly written clip runs at a third of the later ones whatever its arguments: the first read of
+            # just-written tmpfs pages does not scale with threads (12-14 GB/s with 1, 4 or 8 readers, 58-65 on the second pass;
+            # tools/first_pass_probe.sh, profiles/r04y_first_pass_probe.log) -- reported apart as `first_pass`
             for label, extra in (("first_pass", []), ("default", []), ("batch16", ["--batch", "16"])):
                 t0 = time.perf_counter()
                 r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, timeout=300)

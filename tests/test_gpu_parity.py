@@ -1029,6 +1029,16 @@ def test_upload_fences_say_when_a_page_locked_frame_may_be_overwritten():
     eng.compute_async(2); eng.sync()
     for slot in range(2):
         assert np.array_equal(eng.raw_sums(slot), want) and eng.sse(slot) == want_sse, slot
+    # tokens older than the ring of 256 fence events are answered by the events that took their place (a later fence of the same
+    # stream; the most recent fence of the second upload stream): done, and still valid -- never an error, never early
+    first = eng.upload_fence()
+    for k in range(300):
+        eng.set_pair(k & 1, tm.HwFrame.nv12(pr, rp, rch), tm.HwFrame.nv12(pd, dp, dch))
+        last = eng.upload_fence()
+    assert last - first == 300
+    assert L.tm_engine_upload_done(hnd, first, 1) == 1 and L.tm_engine_upload_done(hnd, first, 0) == 1
+    assert L.tm_engine_upload_done(hnd, last, 1) == 1
+    assert L.tm_engine_upload_done(hnd, last + 1, 0) < 0  # not handed out yet
     free, total = C.c_size_t(), C.c_size_t()
     assert L.tm_device_mem_info(C.byref(free), C.byref(total)) == 0 and 0 < free.value <= total.value and total.value > (64 << 30)
     eng.close()

@@ -186,6 +186,7 @@ struct tm_engine {
     std::vector<hipEvent_t> up_ev;    // upload fences (tm_engine_upload_fence): a small ring of events on the engine's stream
     std::vector<hipEvent_t> up_ev2;   // ... and on the second upload stream, for the fences that had copies on it (up_has2)
     std::vector<char> up_has2;
+    uint64_t up_last2 = UINT64_MAX;   // token of the most recent fence that recorded an event on the second upload stream
     hipStream_t up_stream = nullptr;  // the device's second upload stream (page-locked frames of the distorted side)
     hipEvent_t ev_up_join = nullptr, ev_stage_free = nullptr;
     bool up_pending = false;          // copies on up_stream that the engine's stream has not been made to wait for yet
@@ -817,20 +818,26 @@ int tm_engine_upload_fence(tm_engine *e, uint64_t *token)
     if (e->up_since_fence) { // the copies of this fence that went up on the second upload stream
         HIPCHK(hipEventRecord(e->up_ev2[i], e->up_stream));
         e->up_since_fence = false;
+        e->up_last2 = e->up_next;
     }
     *token = e->up_next++;
     return TM_OK;
 }
 
 // 1: every upload enqueued before the fence has left host memory; 0: not yet (block = 0) -- with block != 0 the call waits for it.
-// A token older than the last TM_UPLOAD_FENCES fences counts as done (its event has been reused by a later fence on the same
-// in-order stream).  < 0: error (the negated TM_* code).
+// A token older than the last TM_UPLOAD_FENCES fences is answered by the events that took its place: the slot's event on the engine's
+// stream now stands for a later fence of the same in-order stream, and the second upload stream is represented by its most recent
+// fence -- done there means done for everything older (conservative, never early).  < 0: error (the negated TM_* code).
 int tm_engine_upload_done(tm_engine *e, uint64_t token, int block)
 {
     if (!e || token >= e->up_next) return -TM_ERR_INVALID_ARG;
-    if (e->up_next - token > TM_UPLOAD_FENCES) return 1;
     if (hipSetDevice(e->device) != hipSuccess) { (void)hip_fail(hipGetLastError(), "hipSetDevice"); return -TM_ERR_HIP; }
-    hipEvent_t evs[2] = {e->up_ev[token % TM_UPLOAD_FENCES], e->up_has2[token % TM_UPLOAD_FENCES] ? e->up_ev2[token % TM_UPLOAD_FENCES] : nullptr};
+    const size_t i = token % TM_UPLOAD_FENCES;
+    const bool recycled = e->up_next - token > TM_UPLOAD_FENCES;
+    hipEvent_t ev2 = nullptr;
+    if (!recycled) ev2 = e->up_has2[i] ? e->up_ev2[i] : nullptr;
+    else if (e->up_last2 != UINT64_MAX) ev2 = e->up_ev2[e->up_last2 % TM_UPLOAD_FENCES];
+    hipEvent_t evs[2] = {e->up_ev[i], ev2};
     for (hipEvent_t ev : evs) {
         if (!ev) continue;
         if (block) {
