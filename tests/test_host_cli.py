@@ -17,9 +17,11 @@ from tm_pkg import tm
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "turbo-metrics_amd", "host")
-# TM_HOST_SANITIZE=1: the helper (decoders, stream readers, formatters) built with AddressSanitizer + UBSan, aborting on the first report
-SANITIZE = os.environ.get("TM_HOST_SANITIZE") == "1"
-HELPER = os.path.join(ROOT, "tests", "host", "tm_host_test_san" if SANITIZE else "tm_host_test")
+# TM_HOST_SANITIZE=1: the helper (decoders, stream readers, formatters) built with AddressSanitizer + UBSan, aborting on the first report;
+# TM_HOST_SANITIZE=thread: with ThreadSanitizer (the read-ahead pool, the row workers, the ring helper)
+SANITIZE = os.environ.get("TM_HOST_SANITIZE") in ("1", "thread")
+TSAN = os.environ.get("TM_HOST_SANITIZE") == "thread"
+HELPER = os.path.join(ROOT, "tests", "host", "tm_host_test_tsan" if TSAN else "tm_host_test_san" if SANITIZE else "tm_host_test")
 CLI = os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")
 
 
@@ -28,14 +30,17 @@ def helper():
     srcs = [os.path.join(ROOT, "tests", "host", "tm_host_test.cpp")] + [os.path.join(HOST, f) for f in ("frame_sources.cpp", "video_input.cpp", "output.cpp", "turbo_metrics.cpp")]
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
     if not os.path.exists(HELPER) or any(os.path.getmtime(d) > os.path.getmtime(HELPER) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17"] + (["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"] if SANITIZE else [])
+        subprocess.check_call(["g++", "-O1", "-std=c++17"] + (["-fsanitize=thread", "-fno-omit-frame-pointer", "-g"] if TSAN else ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"] if SANITIZE else [])
                               + ["-o", HELPER] + srcs + ["-L" + os.path.join(ROOT, "turbo-metrics_amd"),
                               "-lturbometrics_hip", "-lz", "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "turbo-metrics_amd")])
     return HELPER
 
 
 def run(helper, *args, stdin=None):
-    return subprocess.run([helper] + [str(a) for a in args], input=stdin, capture_output=True, text=True, check=False).stdout
+    r = subprocess.run([helper] + [str(a) for a in args], input=stdin, capture_output=True, text=True, check=False)
+    if SANITIZE:  # a report of a sanitizer fails the test that provoked it, whatever the helper printed
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    return r.stdout
 
 
 # ---- number formatting ---------------------------------------------------------------------------------------------
