@@ -1,6 +1,8 @@
 """GPU tier (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
 Bar: bit-exact for every f32 plane and the integer SSE; 1e-12 relative for the f64 sums (summation
 order differs); |score difference| <= 1e-4 per north_star (observed ~1e-12)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1190,3 +1192,12 @@ def test_page_locked_frames_on_two_upload_streams_keep_their_order_with_the_laun
     check(0); check(1)
     for e in engs + [one]:
         e.close()
+
+
+def test_device_numa_node_is_a_node_of_this_host_or_unknown():
+    """tm_device_numa_node: the host NUMA node next to the device (what the CLI binds its threads to), -1 when unknown or for a device
+    that does not exist"""
+    L = tm.ffi.lib()
+    node = L.tm_device_numa_node(0)
+    assert node == -1 or os.path.isdir(f"/sys/devices/system/node/node{node}"), node
+    assert L.tm_device_numa_node(4096) == -1 and L.tm_device_numa_node(-1) == -1

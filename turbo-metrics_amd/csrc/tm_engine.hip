@@ -514,6 +514,14 @@ int tm_device_count(void)
     return n;
 }
 
+int tm_device_numa_node(int device)
+{
+    int n = 0, node = -1;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return -1; }
+    if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return node;
+}
+
 int tm_device_mem_info(size_t *free_bytes, size_t *total_bytes)
 {
     size_t f = 0, t = 0;

@@ -31,6 +31,7 @@ SYMBOLS = {
     "tm_init": (_i, [_i]),
     "tm_device_count": (_i, []),
     "tm_device_mem_info": (_i, [C.POINTER(_sz), C.POINTER(_sz)]),
+    "tm_device_numa_node": (_i, [_i]),
     "tm_host_alloc": (_vp, [_sz]),
     "tm_host_free": (None, [_vp]),
     "tm_set_placement_candidates": (None, [_i]),

@@ -2,6 +2,9 @@
 // slots, ping-pong pipelining of two engines; every number comes out of libturbometrics_hip.so.
 #include "turbo_metrics.hpp"
 #include <chrono>
+#include <fstream>
+#include <sched.h>
+#include <string>
 
 #include <condition_variable>
 #include <cstring>
@@ -22,7 +25,44 @@ static void chk(int code, const char *where)
     if (code != TM_OK) throw TmError(code, where);
 }
 
-void init_hip(int device) { chk(tm_init(device), "tm_init"); }
+// The calling thread (and every thread it starts afterwards: the sources' readers, the ring helper, the fetch helper) is bound to the CPUs
+// of the NUMA node next to the device.  Frames are copied from the page cache into page-locked memory that the runtime places on that
+// node and are then read by the device's copy engines through that socket: from the other socket the same CLI run delivers 4.3-4.9 k
+// pairs/s of 1080p instead of 6.6-7.4 k, and left to the scheduler it lands in between and differs from box to box
+// (tools/numa_probe.sh, profiles/r04y_numa_probe.log).  TM_NUMA_BIND=0 leaves the affinity alone; nothing happens when the node is
+// unknown or the process may not run on any of its CPUs.
+static void bind_to_device_node(int device)
+{
+    const char *env = getenv("TM_NUMA_BIND");
+    if (env && atoi(env) == 0) return;
+    const int node = tm_device_numa_node(device);
+    if (node < 0) return;
+    std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    std::string list;
+    if (!(f >> list)) return;
+    cpu_set_t now, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof now, &now) != 0) return;
+    int n = 0;
+    for (size_t i = 0; i < list.size();) { // "0-63,128-191"
+        char *end = nullptr;
+        const long lo = strtol(list.c_str() + i, &end, 10);
+        long hi = lo;
+        if (end && *end == '-') hi = strtol(end + 1, &end, 10);
+        if (!end || lo < 0 || hi < lo) return;
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET((int)c, &now)) { CPU_SET((int)c, &want); ++n; }
+        i = (size_t)(end - list.c_str());
+        if (i < list.size() && list[i] == ',') ++i; else break;
+    }
+    if (n > 0 && n < CPU_COUNT(&now)) (void)sched_setaffinity(0, sizeof want, &want);
+}
+
+void init_hip(int device)
+{
+    chk(tm_init(device), "tm_init");
+    bind_to_device_node(device);
+}
 
 // ---- colour metadata ---------------------------------------------------------------------------------------------
 ColorCharacteristics ColorCharacteristics::from_codes(int cp, int mc, int tc)
