@@ -24,7 +24,9 @@ Objects on the line (besides the contract fields, which describe the headline wo
   host_fed      SURVEY 8d config 2 (ii): the same pairs uploaded from page-locked host memory for every step
                 (two engines ping-pong: the upload of batch k+1 overlaps the kernels of batch k).  Never `value`.
   batch_curve   the headline workload at 1, 2, 4, 8, 16, 32, 64 pairs per launch (the reference's compute_one is ONE pair per
-                call): pairs/s, ms per step, engine memory.  N = 1 only.
+                call): pairs/s, ms per step, engine memory; for 1 .. 8 pairs per launch also with 2 launches IN FLIGHT (two
+                engines taking turns, each waited for only before its next launch: what an asynchronous caller of the C ABI
+                -- or compute_all -- gets at the same call granularity).  N = 1 only.
   cli_end_to_end  the C++ `turbo-metrics` binary on Y4M clips in tmpfs (1080p 8-bit, 4K 10-bit): file -> pinned ring -> upload
                 -> SSIMULACRA2 -> JSON lines, its own "Processed ... fps" figure.  N = 1 only.  Never `value`.
   cpu_baseline  the restated reference CPU path timed on this host on a bounded sample (rank 0, N=1).
@@ -503,8 +505,42 @@ def run_batch_curve(ctx, args, name, head_B, head_res):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out.append({"batch": B, "value": B * k / dt, "ms_per_step": dt / k * 1e3, "steps": k, "engine_mem_GB": round(eng.mem_usage() / 1e9, 2)})
+        if B <= 8:  # the same call granularity with several launches in flight: n engines take turns
+            # (engines of their own, created together: the runtime spreads streams over its four hardware queues in the order in which
+            # they are created, and an engine whose stream shares a queue with another's cannot run beside it)
+            ref_scores = [sc.ssimulacra2 for sc in eng.scores_batch(B)]
+            eng.close()
+            engs = [tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B) for _ in range(2)]
+            for e in engs:
+                ctx.fill_slots(e, name, max(1, min(args.distinct, B)), 0, B)
+            eng, extra = engs[0], engs[1:]
+            fl = {}
+            for n in (2,):  # (four in flight: 8.4 k pairs/s at one pair per launch when every engine's stream gets a hardware queue of its own --
+                # the runtime has four by default and hands them out by its own rules: tools/inflight_probe.py)
+                def turns(steps):
+                    busy = [False] * n
+                    for i in range(steps):
+                        e = engs[i % n]
+                        if busy[i % n]:
+                            e.sync()
+                        e.compute_async(B); busy[i % n] = True
+                    for i in range(n):
+                        if busy[i]:
+                            engs[i].sync()
+                turns(max(8, k // 10))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                turns(k)
+                torch.cuda.synchronize()
+                fl[str(n)] = B * k / (time.perf_counter() - t0)
+            same = all([sc.ssimulacra2 for sc in e.scores_batch(B)] == ref_scores for e in engs)
+            out[-1]["in_flight"] = fl
+            out[-1]["in_flight_scores_identical"] = same
+            for e in extra:
+                e.close()
         eng.close()
-    return {"workload": name, "note": "one compute_async + sync per step, inputs resident in HBM; batch 1 = the reference's compute_one granularity",
+    return {"workload": name, "note": "one compute_async + sync per step, inputs resident in HBM; batch 1 = the reference's compute_one granularity; "
+            "in_flight: pairs/s of the same launches with 2 of them in flight (two engines taking turns)",
             "points": out}
 
 
@@ -687,6 +723,10 @@ def compact_line(d):
     bc = d.get("batch_curve")
     if bc:
         sm["batch_curve"] = [[p["batch"], _r(p["value"], 0)] for p in bc.get("points", [])]
+        fl = [[p["batch"], int(n), _r(v, 0)] for p in bc.get("points", []) for n, v in sorted((p.get("in_flight") or {}).items())]
+        if fl:
+            sm["batch_curve_in_flight"] = fl
+            sm["_batch_curve_in_flight"] = "[pairs per launch, launches in flight, pairs/s]"
     cli = d.get("cli_end_to_end")
     if cli:
         sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("first_pass", "default", "batch16") if isinstance(v.get(lab), dict)}
@@ -703,7 +743,7 @@ def compact_line(d):
     out["summary"] = sm
     line = json.dumps(out, separators=(",", ":"))
     # never let an unforeseen long string take the line over the limit: drop the least important entries first
-    for victim in ("cli_end_to_end", "batch_curve", "host_fed", "_host_fed", "_workloads", "pipeline", "fixed_stream_long"):
+    for victim in ("_batch_curve_in_flight", "batch_curve_in_flight", "cli_end_to_end", "batch_curve", "host_fed", "_host_fed", "_workloads", "pipeline", "fixed_stream_long"):
         if len(line) <= LINE_LIMIT:
             break
         sm.pop(victim, None)
