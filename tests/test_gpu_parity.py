@@ -643,6 +643,27 @@ def test_ssim_and_msssim_match_oracle(w, h, metrics):
     eng.close(); only.close()
 
 
+def test_ssim_and_msssim_match_the_float64_twin():
+    """The HIP kernels against the SECOND statement of the two metrics (oracle/twin_ssim.py: float64 scipy written from the
+    papers, independent of oracle/tm_ssim.c): per-scale window means 5e-6 relative, scores 1e-6 (tests/test_ssim_twin.py
+    explains the tolerances)."""
+    from oracle import twin_ssim as T
+    for w, h in [(333, 203), (640, 360)]:
+        eng = tm.TurboMetrics(w, h, tm.Metrics(ssim=True, msssim=True), batch=1)
+        fr, fd = nv12_frames(w, h, 4)
+        got = eng.compute_one(fr, fd)
+        eng.set_full_sums(True)
+        eng.compute_async(); eng.sync()
+        lr, ld = oracle_linear(fr, w, h), oracle_linear(fd, w, h)
+        want = T.scale_means(lr, ld, 5, odd="drop")
+        counts, sw, sh = [], w, h
+        for _ in range(5):
+            counts.append((sw - 10) * (sh - 10)); sw //= 2; sh //= 2
+        np.testing.assert_allclose(eng.ssim_sums(0) / np.asarray(counts, np.float64)[None, :, None], want, rtol=5e-6)
+        assert abs(got.ssim - T.ssim(lr, ld)) <= 1e-6 and abs(got.msssim - T.msssim(lr, ld)) <= 1e-6
+        eng.close()
+
+
 def test_ssim_of_identical_frames_is_one_and_size_limits():
     w, h = 192, 176
     fr, _ = nv12_frames(w, h, 1)
