@@ -101,6 +101,15 @@ def csrc_sha16():
     return hh.hexdigest()[:16]
 
 
+def launch_module():
+    """turbo-metrics_amd/launch.py loaded on its own: no numpy, no torch, nothing that touches the GPU"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tm_launch_standalone", os.path.join(ROOT, "turbo-metrics_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 class Ctx:
     """what every leg needs: rank layout, torch, the package, the (optional) process group"""
 
@@ -110,9 +119,13 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
             raise SystemExit(f"WORLD_SIZE={self.world} but --gpus {args.gpus}")
+        # this rank's share of the CPUs the job may use (cgroup quota / affinity), set before numpy and torch load their thread pools
+        # (launch.py on its own: importing the package pulls in numpy)
+        self.cpu_share = launch_module().cap_rank_threads(self.world)
+        from tm_pkg import tm
         import numpy as np
         import torch
-        from tm_pkg import tm
+        torch.set_num_threads(self.cpu_share)
         self.np, self.torch, self.tm = np, torch, tm
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the product has no CPU path")
@@ -138,6 +151,9 @@ class Ctx:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
             self.dist = dist
         tm.init_hip(self.local_rank)
+        # the rank's threads (surface generators, page-locked allocations) next to its device, like the CLI's
+        self.numa_node = tm.ffi.lib().tm_device_numa_node(self.local_rank)
+        self.cpus_bound = tm.launch.bind_to_numa_node(self.numa_node)
         self._surfaces = {}
 
     def barrier(self):
@@ -151,6 +167,21 @@ class Ctx:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def device_mem_used_gb(self):
+        import ctypes as C
+        free, total = C.c_size_t(), C.c_size_t()
+        if self.tm.ffi.lib().tm_device_mem_info(C.byref(free), C.byref(total)) != 0:
+            return None
+        return round((total.value - free.value) / 1e9, 2)
+
+    def min_max_over_ranks(self, x):
+        """[min, max] of a per-rank figure: a straggler shows on the one line the driver keeps"""
+        if self.dist is None:
+            return [x, x]
+        t = self.torch.tensor([x, -x], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [-float(t[1].item()), float(t[0].item())]
+
     def surfaces(self, name, distinct, pinned=False):
         """`distinct` synthetic pairs of the workload (the same on every rank: pair i of a stream has content i % distinct),
         resident in HBM -- or in page-locked host memory for the host-fed leg.  Cached: 4K pairs take seconds to generate."""
@@ -161,7 +192,7 @@ class Ctx:
             host = self._surfaces.get((name, distinct, "host"))
             if host is None:
                 from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(min(8, distinct)) as ex:  # numpy releases the GIL in the heavy parts
+                with ThreadPoolExecutor(max(1, min(8, distinct, self.cpu_share))) as ex:  # numpy releases the GIL in the heavy parts
                     host = self._surfaces[(name, distinct, "host")] = list(ex.map(lambda n: gen(w, h, n), range(distinct)))
             put = (lambda a: self.torch.from_numpy(a).pin_memory()) if pinned else (lambda a: self.torch.from_numpy(a).cuda())
             self._surfaces[key] = [((put(rs), rp, rch), (put(ds), dp, dch)) for (rs, rp, rch), (ds, dp, dch) in host]
@@ -222,10 +253,12 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         for _ in range(k):
             step()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
         ctx.barrier()
         dt = time.perf_counter() - t0
         ms, n = eng.stage_ms(reset=True)
         eng.set_profiling(False)
+        timed.own_s = own
         return dt, [m / max(n, 1) for m in ms]
 
     eng.set_full_sums(args.full_sums)
@@ -238,12 +271,20 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
         step()
     elapsed, stage_ms = timed(steps)
     elapsed = ctx.max_over_ranks(elapsed)
+    per_rank = ctx.min_max_over_ranks(B * steps / timed.own_s)
     modes = eng.job_modes()
     has_s2 = "ssimulacra2" in mets
     sc = eng.scores_batch(B)
     scores_local = np.array([(s.ssimulacra2 if has_s2 else s.psnr) or 0.0 for s in sc], np.float64)
     # the single collective of the path: per-frame scores reduced (sum into zeros) to rank 0
-    all_scores = tm.shard.reduce_scores(scores_local, ctx.rank * B, ctx.world * B, 1, ctx.dist, ctx.cdev if ctx.dist is not None else "cpu")
+    rdev = ctx.cdev if ctx.dist is not None else "cpu"
+    reduce_ms = []
+    for _ in range(2 if ctx.dist is not None else 1):  # the first reduce of a process group also builds its channels: timed apart
+        torch.cuda.synchronize()
+        t_r = time.perf_counter()
+        all_scores = tm.shard.reduce_scores(scores_local, ctx.rank * B, ctx.world * B, 1, ctx.dist, rdev)
+        torch.cuda.synchronize()
+        reduce_ms.append(ctx.max_over_ranks(time.perf_counter() - t_r) * 1e3)
 
     alone = None
     if has_s2 and eng.uses_fused_edge(B) and args.edge_beside == 1:
@@ -380,6 +421,13 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
                    "full_pipeline_GBs": (pairs / elapsed) * (stage_bytes + 24 * spx + in_bytes) / 1e9 / ctx.world}
         if has_s2 else {"full_pipeline_GBs": (pairs / elapsed) * (ingest_bytes / B) / 1e9 / ctx.world},
         "score_mean": float(np.mean(all_scores)) if all_scores is not None else None,
+        # per-rank pairs/s over the rank's own K steps (before the closing barrier), [slowest, fastest]; the one collective of the
+        # path, max over ranks: steady state, and the first call (which builds the process group's channels)
+        "per_rank": per_rank,
+        "stage_ms": [stage_ms[F.TM_STAGE_INGEST], stage_ms[F.TM_STAGE_BLUR_V], stage_ms[F.TM_STAGE_BLUR_H], stage_ms[F.TM_STAGE_EDGE], stage_ms[F.TM_STAGE_SSIM]],
+        "reduce_ms": reduce_ms[-1], "reduce_first_ms": reduce_ms[0],
+        "rank_cpu": {"threads": ctx.cpu_share, "numa_node": ctx.numa_node, "cpus_bound": ctx.cpus_bound},
+        "device_mem_used_GB": ctx.device_mem_used_gb(),  # of rank 0's device, every process on it included, while the engine is alive
     }
     if other is not None:
         mv, mh, me = other["stage_ms"]["blur_v"], other["stage_ms"]["blur_h"], other["stage_ms"]["edge_fused"]
@@ -534,6 +582,34 @@ def run_batch_curve(ctx, args, name, head_B, head_res):
                 torch.cuda.synchronize()
                 fl[str(n)] = B * k / (time.perf_counter() - t0)
             same = all([sc.ssimulacra2 for sc in e.scores_batch(B)] == ref_scores for e in engs)
+            if B == 1:
+                # the same through the host layer's API for reference-style callers: compute_one_deferred(pair) -> ticket, collect(ticket)
+                # one call later (set_pair + launch per call, the scores of every pair fetched: what replaces compute_one in the
+                # reference's loop, turbo-metrics-cli/src/main.rs:290-326)
+                for e in extra:
+                    e.close()
+                extra = []
+                kind = WORKLOADS[name][2]
+                mk = tm.HwFrame.nv12 if kind == "nv12" else tm.HwFrame.p016
+                sf = ctx.surfaces(name, max(1, min(args.distinct, 8)))
+                pairs_hw = [(mk(rt, rp, rch), mk(dt_, dp, dch)) for (rt, rp, rch), (dt_, dp, dch) in sf]
+                blocking = [eng.compute_one(a, b).ssimulacra2 for a, b in pairs_hw]
+
+                def deferred(steps):
+                    got, last = [], None
+                    for i in range(steps):
+                        t = eng.compute_one_deferred(*pairs_hw[i % len(pairs_hw)])
+                        if last is not None:
+                            got.append(eng.collect(last).ssimulacra2)
+                        last = t
+                    got.append(eng.collect(last).ssimulacra2)
+                    return got
+                deferred(max(8, k // 10))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                got = deferred(k)
+                fl["2_api"] = k / (time.perf_counter() - t0)
+                same = same and got[:len(blocking)] == blocking
             out[-1]["in_flight"] = fl
             out[-1]["in_flight_scores_identical"] = same
             for e in extra:
@@ -573,10 +649,15 @@ def run_cli_end_to_end(ctx):
                     for i in range(frames):
                         f.write(blobs[i % len(blobs)])
             res = {"pairs": frames, "clip_GB_each": round(os.path.getsize(paths[0]) / 1e9, 2), "clips_in": base}
-            # the first pass over a freshly written clip runs at a third of the later ones whatever its arguments: the first read of
-            # just-written tmpfs pages does not scale with threads (12-14 GB/s with 1, 4 or 8 readers, 58-65 on the second pass;
-            # tools/first_pass_probe.sh, profiles/r04y_first_pass_probe.log) -- reported apart as `first_pass`
-            for label, extra in (("first_pass", []), ("default", []), ("batch16", ["--batch", "16"])):
+            # the first pass over a clip this process has JUST WRITTEN into tmpfs runs at a third of the later ones whatever its
+            # arguments: the first read of just-written tmpfs pages does not scale with threads (12-14 GB/s with 1, 4 or 8 readers,
+            # 58-65 on the second pass; tools/first_pass_probe.sh, profiles/r04y_first_pass_probe.log).  That is an artefact of
+            # making the clip here, not what a user's single run over an existing file sees: it is kept in the detail record as
+            # `tmpfs_just_written` and stays off the compact line.
+            for label, extra in (("tmpfs_just_written", []), ("default", []), ("batch16", ["--batch", "16"]),
+                                 # the reference's own loop -- one blocking compute_one per pair -- and the same loop on
+                                 # compute_one_deferred + collect (two pairs in flight): what a reference-style caller gets end to end
+                                 ("loop_reference", ["--loop", "reference"]), ("loop_deferred", ["--loop", "deferred"])):
                 t0 = time.perf_counter()
                 r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, timeout=300)
                 wall = time.perf_counter() - t0
@@ -596,26 +677,7 @@ def run_cli_end_to_end(ctx):
 
 
 def effective_cpus():
-    """CPUs this process may really use: the smallest of the visible CPUs, the affinity mask and the cgroup CPU quota.  The GPU boxes
-    of this pool show 256 CPUs and allow 16 CPUs' worth of time (cpu.max = "1600000 100000"): more busy threads than that only buy
-    throttling (round 3's "all cores" figure: 256 threads delivered less than 64)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
-        try:
-            if period_file is None:
-                q, per = open(quota_file).read().split()[:2]
-            else:
-                q, per = open(quota_file).read().strip(), open(period_file).read().strip()
-            if q != "max" and int(q) > 0 and int(per) > 0:
-                n = min(n, max(1, -(-int(q) // int(per))))
-                break
-        except Exception:
-            continue
-    return n
+    return launch_module().effective_cpus()
 
 
 def cpu_baseline(tm, w, h, kind, n_pairs):
@@ -684,6 +746,9 @@ def compact_line(d):
     cfg = d.get("config", {})
     out = {k: _r(d.get(k)) for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step",
                                       "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    if d.get("per_rank"):
+        out["per_rank"] = [_r(v, 1) for v in d["per_rank"]]  # [slowest, fastest] rank, pairs/s over its own K steps
+        out["reduce_ms"] = _r(d.get("reduce_ms"), 3)
     out["config"] = {k: cfg.get(k) for k in ("workload", "baseline_config", "width", "height", "input", "pairs_per_step_per_gpu",
                                              "metrics", "full_sums", "pipeline_depth", "engine_mem_GB", "parallelism") if k in cfg}
     rf = d.get("roofline") or {}
@@ -706,9 +771,11 @@ def compact_line(d):
             out["cpu_baseline"]["points"] = [[p["cores"], _r(p["value"], 2)] for p in cb["points"]]
     sm = {}
     for name, w in (d.get("workloads") or {}).items():
-        sm[name] = [_r(w.get("value"), 1), _r((w.get("roofline") or {}).get("frac"))]
+        sm[name] = [_r(w.get("value"), 1), _r((w.get("roofline") or {}).get("frac")), [_r(v, 3) for v in w.get("stage_ms") or []]]
+    if d.get("stage_ms"):
+        sm["stage_ms"] = [_r(v, 3) for v in d["stage_ms"]]
     if sm:
-        sm["_workloads"] = "name: [pairs/s, blur+reduce stage frac of 8 TB/s]"
+        sm["_workloads"] = "[pairs/s, blur+reduce frac, stage ms [ingest,col,row,edge(beside),ssim|finish]]"
     fs = d.get("fixed_stream")
     if fs:
         sm["fixed_stream"] = {"pairs": fs.get("total_pairs"), "value": _r(fs.get("value"), 1), "scaling": fs.get("scaling"),
@@ -723,13 +790,13 @@ def compact_line(d):
     bc = d.get("batch_curve")
     if bc:
         sm["batch_curve"] = [[p["batch"], _r(p["value"], 0)] for p in bc.get("points", [])]
-        fl = [[p["batch"], int(n), _r(v, 0)] for p in bc.get("points", []) for n, v in sorted((p.get("in_flight") or {}).items())]
+        fl = [[p["batch"], n, _r(v, 0)] for p in bc.get("points", []) for n, v in sorted((p.get("in_flight") or {}).items())]
         if fl:
             sm["batch_curve_in_flight"] = fl
-            sm["_batch_curve_in_flight"] = "[pairs per launch, launches in flight, pairs/s]"
+            sm["_batch_curve_in_flight"] = "[pairs per launch, launches in flight (2_api: via compute_one_deferred/collect), pairs/s]"
     cli = d.get("cli_end_to_end")
     if cli:
-        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("first_pass", "default", "batch16") if isinstance(v.get(lab), dict)}
+        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("default", "batch16", "loop_reference", "loop_deferred") if isinstance(v.get(lab), dict)}
                                 if isinstance(v, dict) and "error" not in v else (v.get("error", "")[:60] if isinstance(v, dict) else None)
                                 for tag, v in cli.items() if tag != "note"}
     pl = d.get("pipeline")
@@ -806,10 +873,11 @@ def run_rank(args):
             return None
 
     if extras:
-        ks, kw = max(2, min(args.steps, 10)), min(args.warmup, 2)
+        # the same K, W and settling as the headline: a 10-step run after 150 ms of settling differed by 13 % from box to box (r04)
+        ks, kw = max(2, args.steps), args.warmup
         for wl, m in EXTRAS:
             tag = wl + ("_fused" if m == FUSED else "")
-            got = leg(tag, lambda: run_workload(ctx, args, wl, set(m.split(",")), WORKLOADS[wl][3], ks, kw, 150.0, compare=False))
+            got = leg(tag, lambda: run_workload(ctx, args, wl, set(m.split(",")), WORKLOADS[wl][3], ks, kw, args.settle_ms, compare=False))
             if got is not None:
                 r = got[0]
                 r.pop("unit", None)
@@ -817,7 +885,7 @@ def run_rank(args):
         if ctx.world == 1:  # a per-GPU PCIe figure: measured on one GPU only (>= 40 steps: 8 pairs x 10 steps was too short to be stable)
             host_fed = {}
             for wl in ("1080p_nv12", "4k_p016"):
-                got = leg("host_fed_" + wl, lambda: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, max(ks, 40), kw))
+                got = leg("host_fed_" + wl, lambda: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, max(ks, 40), min(kw, 2)))
                 if got is not None:
                     host_fed[wl] = got
     batch_curve = cli = None
@@ -841,7 +909,7 @@ def run_rank(args):
             "dtype": "f32",
             "data": "synthetic",
         }
-        for k in ("config", "roofline", "kernels", "kernels_alone", "stages", "score_mean", "compare"):
+        for k in ("config", "roofline", "kernels", "kernels_alone", "stages", "score_mean", "compare", "per_rank", "reduce_ms", "reduce_first_ms", "stage_ms", "rank_cpu", "device_mem_used_GB"):
             if k in res:
                 out[k] = res[k]
         if leg_errors:
@@ -872,8 +940,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under torchrun: become the launcher.  Nothing has touched the GPU (torch is not even imported yet).
-        from tm_pkg import tm
-        sys.exit(tm.launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        sys.exit(launch_module().spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     run_rank(args)
 
 

@@ -83,6 +83,50 @@ def test_eight_ranks_rendezvous_shard_and_reduce_like_one_rank():
     assert wall < 120.0, wall
 
 
+def test_the_drivers_eight_gpu_command_with_default_arguments_on_one_device():
+    """the command the driver runs at round end -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps 20 --warmup 5`, batch 64, both fixed streams -- rehearsed
+    on ONE device (TM_BENCH_BACKEND=gloo: the ranks share device 0, gloo carries the collectives).  Every rank caps its thread
+    pools to its share of the CPU quota and binds next to its device before any work; the line names the real backend, shows
+    the slowest and the fastest rank and the time of the one reduce; < 600 s, <= 4 KB.  The record goes to gpurun_out/ (copied
+    to profiles/r05_bench_8ranks_gloo_one_device.json)."""
+    import tempfile
+    import time
+    from tm_pkg import tm
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update({"TM_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, "detail.json")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(tm.launch.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+               "--detail-file", detail]
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        wall = time.time() - t0
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) <= 4096, (len(lines), [len(l) for l in lines])
+        line = json.loads(lines[0])
+        full = json.load(open(detail))
+    assert wall < 600.0, wall
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["config"]["pairs_per_step_per_gpu"] == 64 and "gloo" in line["config"]["parallelism"]
+    lo, hi = line["per_rank"]
+    assert 0 < lo <= hi and line["reduce_ms"] >= 0
+    # value = the pairs of all ranks over the slowest rank's time: never above the sum of the per-rank rates
+    assert line["value"] <= 8 * hi * 1.001
+    sm = line["summary"]
+    assert sm["fixed_stream"]["pairs"] == 2048 and sm["fixed_stream"]["bit_identical"]
+    assert sm["fixed_stream_long"]["pairs"] == 16384 and sm["fixed_stream_long"]["bit_identical"]
+    assert full["rank_cpu"]["threads"] >= 1 and full["rank_cpu"]["threads"] <= max(1, tm.launch.effective_cpus() // 8)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "r05_bench_8ranks_gloo_one_device.json"), "w") as f:
+            json.dump({"command": " ".join(cmd[1:]).replace(ROOT + "/", ""), "env": {"TM_BENCH_BACKEND": "gloo"}, "wall_s": round(wall, 1),
+                       "line_bytes": len(lines[0]), "device_mem_used_GB": full.get("device_mem_used_GB"), "rank_cpu": full["rank_cpu"],
+                       "line": line}, f, indent=1)
+
+
 def test_asking_for_more_gpus_than_exist_fails_loudly():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TM_BENCH_BACKEND")}
     import torch

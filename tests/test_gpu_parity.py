@@ -1067,6 +1067,83 @@ def test_upload_fences_say_when_a_page_locked_frame_may_be_overwritten():
     eng.close()
 
 
+def test_a_fence_covers_second_stream_copies_from_before_an_earlier_fence():
+    """a fence stands for EVERY upload enqueued so far.  Distorted-side page-locked frames go up on the second upload
+    stream; a later fence that only saw reference-side copies must still not be done before those (nothing on the engine's stream
+    waits for them until the next launch).  4K P016 frames (25 MB, ~0.5 ms on the link each) make an early answer observable: once
+    the newest fence is done, every older fence is done too."""
+    torch = pytest.importorskip("torch")
+    w, h = 3840, 2160
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=4)
+    (rs, rp, rch), (ds, dp, dch) = tm.synth.p016_pair(w, h, 1)
+    pr = torch.from_numpy(np.asarray(rs).copy()).pin_memory()
+    pd = torch.from_numpy(np.asarray(ds).copy()).pin_memory()
+    for rounds in range(8):
+        older = []
+        for slot in range(4):  # four 25-MB copies queued on the second stream, a fence after each
+            eng.set_frame(slot, F.TM_SIDE_DIS, tm.HwFrame.p016(pd, dp, dch))
+            older.append(eng.upload_fence())
+        eng.set_frame(0, F.TM_SIDE_REF, tm.HwFrame.p016(pr, rp, rch))  # one copy on the engine's own stream
+        newest = eng.upload_fence()
+        assert eng.upload_done(newest, block=True)
+        assert all(eng.upload_done(t, block=False) for t in older), rounds
+    # and a distorted-side frame set again from pageable memory (engine's stream) lands AFTER the page-locked one (second stream)
+    one = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)
+    want = one.compute_one(tm.HwFrame.p016(rs, rp, rch), tm.HwFrame.p016(ds, dp, dch)).ssimulacra2
+    for _ in range(4):
+        eng.set_frame(0, F.TM_SIDE_REF, tm.HwFrame.p016(pr, rp, rch))
+        eng.set_frame(0, F.TM_SIDE_DIS, tm.HwFrame.p016(pr, rp, rch))   # page-locked, second stream: the WRONG picture ...
+        eng.set_frame(0, F.TM_SIDE_DIS, tm.HwFrame.p016(ds, dp, dch))   # ... replaced from pageable memory on the engine's stream
+        eng.compute_async(1); eng.sync()
+        assert eng.scores(0).ssimulacra2 == want
+    eng.close(); one.close()
+
+
+def test_compute_one_deferred_gives_compute_ones_scores_with_two_pairs_in_flight():
+    """compute_one without its blocking sync -- a ticket per pair, collect(ticket) one call later (the three-line change
+    to the reference's loop).  Same FrameScores as compute_one, bit for bit, whatever the collection order."""
+    w, h = 640, 360
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True, ssim=True), batch=1)
+    frames = [nv12_frames(w, h, i) for i in range(5)]
+    want = [eng.compute_one(fr, fd) for fr, fd in frames]
+    assert len({s.ssimulacra2 for s in want}) == 5
+    mem_one = eng.mem_usage()
+    got, last = [], None
+    for k in range(15):  # the reference's loop with a lag of one: submit pair k, then collect pair k - 1
+        t = eng.compute_one_deferred(*frames[k % 5])
+        if last is not None:
+            got.append(eng.collect(last))
+        last = t
+    got.append(eng.collect(last))
+    assert got == want * 3
+    tickets = [eng.compute_one_deferred(*frames[k]) for k in range(5)]  # nothing collected in between: older pairs are finished and kept
+    assert [eng.collect(t) for t in reversed(tickets)] == list(reversed(want))
+    with pytest.raises(tm.TmError):
+        eng.collect(tickets[0])  # a ticket is good for one collect
+    with pytest.raises(tm.TmError):
+        eng.collect(10 ** 6)
+    assert eng.compute_one(*frames[2]) == want[2]  # the blocking call still works beside it
+    assert eng.mem_usage() == mem_one  # (the second engine is its own object)
+    batched = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=4)
+    with pytest.raises(ValueError):
+        batched.compute_one_deferred(*frames[0])
+    batched.close(); eng.close()
+
+
+def test_destroying_a_chained_peer_first_unhooks_it():
+    w, h = 320, 200
+    a = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)
+    b = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)
+    fr, fd = nv12_frames(w, h, 2)
+    want = a.compute_one(fr, fd).ssimulacra2
+    a.set_graph(False)
+    a.debug_chain(b)
+    assert a.compute_one(fr, fd).ssimulacra2 == want
+    b.close()  # a's launches waited on b's events
+    assert a.compute_one(fr, fd).ssimulacra2 == want
+    a.close()
+
+
 @pytest.mark.parametrize("w,h", [(16384, 40), (40, 16384)])
 def test_maximum_width_and_height_against_the_oracle(w, h):
     """the largest picture sides tm_engine_create accepts (16 384): 512 tiles / 512 bands in the fused kernel, 256 column blocks / 256 row

@@ -469,6 +469,14 @@ def test_cli_y4m_stream_frame_selection_batching_and_pipeline(tmp_path, bits):
     assert scores("--skip", 2, "--frames", 3)[0] == base[2:5]
     got, _ = scores("--skip-ref", 1)
     assert len(got) == n - 1 and got != base[1:]                 # reference frame i+1 against distorted frame i
+    # the reference's own loop (one blocking compute_one per pair) and the same loop on compute_one_deferred + collect
+    for mode in ("reference", "deferred"):
+        assert scores("--loop", mode)[0] == base
+        assert scores("--loop", mode, "--every", 3)[0] == [base[i] for i in (0, 3, 6, 9)]
+        assert scores("--loop", mode, "--skip", 2, "--frames", 3)[0] == base[2:5]
+    rc, out1, _ = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines")
+    rc2, out2, _ = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--loop", "deferred")
+    assert rc == 0 and rc2 == 0 and out1 == out2                 # byte-identical stdout
     # explicit BT.709 metadata overrides the fallback
     rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--output", "json", "--color-primaries", 1, "--matrix-coefficients", 1, "--transfer-characteristics", 1)
     assert rc == 0 and "mc=BT709" in err and json.loads(out)["ssimulacra2"]["scores"] != base

@@ -86,6 +86,9 @@ void up_stream_release(int device)
     if (--g_up_users[device] == 0 && g_up_stream[device]) { (void)hipStreamSynchronize(g_up_stream[device]); (void)hipStreamDestroy(g_up_stream[device]); g_up_stream[device] = nullptr; }
 }
 
+// engines alive in this process (tm_engine_debug_chain keeps a raw pointer to a peer: destroying the peer must unhook it)
+std::vector<tm_engine *> g_engines;
+
 const uint32_t k_lut_bits[256] = {TM_SRGB_LUT_BITS};
 const double k_weights[108] = {TM_SSIMU2_WEIGHTS};
 // the math table buffer of tm_device_math.h (TM_TAB_DOUBLES): pow_pos tables, then the binary64 transfer-function cubics
@@ -147,6 +150,7 @@ struct tm_engine {
     int ef_tiles = 0, ef_bands = 0, ef_ne = 0;
     size_t hs_elems = 0, erows_elems = 0; // what HS / EROWS hold (mem_bytes bookkeeping; the geometry above is what the kernels index with)
     unsigned ef_epoch_host = 1;      // host mirror of d_epoch[0] (one step per fused launch): HS is cleared when the 24-bit tag epoch wraps
+    bool ef_epoch_unknown = false;   // a fused launch failed part-way or bailed out: the mirror is re-read from the device before the next one
     // The tuning values below are fixed in a release build's behaviour: no environment variable reaches them.  tools/ and tests move
     // them through tm_engine_debug_set_param (TM_DBG_*), per engine.
     long long fused_edge_from = 400; // bands of 32 rows of EDGE planes per launch (slots x jobs x ceil(h / 32)) from which those jobs take the fused kernel: 6 pairs of
@@ -185,7 +189,7 @@ struct tm_engine {
     double *d_powtab = nullptr;
     std::vector<hipEvent_t> up_ev;    // upload fences (tm_engine_upload_fence): a small ring of events on the engine's stream
     std::vector<hipEvent_t> up_ev2;   // ... and on the second upload stream, for the fences that had copies on it (up_has2)
-    std::vector<char> up_has2;
+    std::vector<uint64_t> up_tok2;    // per fence: token of the most recent fence (itself included) that recorded on the second upload stream, or UINT64_MAX
     uint64_t up_last2 = UINT64_MAX;   // token of the most recent fence that recorded an event on the second upload stream
     hipStream_t up_stream = nullptr;  // the device's second upload stream (page-locked frames of the distorted side)
     hipEvent_t ev_up_join = nullptr, ev_stage_free = nullptr;
@@ -248,7 +252,16 @@ int stage_rows(tm_engine *e, hipStream_t st, void *dst, size_t dst_pitch, const 
 int upload_stream(tm_engine *e, int side, int mem, hipStream_t *out)
 {
     *out = e->stream;
-    if (mem != TM_MEM_HOST_PINNED || side != TM_SIDE_DIS || !e->up_stream || e->upload_streams < 2) return TM_OK;
+    if (mem != TM_MEM_HOST_PINNED || side != TM_SIDE_DIS || !e->up_stream || e->upload_streams < 2) {
+        // a distorted-side copy on the engine's own stream after page-locked ones on the second stream: same staging surface, two
+        // streams -- the engine's stream waits for the second one first (what tm_engine_compute_async would do later anyway)
+        if (side == TM_SIDE_DIS && mem != TM_MEM_DEVICE && e->up_pending) {
+            HIPCHK(hipEventRecord(e->ev_up_join, e->up_stream));
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_up_join, 0));
+            e->up_pending = false;
+        }
+        return TM_OK;
+    }
     if (e->stage_busy) {
         HIPCHK(hipStreamWaitEvent(e->up_stream, e->ev_stage_free, 0));
         e->stage_busy = false;
@@ -699,6 +712,10 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     e->staging_size.assign(B * 2, 0);
     for (int i = 0; i < 7; ++i)
         if ((he = hipEventCreate(&e->ev[i])) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
+    {
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        g_engines.push_back(e);
+    }
     *out = e;
     return TM_OK;
 }
@@ -706,6 +723,14 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
 void tm_engine_destroy(tm_engine *e)
 {
     if (!e) return;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        for (size_t i = 0; i < g_engines.size();) {
+            if (g_engines[i] == e) { g_engines[i] = g_engines.back(); g_engines.pop_back(); continue; }
+            if (g_engines[i]->chain_peer == e) g_engines[i]->chain_peer = nullptr; // (its launches would wait on this engine's destroyed events)
+            ++i;
+        }
+    }
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
@@ -811,23 +836,30 @@ int tm_engine_upload_fence(tm_engine *e, uint64_t *token)
 {
     if (!e || !token) return TM_ERR_INVALID_ARG;
     TM_BIND(e);
-    if (e->up_ev.empty()) {
-        e->up_ev.assign(TM_UPLOAD_FENCES, nullptr);
-        e->up_ev2.assign(TM_UPLOAD_FENCES, nullptr);
-        e->up_has2.assign(TM_UPLOAD_FENCES, 0);
-        for (hipEvent_t &ev : e->up_ev)
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventCreate");
-        for (hipEvent_t &ev : e->up_ev2)
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventCreate");
+    if (e->up_ev.empty()) { // all or nothing: a ring with holes would let tm_engine_upload_done answer early
+        std::vector<hipEvent_t> a(TM_UPLOAD_FENCES, nullptr), b(TM_UPLOAD_FENCES, nullptr);
+        hipError_t he = hipSuccess;
+        for (size_t k = 0; k < 2 * (size_t)TM_UPLOAD_FENCES && he == hipSuccess; ++k)
+            he = hipEventCreateWithFlags(k < TM_UPLOAD_FENCES ? &a[k] : &b[k - TM_UPLOAD_FENCES], hipEventDisableTiming);
+        if (he != hipSuccess) {
+            for (hipEvent_t ev : a) if (ev) (void)hipEventDestroy(ev);
+            for (hipEvent_t ev : b) if (ev) (void)hipEventDestroy(ev);
+            return hip_fail(he, "hipEventCreate");
+        }
+        e->up_ev.swap(a);
+        e->up_ev2.swap(b);
+        e->up_tok2.assign(TM_UPLOAD_FENCES, UINT64_MAX);
     }
     const size_t i = e->up_next % TM_UPLOAD_FENCES;
     HIPCHK(hipEventRecord(e->up_ev[i], e->stream));
-    e->up_has2[i] = e->up_since_fence;
     if (e->up_since_fence) { // the copies of this fence that went up on the second upload stream
         HIPCHK(hipEventRecord(e->up_ev2[i], e->up_stream));
         e->up_since_fence = false;
         e->up_last2 = e->up_next;
     }
+    // A fence covers EVERY upload enqueued so far: also second-stream copies from before an earlier fence, which nothing on the
+    // engine's stream waits for until the next launch -- so each fence remembers the latest second-stream fence.
+    e->up_tok2[i] = e->up_last2;
     *token = e->up_next++;
     return TM_OK;
 }
@@ -843,11 +875,12 @@ int tm_engine_upload_done(tm_engine *e, uint64_t token, int block)
     const size_t i = token % TM_UPLOAD_FENCES;
     const bool recycled = e->up_next - token > TM_UPLOAD_FENCES;
     hipEvent_t ev2 = nullptr;
-    if (!recycled) ev2 = e->up_has2[i] ? e->up_ev2[i] : nullptr;
-    else if (e->up_last2 != UINT64_MAX) ev2 = e->up_ev2[e->up_last2 % TM_UPLOAD_FENCES];
+    // (the event in the slot of token t was last recorded by a fence >= t of the same in-order stream: done there covers t)
+    const uint64_t t2 = recycled ? e->up_last2 : e->up_tok2[i];
+    if (t2 != UINT64_MAX) ev2 = e->up_ev2[t2 % TM_UPLOAD_FENCES];
     hipEvent_t evs[2] = {e->up_ev[i], ev2};
     for (hipEvent_t ev : evs) {
-        if (!ev) continue;
+        if (!ev) continue; // (no copy ever went up on the second stream)
         if (block) {
             const hipError_t r = hipEventSynchronize(ev);
             if (r != hipSuccess) { (void)hip_fail(r, "hipEventSynchronize"); return -TM_ERR_HIP; }
@@ -1084,6 +1117,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     }
     hipStream_t st = e->stream;
     const int n = (int)n_slots;
+    bool fused_launch = false;
     const int want_sse = (e->mask & TM_METRIC_PSNR) ? 1 : 0;
     if (e->up_pending) { // frames that went up on the second upload stream: the launch waits for them
         HIPCHK(hipEventRecord(e->ev_up_join, e->up_stream));
@@ -1113,9 +1147,14 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
         // keep their old tags: after a wrap an old tag could match a new launch's.  Whenever the epoch is back at 1 --
         // every 2^24 - 1 fused launches -- the words are cleared first (tag 0 is never expected); on the engine's stream, in front of
         // everything this launch enqueues or replays.
+        if (e->ef_epoch_unknown) { // an earlier fused launch failed part-way or bailed out: ask the device where its epoch stands
+            HIPCHK(hipStreamSynchronize(st));
+            if (e->stream2) HIPCHK(hipStreamSynchronize(e->stream2));
+            HIPCHK(hipMemcpy(&e->ef_epoch_host, e->d_epoch, sizeof(unsigned), hipMemcpyDeviceToHost));
+        }
         if (e->ef_epoch_host == 1u && e->HS) HIPCHK(hipMemsetAsync(e->HS, 0, e->hs_elems * sizeof(unsigned long long), st));
-        const unsigned next = (e->ef_epoch_host + 1u) & 0xFFFFFFu; // what k_finish_edge does on the device
-        e->ef_epoch_host = next ? next : 1u;
+        e->ef_epoch_unknown = true; // until this launch has been enqueued in full (any early return below leaves it set)
+        fused_launch = true;
     }
     int kind = e->h_desc[0].kind;
     for (int i = 1; i < 2 * n; ++i) if (e->h_desc[i].kind != kind) kind = -1;
@@ -1144,6 +1183,11 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
         if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
+    if (fused_launch) { // enqueued in full: the mirror takes the step k_finish_edge takes on the device
+        const unsigned next = (e->ef_epoch_host + 1u) & 0xFFFFFFu;
+        e->ef_epoch_host = next ? next : 1u;
+        e->ef_epoch_unknown = false;
+    }
     if (e->up_stream && e->upload_streams >= 2) { // the next frame that goes up on the second upload stream must not overtake this launch
         HIPCHK(hipEventRecord(e->ev_stage_free, st));
         e->stage_busy = true;
@@ -1182,6 +1226,7 @@ int tm_engine_sync(tm_engine *e)
         (void)hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream);
         (void)hipStreamSynchronize(e->stream);
         e->have_results = false;
+        e->ef_epoch_unknown = true;
         snprintf(g_hip_err, sizeof g_hip_err, "k_blur_edge_fused: a state hand-off between bands timed out");
         return TM_ERR_HIP;
     }
@@ -1392,6 +1437,7 @@ int tm_engine_debug_set_edge_epoch(tm_engine *e, uint32_t epoch)
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->d_epoch, &epoch, sizeof epoch, hipMemcpyHostToDevice));
     e->ef_epoch_host = epoch;
+    e->ef_epoch_unknown = false;
     return TM_OK;
 }
 

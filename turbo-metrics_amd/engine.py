@@ -165,6 +165,10 @@ class TurboMetrics:
 
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
+        d = getattr(self, "_def", None)
+        if d is not None:
+            self._def = None
+            d["ring"][1].close()
         if getattr(self, "_h", None):
             self._L.tm_engine_destroy(self._h)
             self._h = None
@@ -287,6 +291,40 @@ class TurboMetrics:
         self.compute_async(1)
         self.sync()
         return self.scores(0)
+
+    def compute_one_deferred(self, fref: HwFrame, fdis: HwFrame) -> int:
+        """compute_one without its blocking stream sync (lib.rs:352): hand the pair over, launch, return a ticket at once;
+        collect(ticket) blocks until THAT pair's scores are there.  Two launches may be in flight -- two engines taking turns, the
+        second one created at the first call (host/turbo_metrics.hpp: the same two methods on the C++ side).  A third submission
+        first finishes the oldest pair and keeps its scores until collected.  Scores are bit-identical with compute_one's."""
+        if self.batch != 1:
+            raise ValueError("compute_one_deferred is the one-pair-per-call path: create the engine with batch=1")
+        if getattr(self, "_def", None) is None:
+            self._def = {"ring": [self, TurboMetrics(self.width, self.height, self._metrics, batch=1)], "pending": [None, None], "done": {}, "next": 0}
+        d = self._def
+        ticket = d["next"]
+        d["next"] += 1
+        i = ticket & 1
+        e = d["ring"][i]
+        if d["pending"][i] is not None:
+            e.sync()
+            d["done"][d["pending"][i]] = e.scores(0)
+        e.set_pair(0, fref, fdis)
+        e.compute_async(1)
+        d["pending"][i] = ticket
+        return ticket
+
+    def collect(self, ticket: int) -> FrameScores:
+        d = getattr(self, "_def", None)
+        if d is not None:
+            for i in range(2):
+                if d["pending"][i] == ticket:
+                    d["pending"][i] = None
+                    d["ring"][i].sync()
+                    return d["ring"][i].scores(0)
+            if ticket in d["done"]:
+                return d["done"].pop(ticket)
+        raise TmError(ffi.TM_ERR_INVALID_ARG, "collect: no such ticket (never issued, or collected already)")
 
     def compute_all(self, frames_ref: Iterable[HwFrame], frames_dis: Iterable[HwFrame], opts: Options = Options()) -> List[FrameScores]:
         """== TurboMetrics::compute_all frame selection (lib.rs:385-404), batched over the slots."""

@@ -52,6 +52,8 @@ void usage(std::ostream &os)
           "      --device <N>           GPU ordinal [default: 0]\n"
           "      --devices <N>          shard the frame pairs of two regular files over N GPUs (0 = all visible) [default: 1]\n"
           "      --no-pipeline          do not overlap reading/upload of the next batch with the current one\n"
+          "      --loop <MODE>          batched (default: compute_all), reference (the reference's loop: one blocking compute_one per pair),\n"
+          "                             deferred (that loop with compute_one_deferred + collect: two pairs in flight)\n"
           "      --full-sums            compute all 108 SSIMULACRA2 sums, also the zero-weighted ones\n"
           "      --width <W> --height <H> [--bits 8|10|12|16]   headerless planar 4:2:0 input\n"
           "      --color-primaries <N> --matrix-coefficients <N> --transfer-characteristics <N>   H.273 codes (1, 5, 6; 2 = by height)\n"
@@ -119,6 +121,7 @@ int main(int argc, char **argv)
     SourceHints hints;
     uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1;
     bool pipeline = true, full_sums = false;
+    enum class Loop { Batched, Reference, Deferred } loop = Loop::Batched;
     std::vector<std::pair<int, long long>> tune;
 
     auto bad = [&](const std::string &m) {
@@ -167,6 +170,12 @@ int main(int argc, char **argv)
         else if (a == "--device") { if (!u32(device)) return bad("invalid value for '--device <N>'"); }
         else if (a == "--devices") { if (!u32(devices)) return bad("invalid value for '--devices <N>'"); }
         else if (a == "--no-pipeline") pipeline = false;
+        else if (a == "--loop") {
+            std::string s;
+            if (!value(s)) return bad("a value is required for '--loop <MODE>'");
+            if (s == "batched") loop = Loop::Batched; else if (s == "reference") loop = Loop::Reference; else if (s == "deferred") loop = Loop::Deferred;
+            else return bad("invalid value '" + s + "' for '--loop <MODE>'\n  [possible values: batched, reference, deferred]");
+        }
         else if (a == "--full-sums") full_sums = true;
         else if (a == "--tune") { // --tune <param>=<value>: tm_engine_debug_set_param (measurements; not in the usage text)
             std::string kv; if (!value(kv) || kv.find('=') == std::string::npos) return bad("invalid value for '--tune <param>=<value>'");
@@ -312,6 +321,7 @@ int main(int argc, char **argv)
         const size_t known = std::min(source_ref->frame_count(), source_dis->frame_count());
         if (batch == 0) batch = auto_batch(source_ref->width(), source_ref->height());
         if (known > 0 && known <= batch) { batch = (uint32_t)known; pipeline = false; }
+        if (loop != Loop::Batched) { batch = 1; pipeline = false; } // one pair per call, like the reference
         // the placement search of tm_engine_create (~10 ms per candidate and engine) pays off on long streams only
         if (known > 0 && known < 20000) tm_set_placement_candidates(1);
         turbo = std::make_unique<TurboMetrics>(source_ref->width(), source_ref->height(), metrics, batch, pipeline);
@@ -340,8 +350,34 @@ int main(int argc, char **argv)
     MetricsResults results;
     uint32_t decode_count = 0;
     try {
-        results = turbo->compute_all(*source_ref, *source_dis, opts,
-                                     [&](const FrameScores &r) { output_single_score(output, r, std::cout); }, &decode_count);
+        if (loop == Loop::Batched) {
+            results = turbo->compute_all(*source_ref, *source_dis, opts,
+                                         [&](const FrameScores &r) { output_single_score(output, r, std::cout); }, &decode_count);
+        } else {
+            // The reference's own loop, statement for statement (turbo-metrics-cli/src/main.rs:284-326): one pair per call.  `deferred`
+            // is the same loop with the two-line change INTEGRATION.md section 3 shows: submit pair k, then collect pair k - 1.
+            const auto cref = source_ref->color_characteristics(), cdis = source_dis->color_characteristics();
+            std::vector<FrameScores> all;
+            const auto emit = [&](const FrameScores &r) { output_single_score(output, r, std::cout); all.push_back(r); };
+            source_ref->skip_frames(opts.skip_ref + opts.skip);
+            source_dis->skip_frames(opts.skip_dis + opts.skip);
+            HwFrame fref, fdis;
+            uint64_t last = 0;
+            while (source_ref->next_frame(fref) && source_dis->next_frame(fdis)) {
+                if (opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0) { decode_count += 1; continue; }
+                if (opts.frames > 0 && decode_count >= opts.frames) break;
+                decode_count += 1;
+                if (loop == Loop::Reference) {
+                    emit(turbo->compute_one(fref, cref, fdis, cdis));
+                } else {
+                    const uint64_t ticket = turbo->compute_one_deferred(fref, cref, fdis, cdis);
+                    if (last) emit(turbo->collect(last));
+                    last = ticket;
+                }
+            }
+            if (last) emit(turbo->collect(last));
+            results = aggregate_scores(all, metrics);
+        }
     } catch (const std::exception &e) {
         std::cout.flush();
         log_line(L_ERROR, kTarget, std::string("Computation failed : ") + e.what());

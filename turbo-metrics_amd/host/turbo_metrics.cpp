@@ -11,6 +11,7 @@
 #include <exception>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 
 namespace tm_host {
 
@@ -40,9 +41,16 @@ static void bind_to_device_node(int device)
     std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
     std::string list;
     if (!(f >> list)) return;
-    cpu_set_t now, want;
+    // The mask the PROCESS was started with, taken once before the first bind: with --devices N the main thread is bound to device 0's
+    // node before the shard threads start, they inherit that narrowed mask, and a device on the other socket would intersect to nothing
+    // and stay on device 0's CPUs.
+    static cpu_set_t original;
+    static std::once_flag once;
+    static bool have_original = false;
+    std::call_once(once, [] { have_original = sched_getaffinity(getpid(), sizeof original, &original) == 0; });
+    if (!have_original) return;
+    cpu_set_t now = original, want;
     CPU_ZERO(&want);
-    if (sched_getaffinity(0, sizeof now, &now) != 0) return;
     int n = 0;
     for (size_t i = 0; i < list.size();) { // "0-63,128-191"
         char *end = nullptr;
@@ -249,6 +257,43 @@ FrameScores TurboMetrics::compute_one(const HwFrame &fref, const ColorInfo &cref
     chk(tm_engine_compute_async(eng_[0], 1), "tm_engine_compute_async");
     chk(tm_engine_sync(eng_[0]), "tm_engine_sync");
     return scores_of(eng_[0], 0);
+}
+
+uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis)
+{
+    if (!eng_[1]) { // the second engine the two launches take turns on
+        chk(tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), batch_), "tm_engine_create (second engine of compute_one_deferred)");
+        (void)tm_engine_debug_set_param(eng_[1], TM_DBG_LINEAR_UPLOAD, 1);
+    }
+    const uint64_t ticket = def_next_++;
+    const int i = (int)(ticket & 1);
+    if (def_pending_[i]) { // two pairs are in flight already: the older one (on this engine) is finished first
+        chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
+        def_done_.emplace_back(def_pending_[i], scores_of(eng_[i], 0));
+        def_pending_[i] = 0;
+    }
+    set_frame(eng_[i], 0, TM_SIDE_REF, fref, cref);
+    set_frame(eng_[i], 0, TM_SIDE_DIS, fdis, cdis);
+    chk(tm_engine_compute_async(eng_[i], 1), "tm_engine_compute_async");
+    def_pending_[i] = ticket;
+    return ticket;
+}
+
+FrameScores TurboMetrics::collect(uint64_t ticket)
+{
+    for (int i = 0; i < 2; ++i)
+        if (ticket && def_pending_[i] == ticket) {
+            def_pending_[i] = 0;
+            chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
+            return scores_of(eng_[i], 0);
+        }
+    for (size_t k = 0; k < def_done_.size(); ++k)
+        if (def_done_[k].first == ticket) {
+            FrameScores r = def_done_[k].second;
+            def_done_.erase(def_done_.begin() + (long)k);
+            return r;
+        }
+    throw TmError(TM_ERR_INVALID_ARG, "collect: no such ticket (never issued, or collected already)");
 }
 
 MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Metrics &metrics)

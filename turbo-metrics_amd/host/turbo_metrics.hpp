@@ -215,6 +215,16 @@ public:
     // == compute_one (lib.rs:268-360): convert both frames, compute every selected metric, block, return the scores
     FrameScores compute_one(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis);
 
+    // compute_one WITHOUT its blocking stream sync (lib.rs:352): hands the pair over, launches, and returns a ticket at once;
+    // collect(ticket) blocks until THAT pair's scores are there.  Two launches may be in flight (two engines taking turns -- the
+    // second one is created at the first call, the cost of one more engine in device memory): a caller that collects pair k after
+    // submitting pair k+1 keeps the device busy while it fetches / decodes the next frames, which is worth 1.6 x at one 1080p pair
+    // per call (2.9 k -> 4.8 k pairs/s).  A third submission first finishes the oldest pair and keeps its scores until collected.
+    // Frames: host memory is read before the call returns unless `pinned` (then until collect(ticket)); device memory until collect.
+    // Scores are bit-identical with compute_one's.  Tickets are collected at most once, in any order.
+    uint64_t compute_one_deferred(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis);
+    FrameScores collect(uint64_t ticket);
+
     // == compute_all (lib.rs:362-433) with the frame selection of Options; `on_frame` (optional) sees every FrameScores
     // in stream order (the CLI's output_single_score).  Returns the number of frames decoded (for the CLI's log line).
     MetricsResults compute_all(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts,
@@ -230,6 +240,10 @@ private:
     Metrics metrics_;
     tm_engine *eng_[2] = {nullptr, nullptr};
     LoopTiming timing_;
+    // compute_one_deferred: the ticket in flight on each engine (0 = none), finished-but-uncollected scores, next ticket
+    uint64_t def_pending_[2] = {0, 0};
+    std::vector<std::pair<uint64_t, FrameScores>> def_done_;
+    uint64_t def_next_ = 1;
 };
 
 } // namespace tm_host
