@@ -1,10 +1,11 @@
-/* tests/host/abi_c_check.c -- TEST INFRASTRUCTURE: include/turbo_metrics_hip.h must be plain C (a Rust `extern "C"` block,
+/* tests/host/abi_c_check.c -- TEST INFRASTRUCTURE: include/turbo_metrics_hip.h and turbo_metrics_hip_debug.h must be plain C (a Rust `extern "C"` block,
  * cgo or ctypes bind the same declarations).  Compiled with gcc -std=c99 -pedantic and linked against the library; runs
  * only the host-side entry points (no GPU needed). */
 #include <stdio.h>
 #include <string.h>
 
 #include "../../include/turbo_metrics_hip.h"
+#include "../../include/turbo_metrics_hip_debug.h"
 
 int main(void)
 {

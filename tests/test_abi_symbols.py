@@ -1,4 +1,5 @@
-"""No-GPU tier: the C-ABI library loads and exports every symbol include/turbo_metrics_hip.h declares;
+"""No-GPU tier: the C-ABI library loads and exports every symbol include/turbo_metrics_hip.h (the facade a binder needs) and
+include/turbo_metrics_hip_debug.h (the laboratory) declare;
 host-only entry points behave; nothing here computes on a device."""
 import ctypes as C
 import os
@@ -13,16 +14,22 @@ from tm_pkg import tm
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "turbo_metrics_hip.h")).read()
+def declared_symbols(header="turbo_metrics_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(tm_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_are_exported_and_bound():
     L = tm.ffi.lib()
-    names = declared_symbols()
-    assert len(names) >= 20
+    facade, lab = declared_symbols(), declared_symbols("turbo_metrics_hip_debug.h")
+    # the facade is what INTEGRATION.md binds: small, and free of variants / tuning / read-back hooks
+    assert 30 <= len(facade) <= 40, len(facade)
+    assert not [n for n in facade if "debug" in n or "variant" in n or "profiling" in n or "stage_ms" in n]
+    assert not set(facade) & set(lab)
+    src = open(os.path.join(ROOT, "include", "turbo_metrics_hip.h")).read()
+    assert "TM_DBG_" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S) and "TM_VARIANT_" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(facade + lab)
     for n in names:
         assert hasattr(L, n), f"{n} declared in the header but not exported"
         assert n in tm.ffi.SYMBOLS, f"{n} has no ctypes prototype"

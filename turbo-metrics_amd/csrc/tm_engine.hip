@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/turbo_metrics_hip.h"
+#include "../../include/turbo_metrics_hip_debug.h"
 #include "tm_geom.h"
 #include "tm_kernels.h"
 #include "tm_ssim_kernels.h"
@@ -1459,6 +1460,11 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values
     return TM_OK;
+}
+
+int tm_engine_set_linear_upload(tm_engine *e, int on)
+{
+    return tm_engine_debug_set_param(e, TM_DBG_LINEAR_UPLOAD, on ? 1 : 0);
 }
 
 int tm_engine_debug_chain(tm_engine *e, tm_engine *peer)

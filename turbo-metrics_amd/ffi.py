@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI (include/turbo_metrics_hip.h).  Loads the in-tree
+"""ctypes binding of the C ABI (include/turbo_metrics_hip.h + the laboratory half, include/turbo_metrics_hip_debug.h).  Loads the in-tree
 libturbometrics_hip.so; raises loudly if it is missing -- there is no fallback."""
 import ctypes as C
 import os
@@ -25,7 +25,7 @@ class FrameScoresC(C.Structure):
                 ("ssimulacra2", C.c_double), ("valid", C.c_uint32)]
 
 
-# every symbol include/turbo_metrics_hip.h declares: name -> (restype, argtypes)
+# every symbol the two headers declare: name -> (restype, argtypes)
 _vp, _u32, _i, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
 SYMBOLS = {
     "tm_init": (_i, [_i]),
@@ -72,6 +72,7 @@ SYMBOLS = {
     "tm_engine_set_profiling": (_i, [_vp, _i]),
     "tm_engine_get_stage_ms": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), _i]),
     "tm_engine_set_graph": (_i, [_vp, _i]),
+    "tm_engine_set_linear_upload": (_i, [_vp, _i]),
     "tm_engine_set_variant": (_i, [_vp, _i]),
     "tm_engine_debug_set_v_offset": (_i, [_vp, _sz]),
     "tm_engine_debug_set_ingest_rows": (_i, [_vp, _i]),

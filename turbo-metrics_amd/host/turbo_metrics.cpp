@@ -1,6 +1,7 @@
 // turbo_metrics.cpp -- see turbo_metrics.hpp.  Host orchestration only: frame selection, batching over the engine's
 // slots, ping-pong pipelining of two engines; every number comes out of libturbometrics_hip.so.
 #include "turbo_metrics.hpp"
+#include "../../include/turbo_metrics_hip_debug.h" // tm_engine_debug_set_param: only behind TurboMetrics::debug_set_param (the CLI's --tune)
 #include <chrono>
 #include <fstream>
 #include <sched.h>
@@ -185,7 +186,7 @@ TurboMetrics::TurboMetrics(uint32_t width, uint32_t height, const Metrics &metri
     // compute_all hands pictures over one by one, as they arrive, with a fence per pair: for that pattern a picture of a planar file is
     // fastest as one linear copy (the library's default suits callers that queue whole batches; tm_engine.hip, set_frame_planar)
     for (tm_engine *e : eng_)
-        if (e) (void)tm_engine_debug_set_param(e, TM_DBG_LINEAR_UPLOAD, 1);
+        if (e) (void)tm_engine_set_linear_upload(e, 1);
 }
 
 TurboMetrics::~TurboMetrics()
@@ -263,7 +264,7 @@ uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo
 {
     if (!eng_[1]) { // the second engine the two launches take turns on
         chk(tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), batch_), "tm_engine_create (second engine of compute_one_deferred)");
-        (void)tm_engine_debug_set_param(eng_[1], TM_DBG_LINEAR_UPLOAD, 1);
+        (void)tm_engine_set_linear_upload(eng_[1], 1);
     }
     const uint64_t ticket = def_next_++;
     const int i = (int)(ticket & 1);
