@@ -5,18 +5,30 @@
 thread_local uint3_ threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 
-static double g_acc6[6];
 static unsigned g_accu[3];
 static inline unsigned lane_id() { return (threadIdx.x + threadIdx.y * blockDim.x) & 63; }
-bool tm_wave_sum6(double (&a)[6])
-{
-    if (lane_id() == 0) for (int k = 0; k < 6; ++k) g_acc6[k] = 0.0;
-    for (int k = 0; k < 6; ++k) g_acc6[k] += a[k];
-    if (lane_id() == 63) { for (int k = 0; k < 6; ++k) a[k] = g_acc6[k]; return true; }
-    return false;
-}
 void tm_emul_wave_barrier();
 static bool lockstep_on();
+// the device's tm_wave_sum6 is a shuffle tree (a[l] += a[l + off], off = 32 .. 1): the same additions in the same order here, so
+// that the f64 partial sums of the emulated kernels carry the bits the GPU's carry
+static void tree_sum64(double *v) { for (int off = 32; off > 0; off >>= 1) for (int i = 0; i < off; ++i) v[i] += v[i + off]; }
+bool tm_wave_sum6(double (&a)[6])
+{
+    static double buf[16][6][64]; // per wave of the workgroup
+    const unsigned l = lane_id(), wv = ((threadIdx.x + threadIdx.y * blockDim.x) >> 6) & 15;
+    if (lockstep_on()) { // the 64 lanes are concurrent fibers / host threads: sum through memory, lane 0 holds the total
+        for (int k = 0; k < 6; ++k) buf[wv][k][l] = a[k];
+        tm_emul_wave_barrier();
+        if (l == 0)
+            for (int k = 0; k < 6; ++k) { tree_sum64(buf[wv][k]); a[k] = buf[wv][k][0]; }
+        tm_emul_wave_barrier();
+        return l == 0;
+    }
+    // lanes of one wave run back to back (x fastest): the last one adds them up
+    for (int k = 0; k < 6; ++k) buf[0][k][l] = a[k];
+    if (l == 63) { for (int k = 0; k < 6; ++k) { tree_sum64(buf[0][k]); a[k] = buf[0][k][0]; } return true; }
+    return false;
+}
 bool tm_wave_sum_u32x3(unsigned (&v)[3])
 {
     if (lockstep_on()) { // the 64 lanes are concurrent host threads: sum through memory

@@ -14,12 +14,7 @@
 //
 // Must be compiled with -ffp-contract=off: the fma() calls are the only fused operations.
 #pragma once
-#ifdef TM_EMULATE /* CPU lane-by-lane execution of this source for the no-GPU test tier (tests/emul) */
-#include "hip_emul.h"
-#else
-#include <hip/hip_runtime.h>
-#endif
-#include <stdint.h>
+#include "tm_platform.h" // the machine vocabulary (gfx950; host stand-ins for the no-GPU test tier)
 
 namespace tmdev {
 
@@ -28,19 +23,8 @@ namespace tmdev {
 __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
 
-// ---- two-lane f32 vectors: gfx950 executes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on two floats per lane at the
-// rate of one scalar VALU instruction, so everything below that can be said on pairs is said on pairs ----------------
-#ifdef TM_EMULATE
-struct tm_f2 { float x, y; };
-static inline tm_f2 operator*(tm_f2 a, tm_f2 b) { return {a.x * b.x, a.y * b.y}; }
-static inline tm_f2 operator-(tm_f2 a, tm_f2 b) { return {a.x - b.x, a.y - b.y}; }
-static inline tm_f2 operator+(tm_f2 a, tm_f2 b) { return {a.x + b.x, a.y + b.y}; }
-static inline tm_f2 operator-(tm_f2 a) { return {-a.x, -a.y}; }
-static inline tm_f2 f2_fma(tm_f2 a, tm_f2 b, tm_f2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
-#else
-typedef float tm_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ tm_f2 f2_fma(tm_f2 a, tm_f2 b, tm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
+// ---- two-lane f32 vectors (tm_f2, f2_fma: tm_platform.h): gfx950 executes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on two
+// floats per lane in one VALU instruction, so everything below that can be said on pairs is said on pairs ------------
 __device__ __forceinline__ tm_f2 f2_make(float a, float b) { tm_f2 v; v.x = a; v.y = b; return v; }
 __device__ __forceinline__ tm_f2 f2_splat(float a) { return f2_make(a, a); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
@@ -185,14 +169,7 @@ __device__ __forceinline__ float div_const_pos(float x, float c, float rc)
 }
 
 // s - floor(s) for s >= 0 (exact): v_fract_f32
-__device__ __forceinline__ float fract_pos(float s)
-{
-#ifdef TM_EMULATE
-    return s - floorf(s);
-#else
-    return __builtin_amdgcn_fractf(s);
-#endif
-}
+__device__ __forceinline__ float fract_pos(float s) { return tm_fract_pos(s); }
 
 // BT709::eotf, cuda-colorspace-kernel/src/lib.rs:221-236 (same body for both BT601 structs).  Power branch: the reference
 // evaluates powf_fast((v + (ALPHA - 1)) / ALPHA, 1 / 0.45) (exp2(y log2 x), ~8 ulp).  Here the base x is formed with the
@@ -226,15 +203,8 @@ __device__ __forceinline__ float bt709_eotf(float v, const double *__restrict__ 
     return div_const(v, 4.5f, 1.0f / 4.5f);
 }
 
-// "does any lane of the wave ..." -- a wave-uniform branch (the emulator runs its lanes one after the other: always true there,
-// which is why every use below computes the same bits on either side of the branch)
-#ifdef TM_EMULATE
-#define TM_WAVE_ANY(c) true
-#define TM_NO_IF_CONVERSION() ((void)0)
-#else
-#define TM_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
-#define TM_NO_IF_CONVERSION() asm volatile("; rare path") /* keeps the compiler from turning the uniform branch into selects */
-#endif
+// (TM_WAVE_ANY -- "does any lane of the wave ...", a wave-uniform branch -- and TM_NO_IF_CONVERSION: tm_platform.h; every use below
+// computes the same bits on either side of the branch)
 
 // The power branch of bt709_eotf for TWO values at once (the ref and the dis sample of one pixel-channel: the side-packed ingest
 // kernel), without a test: same operations as bt709_eotf on each component.  The base and its constant division (-> s = 512 x)

@@ -32,67 +32,12 @@
 #include "tm_geom.h"
 #include <type_traits>
 
-#ifndef TM_EMULATE
-// wave-level sum helpers; return true on the lane that ends up holding the total
-__device__ __forceinline__ bool tm_wave_sum6(double (&a)[6])
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] += __shfl_down(a[k], off, 64);
-    }
-    return (threadIdx.x & 63) == 0;
-}
-__device__ __forceinline__ float tm_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
-__device__ __forceinline__ unsigned tm_shfl_xor_u32(unsigned v, int mask) { return (unsigned)__shfl_xor((int)v, mask, 64); }
-__device__ __forceinline__ bool tm_wave_sum_u32x3(unsigned (&v)[3])
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] += __shfl_down(v[k], off, 64);
-    }
-    return ((threadIdx.x + threadIdx.y * blockDim.x) & 63) == 0;
-}
-#endif
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding GLOBAL
-// store of the wave (s_waitcnt vmcnt(0)); the ingest kernel only ever exchanges data through LDS, and
-// waiting ~2 us for store acknowledgements at each of its 12 barriers was most of a workgroup's lifetime.
-#ifdef TM_EMULATE
-#define TM_WAVES_PER_SIMD(n)
-#else
-#define TM_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n))) // holds the register allocation to 512 / n VGPRs
-#endif
-#ifdef TM_EMULATE
-#define TM_LDS_BARRIER() __syncthreads()
-#else
-#define TM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
+// (wave-level sum / shuffle helpers, TM_LDS_BARRIER, TM_WAVES_PER_SIMD, tm_mul24, tm_f4 / tm_g2, DPP lane exchanges: tm_platform.h)
 
 namespace tmk {
 
-// lane-dependent row * pitch products of the ingest kernel: v_mul_u32_u24 (full rate) instead of the 64-bit / 32-bit integer
-// multiplies (quarter rate) that size_t arithmetic compiles to.  Both factors are below 2^24 and the product below 2^32: rows
-// <= 16 384, pitches of the engine's own planes <= 2^16 floats, and tm_engine_set_frame_* refuses surfaces of 4 GB and more.
-__device__ __forceinline__ unsigned tm_mul24(unsigned a, unsigned b)
-{
-#ifdef TM_EMULATE
-    return a * b;
-#else
-    return __umul24(a, b);
-#endif
-}
-
 // row `row` of a plane whose base pointer is wave-uniform: the row address stays in SGPRs and the load uses
 // the scalar-base + per-lane-offset form, so a whole window of in-flight loads costs one VGPR of addressing
-#ifdef TM_EMULATE
-#define TM_GLOBAL_AS
-struct alignas(16) tm_f4 { float x, y, z, w; };
-#else
-#define TM_GLOBAL_AS __attribute__((address_space(1)))
-typedef float tm_f4 __attribute__((ext_vector_type(4))); // plain vector: assignable through address_space(1)
-#endif
 __device__ __forceinline__ tm_f4 tm_make_f4(float a, float b, float c, float d) { tm_f4 v = {a, b, c, d}; return v; }
 template <typename T> __device__ __forceinline__ TM_GLOBAL_AS T *tm_uniform_ptr(T *p)
 {
@@ -101,17 +46,10 @@ template <typename T> __device__ __forceinline__ TM_GLOBAL_AS T *tm_uniform_ptr(
     // for every load of the window (2 VGPRs and a v_lshl_add_u64 each) instead of selecting the
     // scalar-base + 32-bit-lane-offset form of global_load / global_store.
     unsigned long long v = (unsigned long long)p;
-#ifndef TM_EMULATE
-    asm("" : "+s"(v));
-#endif
+    TM_PIN_SGPR(v);
     return (TM_GLOBAL_AS T *)v;
 }
 
-#ifdef TM_EMULATE
-struct alignas(8) tm_g2 { float x, y; };
-#else
-typedef float tm_g2 __attribute__((ext_vector_type(2)));
-#endif
 __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, int nrows, int pitch)
 {
     const int rc = row < nrows ? row : nrows - 1;
@@ -577,15 +515,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
 // grid (ceil(ceil(w/2) / 64), ceil(ceil(h/2) / (4 * rows_per_wave)), slots), block 256 = four independent waves that share one
 // staging of the table; rows_per_wave even, <= 128.
 // ------------------------------------------------------------------------------------------------
-#ifdef TM_EMULATE
-__device__ __forceinline__ float tm_swap1(float v) { return tm_shfl_xor(v, 1); }
-#else
-__device__ __forceinline__ float tm_swap1(float v)
-{
-    // lane ^ 1 through DPP quad_perm [1, 0, 3, 2]: one full-rate VALU move, no LDS crossbar
-    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xF, 0xF, true));
-}
-#endif
+using ::tm_swap1; // (the one-float form: tm_platform.h)
 __device__ __forceinline__ tmdev::tm_f2 tm_swap1(tmdev::tm_f2 v) { return tmdev::f2_make(tm_swap1(v.x), tm_swap1(v.y)); }
 
 // ds4 on {ref, dis} pairs with wave-uniform-per-lane flags (level 2 only; level 1 never clamps: an incomplete quad is all zeros)
@@ -656,12 +586,10 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
     unsigned prn0[3] = {0, 0, 0}, prn1[3] = {0, 0, 0};
     const unsigned xo_y = (unsigned)(2 * qx) * (unsigned)sizeof(T), xo_c = (unsigned)qx * (unsigned)sizeof(T); // this lane's byte offsets inside a luma (CbCr) / a planar chroma row
     if (colq && 2 * qy_begin + 1 < h) { yuv_row_load_pairs<T, PLANAR>(dd0, xo_y, xo_c, qy_begin, prn0); yuv_row_load_pairs<T, PLANAR>(dd1, xo_y, xo_c, qy_begin, prn1); }
-#ifndef TM_EMULATE
     // (taken before the loop for the same reason as inside it: a load still pending at the loop header would make the compiler wait
     // for everything outstanding -- the previous row's stores included -- at the top of every iteration)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(prn0[i])); asm volatile("" : "+v"(prn1[i])); }
-#endif
+    for (int i = 0; i < 3; ++i) { TM_KEEP_IN_VGPR(prn0[i]); TM_KEEP_IN_VGPR(prn1[i]); }
     TM_LDS_BARRIER(); // the table is in place (the only barrier: from here on the waves never meet again)
     float *xi = XYB ? XYB + (size_t)slot * 2 * g.pyr : nullptr; // the slot's interleaved pyramid
     unsigned sse3[3] = {0, 0, 0};
@@ -721,12 +649,10 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
                 }
             }
         }
-#ifndef TM_EMULATE
         if (QUANT) { // (see below: with the u8-plane stores ahead, the next row's samples are taken before them)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(prn0[i])); asm volatile("" : "+v"(prn1[i])); }
+            for (int i = 0; i < 3; ++i) { TM_KEEP_IN_VGPR(prn0[i]); TM_KEEP_IN_VGPR(prn1[i]); }
         }
-#endif
         if (QUANT) { // sample_conv.rs:6-35 quantisation; out-of-image samples are 0 on both sides
             const tm_f2 *pc[3] = {pr, pg, pb};
 #pragma unroll
@@ -763,12 +689,10 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
         linear_to_xyb_sides<5>(lr, lg, lb, xa, xb, xc);
         // the next row's samples (requested at the top of this iteration) are taken HERE, before this row's fifteen stores are
         // issued: gfx950 counts stores in vmcnt in order, so waiting for those loads at the loop's latch would wait for the stores too
-#ifndef TM_EMULATE
         if (!QUANT) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { asm volatile("" : "+v"(prn0[i])); asm volatile("" : "+v"(prn1[i])); }
+            for (int i = 0; i < 3; ++i) { TM_KEEP_IN_VGPR(prn0[i]); TM_KEEP_IN_VGPR(prn1[i]); }
         }
-#endif
         {
             const tm_f2 *xv[3] = {xa, xb, xc};
 #pragma unroll
@@ -1186,11 +1110,9 @@ __global__ void __launch_bounds__(SOLO ? 64 : 320, 4) k_blur_v_jobs(TmGeom g, Tm
 {
     using TT = BlurVTile<R>;
     __shared__ float tiles[(SOLO ? 1 : 5) * R * TT::S];
-#ifndef TM_EMULATE
     // the fused kernel of the EDGE jobs runs beside this pass (k_blur_edge_fused, second stream): its waves are the oldest on their
     // SIMDs and would win every issue arbitration; this pass needs few issue slots but needs them promptly to keep HBM busy
-    if (jobs.prio > 0) __builtin_amdgcn_s_setprio(2);
-#endif
+    if (jobs.prio > 0) TM_SETPRIO(2);
     const int b = blockIdx.y, slot = blockIdx.x;
     const int j = tm_find_job(jobs.vstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
@@ -1443,9 +1365,7 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
                                                       const float *__restrict__ V, double *__restrict__ PART)
 {
     __shared__ float tile[2][2][64][17];
-#ifndef TM_EMULATE
-    if (jobs.prio > 0) __builtin_amdgcn_s_setprio(2);
-#endif
+    if (jobs.prio > 0) TM_SETPRIO(2);
     const int b = blockIdx.y, slot = blockIdx.x;
     const int j = tm_find_job(jobs.hstart, b);
     const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
@@ -1464,24 +1384,11 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
     double acc[6] = {0, 0, 0, 0, 0, 0};
     if (mode == TM_MODE_FULL) blur_h_job_x<true, WNF, DF>(tile, rdn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
     else blur_h_job_x<false, WNE, DE>(tile, rdn, v0, v1, v2, v3, v4, y0, sg.w, sg.h, sg.pitch, sg.pitch_t, valid, acc);
-#ifdef TM_EMULATE
-    { // the lockstep emulator runs the lanes as concurrent host threads: sum through memory
-        __shared__ double redl[6][64];
-        for (int k = 0; k < 6; ++k) redl[k][threadIdx.x] = acc[k];
-        __builtin_amdgcn_wave_barrier();
-        if (threadIdx.x == 0) {
-            double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
-            for (int k = 0; k < 6; ++k) { double tsum = 0.0; for (int i = 0; i < 64; ++i) tsum += redl[k][i]; o[k] = tsum; }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#else
     if (tm_wave_sum6(acc)) {
         double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = acc[k];
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1700,31 +1607,11 @@ __global__ void __launch_bounds__(64 * TM_SPLIT_WAVES) k_blur_h_jobs_split(TmGeo
     // a consumer holds some of the six sums of the row block (zeros elsewhere); the shuffle tree adds every entry in the order
     // k_blur_h_jobs_x adds it, so the entries come out bit-identical.  An EDGE job has no ssim sums: zeros, as k_blur_h_jobs_x writes
     const bool w_ssim = (mine & 1) || !full, w_edge = (mine & 2) != 0;
-#ifdef TM_EMULATE
-    { // the lockstep emulator runs the lanes as concurrent fibers: sum through memory, in lane order like the shuffle tree's result
-        __shared__ double redl[2][6][64];
-        const int slotw = wave - 6; // waves 6 and 7
-        for (int k = 0; k < 6; ++k) redl[slotw][k][lane] = acc[k];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
-            for (int k = 0; k < 6; ++k) {
-                const bool is_ssim = k == 0 || k == 3;
-                if (is_ssim ? !w_ssim : !w_edge) continue;
-                double tsum = 0.0;
-                for (int i = 0; i < 64; ++i) tsum += redl[slotw][k][i];
-                o[k] = tsum;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#else
     if (tm_wave_sum6(acc)) {
         double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
         if (w_ssim) { o[0] = acc[0]; o[3] = acc[3]; }
         if (w_edge) { o[1] = acc[1]; o[2] = acc[2]; o[4] = acc[4]; o[5] = acc[5]; }
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1767,18 +1654,7 @@ __global__ void __launch_bounds__(64 * TM_SPLIT_WAVES) k_blur_h_jobs_split(TmGeo
 // HS[plane][2][hs_tiles][6][64], EROWS[plane][er_bands][64][2].
 // ------------------------------------------------------------------------------------------------
 #define TM_EF_S 132
-#ifdef TM_EMULATE
-__device__ __forceinline__ void tm_ll_store(unsigned long long *p, float v, unsigned tag) { *(volatile unsigned long long *)p = ((unsigned long long)tag << 32) | __float_as_uint(v); }
-__device__ __forceinline__ unsigned long long tm_ll_load(const unsigned long long *p) { return *(const volatile unsigned long long *)p; }
-#define TM_WAVE_ALL(c) (c)
-#else
-__device__ __forceinline__ void tm_ll_store(unsigned long long *p, float v, unsigned tag)
-{
-    __hip_atomic_store(p, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long tm_ll_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#define TM_WAVE_ALL(c) (__builtin_amdgcn_ballot_w64(c) == ~0ull)
-#endif
+// (tm_ll_store / tm_ll_load -- the tagged 64-bit hand-off words, relaxed agent-scope atomics -- and TM_WAVE_ALL: tm_platform.h)
 
 // what the fused kernel needs to know about its jobs (a small kernarg: the tile loop keeps its scalars in registers)
 struct TmEdgeJob {
@@ -1815,18 +1691,9 @@ static inline void tm_make_edge_args(TmEdgeArgs *a, const TmGeom *g, const TmJob
 __device__ __forceinline__ void ef_accumulate(float og, float mu, bool dis, unsigned sgn, double &a1, double &a4)
 {
     const float e = 1.0f + fabsf(og - mu);
-#ifdef TM_EMULATE
-    const float pe = tm_swap1(e);
-    const float e_ref = dis ? pe : e, e_dis = dis ? e : pe;
-    const float denom = 1.0f / e_ref;
-#else
-    const float e_ref = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(e), 0xA0, 0xF, 0xF, true)); // quad_perm [0, 0, 2, 2]
-    const float e_dis = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(e), 0xF5, 0xF, 0xF, true)); // quad_perm [1, 1, 3, 3]
-    const float r0 = __builtin_amdgcn_rcpf(e_ref);
-    const float r1 = __builtin_fmaf(__builtin_fmaf(-e_ref, r0, 1.0f), r0, r0);
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-e_ref, r1, 1.0f), r1, r1);
-    const float denom = __builtin_fmaf(__builtin_fmaf(-e_ref, q1, 1.0f), r1, q1);                                           // 1 / (1 + |source - mu1|)
-#endif
+    float e_ref, e_dis;
+    tm_pair_values(e, dis, e_ref, e_dis);           // the even lane of a pair is the ref side, the odd lane the dis side
+    const float denom = tm_rcp_inrange(e_ref);      // 1 / (1 + |source - mu1|)
     const float d1 = __builtin_fmaf(e_dis, denom, -1.0f);                                                                    // numer = 1 + |distorted - mu2|
     const int bits = (int)(__float_as_uint(d1) ^ sgn);
     const float m = __uint_as_float((unsigned)(bits > 0 ? bits : 0));
@@ -1863,13 +1730,7 @@ struct TmEfMailbox {
     float v[3][TM_EF_MS][6][64];
     unsigned full[3][TM_EF_MS], done[3][TM_EF_MS];
 };
-#ifdef TM_EMULATE
-#define TM_EF_SPIN_PAUSE() ::tm_emul_yield()
-#define TM_EF_LDS_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
-#else
-#define TM_EF_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
-#define TM_EF_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
-#endif
+// (TM_EF_SPIN_PAUSE: s_sleep 1; TM_EF_LDS_FENCE: a workgroup-scope fence -- tm_platform.h)
 
 // one band of one plane (see above); tile: this wave's LDS tile
 template <bool GROUPED>
@@ -1938,9 +1799,7 @@ __device__ __forceinline__ void ef_band(float *__restrict__ tile, TmEfMailbox *_
                 for (int k = 0; k < 6; ++k) ok = ok && (unsigned)(st[k] >> 32) == tag_in;
                 if (TM_WAVE_ALL(ok) || (dbg & 1)) break;
                 if (++polls > ((dbg & 2) ? (1 << 10) : (1 << 22)) || *(volatile int *)status) { *(volatile int *)status = 1; break; } // (fault injection gives up soon: the test does not wait seconds)
-#ifndef TM_EMULATE
-                __builtin_amdgcn_s_sleep(8);
-#endif
+                TM_SLEEP(8);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) st[k] = tm_ll_load(hs_in + (size_t)i * 384 + k * 64);
             }
@@ -2063,15 +1922,10 @@ __global__ void __launch_bounds__(64) k_finish_edge(TmEdgeArgs A, const double *
             const int band = 2 * blk + (i >> 5);
             a[i] = band < nbands ? EROWS[(((size_t)p * er_bands + band) * 64 + 2 * (i & 31) + side) * 2 + pw] : 0.0;
         }
-        double tot;
-#ifdef TM_EMULATE
-        tot = 0.0; // the emulator's k_blur_h_jobs_x adds the lanes of a wave one after the other
-        for (int i = 0; i < 64; ++i) tot += a[i];
-#else
+        // the order in which tm_wave_sum6 adds the 64 lanes of a row block in k_blur_h_jobs_x: the entries come out bit-identical
         for (int off = 32; off > 0; off >>= 1)
             for (int i = 0; i < off; ++i) a[i] += a[i + off];
-        tot = a[0];
-#endif
+        const double tot = a[0];
         PART[((size_t)slot * A.part_stride + J.part0 + blk) * 6 + 1 + side + 3 * pw] = tot;
     }
     if (p == 0 && threadIdx.x == 0) { // next launch: new tags (the tag holds 24 bits of the epoch; 0 is never used: memory starts out as zeros), tickets from 0

@@ -139,18 +139,7 @@ __global__ void __launch_bounds__(64) k_ssim_pyramid(TmSsimGeom sg, const unsign
 // compiler emits for an IEEE division -- reciprocal, one Newton step on it, quotient, two residual corrections -- without
 // v_div_scale / v_div_fixup, which only act on operands that need rescaling or are special: same operations on the same
 // values, hence the same correctly rounded quotient, 8 instead of 12 instructions.
-__device__ __forceinline__ float ssim_div(float n, float d)
-{
-#ifdef TM_EMULATE
-    return n / d;
-#else
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    const float r1 = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
-    const float q0 = n * r1;
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
-    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
-#endif
-}
+__device__ __forceinline__ float ssim_div(float n, float d) { return tm_div_inrange(n, d); } // (tm_platform.h)
 
 // one image column of one row on its way through LDS: the sample pair and its two per-sample quantities
 struct __attribute__((aligned(16))) TmSsimCol { tmdev::tm_f2 rd, sp; }; // {ref, dis}, {ref^2 + dis^2, ref * dis}
@@ -308,26 +297,11 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(TM_SSIM_WAVES) k_ssim_st
         if (nl) ssim_strip<false, true>(bufE, bufO, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
         else ssim_strip<false, false>(bufE, bufO, fr, fd, sg.pitch[s], inv, w, h, x, y_base, y_end, gw, acc);
     }
-#ifdef TM_EMULATE
-    { // CPU lane emulation runs the 64 lanes as concurrent host threads: sum through memory, not through shuffles
-        __shared__ double redl[2][64];
-        redl[0][lane] = acc[0]; redl[1][lane] = acc[1];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            double t0 = 0.0, t1 = 0.0;
-            for (int i = 0; i < 64; ++i) { t0 += redl[0][i]; t1 += redl[1][i]; }
-            double *o = PART + (((size_t)slot * 3 + c) * sg.item_off[TM_SSIM_SCALES] + blockIdx.y) * 2;
-            o[0] = t0; o[1] = t1;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#else
     double a6[6] = {acc[0], acc[1], 0, 0, 0, 0};
     if (tm_wave_sum6(a6)) {
         double *o = PART + (((size_t)slot * 3 + c) * sg.item_off[TM_SSIM_SCALES] + blockIdx.y) * 2;
         o[0] = a6[0]; o[1] = a6[1];
     }
-#endif
 }
 
 // SUMS[slot][channel 3][scale 5][ssim, cs]: lane l adds items l, l+64, ... in order, then the 64 lane totals are added
