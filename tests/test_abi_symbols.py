@@ -36,6 +36,16 @@ def test_header_symbols_are_exported_and_bound():
     assert sorted(tm.ffi.SYMBOLS) == names
 
 
+def test_the_rust_binding_in_integration_md_is_the_facade_header():
+    """INTEGRATION.md section 2 shows the `extern "C"` block a maintainer adds on the reference's side: exactly the entry points of
+    include/turbo_metrics_hip.h -- none missing, none of the laboratory header's"""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = txt[txt.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    bound = sorted(set(re.findall(r"pub fn (tm_[a-z0-9_]+)\(", block)))
+    assert bound == declared_symbols(), (sorted(set(declared_symbols()) - set(bound)), sorted(set(bound) - set(declared_symbols())))
+
+
 def test_strerror_and_version():
     L = tm.ffi.lib()
     assert L.tm_strerror(0) == b"ok"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rewrites the measured block of DESIGN.md section 5 (between the bench-table markers) from profiles/<TAG>_*: the table of the
+"""Rewrites the measured block of docs/LABBOOK.md section 5 (between the bench-table markers) from profiles/<TAG>_*: the table of the
 default bench line and the rocprofv3 cross-check.  usage: design_table.py TAG"""
 import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -79,7 +79,7 @@ if os.path.exists(P(f"{T}_kernel_stats_1080p_b64_alone.csv")):
 Every kernel alone on the chip (`bench.py --edge-beside 0`: the fused kernel behind the row pass; `profiles/{T}_kernel_stats_1080p_b64_alone.csv`, rocprofv3 of
 `bench.py --no-extras` in that mode): `k_blur_v_jobs<32,16,0>` {sa['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms = {7424901120 / sa['tmk::k_blur_v_jobs<32, 16, 0>'][1] / 8e9 * 1e3 / 1e3:.3f} of 8 TB/s on its 7.42 GB (`kernels_alone` of the bench line: {al['k_blur_v_jobs']['avg_launch_ms']:.3f} ms,
 {al['k_blur_v_jobs']['frac']:.3f}), row pass {sa['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} ms = {7424901120 / sa['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1] / 8e9 * 1e3 / 1e3:.3f} ({al['k_blur_h_jobs_x']['avg_launch_ms']:.3f}, {al['k_blur_h_jobs_x']['frac']:.3f}), `{efa.replace('tmk::', '')}` {sa[efa][1]:.3f} ms ({al['k_blur_edge_fused']['avg_launch_ms']:.3f})."""
-p = os.path.join(ROOT, "DESIGN.md")
+p = os.path.join(ROOT, "docs", "LABBOOK.md")
 s = open(p).read()
 a, b = "<!-- bench-table:begin -->", "<!-- bench-table:end -->"
 i, j = s.index(a) + len(a), s.index(b)

@@ -323,7 +323,7 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         if ((rc = upload_stream(e, side, mem, &us))) return rc;
         char *s = (char *)e->staging[idx];
         const size_t uv_bytes = yuv ? (size_t)((e->w + 1) / 2) * 2 * bps : 0, uv_row = uv_bytes <= pitch ? uv_bytes : pitch;
-        // ONE 2-D copy of all rows instead of two (the per-copy cost is what limits small frames: DESIGN.md section 5, host-fed) in
+        // ONE 2-D copy of all rows instead of two (the per-copy cost is what limits small frames: docs/LABBOOK.md section 5, host-fed) in
         // exactly two cases, neither of which reads a byte the caller has not declared:
         //   * the caller declared a surface (tm_engine_set_surface_*: coded_rows luma rows, the padding rows included, then the CbCr rows);
         //   * the CbCr rows start exactly where the h luma rows end (gap == pitch * h): every row of the copy belongs to one of the two planes.
@@ -1026,7 +1026,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
     };
     const bool has_ssim_stage = (e->mask & (TM_METRIC_SSIM | TM_METRIC_MSSSIM)) != 0;
     // (the SSIM stage only needs the u8 planes of the ingest kernel and is bound by arithmetic while the blur passes are bound by
-    // HBM -- but running it on a second stream beside them was measured: 7.63 k vs 7.77 k pairs/s)
+    // HBM -- but running it on a second stream beside them was measured: 7.63 k vs 7.77 k pairs/s, docs/LABBOOK.md section 5.1)
     if (ssimu2) {
         // the EDGE jobs (scale 0 of X and B with the reference's weights) go through ONE kernel without the pass-1 arena; the two
         // passes then run the FULL jobs only (the first nfull entries of the edge-last table)

@@ -198,7 +198,7 @@ __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const uns
     const float g_ = __builtin_fmaf(k[3], cb, k[4] * cr);
     const float b_ = k[2] * cb;
     // (memoising R and B of 8-bit frames in two 256 x 256 tables per matrix, and a 10-bit variant for P016, were measured: the
-    // gathers cost more than the evaluations they replace)
+    // gathers cost more than the evaluations they replace; docs/LABBOOK.md section 5.1)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const unsigned ys = raw[q];
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     const int qx = lane & 15, qy = lane >> 4;
     const int slot = blockIdx.z;
     // (an XCD-aware tile order -- the four tiles that share a 128-B line of an NV12 row sent to the same XCD's L2 -- measured
-    // 8 % slower: four L2s fetching the line in parallel beat one fetching it once)
+    // 8 % slower: four L2s fetching the line in parallel beat one fetching it once; docs/LABBOOK.md section 5.1)
     const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
     const int X0 = tx0 + 2 * qx, Y0 = ty0 + 2 * qy;
     const int w = g.s[0].w, h = g.s[0].h;
@@ -1099,7 +1099,7 @@ __device__ __forceinline__ int tm_find_job(const int (&start)[TM_MAX_JOBS + 1], 
 // PROBE: a second instantiation of the same code for the placement probe of tm_engine_create, so that profilers list its
 // launches (cold caches, zeros) apart from the batch launches
 // (W = 32 -- 22 rows of loads in flight instead of 6 -- was measured in round 4 for launches that leave most of the chip idle: one 1080p pair
-// 0.104 -> 0.101 ms, two pairs slower; large launches are bound by their write stream anyway, DESIGN.md 5.1: not kept)
+// 0.104 -> 0.101 ms, two pairs slower; large launches are bound by their write stream anyway, docs/LABBOOK.md 5.1: not kept)
 // SOLO (launches of a pair or two): the five role-waves of a column block as five single-wave workgroups (grid z = role) -- on an idle
 // chip every wave then has a SIMD to itself, while the five waves of one workgroup share the four SIMDs of one CU and the pair that
 // shares a SIMD sets the pace of all five (they meet at the barrier): one 1080p pair 0.105 -> 0.094 ms, 2.94 k -> 3.05 k pairs/s (a lone wave
