@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Static cost breakdown of k_ingest_rows<NV12> (the SSIMULACRA2-only instantiation) BY PURPOSE, from ablation builds: the kernel is
+"""HISTORICAL (round 3): needs the -DTM_ABLATE_CBRT / -DTM_ABLATE_EOTF switches that lived in the kernel sources up to commit 3773fd2 (round 4);
+the product sources carry no lab switches since round 5.  Its output is profiles/r03_ingest_rows_breakdown.txt.
+
+Static cost breakdown of k_ingest_rows<NV12> (the SSIMULACRA2-only instantiation) BY PURPOSE, from ablation builds: the kernel is
 compiled (device code only, nothing is run) as it ships and with one ingredient removed at a time (-DTM_ABLATE_*), and the
 difference in instructions and in VALU pipe cycles of the loop body is that ingredient's cost.  VALU pipe cycles per 64-lane
 instruction on gfx950: 2 for a full-rate f32 / integer instruction, 4 for a packed-f32 or binary64 one, 8 for v_mul_hi_u32 and

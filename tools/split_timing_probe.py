@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""GPU box, lab build (make -C turbo-metrics_amd/csrc exp; TM_HIP_LIB=build_exp/libturbometrics_hip.so): which wave of the multi-wave row
+"""HISTORICAL (round 4): needs the -DTM_SPLIT_TIMING lab build (`make -C turbo-metrics_amd/csrc exp`) of commit 3773fd2; the product sources
+carry no lab switches since round 5.  Its output is profiles/r04r_ / r04s_split_timing.log.
+
+GPU box, lab build (make -C turbo-metrics_amd/csrc exp; TM_HIP_LIB=build_exp/libturbometrics_hip.so): which wave of the multi-wave row
 pass does a phase wait for?  Per wave of the first row block (scale 0, channel Y, rows 0-63) of a one-pair launch: shader cycles of WORK
 between barriers, per phase and per step, against the kernel's total.  usage: TM_HIP_LIB=... split_timing_probe.py [pairs]"""
 import ctypes as C, os, sys

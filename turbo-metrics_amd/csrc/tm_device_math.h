@@ -305,11 +305,7 @@ __device__ __forceinline__ void linear_to_xyb_sides(const tm_f2 (&r)[N], const t
         const tm_f2 m0 = f2_fma(f2_splat(K_M00), r[i], f2_fma(f2_splat(K_M01), g[i], f2_fma(f2_splat(K_M02), b[i], f2_splat(K_B0))));
         const tm_f2 m1 = f2_fma(f2_splat(K_M10), r[i], f2_fma(f2_splat(K_M11), g[i], f2_fma(f2_splat(K_M12), b[i], f2_splat(K_B0))));
         const tm_f2 m2 = f2_fma(f2_splat(K_M20), r[i], f2_fma(f2_splat(K_M21), g[i], f2_fma(f2_splat(K_M22), b[i], f2_splat(K_B0))));
-#ifdef TM_ABLATE_CBRT /* tools/ingest_breakdown.py: what the ingest kernel costs without the cube roots */
-        const tm_f2 rg = m0 - f2_splat(K_B0_ROOT), gr = m1 - f2_splat(K_B0_ROOT), bb = m2 - f2_splat(K_B0_ROOT);
-#else
         const tm_f2 rg = cbrt_core2(m0) - f2_splat(K_B0_ROOT), gr = cbrt_core2(m1) - f2_splat(K_B0_ROOT), bb = cbrt_core2(m2) - f2_splat(K_B0_ROOT);
-#endif
         const tm_f2 x = f2_splat(0.5f) * (rg - gr);
         const tm_f2 y = f2_splat(0.5f) * (rg + gr);
         X[i] = f2_fma(x, f2_splat(14.0f), f2_splat(0.42f));

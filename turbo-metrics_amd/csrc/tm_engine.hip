@@ -1475,16 +1475,6 @@ int tm_engine_debug_chain(tm_engine *e, tm_engine *peer)
     return TM_OK;
 }
 
-#ifdef TM_SPLIT_TIMING
-// lab build only: {work cycles, phases, total cycles, -} per wave of the first row block of slot 0 of the last k_blur_h_jobs_split launch
-extern "C" int tm_debug_read_split_timing(unsigned long long out[TM_SPLIT_WAVES * 4])
-{
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(tmk::tm_split_timing), sizeof(unsigned long long) * TM_SPLIT_WAVES * 4));
-    return TM_OK;
-}
-#endif
-
 int tm_engine_debug_set_ingest_rows(tm_engine *e, int rows)
 {
     if (!e || rows < 0 || rows > 128 || (rows & 1)) return TM_ERR_INVALID_ARG;

@@ -620,13 +620,9 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
                 const tm_f2 luma = (f2_make(fmaxf((float)ra[q], ymin), fmaxf((float)rb[q], ymin)) - f2_splat(ymin)) * k0;
                 vr[q] = luma + r_; vg[q] = luma + g_; vb[q] = luma + b_;
                 vmin = fminf(fminf(vmin, fminf(vr[q].x, vr[q].y)), fminf(fminf(vg[q].x, vg[q].y), fminf(vb[q].x, vb[q].y)));
-#ifdef TM_ABLATE_EOTF /* tools/ingest_breakdown.py: what the kernel costs without the transfer function */
-                pr[q] = vr[q]; pg[q] = vg[q]; pb[q] = vb[q];
-#else
                 pr[q] = bt709_power2(vr[q], et64);
                 pg[q] = bt709_power2(vg[q], et64);
                 pb[q] = bt709_power2(vb[q], et64);
-#endif
             }
             // the linear branch (v < 0.0812: luma codes below ~35) is rare in pictures: a wave evaluates it only when one of
             // its 24 x 64 arguments needs it (same bits either way)
@@ -1423,19 +1419,6 @@ __global__ void __launch_bounds__(64) k_blur_h_jobs_x(TmGeom g, TmJobs jobs, con
 // 16: 11.7 k -> 12.8 k, 32: 12.5 k -> 13.5 k.  grid (slots, jobs.hstart[n]), block 512.
 // ------------------------------------------------------------------------------------------------
 #define TM_SPLIT_WAVES 8
-// Lab build only (make -C csrc exp: -DTM_SPLIT_TIMING, tools/split_timing_probe.py): every wave of the first row block of slot 0 adds
-// up the shader cycles it spends between leaving a phase barrier and arriving at the next one (its WORK per phase; the rest of a
-// phase it waits for the slowest wave) -> tm_split_timing[wave] = {work cycles, phases, total cycles}.  Not in the shipped library.
-#ifdef TM_SPLIT_TIMING
-__device__ unsigned long long tm_split_timing[TM_SPLIT_WAVES][4];
-#define TM_SPLIT_T0() const unsigned long long tm_t_begin = __builtin_amdgcn_s_memtime(); unsigned long long tm_t_mark = tm_t_begin, tm_t_work = 0, tm_t_n = 0; const bool tm_t_on = blockIdx.x == 0 && blockIdx.y == 0
-#define TM_SPLIT_BARRIER() do { if (tm_t_on) { tm_t_work += __builtin_amdgcn_s_memtime() - tm_t_mark; ++tm_t_n; } TM_LDS_BARRIER(); if (tm_t_on) tm_t_mark = __builtin_amdgcn_s_memtime(); } while (0)
-#define TM_SPLIT_T1() do { if (tm_t_on && (threadIdx.x & 63) == 0) { unsigned long long *o = tm_split_timing[threadIdx.x >> 6]; o[0] = tm_t_work; o[1] = tm_t_n; o[2] = __builtin_amdgcn_s_memtime() - tm_t_begin; } } while (0)
-#else
-#define TM_SPLIT_T0() do {} while (0)
-#define TM_SPLIT_BARRIER() TM_LDS_BARRIER()
-#define TM_SPLIT_T1() do {} while (0)
-#endif
 __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)[16][5][64], const float *__restrict__ v, int plane, int w, int pt, int nphases)
 {
     // v: this lane's row of a transposed blurred plane (column x at v[x * pt]); step t emits column t - 4 into ring[phase & 1][t & 15][plane]
@@ -1450,7 +1433,6 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
 #pragma unroll
     for (int j = 0; j < WN; ++j) win[j] = j < P ? ld_col(j) : 0.0f;
     tmdev::Iir f = {0, 0, 0, 0, 0, 0};
-    TM_SPLIT_T0();
     for (int ph0 = 0; ph0 < nphases; ph0 += 2) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -1466,10 +1448,9 @@ __device__ __forceinline__ void blur_h_split_producer(float (*__restrict__ ring)
                 win[(sl + P) % WN] = ld_col(t + P);
                 ring[ph & 1][j][plane][lane] = o;
             }
-            TM_SPLIT_BARRIER();
+            TM_LDS_BARRIER();
         }
     }
-    TM_SPLIT_T1();
 }
 
 // the ref / dis blocks: block e = rows y0 + 4 i + (lane >> 4) (i = 0 .. 15), columns 16 e + (lane & 15) -- one 8-byte load per lane and
@@ -1491,7 +1472,6 @@ __device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch_block(d, qa[d], qb[d]);
-    TM_SPLIT_T0();
     for (int ph0 = 0; ph0 < nphases; ph0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -1500,10 +1480,9 @@ __device__ __forceinline__ void blur_h_split_fetcher(float (*__restrict__ tile)[
 #pragma unroll
             for (int i = 0; i < 16; ++i) { tile[0][ph & 3][4 * i + lr][lc] = qa[d][i]; tile[1][ph & 3][4 * i + lr][lc] = qb[d][i]; }
             fetch_block(ph + D, qa[d], qb[d]);
-            TM_SPLIT_BARRIER();
+            TM_LDS_BARRIER();
         }
     }
-    TM_SPLIT_T1();
 }
 
 // SSIM: the ssim map and its two sums (all five blurred values); otherwise the two edge maps and their four sums (mu1, mu2, ref, dis).
@@ -1538,7 +1517,6 @@ __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__
             acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
         }
     };
-    TM_SPLIT_T0();
     for (int ph = 0; ph < nphases; ++ph) {
         if (ph > 0) {
             const int tb = 16 * (ph - 1);
@@ -1557,9 +1535,8 @@ __device__ __forceinline__ void blur_h_split_consumer(const float (*__restrict__
                     if (tb + j >= 4 && tb + j < T) step(fetch(ph - 1, j, tb + j));
             }
         }
-        TM_SPLIT_BARRIER();
+        TM_LDS_BARRIER();
     }
-    TM_SPLIT_T1();
     if (!valid) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[k] = 0.0;
