@@ -936,6 +936,8 @@ def run_rank(args):
 
 def main():
     args = parse_args()
+    # dmabuf IPC is what RCCL (and tensor sharing between processes) needs on this driver; the pool exports it, a bare shell may not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
