@@ -1123,6 +1123,9 @@ def test_compute_one_deferred_gives_compute_ones_scores_with_two_pairs_in_flight
     with pytest.raises(tm.TmError):
         eng.collect(10 ** 6)
     assert eng.compute_one(*frames[2]) == want[2]  # the blocking call still works beside it
+    t0, t1 = eng.compute_one_deferred(*frames[0]), eng.compute_one_deferred(*frames[1])
+    assert eng.compute_one(*frames[3]) == want[3]  # ... also with two pairs in flight: they are finished first and kept
+    assert eng.collect(t1) == want[1] and eng.collect(t0) == want[0]
     assert eng.mem_usage() == mem_one  # (the second engine is its own object)
     batched = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=4)
     with pytest.raises(ValueError):

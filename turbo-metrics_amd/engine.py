@@ -285,8 +285,19 @@ class TurboMetrics:
         """PSNR / SSIM / MS-SSIM from channel 0 only instead of pooled / averaged over R, G, B (see the header)"""
         _chk(self._L.tm_engine_set_channel_mode(self._h, ffi.TM_CHANNELS_FIRST if first_channel_only else ffi.TM_CHANNELS_POOLED), "tm_engine_set_channel_mode")
 
+    def _retire_deferred(self):
+        """finish the pairs in flight for compute_one_deferred and keep their scores for collect()"""
+        d = getattr(self, "_def", None)
+        if d is not None:
+            for i in range(2):
+                if d["pending"][i] is not None:
+                    d["ring"][i].sync()
+                    d["done"][d["pending"][i]] = d["ring"][i].scores(0)
+                    d["pending"][i] = None
+
     def compute_one(self, fref: HwFrame, fdis: HwFrame) -> FrameScores:
         """== TurboMetrics::compute_one: convert, compute, block, return FrameScores."""
+        self._retire_deferred()  # (slot 0 may hold a deferred pair)
         self.set_pair(0, fref, fdis)
         self.compute_async(1)
         self.sync()
@@ -328,6 +339,7 @@ class TurboMetrics:
 
     def compute_all(self, frames_ref: Iterable[HwFrame], frames_dis: Iterable[HwFrame], opts: Options = Options()) -> List[FrameScores]:
         """== TurboMetrics::compute_all frame selection (lib.rs:385-404), batched over the slots."""
+        self._retire_deferred()
         it_r, it_d = iter(frames_ref), iter(frames_dis)
         for _ in range(opts.skip_ref + opts.skip):
             next(it_r, None)

@@ -251,8 +251,19 @@ FrameScores TurboMetrics::scores_of(tm_engine *e, uint32_t slot)
     return r;
 }
 
+void TurboMetrics::retire_deferred()
+{
+    for (int i = 0; i < 2; ++i)
+        if (def_pending_[i]) {
+            chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
+            def_done_.emplace_back(def_pending_[i], scores_of(eng_[i], 0));
+            def_pending_[i] = 0;
+        }
+}
+
 FrameScores TurboMetrics::compute_one(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis)
 {
+    retire_deferred(); // (slot 0 of this engine may hold a deferred pair)
     set_frame(eng_[0], 0, TM_SIDE_REF, fref, cref);
     set_frame(eng_[0], 0, TM_SIDE_DIS, fdis, cdis);
     chk(tm_engine_compute_async(eng_[0], 1), "tm_engine_compute_async");
@@ -352,6 +363,7 @@ MetricsResults TurboMetrics::compute_all(FrameSource &frames_ref, FrameSource &f
     if (frames_ref.width() != frames_dis.width() || frames_ref.height() != frames_dis.height())
         throw std::runtime_error("Reference and distorted are not the same size"); // assert_eq! at lib.rs:368-372
     const ColorInfo cref = frames_ref.color_characteristics(), cdis = frames_dis.color_characteristics();
+    retire_deferred(); // (the engines' slots may hold deferred pairs)
 
     std::optional<std::vector<double>> s_psnr, s_ssim, s_msssim, s_ssimu;
     if (metrics_.psnr) s_psnr.emplace();

@@ -221,7 +221,8 @@ public:
     // submitting pair k+1 keeps the device busy while it fetches / decodes the next frames, which is worth 1.6 x at one 1080p pair
     // per call (2.9 k -> 4.8 k pairs/s).  A third submission first finishes the oldest pair and keeps its scores until collected.
     // Frames: host memory is read before the call returns unless `pinned` (then until collect(ticket)); device memory until collect.
-    // Scores are bit-identical with compute_one's.  Tickets are collected at most once, in any order.
+    // Scores are bit-identical with compute_one's.  Tickets are collected at most once, in any order; compute_one and compute_all
+    // may be called in between (they first finish what is in flight and keep those scores for collect).
     uint64_t compute_one_deferred(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis);
     FrameScores collect(uint64_t ticket);
 
@@ -236,6 +237,7 @@ public:
 private:
     void set_frame(tm_engine *e, uint32_t slot, int side, const HwFrame &f, const ColorInfo &c);
     FrameScores scores_of(tm_engine *e, uint32_t slot);
+    void retire_deferred(); // finish the pairs that are in flight for compute_one_deferred and keep their scores for collect()
     uint32_t w_, h_, batch_;
     Metrics metrics_;
     tm_engine *eng_[2] = {nullptr, nullptr};
