@@ -249,6 +249,8 @@ int main(int argc, char **argv)
             log_line(L_WARN, kTarget, "--devices needs two regular planar-YUV files of known length: running on one device");
             want = 1;
         }
+        if (want > 1 && loop != Loop::Batched) log_line(L_WARN, kTarget, "--loop reference / deferred run on one device: --devices ignored");
+        if (want > 1 && loop != Loop::Batched) want = 1;
         if (want > 1) {
             if (metrics.mask() == 0) { log_line(L_ERROR, kTarget, "Could not initialize engine : no metric selected (-m psnr|ssim|msssim|ssimulacra2)"); return EXIT_FAILURE; }
             uint32_t total = (uint32_t)(known - lead); // decode indices available
