@@ -1133,6 +1133,29 @@ def test_compute_one_deferred_gives_compute_ones_scores_with_two_pairs_in_flight
     batched.close(); eng.close()
 
 
+def test_the_first_launch_after_switching_to_the_reference_pipeline_is_correct():
+    """Round 5 (found by tools/variant_sweep_soak.py): TM_VARIANT_REFERENCE allocates its linear pyramid and transposed XYB copy when it
+    is first selected; their zero fill ran on the null stream and could still be running when the first launch's kernels -- on the engine's
+    non-blocking stream -- wrote into them: at 1080p x 4 the first launch after the switch returned garbage, the second one was right."""
+    w, h, B = 1920, 1080, 4
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=B)
+    for slot in range(B):
+        eng.set_pair(slot, *nv12_frames(w, h, 60 + slot))
+    eng.compute_async(); eng.sync()
+    want = [(eng.raw_sums(i).copy(), eng.sse(i)) for i in range(B)]
+    eng.set_variant(F.TM_VARIANT_REFERENCE)
+    eng.compute_async(); eng.sync()  # the FIRST launch on the freshly allocated arenas
+    for i in range(B):
+        assert np.array_equal(eng.raw_sums(i), want[i][0]) and eng.sse(i) == want[i][1], i
+    eng.set_full_sums(True)  # (may grow the fused kernel's hand-off buffers: the same zero fill)
+    eng.set_variant(F.TM_VARIANT_FUSED_EDGE)
+    eng.compute_async(); eng.sync()
+    m = weight_mask()
+    for i in range(B):
+        assert np.array_equal(eng.raw_sums(i)[m], want[i][0][m]), i
+    eng.close()
+
+
 def test_destroying_a_chained_peer_first_unhooks_it():
     w, h = 320, 200
     a = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=1)

@@ -189,7 +189,7 @@ struct tm_engine {
     float *d_lut = nullptr, *d_coef = nullptr;
     double *d_powtab = nullptr;
     std::vector<hipEvent_t> up_ev;    // upload fences (tm_engine_upload_fence): a small ring of events on the engine's stream
-    std::vector<hipEvent_t> up_ev2;   // ... and on the second upload stream, for the fences that had copies on it (up_has2)
+    std::vector<hipEvent_t> up_ev2;   // ... and on the second upload stream, for the fences that had copies on it
     std::vector<uint64_t> up_tok2;    // per fence: token of the most recent fence (itself included) that recorded on the second upload stream, or UINT64_MAX
     uint64_t up_last2 = UINT64_MAX;   // token of the most recent fence that recorded an event on the second upload stream
     hipStream_t up_stream = nullptr;  // the device's second upload stream (page-locked frames of the distorted side)
@@ -225,7 +225,14 @@ template <typename T> int dev_alloc(tm_engine *e, T **p, size_t count, bool zero
     if (r == hipErrorOutOfMemory) { snprintf(g_hip_err, sizeof g_hip_err, "hipMalloc(%zu): out of memory", bytes); return TM_ERR_OOM; }
     if (r != hipSuccess) return hip_fail(r, "hipMalloc");
     e->mem_bytes += bytes;
-    if (zero) HIPCHK(hipMemset(*p, 0, bytes ? bytes : 1));
+    if (zero) {
+        // hipMemset on device memory returns before the fill has run (it is a kernel on the null stream), and the engine's streams
+        // are non-blocking ones that do not wait for the null stream: a launch enqueued right after an allocation made later than
+        // tm_engine_create (TM_VARIANT_REFERENCE's arenas, grown hand-off buffers) had its first results zeroed under it
+        // (tools/variant_sweep_soak.py found it: the first launch after the switch, large frames only).  Wait for the fill.
+        HIPCHK(hipMemset(*p, 0, bytes ? bytes : 1));
+        HIPCHK(hipStreamSynchronize(nullptr));
+    }
     return TM_OK;
 }
 
