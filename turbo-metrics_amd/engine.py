@@ -194,6 +194,8 @@ class TurboMetrics:
             if len(mems) != 1:
                 raise ValueError("the three planes must live in the same kind of memory")
             pitch = lambda k: int(k.stride(0) * k.element_size()) if hasattr(k, "data_ptr") else int(k.strides[0])
+            if pitch(planes[1][2]) != pitch(planes[2][2]):
+                raise ValueError("Cb and Cr must have the same row pitch (tm_engine_set_frame_i420 takes pitch_uv once)")
             _chk(self._L.tm_engine_set_frame_i420(self._h, slot, side, planes[0][0], planes[1][0], planes[2][0], pitch(planes[0][2]),
                                                   pitch(planes[1][2]), int(f.bits), int(f.matrix), int(f.transfer),
                                                   int(bool(f.full_range)), mems.pop()), "tm_engine_set_frame_i420")
