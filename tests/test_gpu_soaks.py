@@ -35,3 +35,7 @@ def test_abi_survives_random_arguments():
 
 def test_deferred_api_under_repetition():
     assert "deferred soak ok" in _tool("deferred_soak.py", 3000)
+
+
+def test_one_engine_through_random_state_changes():
+    assert "mismatches 0" in _tool("engine_state_soak.py", 1500, 333, 203)
