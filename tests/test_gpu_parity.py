@@ -1127,6 +1127,17 @@ def test_compute_one_deferred_gives_compute_ones_scores_with_two_pairs_in_flight
     assert eng.compute_one(*frames[3]) == want[3]  # ... also with two pairs in flight: they are finished first and kept
     assert eng.collect(t1) == want[1] and eng.collect(t0) == want[0]
     assert eng.mem_usage() == mem_one  # (the second engine is its own object)
+    # settings are the engine's: the second engine follows them, whether they were made before or after it came to be
+    eng.set_channel_mode(True)
+    first = [eng.compute_one(*frames[k]) for k in range(3)]
+    assert first[0].psnr != want[0].psnr and first[0].ssimulacra2 == want[0].ssimulacra2
+    tk = [eng.compute_one_deferred(*frames[k]) for k in range(3)]
+    assert [eng.collect(t) for t in tk] == first
+    fresh = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True, ssim=True), batch=1)
+    fresh.set_channel_mode(True); fresh.set_full_sums(True)
+    tk = [fresh.compute_one_deferred(*frames[k]) for k in range(3)]
+    assert [fresh.collect(t) for t in tk] == first
+    fresh.close()
     batched = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=4)
     with pytest.raises(ValueError):
         batched.compute_one_deferred(*frames[0])

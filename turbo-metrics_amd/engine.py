@@ -283,9 +283,20 @@ class TurboMetrics:
         _chk(self._L.tm_engine_get_sse_channels(self._h, slot, v), "tm_engine_get_sse_channels")
         return [int(x) for x in v]
 
+    def _peer_follows(self, name, *args):
+        """settings are the ENGINE's, and compute_one_deferred runs every other pair on a second engine: it follows (those set before
+        it existed are replayed when it is created)"""
+        self._settings = getattr(self, "_settings", {})
+        self._settings[name] = args
+        d = getattr(self, "_def", None)
+        if d is not None:
+            self._retire_deferred()
+            getattr(d["ring"][1], name)(*args)
+
     def set_channel_mode(self, first_channel_only: bool):
         """PSNR / SSIM / MS-SSIM from channel 0 only instead of pooled / averaged over R, G, B (see the header)"""
         _chk(self._L.tm_engine_set_channel_mode(self._h, ffi.TM_CHANNELS_FIRST if first_channel_only else ffi.TM_CHANNELS_POOLED), "tm_engine_set_channel_mode")
+        self._peer_follows("set_channel_mode", first_channel_only)
 
     def _retire_deferred(self):
         """finish the pairs in flight for compute_one_deferred and keep their scores for collect()"""
@@ -313,7 +324,10 @@ class TurboMetrics:
         if self.batch != 1:
             raise ValueError("compute_one_deferred is the one-pair-per-call path: create the engine with batch=1")
         if getattr(self, "_def", None) is None:
-            self._def = {"ring": [self, TurboMetrics(self.width, self.height, self._metrics, batch=1)], "pending": [None, None], "done": {}, "next": 0}
+            peer = TurboMetrics(self.width, self.height, self._metrics, batch=1)
+            for name, args in getattr(self, "_settings", {}).items():  # channel mode, full sums, variant, graph: as set on this engine
+                getattr(peer, name)(*args)
+            self._def = {"ring": [self, peer], "pending": [None, None], "done": {}, "next": 0}
         d = self._def
         ticket = d["next"]
         d["next"] += 1
@@ -384,6 +398,7 @@ class TurboMetrics:
 
     def set_full_sums(self, on: bool):
         _chk(self._L.tm_engine_set_full_sums(self._h, int(bool(on))), "tm_engine_set_full_sums")
+        self._peer_follows("set_full_sums", on)
 
     def job_modes(self) -> np.ndarray:
         """(6 scales, 3 channels): 0 = nothing computed, 1 = edge terms only, 2 = all three error maps"""
@@ -414,9 +429,11 @@ class TurboMetrics:
 
     def set_graph(self, on: bool):
         _chk(self._L.tm_engine_set_graph(self._h, int(bool(on))), "tm_engine_set_graph")
+        self._peer_follows("set_graph", on)
 
     def set_variant(self, v: int):
         _chk(self._L.tm_engine_set_variant(self._h, int(v)), "tm_engine_set_variant")
+        self._peer_follows("set_variant", v)
 
     def read_plane(self, slot: int, kind: int, scale: int, index: int, channel: int) -> np.ndarray:
         w, h = self.width, self.height

@@ -202,12 +202,14 @@ size_t TurboMetrics::mem_usage() const
 
 void TurboMetrics::debug_set_param(int param, long long value)
 {
+    debug_params_.emplace_back(param, value);
     for (tm_engine *e : eng_)
         if (e) chk(tm_engine_debug_set_param(e, param, value), "tm_engine_debug_set_param");
 }
 
 void TurboMetrics::set_full_sums(bool on)
 {
+    full_sums_ = on; // (an engine created later -- compute_one_deferred's second one -- starts with it)
     for (tm_engine *e : eng_)
         if (e) chk(tm_engine_set_full_sums(e, on ? 1 : 0), "tm_engine_set_full_sums");
 }
@@ -276,6 +278,8 @@ uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo
     if (!eng_[1]) { // the second engine the two launches take turns on
         chk(tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), batch_), "tm_engine_create (second engine of compute_one_deferred)");
         (void)tm_engine_set_linear_upload(eng_[1], 1);
+        if (full_sums_) chk(tm_engine_set_full_sums(eng_[1], 1), "tm_engine_set_full_sums");
+        for (const auto &kv : debug_params_) (void)tm_engine_debug_set_param(eng_[1], kv.first, kv.second);
     }
     const uint64_t ticket = def_next_++;
     const int i = (int)(ticket & 1);

@@ -246,6 +246,8 @@ private:
     uint64_t def_pending_[2] = {0, 0};
     std::vector<std::pair<uint64_t, FrameScores>> def_done_;
     uint64_t def_next_ = 1;
+    bool full_sums_ = false;                                  // settings replayed on an engine that is created later
+    std::vector<std::pair<int, long long>> debug_params_;
 };
 
 } // namespace tm_host
