@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: the C ABI under random (mostly invalid) arguments, through ctypes -- slots and sides out of range, null and misaligned
+"""TEST INFRASTRUCTURE (may use the oracle).  GPU box: the C ABI under random (mostly invalid) arguments, through ctypes -- slots and sides out of range, null and misaligned
 pointers, pitches below a row / above 2^24 / overflowing 4 GB, bit depths out of range, reads before any compute, launches of unset
 slots, tokens never issued, engines of impossible sizes.  Every call must RETURN (a TM_* code), none may crash the process, and
 afterwards the engine must still produce the right scores.  usage: abi_fuzz_soak.py [calls]"""
 import ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from tm_pkg import tm
 F = tm.ffi

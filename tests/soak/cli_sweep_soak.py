@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: the `turbo-metrics` binary on random planar clips -- random size, bit depth, length, metric set, frame selection -- run in
+"""TEST INFRASTRUCTURE (may use the oracle).  GPU box: the `turbo-metrics` binary on random planar clips -- random size, bit depth, length, metric set, frame selection -- run in
 every host arrangement it has: batches through compute_all with and without the second engine, one pair per launch, the reference's
 own loop and the deferred one, two shards on one device, stdin.  Every arrangement must print the same bytes on stdout (JSON lines),
 and the first frame's SSIMULACRA2 must be the oracle's.  usage: cli_sweep_soak.py [cases]"""
 import json, os, subprocess, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np
 from tm_pkg import tm
 from oracle import oracle as O

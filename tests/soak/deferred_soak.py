@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: compute_one_deferred / collect under repetition -- tens of thousands of one-pair submissions with two in flight (two
+"""TEST INFRASTRUCTURE (may use the oracle).  GPU box: compute_one_deferred / collect under repetition -- tens of thousands of one-pair submissions with two in flight (two
 engines taking turns), frames from device memory, page-locked and pageable host memory in turn, collected with a lag of one and,
 every so often, out of order or after a blocking compute_one in between; every score must be compute_one's, bit for bit.
 usage: deferred_soak.py [submissions]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from tm_pkg import tm
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30000

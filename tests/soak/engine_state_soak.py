@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: ONE long-lived engine under a random sequence of state changes -- kernel variant, hipGraph replay on / off, pruned / full
+"""TEST INFRASTRUCTURE (may use the oracle).  GPU box: ONE long-lived engine under a random sequence of state changes -- kernel variant, hipGraph replay on / off, pruned / full
 sums, channel mode, profiling, slots per launch, frames of other KINDS (NV12, P016, planar 8 / 10 bit, RGB8 / 16 / f32) and memory kinds
 in random slots -- every launch checked against what a fresh one-pair engine computes for the same frames (raw sums where a weight
 reads them, SSE, SSIM sums).  State that leaks from one launch into the next shows up here.  usage: engine_state_soak.py [launches] [w h]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from tm_pkg import tm
 F = tm.ffi

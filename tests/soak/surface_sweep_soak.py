@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: every way a 4:2:0 frame can be handed over -- declared surface (random pitch and coded height), planar I420 (random or
+"""TEST INFRASTRUCTURE (may use the oracle).  GPU box: every way a 4:2:0 frame can be handed over -- declared surface (random pitch and coded height), planar I420 (random or
 tight pitches, with and without the one-copy upload), from device / page-locked / pageable memory, with upload fences or without,
 in random slots of a random batch -- against the same samples as tight device surfaces: raw sums and SSE bit for bit.
 usage: surface_sweep_soak.py [cases]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from tm_pkg import tm
 F = tm.ffi

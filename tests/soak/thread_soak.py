@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""GPU box: engines created, used and destroyed from several host threads at once (each engine by one thread at a time, as the header
+"""TEST INFRASTRUCTURE (may use the oracle).  GPU box: engines created, used and destroyed from several host threads at once (each engine by one thread at a time, as the header
 asks; the library's process-wide pieces -- the device's shared side stream and second upload stream, their reference counts, the
 registry of live engines -- are what is exercised).  Every result is compared with the expected one.  usage: thread_soak.py [threads] [cycles]"""
 import os, sys, threading, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from tm_pkg import tm
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 6

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: kernel variants against each other on random sizes far beyond the committed cases -- for each (w, h, batch, kind) the raw sums
+"""TEST INFRASTRUCTURE (may use the oracle).  GPU box: kernel variants against each other on random sizes far beyond the committed cases -- for each (w, h, batch, kind) the raw sums
 and SSE of the default configuration, of the fused EDGE kernel forced, of the two passes forced, of the eight-wave and the one-wave
 row pass, of the tile ingest kernel and of the straight-line reference pipeline must be identical bit for bit.
 usage: variant_sweep_soak.py [cases] [max_side]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from tm_pkg import tm
 F = tm.ffi

@@ -1145,7 +1145,7 @@ def test_compute_one_deferred_gives_compute_ones_scores_with_two_pairs_in_flight
 
 
 def test_the_first_launch_after_switching_to_the_reference_pipeline_is_correct():
-    """Round 5 (found by tools/variant_sweep_soak.py): TM_VARIANT_REFERENCE allocates its linear pyramid and transposed XYB copy when it
+    """Round 5 (found by tests/soak/variant_sweep_soak.py): TM_VARIANT_REFERENCE allocates its linear pyramid and transposed XYB copy when it
     is first selected; their zero fill ran on the null stream and could still be running when the first launch's kernels -- on the engine's
     non-blocking stream -- wrote into them: at 1080p x 4 the first launch after the switch returned garbage, the second one was right."""
     w, h, B = 1920, 1080, 4

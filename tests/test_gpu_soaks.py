@@ -1,4 +1,4 @@
-"""GPU tier: short runs of the soak tools (tools/*_soak.py) -- the long runs of round 5 are in profiles/r05j ... r05o_*.log.  Each tool
+"""GPU tier: short runs of the soak programs (tests/soak/*_soak.py) -- the long runs of round 5 are in profiles/r05j ... r05o_*.log.  Each tool
 compares the product with itself across configurations (kernel variants, hand-over forms, host arrangements) or with the oracle on
 random cases; the variant sweep is the one that found the zero-fill race of late allocations (docs/LABBOOK.md, round 5)."""
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _tool(name, *args, timeout=600):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", name)] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak", name)] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     return r.stdout
 

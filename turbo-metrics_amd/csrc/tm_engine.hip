@@ -229,7 +229,7 @@ template <typename T> int dev_alloc(tm_engine *e, T **p, size_t count, bool zero
         // hipMemset on device memory returns before the fill has run (it is a kernel on the null stream), and the engine's streams
         // are non-blocking ones that do not wait for the null stream: a launch enqueued right after an allocation made later than
         // tm_engine_create (TM_VARIANT_REFERENCE's arenas, grown hand-off buffers) had its first results zeroed under it
-        // (tools/variant_sweep_soak.py found it: the first launch after the switch, large frames only).  Wait for the fill.
+        // (tests/soak/variant_sweep_soak.py found it: the first launch after the switch, large frames only).  Wait for the fill.
         HIPCHK(hipMemset(*p, 0, bytes ? bytes : 1));
         HIPCHK(hipStreamSynchronize(nullptr));
     }
