@@ -23,7 +23,7 @@ Objects on the line (besides the contract fields, which describe the headline wo
                 `long` inside it: the same with 16 384 pairs, so that every rank still has >= 0.15 s of kernels at 8 GPUs.
   host_fed      SURVEY 8d config 2 (ii): the same pairs uploaded from page-locked host memory for every step
                 (two engines ping-pong: the upload of batch k+1 overlaps the kernels of batch k).  Never `value`.
-  batch_curve   the headline workload at 1, 2, 4, 8, 16, 32, 64 pairs per launch (the reference's compute_one is ONE pair per
+  batch_curve   the headline workload at 1, 2, 4, 8, 16, 32, 64, 128 pairs per launch (the reference's compute_one is ONE pair per
                 call): pairs/s, ms per step, engine memory; for 1 .. 8 pairs per launch also with 2 launches IN FLIGHT (two
                 engines taking turns, each waited for only before its next launch: what an asynchronous caller of the C ABI
                 -- or compute_all -- gets at the same call granularity).  N = 1 only.
@@ -44,16 +44,18 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (w, h, kind, default batch, BASELINE.json config it implements)
     # batch: pairs per step.  The row pass is a few thousand long waves on 1 024 SIMDs, and its tail averages out with more
-    # of them: 32 -> 64 slots is worth 2-3 % at 1080p, 16 -> 24 2 % at 4K; memory 15 GB / 23 GB
-    "1080p_nv12": (1920, 1080, "nv12", 64, "configs[1]: synthetic 1080p yuv420p frame-pair stream, SSIMULACRA2"),
-    "4k_p016": (3840, 2160, "p016", 24, "configs[2]: synthetic 4K yuv420p10 stream, SSIMULACRA2"),
+    # of them: 32 -> 64 slots is worth 2-3 % at 1080p, 64 -> 128 another 2.5 % (192: +1 %, 256: nothing more); 4K: 24 -> 36 -> 48
+    # slots +3.0 / +3.7 %, 72 nothing more (profiles/r05t_batch_size.log).  Memory 31 GB / 46 GB of the 288 GB.
+    "1080p_nv12": (1920, 1080, "nv12", 128, "configs[1]: synthetic 1080p yuv420p frame-pair stream, SSIMULACRA2"),
+    "4k_p016": (3840, 2160, "p016", 48, "configs[2]: synthetic 4K yuv420p10 stream, SSIMULACRA2"),
 }
+SHARED_DEVICE_BATCH = {"1080p_nv12": 64, "4k_p016": 24}  # ranks that share ONE device (the gloo rehearsal on a 1-GPU box): half the slots each
 FUSED = "psnr,msssim,ssimulacra2"  # BASELINE configs[4]
 EXTRAS = [("4k_p016", "ssimulacra2"), ("1080p_nv12", FUSED), ("4k_p016", FUSED)]
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec; 6.29 TB/s measured copy ceiling)
 STREAM_PAIRS = 2048
 STREAM_PAIRS_LONG = 16384  # the strong leg's longer companion: 2048 pairs per rank at 8 GPUs (~0.17 s of kernels)
-BATCH_CURVE = (1, 2, 4, 8, 16, 32, 64)
+BATCH_CURVE = (1, 2, 4, 8, 16, 32, 64, 128)
 
 
 def parse_args():
@@ -135,6 +137,7 @@ class Ctx:
         ndev = torch.cuda.device_count()
         if self.backend == "nccl" and ndev < self.world:
             raise SystemExit(f"--gpus {self.world} but only {ndev} device(s) visible")
+        self.shared_device = self.backend != "nccl" and self.world > max(1, ndev)
         if self.backend != "nccl":
             self.local_rank %= max(1, ndev)
         self.cdev = "cuda" if self.backend == "nccl" else "cpu"
@@ -841,7 +844,7 @@ def run_rank(args):
     ctx = Ctx(args)
     head_name = args.workload or "1080p_nv12"
     mets = set(args.metrics.split(","))
-    B = args.batch or WORKLOADS[head_name][3]
+    B = args.batch or (SHARED_DEVICE_BATCH[head_name] if ctx.shared_device else WORKLOADS[head_name][3])
     # the other workloads, the host-fed leg, the batch curve and the CLI describe ONE GPU: with several ranks the line carries the weak
     # leg (`value`) and the strong leg (`fixed_stream`) only -- eight ranks generating 4K frames on a shared CPU quota is setup time that
     # measures nothing

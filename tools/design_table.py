@@ -50,7 +50,7 @@ rows = [
     row("1080p PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["1080p_nv12_fused"], r01="6 545, r02: 8 292, r03: 9 770"),
     row("4K PSNR + MS-SSIM + SSIMULACRA2 in one pass", w["4k_p016_fused"], r01="1 633, r02: 2 059, r03: 2 453"),
 ]
-s1, sf, s4f = stats(f"{T}_kernel_stats_1080p_b64.csv"), stats(f"{T}_kernel_stats_1080p_b64_fused.csv"), stats(f"{T}_kernel_stats_4k_b24_fused.csv")
+s1, sf, s4f = stats(f"{T}_kernel_stats_1080p_b128.csv"), stats(f"{T}_kernel_stats_1080p_b128_fused.csv"), stats(f"{T}_kernel_stats_4k_b48_fused.csv")
 pk = prof["kernels"]
 hf, cb, fx = d["host_fed"], d["cpu_baseline"], d["fixed_stream"]
 bc = d["batch_curve"]["points"]
@@ -65,18 +65,18 @@ text = "\n".join(rows) + f"""
 `batch_curve` (1080p, pairs per launch: pairs/s (ms per step, engine memory)): {curve}.
 `cli_end_to_end` (the C++ binary on Y4M clips in tmpfs, its own "Processed" figure): 1080p 8-bit {fmt(cli['1080p_yuv420p']['default']['pairs_per_s'])} pairs/s with the defaults (`--batch` by picture size: 16) and {fmt(cli['1080p_yuv420p']['batch16']['pairs_per_s'])} with `--batch 16`;
 4K 10-bit {fmt(cli['4k_yuv420p10']['default']['pairs_per_s'])} (batch 4) / {fmt(cli['4k_yuv420p10']['batch16']['pairs_per_s'])}.
-rocprofv3 of the same command (`profiles/{T}_kernel_stats_1080p_b64.csv`): `k_blur_v_jobs<32,16,0>` {s1['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms average over {s1['tmk::k_blur_v_jobs<32, 16, 0>'][0]}
+rocprofv3 of the same command (`profiles/{T}_kernel_stats_1080p_b128.csv`): `k_blur_v_jobs<32,16,0>` {s1['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms average over {s1['tmk::k_blur_v_jobs<32, 16, 0>'][0]}
 launches vs {pk['k_blur_v_jobs']['avg_launch_ms']:.3f} ms from the HIP events of the timed steps of that run; row pass {s1['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} vs {pk['k_blur_h_jobs_x']['avg_launch_ms']:.3f}; `k_ingest_rows` {s1[ing][1]:.3f} +
 `k_ingest_upper_rd` {s1['tmk::k_ingest_upper_rd'][1]:.3f} vs {pk['k_ingest_rows']['avg_launch_ms']:.3f} for the stage; `{efk.replace('tmk::', '')}` {s1[efk][1]:.3f} vs {pk['k_blur_edge_fused']['avg_launch_ms']:.3f} (+ `k_finish_edge`
 {s1['tmk::k_finish_edge'][1]:.3f}); the launches of the placement search are listed apart as `…, 1>`. With the SSIM stage
-(`{T}_kernel_stats_1080p_b64_fused.csv`): `k_ssim_stream` {sf['tmk::k_ssim_stream'][1]:.3f}, `k_ssim_pyramid` {sf['tmk::k_ssim_pyramid'][1]:.3f} (4K, `{T}_kernel_stats_4k_b24_fused.csv`:
+(`{T}_kernel_stats_1080p_b128_fused.csv`): `k_ssim_stream` {sf['tmk::k_ssim_stream'][1]:.3f}, `k_ssim_pyramid` {sf['tmk::k_ssim_pyramid'][1]:.3f} (4K, `{T}_kernel_stats_4k_b48_fused.csv`:
 {s4f['tmk::k_ssim_stream'][1]:.3f} and {s4f['tmk::k_ssim_pyramid'][1]:.3f})."""
-if os.path.exists(P(f"{T}_kernel_stats_1080p_b64_alone.csv")):
-    sa = stats(f"{T}_kernel_stats_1080p_b64_alone.csv")
+if os.path.exists(P(f"{T}_kernel_stats_1080p_b128_alone.csv")):
+    sa = stats(f"{T}_kernel_stats_1080p_b128_alone.csv")
     efa = [k for k in sa if "k_blur_edge_fused" in k][0]
     al = d["kernels_alone"]["kernels"]
     text += f"""
-Every kernel alone on the chip (`bench.py --edge-beside 0`: the fused kernel behind the row pass; `profiles/{T}_kernel_stats_1080p_b64_alone.csv`, rocprofv3 of
+Every kernel alone on the chip (`bench.py --edge-beside 0`: the fused kernel behind the row pass; `profiles/{T}_kernel_stats_1080p_b128_alone.csv`, rocprofv3 of
 `bench.py --no-extras` in that mode): `k_blur_v_jobs<32,16,0>` {sa['tmk::k_blur_v_jobs<32, 16, 0>'][1]:.3f} ms = {7424901120 / sa['tmk::k_blur_v_jobs<32, 16, 0>'][1] / 8e9 * 1e3 / 1e3:.3f} of 8 TB/s on its 7.42 GB (`kernels_alone` of the bench line: {al['k_blur_v_jobs']['avg_launch_ms']:.3f} ms,
 {al['k_blur_v_jobs']['frac']:.3f}), row pass {sa['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1]:.3f} ms = {7424901120 / sa['tmk::k_blur_h_jobs_x<16, 8, 32, 16, 0>'][1] / 8e9 * 1e3 / 1e3:.3f} ({al['k_blur_h_jobs_x']['avg_launch_ms']:.3f}, {al['k_blur_h_jobs_x']['frac']:.3f}), `{efa.replace('tmk::', '')}` {sa[efa][1]:.3f} ms ({al['k_blur_edge_fused']['avg_launch_ms']:.3f})."""
 p = os.path.join(ROOT, "docs", "LABBOOK.md")

@@ -9,9 +9,9 @@ TAG=${1:-r02z}
 bash tools/pmc_traffic.sh $TAG 1080p_nv12 > /dev/null
 bash tools/pmc_traffic.sh $TAG 1080p_nv12 --full-sums > /dev/null
 bash tools/pmc_traffic.sh $TAG 4k_p016 > /dev/null
-cp gpurun_out/${TAG}_pmc_traffic_1080p_nv12.json profiles/pmc_traffic_1080p_nv12_b64.json
-cp gpurun_out/${TAG}_pmc_traffic_1080p_nv12_full.json profiles/pmc_traffic_1080p_nv12_b64_full.json
-cp gpurun_out/${TAG}_pmc_traffic_4k_p016.json profiles/pmc_traffic_4k_p016_b24.json
+cp gpurun_out/${TAG}_pmc_traffic_1080p_nv12.json profiles/pmc_traffic_1080p_nv12_b128.json
+cp gpurun_out/${TAG}_pmc_traffic_1080p_nv12_full.json profiles/pmc_traffic_1080p_nv12_b128_full.json
+cp gpurun_out/${TAG}_pmc_traffic_4k_p016.json profiles/pmc_traffic_4k_p016_b48.json
 bash tools/gpu_check.sh $TAG
 bash tools/gpu_prof.sh ${TAG}_fused --metrics psnr,msssim,ssimulacra2
 bash tools/gpu_prof.sh ${TAG}_alone --edge-beside 0   # every kernel alone on the chip: the fused kernel of the EDGE jobs behind the row pass
