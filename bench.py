@@ -156,6 +156,12 @@ class Ctx:
         tm.init_hip(self.local_rank)
         # the rank's threads (surface generators, page-locked allocations) next to its device, like the CLI's
         self.numa_node = tm.ffi.lib().tm_device_numa_node(self.local_rank)
+        if self.numa_node < 0:  # (torch's bundled HIP runtime answers -1: ask sysfs for the PCI device's node)
+            try:
+                pr = torch.cuda.get_device_properties(self.local_rank)
+                self.numa_node = tm.launch.pci_numa_node(int(pr.pci_domain_id), int(pr.pci_bus_id), int(pr.pci_device_id))
+            except Exception:  # noqa: BLE001
+                pass
         self.cpus_bound = tm.launch.bind_to_numa_node(self.numa_node)
         self._surfaces = {}
 

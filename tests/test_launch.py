@@ -131,3 +131,17 @@ def test_binding_to_a_numa_node_narrows_the_affinity_and_children_inherit_it(tmp
     script.write_text(body)
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+def test_pci_numa_node_from_sysfs(tmp_path):
+    from tm_pkg import tm
+    d = tmp_path / "0000:c1:00.0"
+    d.mkdir()
+    (d / "numa_node").write_text("1\n")
+    e = tmp_path / "0001:05:00.0"
+    e.mkdir()
+    (e / "numa_node").write_text("-1\n")
+    f = tm.launch.pci_numa_node
+    assert f(0, 0xC1, 0, str(tmp_path)) == 1
+    assert f(1, 5, 0, str(tmp_path)) == -1      # the kernel does not know
+    assert f(0, 0xC2, 0, str(tmp_path)) == -1    # no such device

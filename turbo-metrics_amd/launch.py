@@ -70,6 +70,16 @@ def parse_cpulist(text: str) -> Set[int]:
     return out
 
 
+def pci_numa_node(domain: int, bus: int, device: int, sysfs: str = "/sys/bus/pci/devices") -> int:
+    """NUMA node of a PCI device from sysfs (function 0), -1 when unknown.  The fallback for tm_device_numa_node under a HIP runtime
+    that does not know hipDeviceAttributeHostNumaId (the one bundled with torch answers -1; /opt/rocm's, which the CLI loads, does)."""
+    try:
+        v = int(open(os.path.join(sysfs, f"{domain:04x}:{bus:02x}:{device:02x}.0", "numa_node")).read().strip())
+        return v if v >= 0 else -1
+    except (OSError, ValueError):
+        return -1
+
+
 def bind_to_numa_node(node: int, sysfs: str = "/sys/devices/system/node") -> Optional[int]:
     """Bind the calling thread (and every thread it starts afterwards) to the CPUs of host NUMA node `node` that the process may run
     on -- the rule of the CLI's bind_to_device_node (host/turbo_metrics.cpp): page-locked memory then lands next to the device and the
