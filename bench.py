@@ -667,13 +667,22 @@ def run_cli_end_to_end(ctx):
                                  # the reference's own loop -- one blocking compute_one per pair -- and the same loop on
                                  # compute_one_deferred + collect (two pairs in flight): what a reference-style caller gets end to end
                                  ("loop_reference", ["--loop", "reference"]), ("loop_deferred", ["--loop", "deferred"])):
-                t0 = time.perf_counter()
-                r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, timeout=300)
-                wall = time.perf_counter() - t0
-                m = re.search(r"Processed: (\d+) .*?\((\d+) fps\)", r.stderr)
+                # `default` is the STEADY rate with the clip in the page cache: the passes right after the clip was written run at a
+                # third to a half of the later ones, and for how many passes differs from box to box and run to run (1-2 of 5 in
+                # tools-free probes: [2970, 4063, 7529, 7492, 7566]) -- the leg repeats until two consecutive passes agree within
+                # 10 % (at most 6) and lists every pass
+                passes = []
+                for attempt in range(6 if label == "default" else 1):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, timeout=300)
+                    wall = time.perf_counter() - t0
+                    m = re.search(r"Processed: (\d+) .*?\((\d+) fps\)", r.stderr)
+                    passes.append(int(m.group(2)) if m else None)
+                    if r.returncode != 0 or passes[-1] is None or (len(passes) >= 2 and passes[-2] and abs(passes[-1] - passes[-2]) <= 0.1 * passes[-2]):
+                        break
                 lines = sum(1 for l in r.stdout.splitlines() if l.startswith("{"))
-                res[label] = {"rc": r.returncode, "pairs_per_s": int(m.group(2)) if m else None, "process_wall_s": round(wall, 2), "score_lines": lines,
-                              "args": " ".join(extra) or "(CLI defaults)"}
+                res[label] = {"rc": r.returncode, "pairs_per_s": passes[-1], "process_wall_s": round(wall, 2), "score_lines": lines,
+                              "args": " ".join(extra) or "(CLI defaults)", **({"passes": passes} if len(passes) > 1 else {})}
             out[tag] = res
         except Exception as ex:  # the leg is informative: never take the headline down with it
             out[tag] = {"error": repr(ex)[:200]}
