@@ -874,7 +874,6 @@ def run_rank(args):
             longer = run_fixed_stream(ctx, eng, head_name, B, distinct, STREAM_PAIRS_LONG)
             if fixed is not None and longer is not None:
                 fixed["long"] = {k: longer[k] for k in ("total_pairs", "seconds_first_submit_to_scores_on_rank0", "value", "pairs_per_rank", "scores_periodic_bit_identical", "scores_sha256_16")}
-    eng.close()
     # The legs below describe the machine around the headline (other workloads, PCIe, call granularity, the CLI): a failure in one of
     # them -- a box out of memory, no room in tmpfs -- is recorded on the line and never takes the headline down with it.
     workloads, host_fed, leg_errors = {}, None, {}
@@ -890,6 +889,14 @@ def run_rank(args):
                 pass
             return None
 
+    # The CLI leg runs FIRST, while the headline engine is still alive: every engine closed before it returns tens of GB to the driver, and
+    # this driver clears freed device memory in the background with the copy engines the CLI's uploads need -- behind the four big
+    # engines of the other workloads the CLI ran at half its rate for four passes and more (3.9 k instead of 7.8 k pairs/s at 1080p;
+    # profiles/r05u_cli_after_frees.log), behind nothing it is at its rate from the second pass on.
+    cli = None
+    if extras and ctx.world == 1 and head_name == "1080p_nv12" and not args.no_cli:
+        cli = leg("cli_end_to_end", lambda: run_cli_end_to_end(ctx))
+    eng.close()
     if extras:
         # the same K, W and settling as the headline: a 10-step run after 150 ms of settling differed by 13 % from box to box (r04)
         ks, kw = max(2, args.steps), args.warmup
@@ -906,11 +913,9 @@ def run_rank(args):
                 got = leg("host_fed_" + wl, lambda: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, max(ks, 40), min(kw, 2)))
                 if got is not None:
                     host_fed[wl] = got
-    batch_curve = cli = None
+    batch_curve = None
     if extras and ctx.world == 1 and head_name == "1080p_nv12":
         batch_curve = leg("batch_curve", lambda: run_batch_curve(ctx, args, head_name, B, res))
-        if not args.no_cli:
-            cli = leg("cli_end_to_end", lambda: run_cli_end_to_end(ctx))
     if ctx.rank == 0:
         out = {
             "metric": "ssimulacra2_frame_pairs_per_sec" if "ssimulacra2" in mets else "frame_pairs_per_sec",
