@@ -889,10 +889,11 @@ def run_rank(args):
                 pass
             return None
 
-    # The CLI leg runs FIRST, while the headline engine is still alive: every engine closed before it returns tens of GB to the driver, and
-    # this driver clears freed device memory in the background with the copy engines the CLI's uploads need -- behind the four big
-    # engines of the other workloads the CLI ran at half its rate for four passes and more (3.9 k instead of 7.8 k pairs/s at 1080p;
-    # profiles/r05u_cli_after_frees.log), behind nothing it is at its rate from the second pass on.
+    # The CLI leg runs FIRST, while the headline engine is still alive.  Behind the other legs -- four engines of 31 ... 46 GB created and
+    # closed by THIS process, the host-fed engines, the batch curve's -- the CLI child ran at half its rate for four passes and more
+    # (3.9 k instead of 7.8 k pairs/s at 1080p); with one engine closed before it, for one or two passes; with nothing closed before it,
+    # from the second pass on it is at its rate (three runs: 7.2-7.9 k).  The mechanism is not established: inside one process neither
+    # the device's copy rate nor its H2D rate moves after freeing 46 or 150 GB (profiles/r05u_cli_after_frees.log holds both probes).
     cli = None
     if extras and ctx.world == 1 and head_name == "1080p_nv12" and not args.no_cli:
         cli = leg("cli_end_to_end", lambda: run_cli_end_to_end(ctx))
