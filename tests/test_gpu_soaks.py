@@ -39,3 +39,11 @@ def test_deferred_api_under_repetition():
 
 def test_one_engine_through_random_state_changes():
     assert "mismatches 0" in _tool("engine_state_soak.py", 1500, 333, 203)
+
+
+def test_ssim_kernels_against_the_float64_twin_on_random_sizes():
+    assert "mismatches 0" in _tool("ssim_twin_sweep_soak.py", 16, 500)
+
+
+def test_rgb_frames_with_random_pitches():
+    assert "mismatches 0" in _tool("rgb_pitch_sweep_soak.py", 120)
