@@ -185,11 +185,7 @@ class Ctx:
 
     def min_max_over_ranks(self, x):
         """[min, max] of a per-rank figure: a straggler shows on the one line the driver keeps"""
-        if self.dist is None:
-            return [x, x]
-        t = self.torch.tensor([x, -x], dtype=self.torch.float64, device=self.cdev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return [-float(t[1].item()), float(t[0].item())]
+        return self.tm.shard.min_max_over_ranks(x, self.dist, self.cdev)
 
     def surfaces(self, name, distinct, pinned=False):
         """`distinct` synthetic pairs of the workload (the same on every rank: pair i of a stream has content i % distinct),

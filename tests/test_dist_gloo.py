@@ -38,9 +38,10 @@ def _worker(rank, world, port, n_frames, q):
     lo, hi = tm.shard.shard_range(n_frames, rank, world)
     local = [_score_frame(n) for n in range(lo, hi)]
     out = tm.shard.reduce_scores(local, lo, n_frames, n_metrics=2, dist=dist)
+    span = tm.shard.min_max_over_ranks(100.0 + 7.0 * rank, dist)  # bench.py's per_rank: [slowest, fastest]
     dist.barrier()
     if rank == 0:
-        q.put(out)
+        q.put((out, span))
     dist.destroy_process_group()
 
 
@@ -53,7 +54,8 @@ def test_two_rank_shard_and_reduce_matches_single_process(n_frames):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got, span = q.get(timeout=120)
+    assert span == [100.0, 107.0]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -65,6 +67,7 @@ def test_two_rank_shard_and_reduce_matches_single_process(n_frames):
 def test_shard_ranges_cover_the_stream():
     sys.path.insert(0, ROOT)
     from tm_pkg import tm
+    assert tm.shard.min_max_over_ranks(3.5) == [3.5, 3.5]  # no process group: one rank
     for n in (0, 1, 7, 8, 2048):
         for world in (1, 2, 4, 8):
             blocks = [tm.shard.shard_range(n, r, world) for r in range(world)]

@@ -32,3 +32,14 @@ def reduce_scores(local_scores: Sequence[float], lo: int, n_frames: int, n_metri
     if dist.get_rank() == 0:
         return t.cpu().numpy().reshape(n_frames, n_metrics)
     return None
+
+
+def min_max_over_ranks(x: float, dist=None, device="cpu"):
+    """[min, max] over the ranks of a per-rank figure (one all_reduce(MAX) of (x, -x)): bench.py's `per_rank`, which makes a
+    straggler visible on the one line the driver keeps.  dist = torch.distributed (initialised) or None."""
+    if dist is None:
+        return [float(x), float(x)]
+    import torch
+    t = torch.tensor([x, -x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [-float(t[1].item()), float(t[0].item())]
