@@ -4,9 +4,9 @@ hipMemGetInfo) -- no torch in the process, so no caching allocator between the m
 torch.cuda.mem_get_info before and after while torch still held the test's device tensors in its cache: its "leak MiB 412.0").
 200 cycles over several sizes, metric masks and batch sizes, every cycle with the fused kernel's side stream and hand-off buffers,
 every fourth with a second engine alive at the same time; must end within 16 MiB of where it stood after the first cycle (the first
-engine leaves the runtime's own pools and code objects behind).  usage: soak_create_destroy.py [cycles]"""
+engine leaves the runtime's own pools and code objects behind).  usage: create_destroy_soak.py [cycles]"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np
 from tm_pkg import tm
 assert "torch" not in sys.modules or os.environ.get("TM_SOAK_ALLOW_TORCH"), "this probe must run without torch in the process"

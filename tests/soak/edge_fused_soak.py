@@ -3,7 +3,7 @@
 hand-off tags, tickets from zero, the side stream forked and joined), alternating with two-pass launches and with engines created
 and destroyed in between; every launch must return the sums of the first one, bit for bit, and no hand-off wait may time out."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from tm_pkg import tm
@@ -40,7 +40,7 @@ for rnd, (w, h, B, steps) in enumerate([(1920, 1080, 64, 1500), (1920, 1080, 8, 
     assert bad == 0
 # the device tensors of the last round are still referenced and torch keeps freed blocks in its caching allocator: release both before
 # looking (round 3 printed "leak MiB 412.0" here -- that was torch's cache; the engines' own memory is checked without torch in the
-# process by tools/soak_create_destroy.py)
+# process by tests/soak/create_destroy_soak.py)
 del pairs, rt, dt, eng
 torch.cuda.synchronize(); torch.cuda.empty_cache()
 free1 = torch.cuda.mem_get_info()[0]

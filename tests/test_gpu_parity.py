@@ -1144,6 +1144,30 @@ def test_compute_one_deferred_gives_compute_ones_scores_with_two_pairs_in_flight
     batched.close(); eng.close()
 
 
+def test_a_setting_changed_between_submit_and_collect_keeps_the_pairs_in_flight():
+    """tm_engine_set_full_sums drops the engine's results, so a setter that ran before the deferred pairs were retired lost
+    their scores and wedged every later collect.  Setters retire first: a pair in flight is scored under the settings it was submitted
+    with, and the engines then take the new one."""
+    w, h = 416, 240
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=1)
+    frames = [nv12_frames(w, h, 20 + i) for i in range(4)]
+    want = [eng.compute_one(fr, fd) for fr, fd in frames]
+    t0, t1 = eng.compute_one_deferred(*frames[0]), eng.compute_one_deferred(*frames[1])
+    eng.set_full_sums(True)  # both engines have a pair in flight
+    assert eng.collect(t0) == want[0] and eng.collect(t1) == want[1]
+    t2 = eng.compute_one_deferred(*frames[2])
+    eng.set_channel_mode(True)  # the pair in flight is scored pooled, the next one from channel 0
+    t3 = eng.compute_one_deferred(*frames[3])
+    assert eng.collect(t2) == want[2]
+    got3 = eng.collect(t3)
+    assert got3.ssimulacra2 == want[3].ssimulacra2 and got3.psnr != want[3].psnr
+    t = eng.compute_one_deferred(*frames[0])
+    eng.set_full_sums(False); eng.set_channel_mode(False)
+    assert eng.collect(t).ssimulacra2 == want[0].ssimulacra2
+    assert eng.compute_one(*frames[1]) == want[1]
+    eng.close()
+
+
 def test_the_first_launch_after_switching_to_the_reference_pipeline_is_correct():
     """Round 5 (found by tests/soak/variant_sweep_soak.py): TM_VARIANT_REFERENCE allocates its linear pyramid and transposed XYB copy when it
     is first selected; their zero fill ran on the null stream and could still be running when the first launch's kernels -- on the engine's

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """GPU box: A/B of two builds of libturbometrics_hip.so (the shipped one against a lab build from `make -C turbo-metrics_amd/csrc ab
 EXPFLAGS=... EXPNAME=...`).  Each arm runs in a process of its own (TM_HIP_LIB), the arms alternate A B A B ..., every run = one
-engine, 64 1080p NV12 pairs per step (or 24 4K P016), 32 distinct pairs, 400 ms of settling, 60 timed steps with stage events.
+engine, bench.py's pairs per step (bench.WORKLOADS: 128 1080p NV12 / 48 4K P016; --batch B overrides), 32 distinct pairs, 400 ms of
+settling, 60 timed steps with stage events.
 Reports per arm: step ms, pairs/s, stage ms [ingest, col, row, edge, finish] and the scores' checksum (the arms must agree).
 
-    python tools/lib_ab.py A=turbo-metrics_amd/libturbometrics_hip.so B=build_exp/libtm_x.so [--rounds 3] [--workload 4k_p016]
+    python tools/lib_ab.py A=turbo-metrics_amd/libturbometrics_hip.so B=build_exp/libtm_x.so [--rounds 3] [--workload 4k_p016] [--batch B]
 """
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +16,8 @@ sys.path.insert(0, %(root)r)
 import numpy as np, torch
 from tm_pkg import tm
 wl = %(wl)r
-w, h, B, gen, mk = (1920, 1080, 64, tm.synth.nv12_pair, tm.HwFrame.nv12) if wl == "1080p_nv12" else (3840, 2160, 24, tm.synth.p016_pair, tm.HwFrame.p016)
+w, h, gen, mk = (1920, 1080, tm.synth.nv12_pair, tm.HwFrame.nv12) if wl == "1080p_nv12" else (3840, 2160, tm.synth.p016_pair, tm.HwFrame.p016)
+B = %(batch)d
 tm.init_hip(0)
 ND = 32 if wl == "1080p_nv12" else 2
 from concurrent.futures import ThreadPoolExecutor
@@ -45,11 +47,14 @@ def main():
     arms = [a.split("=", 1) for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
     rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 3
     wl = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "1080p_nv12"
+    sys.path.insert(0, ROOT)
+    import bench  # the pairs per step of the committed bench and PMC figures
+    batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else bench.WORKLOADS[wl][3]
     res = {name: [] for name, _ in arms}
     for r in range(rounds):
         for name, lib in arms:
             env = dict(os.environ, TM_HIP_LIB=os.path.join(ROOT, lib))
-            p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "wl": wl}], capture_output=True, text=True, env=env, timeout=600)
+            p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "wl": wl, "batch": batch}], capture_output=True, text=True, env=env, timeout=600)
             if p.returncode != 0:
                 print(name, "FAILED", p.stderr[-800:])
                 continue

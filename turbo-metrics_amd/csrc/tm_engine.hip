@@ -1159,8 +1159,11 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
             HIPCHK(hipStreamSynchronize(st));
             if (e->stream2) HIPCHK(hipStreamSynchronize(e->stream2));
             HIPCHK(hipMemcpy(&e->ef_epoch_host, e->d_epoch, sizeof(unsigned), hipMemcpyDeviceToHost));
+            // the failed launch may have run k_blur_edge_fused without k_finish_edge: the device epoch then still reads E while words
+            // tagged E are already in HS, and the next launch -- tag E again -- would accept them without waiting: clear them
+            if (e->HS) HIPCHK(hipMemsetAsync(e->HS, 0, e->hs_elems * sizeof(unsigned long long), st));
         }
-        if (e->ef_epoch_host == 1u && e->HS) HIPCHK(hipMemsetAsync(e->HS, 0, e->hs_elems * sizeof(unsigned long long), st));
+        else if (e->ef_epoch_host == 1u && e->HS) HIPCHK(hipMemsetAsync(e->HS, 0, e->hs_elems * sizeof(unsigned long long), st));
         e->ef_epoch_unknown = true; // until this launch has been enqueued in full (any early return below leaves it set)
         fused_launch = true;
     }

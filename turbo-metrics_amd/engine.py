@@ -168,7 +168,7 @@ class TurboMetrics:
         d = getattr(self, "_def", None)
         if d is not None:
             self._def = None
-            d["ring"][1].close()
+            d["peer"].close()
         if getattr(self, "_h", None):
             self._L.tm_engine_destroy(self._h)
             self._h = None
@@ -290,11 +290,11 @@ class TurboMetrics:
         self._settings[name] = args
         d = getattr(self, "_def", None)
         if d is not None:
-            self._retire_deferred()
-            getattr(d["ring"][1], name)(*args)
+            getattr(d["peer"], name)(*args)
 
     def set_channel_mode(self, first_channel_only: bool):
         """PSNR / SSIM / MS-SSIM from channel 0 only instead of pooled / averaged over R, G, B (see the header)"""
+        self._retire_deferred()  # a pair in flight is scored with the mode it was submitted under (ADVICE r05)
         _chk(self._L.tm_engine_set_channel_mode(self._h, ffi.TM_CHANNELS_FIRST if first_channel_only else ffi.TM_CHANNELS_POOLED), "tm_engine_set_channel_mode")
         self._peer_follows("set_channel_mode", first_channel_only)
 
@@ -302,10 +302,10 @@ class TurboMetrics:
         """finish the pairs in flight for compute_one_deferred and keep their scores for collect()"""
         d = getattr(self, "_def", None)
         if d is not None:
-            for i in range(2):
-                if d["pending"][i] is not None:
-                    d["ring"][i].sync()
-                    d["done"][d["pending"][i]] = d["ring"][i].scores(0)
+            for i, e in enumerate((self, d["peer"])):  # (no reference to self inside _def: an engine dropped without close() must
+                if d["pending"][i] is not None:            # not wait for the cyclic collector with two engines' worth of HBM)
+                    e.sync()
+                    d["done"][d["pending"][i]] = e.scores(0)
                     d["pending"][i] = None
 
     def compute_one(self, fref: HwFrame, fdis: HwFrame) -> FrameScores:
@@ -327,12 +327,12 @@ class TurboMetrics:
             peer = TurboMetrics(self.width, self.height, self._metrics, batch=1)
             for name, args in getattr(self, "_settings", {}).items():  # channel mode, full sums, variant, graph: as set on this engine
                 getattr(peer, name)(*args)
-            self._def = {"ring": [self, peer], "pending": [None, None], "done": {}, "next": 0}
+            self._def = {"peer": peer, "pending": [None, None], "done": {}, "next": 0}
         d = self._def
         ticket = d["next"]
         d["next"] += 1
         i = ticket & 1
-        e = d["ring"][i]
+        e = (self, d["peer"])[i]
         if d["pending"][i] is not None:
             e.sync()
             d["done"][d["pending"][i]] = e.scores(0)
@@ -346,9 +346,10 @@ class TurboMetrics:
         if d is not None:
             for i in range(2):
                 if d["pending"][i] == ticket:
+                    e = (self, d["peer"])[i]
                     d["pending"][i] = None
-                    d["ring"][i].sync()
-                    return d["ring"][i].scores(0)
+                    e.sync()
+                    return e.scores(0)
             if ticket in d["done"]:
                 return d["done"].pop(ticket)
         raise TmError(ffi.TM_ERR_INVALID_ARG, "collect: no such ticket (never issued, or collected already)")
@@ -397,6 +398,7 @@ class TurboMetrics:
         return list(ms), int(n.value)
 
     def set_full_sums(self, on: bool):
+        self._retire_deferred()  # tm_engine_set_full_sums drops the engine's results: collect the pair in flight first
         _chk(self._L.tm_engine_set_full_sums(self._h, int(bool(on))), "tm_engine_set_full_sums")
         self._peer_follows("set_full_sums", on)
 
@@ -428,10 +430,12 @@ class TurboMetrics:
         _chk(self._L.tm_engine_debug_set_edge_epoch(self._h, int(epoch)), "tm_engine_debug_set_edge_epoch")
 
     def set_graph(self, on: bool):
+        self._retire_deferred()
         _chk(self._L.tm_engine_set_graph(self._h, int(bool(on))), "tm_engine_set_graph")
         self._peer_follows("set_graph", on)
 
     def set_variant(self, v: int):
+        self._retire_deferred()
         _chk(self._L.tm_engine_set_variant(self._h, int(v)), "tm_engine_set_variant")
         self._peer_follows("set_variant", v)
 

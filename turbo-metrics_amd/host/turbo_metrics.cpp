@@ -202,6 +202,7 @@ size_t TurboMetrics::mem_usage() const
 
 void TurboMetrics::debug_set_param(int param, long long value)
 {
+    retire_deferred(); // a setting never changes under a pair in flight: its scores are collected first
     debug_params_.emplace_back(param, value);
     for (tm_engine *e : eng_)
         if (e) chk(tm_engine_debug_set_param(e, param, value), "tm_engine_debug_set_param");
@@ -209,6 +210,7 @@ void TurboMetrics::debug_set_param(int param, long long value)
 
 void TurboMetrics::set_full_sums(bool on)
 {
+    retire_deferred(); // tm_engine_set_full_sums drops the engine's results: a pair in flight keeps its scores for collect()
     full_sums_ = on; // (an engine created later -- compute_one_deferred's second one -- starts with it)
     for (tm_engine *e : eng_)
         if (e) chk(tm_engine_set_full_sums(e, on ? 1 : 0), "tm_engine_set_full_sums");
@@ -275,8 +277,11 @@ FrameScores TurboMetrics::compute_one(const HwFrame &fref, const ColorInfo &cref
 
 uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis)
 {
+    // the one-pair-per-call path, as in the Python mirror: on a batched object the lazily created second engine would cost a whole
+    // batch of device memory for one-pair launches
+    if (batch_ != 1) throw TmError(TM_ERR_INVALID_ARG, "compute_one_deferred: create the TurboMetrics object with batch = 1");
     if (!eng_[1]) { // the second engine the two launches take turns on
-        chk(tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), batch_), "tm_engine_create (second engine of compute_one_deferred)");
+        chk(tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), 1), "tm_engine_create (second engine of compute_one_deferred)");
         (void)tm_engine_set_linear_upload(eng_[1], 1);
         if (full_sums_) chk(tm_engine_set_full_sums(eng_[1], 1), "tm_engine_set_full_sums");
         for (const auto &kv : debug_params_) (void)tm_engine_debug_set_param(eng_[1], kv.first, kv.second);

@@ -221,6 +221,8 @@ public:
     // submitting pair k+1 keeps the device busy while it fetches / decodes the next frames, which is worth 1.6 x at one 1080p pair
     // per call (2.9 k -> 4.8 k pairs/s).  A third submission first finishes the oldest pair and keeps its scores until collected.
     // Frames: host memory is read before the call returns unless `pinned` (then until collect(ticket)); device memory until collect.
+    // Needs an object created with batch = 1 (throws TmError(TM_ERR_INVALID_ARG) otherwise, like the Python mirror): the second engine has one slot.
+    // A setting changed while pairs are in flight (set_full_sums, debug_set_param) first finishes them and keeps their scores for collect.
     // Scores are bit-identical with compute_one's.  Tickets are collected at most once, in any order; compute_one and compute_all
     // may be called in between (they first finish what is in flight and keep those scores for collect).
     uint64_t compute_one_deferred(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis);
