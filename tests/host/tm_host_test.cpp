@@ -12,6 +12,9 @@
 #include "../../turbo-metrics_amd/host/video_input.hpp"
 #include "../../turbo-metrics_amd/host/output.hpp"
 #include "../../turbo-metrics_amd/host/rust_fmt.hpp"
+#include "../../turbo-metrics_amd/host/ranks.hpp"
+#include <thread>
+#include <unistd.h>
 
 using namespace tm_host;
 
@@ -156,6 +159,42 @@ int main(int argc, char **argv)
             const ColorCharacteristics c = ColorCharacteristics::from_codes(atoi(argv[2]), atoi(argv[3]), atoi(argv[4])).or_(color_characteristics_fallback(atoi(argv[5])));
             std::cout << to_string(c.cp) << " " << to_string(c.mc) << " " << to_string(c.tc) << " ";
             std::cout << get_color_matrix(c) << " " << get_transfer(c) << "\n";
+        } else if (cmd == "ranks") {
+            // ranks WORLD N_INDICES EVERY [FAIL_RANK [HANG_RANK]]: the launcher and the pipe transport of `turbo-metrics --ranks N` without a GPU --
+            // this program starts WORLD copies of itself; rank r "scores" the selected decode indices of shard_range(r) with made-up values,
+            // ONE reduce brings them to rank 0, which prints them in decode order (hex floats).  FAIL_RANK exits with code 3 before the
+            // reduce, HANG_RANK never gets there (the launcher must end it).
+            const int world = atoi(argv[2]);
+            const uint32_t total = (uint32_t)atoi(argv[3]), every = (uint32_t)atoi(argv[4]);
+            const int fail_rank = argc > 5 ? atoi(argv[5]) : -1, hang_rank = argc > 6 ? atoi(argv[6]) : -1;
+            RankEnv env;
+            if (!rank_env(env)) return launch_ranks(argv, world, 60.0);
+            if (env.rank == fail_rank) return 3;
+            if (env.rank == hang_rank) { for (;;) std::this_thread::sleep_for(std::chrono::seconds(1)); }
+            Metrics m; m.psnr = true; m.ssimulacra2 = true;
+            ScoreVector sv(m, total);
+            uint32_t lo = 0, hi = 0;
+            shard_range(total, (uint32_t)env.rank, (uint32_t)env.world, lo, hi);
+            for (uint32_t dc = lo; dc < hi; ++dc) {
+                if (every > 1 && dc != 0 && dc % every != 0) continue;
+                FrameScores f;
+                f.psnr = dc == 5 ? INFINITY : 30.0 + 0.1 * dc;
+                f.ssimulacra2 = 100.0 / (1.0 + dc) - 7.0;
+                sv.put(dc, f);
+            }
+            sv.add_decoded(hi - lo);
+            auto tr = make_rank_transport(env, "pipe");
+            tr->reduce_sum_to_root(sv.v);
+            if (env.rank == 0) {
+                std::cout << "lo " << lo << " hi " << hi << " decoded " << sv.decoded() << " " << tr->name() << "\n";
+                for (const FrameScores &f : sv.frames()) printf("%a %a\n", *f.psnr, *f.ssimulacra2);
+            } else std::cout << "rank " << env.rank << " must not be heard on stdout\n";
+        } else if (cmd == "shard") { // shard N WORLD -> "lo hi" per rank
+            for (uint32_t r = 0; r < (uint32_t)atoi(argv[3]); ++r) {
+                uint32_t lo, hi;
+                shard_range((uint32_t)atoi(argv[2]), r, (uint32_t)atoi(argv[3]), lo, hi);
+                std::cout << lo << " " << hi << "\n";
+            }
         } else return 2;
     } catch (const std::exception &e) {
         std::cout << "ERROR: " << e.what() << "\n";

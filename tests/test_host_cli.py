@@ -27,12 +27,12 @@ CLI = os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")
 
 @pytest.fixture(scope="module")
 def helper():
-    srcs = [os.path.join(ROOT, "tests", "host", "tm_host_test.cpp")] + [os.path.join(HOST, f) for f in ("frame_sources.cpp", "video_input.cpp", "output.cpp", "turbo_metrics.cpp")]
+    srcs = [os.path.join(ROOT, "tests", "host", "tm_host_test.cpp")] + [os.path.join(HOST, f) for f in ("frame_sources.cpp", "video_input.cpp", "output.cpp", "turbo_metrics.cpp", "ranks.cpp")]
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
     if not os.path.exists(HELPER) or any(os.path.getmtime(d) > os.path.getmtime(HELPER) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++17"] + (["-fsanitize=thread", "-fno-omit-frame-pointer", "-g"] if TSAN else ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"] if SANITIZE else [])
                               + ["-o", HELPER] + srcs + ["-L" + os.path.join(ROOT, "turbo-metrics_amd"),
-                              "-lturbometrics_hip", "-lz", "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "turbo-metrics_amd")])
+                              "-lturbometrics_hip", "-lz", "-ldl", "-pthread", "-Wl,-rpath," + os.path.join(ROOT, "turbo-metrics_amd")])
     return HELPER
 
 
@@ -397,6 +397,40 @@ def test_corrupt_headers_end_in_errors_not_allocations(helper, tmp_path):
     assert run(helper, "source", y, str(tmp_path / "o.bin")).startswith("ERROR")
 
 
+# ---- `--ranks N` without a GPU: launcher, pipes, the one reduce --------------------------------------------------------
+def test_rank_launcher_and_pipe_reduce_bring_every_score_to_rank_zero(helper):
+    """host/ranks.cpp through the helper: N processes started by the launcher, contiguous blocks of the decode indices (the blocks of
+    shard.py::shard_range), one reduce over the launcher's pipes, rank 0 alone on stdout, every value exactly the one its rank produced."""
+    from tm_pkg import tm as _tm
+    for total, world in ((23, 1), (23, 2), (23, 3), (7, 8), (100, 5)):
+        got = [tuple(map(int, l.split())) for l in run(helper, "shard", total, world).strip().split("\n")]
+        assert got == [_tm.shard.shard_range(total, r, world) for r in range(world)]
+    for world, total, every in ((1, 9, 0), (2, 23, 0), (3, 23, 4), (5, 3, 0), (4, 40, 3)):
+        r = subprocess.run([helper, "ranks", str(world), str(total), str(every)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().split("\n")
+        lo, hi = _tm.shard.shard_range(total, 0, world)
+        assert lines[0] == f"lo {lo} hi {hi} decoded {total} pipe"
+        sel = [dc for dc in range(total) if not (every > 1 and dc != 0 and dc % every != 0)]
+        want = [(float("inf") if dc == 5 else 30.0 + 0.1 * dc, 100.0 / (1.0 + dc) - 7.0) for dc in sel]
+        got = [tuple(float.fromhex(t) for t in l.split()) for l in lines[1:]]
+        assert got == want  # bit for bit: every score was added to zeros only
+        assert "must not be heard" not in r.stdout
+
+
+def test_rank_launcher_ends_the_job_when_a_rank_fails(helper):
+    """launch.py's rules in C++: the first failing rank's exit code is the launcher's, and the ranks still running -- one of them
+    blocked for good -- are terminated by PID instead of being waited for."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([helper, "ranks", "4", "23", "0", "2", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "rank 2 of 4 failed (exit code 3)" in r.stderr
+    assert time.monotonic() - t0 < 30
+    # rank 0 gone: the others' writes fail instead of blocking
+    r = subprocess.run([helper, "ranks", "3", "200000", "0", "0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3
+
+
 # ---- the command line on the device ------------------------------------------------------------------------------------
 def cli(*args, stdin=None, env=None):
     r = subprocess.run([CLI] + [str(a) for a in args], input=stdin, capture_output=True, check=False, env=None if env is None else dict(os.environ, **env))
@@ -508,6 +542,48 @@ def test_cli_shards_the_stream_over_devices_with_identical_output(tmp_path):
     # a pipe has no length: one device, with a warning
     rc, out, err = cli("-", pd, "-m", "ssimulacra2", "--output", "csv", "--devices", 2, stdin=open(pr, "rb").read(), env=share)
     assert rc == 0 and "running on one device" in err and out == cli(pr, pd, "-m", "ssimulacra2", "--output", "csv")[1]
+
+
+@pytest.mark.gpu
+def test_cli_ranks_one_process_per_device_and_one_reduce_with_identical_output(tmp_path):
+    """--ranks N: the launcher starts N rank processes before any GPU call, rank r scores shard_range(r), ONE
+    reduce(sum, f64) of the zero-padded score vector brings everything to rank 0, whose stdout is byte-identical with the one-device
+    run.  On the 1-GPU test box: N ranks sharing the device over the pipe transport (RCCL refuses two ranks on one GPU), and a ONE-rank
+    communicator over RCCL itself (libturbometrics_rccl.so: ncclCommInitRank + ncclReduce on the device)."""
+    w, h, n, bits = 96, 64, 23, 8
+    pairs = [tm.synth.yuv420_pair(w, h, i, bits) for i in range(n)]
+    pr, pd = str(tmp_path / "r.y4m"), str(tmp_path / "d.y4m")
+    write_y4m(pr, [p[0] for p in pairs], w, h, bits)
+    write_y4m(pd, [p[1] for p in pairs], w, h, bits)
+    pipes = {"TM_SHARE_DEVICE": "1", "TM_RANK_TRANSPORT": "pipe", "TM_RANK_TIMEOUT_S": "300"}
+    for extra in ((), ("--every", 4), ("--skip", 3, "--frames", 11), ("--skip-ref", 2, "--every", 3, "--frames", 17), ("-m", "psnr", "-m", "ssim", "--batch", 2)):
+        for fmt in ("json", "json-lines", "csv", "default"):
+            one = cli(pr, pd, "-m", "ssimulacra2", "--output", fmt, "--batch", 4, *extra)
+            assert one[0] == 0, one[2]
+            for nr in (2, 3) if fmt in ("json", "csv") else (2,):
+                many = cli(pr, pd, "-m", "ssimulacra2", "--output", fmt, "--batch", 4, "--ranks", nr, *extra, env=pipes)
+                assert many[0] == 0, many[2]
+                assert many[1] == one[1], (extra, fmt, nr)
+                assert "on %d ranks (pipe)" % nr in many[2]
+    one = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--batch", 4)
+    # more ranks than frames: the tail ranks hold empty blocks
+    many = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--batch", 4, "--frames", 3, "--ranks", 5, env=pipes)
+    assert many[0] == 0 and many[1] == cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--batch", 4, "--frames", 3)[1]
+    # RCCL: a one-rank communicator on the device (everything but the second GPU)
+    rccl = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--batch", 4, "--ranks", 1, env={"TM_RANK_TRANSPORT": "rccl", "TM_RANK_TIMEOUT_S": "300"})
+    assert rccl[0] == 0, rccl[2]
+    assert rccl[1] == one[1] and "on 1 ranks (rccl)" in rccl[2]
+    # without sharing, more ranks than GPUs is an error of every rank and of the launcher
+    import torch
+    rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--ranks", torch.cuda.device_count() + 1, env={"TM_RANK_TRANSPORT": "pipe", "TM_RANK_TIMEOUT_S": "120"})
+    assert rc != 0 and "GPU(s) visible" in err and out == ""
+    # a failing rank ends the job: an unreadable distorted file
+    rc, out, err = cli(pr, str(tmp_path / "missing.y4m"), "-m", "ssimulacra2", "--ranks", 2, env=pipes)
+    assert rc != 0 and "failed" in err
+    rc, _, err = cli("-", pd, "-m", "ssimulacra2", "--ranks", 2, stdin=open(pr, "rb").read(), env=pipes)
+    assert rc == 1 and "not stdin" in err
+    rc, _, err = cli(pr, pd, "-m", "ssimulacra2", "--ranks", 2, "--devices", 2, env=pipes)
+    assert rc == 1 and "exclude each other" in err
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 // main.cpp -- `turbo-metrics`: the command line of the reference (crates/turbo-metrics-cli/src/main.rs:31-356) over the
 // MI355X engine.  Same positional arguments, same flags (-m/--metrics, --every, --skip, --skip-ref, --skip-dis, --frames,
 // --output), same stdout formats (output.cpp), status on stderr, ExitCode::FAILURE on the same conditions.
-// Additions (no counterpart in the reference, all optional): --batch, --device, --devices, --no-pipeline, --full-sums, and the
+// Additions (no counterpart in the reference, all optional): --batch, --device, --devices, --ranks, --no-pipeline, --full-sums, and the
 // description of headerless YUV input (--width, --height, --bits, --color-primaries, --matrix-coefficients,
 // --transfer-characteristics, --full-range).
 #include <algorithm>
@@ -15,6 +15,7 @@
 
 #include "frame_sources.hpp"
 #include "output.hpp"
+#include "ranks.hpp"
 #include "turbo_metrics.hpp"
 
 using namespace tm_host;
@@ -51,6 +52,8 @@ void usage(std::ostream &os)
           "      --batch <N>            frame pairs per GPU launch [default: by picture size, 16 at 1080p, 4 at 4K]\n"
           "      --device <N>           GPU ordinal [default: 0]\n"
           "      --devices <N>          shard the frame pairs of two regular files over N GPUs (0 = all visible) [default: 1]\n"
+          "      --ranks <N>            the same shards as N processes, one per GPU, scores gathered by ONE RCCL reduce to rank 0\n"
+          "                             (TM_RANK_TRANSPORT=pipe: over pipes instead; TM_RANK_TIMEOUT_S: give up after that many seconds)\n"
           "      --no-pipeline          do not overlap reading/upload of the next batch with the current one\n"
           "      --loop <MODE>          batched (default: compute_all), reference (the reference's loop: one blocking compute_one per pair),\n"
           "                             deferred (that loop with compute_one_deferred + collect: two pairs in flight)\n"
@@ -119,7 +122,7 @@ int main(int argc, char **argv)
     Options opts;
     Output output = Output::Default;
     SourceHints hints;
-    uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1;
+    uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1, ranks = 0 /* 0: not asked for */;
     bool pipeline = true, full_sums = false;
     enum class Loop { Batched, Reference, Deferred } loop = Loop::Batched;
     std::vector<std::pair<int, long long>> tune;
@@ -169,6 +172,7 @@ int main(int argc, char **argv)
         } else if (a == "--batch") { if (!u32(batch) || batch == 0) return bad("invalid value for '--batch <N>'"); }
         else if (a == "--device") { if (!u32(device)) return bad("invalid value for '--device <N>'"); }
         else if (a == "--devices") { if (!u32(devices)) return bad("invalid value for '--devices <N>'"); }
+        else if (a == "--ranks") { if (!u32(ranks) || ranks == 0 || ranks > 64) return bad("invalid value for '--ranks <N>'"); }
         else if (a == "--no-pipeline") pipeline = false;
         else if (a == "--loop") {
             std::string s;
@@ -200,6 +204,24 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
 
+    // ---- --ranks N: one process per GPU and ONE RCCL reduce of the per-frame scores (ranks.hpp).  This process is either the launcher
+    // (it makes no GPU call: it starts the N ranks and waits for them) or, with TM_RANK in the environment, one of the ranks.
+    RankEnv renv;
+    bool is_rank = false;
+    try { is_rank = rank_env(renv); }
+    catch (const std::exception &e) { log_line(L_ERROR, kTarget, std::string("Could not join the ranks : ") + e.what()); return EXIT_FAILURE; }
+    if (ranks > 0 && !is_rank) {
+        if (ref_is_stdin || dis_is_stdin) { log_line(L_ERROR, kTarget, "--ranks needs two regular planar-YUV files of known length, not stdin"); return EXIT_FAILURE; }
+        if (loop != Loop::Batched) { log_line(L_ERROR, kTarget, "--loop reference / deferred run on one device: not with --ranks"); return EXIT_FAILURE; }
+        if (devices != 1) { log_line(L_ERROR, kTarget, "--ranks (one process per GPU) and --devices (one process, N GPUs) exclude each other"); return EXIT_FAILURE; }
+        if (metrics.mask() == 0) { log_line(L_ERROR, kTarget, "Could not initialize engine : no metric selected (-m psnr|ssim|msssim|ssimulacra2)"); return EXIT_FAILURE; }
+        const char *to = getenv("TM_RANK_TIMEOUT_S");
+        std::cout.flush();
+        return launch_ranks(argv, (int)ranks, to ? atof(to) : 0.0);
+    }
+    if (is_rank && (ranks == 0 || (int)ranks != renv.world)) { log_line(L_ERROR, kTarget, "TM_RANK is set but --ranks does not match TM_WORLD"); return EXIT_FAILURE; }
+    if (is_rank && renv.rank != 0 && g_level > L_WARN && !getenv("RUST_LOG")) g_level = L_WARN; // rank 0 tells the story once
+
     // The reference initialises the device first because its frame sources decode on it (main.rs:138-139).  Here the sources
     // come first: a compressed-video source starts its decoder as a child process, and that must happen before this process
     // has touched the GPU runtime (a source only page-locks memory when its first frame is asked for, after init_hip).
@@ -221,11 +243,101 @@ int main(int argc, char **argv)
         log_line(L_ERROR, kTarget, "Reference and distorted are not the same size");
         return EXIT_FAILURE;
     }
+    if (is_rank) { // rank r works on device (device + r); TM_SHARE_DEVICE=1 (tests on a 1-GPU box) lets the ranks share what is visible
+        const int visible = std::max(1, tm_device_count());
+        const bool share = getenv("TM_SHARE_DEVICE") && atoi(getenv("TM_SHARE_DEVICE")) != 0;
+        if (!share && renv.world > visible) {
+            if (renv.rank == 0) log_line(L_ERROR, kTarget, "--ranks " + std::to_string(renv.world) + " but only " + std::to_string(visible) + " GPU(s) visible");
+            return EXIT_FAILURE;
+        }
+        device = (device + (uint32_t)renv.rank) % (uint32_t)visible;
+    }
     try {
         init_hip((int)device);
     } catch (const std::exception &e) {
         log_line(L_ERROR, kTarget, std::string("Could not initialize the GPU : ") + e.what());
         return EXIT_FAILURE;
+    }
+
+    // One block of decode indices [lo, hi) on the device this thread is bound to: its own sources (opened on the same files), its own
+    // engines, the reference's selection loop (lib.rs:385-404) with decode_start = lo.  Shared by --devices (a thread per device) and
+    // --ranks (a process per device).
+    struct Block { std::vector<FrameScores> scores; uint32_t decoded = 0; };
+    const auto score_block = [&](uint32_t w, uint32_t h, uint32_t lo, uint32_t hi, Block &out) {
+        if (lo >= hi) return;
+        auto sr = create_source(pos[0], hints), sd = create_source(pos[1], hints);
+        const uint32_t b = std::min(batch, hi - lo);
+        TurboMetrics tmx(w, h, metrics, b, pipeline && hi - lo > b);
+        if (full_sums) tmx.set_full_sums(true);
+        for (auto &t : tune) if (t.first < 100) tmx.debug_set_param(t.first, t.second);
+        Options o = opts;
+        o.decode_start = lo;
+        o.frames = hi; // absolute decode index at which this block stops (lib.rs:396-398)
+        uint32_t dc = lo;
+        try { tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { out.scores.push_back(fs); }, &dc); }
+        catch (const NoFramesSelected &) { dc = hi; } // a block in which `every` selects no frame is empty, not an error (any other exception is one)
+        out.decoded = dc - lo;
+    };
+    // what the one-device run prints behind the last per-frame line
+    const auto report = [&](const std::vector<FrameScores> &all, uint32_t decoded, uint32_t w, uint32_t h, std::chrono::steady_clock::time_point start, const std::string &where) -> int {
+        MetricsResults results;
+        try { results = aggregate_scores(all, metrics); }
+        catch (const std::exception &e) { std::cout.flush(); log_line(L_ERROR, kTarget, std::string("Computation failed : ") + e.what()); return EXIT_FAILURE; }
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start);
+        const long long dms = ms.count() > 0 ? ms.count() : 1;
+        const unsigned long long fps = (unsigned long long)results.frame_count * 1000ull / (unsigned long long)dms;
+        char perf_s[64];
+        snprintf(perf_s, sizeof perf_s, "%.3f", (double)w * (double)h * (double)results.frame_count / (double)dms / 1000.0);
+        log_line(L_INFO, kTarget, "Processed: " + std::to_string(results.frame_count) + " (decoded: ~" + std::to_string(decoded + opts.skip) +
+                                      ") frame pairs in " + format_duration(ms) + " (" + std::to_string(fps) + " fps) (Mpx/s: " + perf_s + ") on " + where);
+        output_results(output, results, std::cout);
+        std::cout.flush();
+        return EXIT_SUCCESS;
+    };
+
+    if (is_rank) {
+        const bool root = renv.rank == 0;
+        const size_t known = std::min(source_ref->frame_count(), source_dis->frame_count());
+        const uint32_t lead = opts.skip + std::max(opts.skip_ref, opts.skip_dis);
+        if (known == 0 || known <= lead || !source_ref->shardable() || !source_dis->shardable()) {
+            if (root) log_line(L_ERROR, kTarget, "--ranks needs two regular planar-YUV files of known length");
+            return EXIT_FAILURE;
+        }
+        uint32_t total = (uint32_t)(known - lead); // decode indices available
+        if (opts.frames > 0) total = std::min(total, opts.frames);
+        if (root) { log_source("reference", *source_ref); log_source("distorted", *source_dis); }
+        const uint32_t w = source_ref->width(), h = source_ref->height();
+        if (batch == 0) batch = auto_batch(w, h);
+        set_concurrent_streams(2 * (unsigned)renv.world); // the ranks' reader threads share the usable CPUs of the node
+        source_ref.reset(); source_dis.reset();
+        if (known < 20000) tm_set_placement_candidates(1);
+        try {
+            std::unique_ptr<RankTransport> transport = make_rank_transport(renv); // (RCCL: the communicator is set up while nothing else runs)
+            if (root) log_line(L_DEBUG, kTarget, std::string("ranks: ") + std::to_string(renv.world) + " over " + transport->name());
+            const auto start = std::chrono::steady_clock::now();
+            uint32_t lo = 0, hi = 0;
+            shard_range(total, (uint32_t)renv.rank, (uint32_t)renv.world, lo, hi);
+            Block blk;
+            score_block(w, h, lo, hi, blk);
+            ScoreVector sv(metrics, total);
+            size_t k = 0;
+            for (uint32_t dc = lo; dc < hi && k < blk.scores.size(); ++dc) {
+                if (opts.every > 1 && dc != 0 && dc % opts.every != 0) continue; // lib.rs:391-394
+                sv.put(dc, blk.scores[k++]);
+            }
+            if (k != blk.scores.size()) throw std::runtime_error("a block produced more scores than it has selected frames");
+            sv.add_decoded(blk.decoded);
+            transport->reduce_sum_to_root(sv.v); // the ONE collective of the path
+            if (!root) return EXIT_SUCCESS;
+            output_prepare(output, metrics, std::cout);
+            const std::vector<FrameScores> all = sv.frames();
+            for (const FrameScores &fs : all) output_single_score(output, fs, std::cout);
+            return report(all, sv.decoded(), w, h, start, std::to_string(renv.world) + " ranks (" + transport->name() + ")");
+        } catch (const std::exception &e) {
+            std::cout.flush();
+            log_line(L_ERROR, kTarget, "Computation failed (rank " + std::to_string(renv.rank) + ") : " + e.what());
+            return EXIT_FAILURE;
+        }
     }
 
     // ---- frame-pair sharding over several GPUs (the reference is single-GPU: device 0 hard-coded, lib.rs:442).
@@ -264,7 +376,7 @@ int main(int argc, char **argv)
             set_concurrent_streams(2 * want); // every shard reads its own pair of streams: the reader threads share the usable CPUs
             source_ref.reset(); source_dis.reset(); // every shard opens its own
             if (known < 20000) tm_set_placement_candidates(1); // as below: the search pays off on long streams only
-            struct Shard { std::vector<FrameScores> scores; uint32_t decoded = 0; std::string err; };
+            struct Shard { Block blk; std::string err; };
             std::vector<Shard> shards(want);
             const auto start = std::chrono::steady_clock::now();
             std::vector<std::thread> th;
@@ -275,18 +387,7 @@ int main(int argc, char **argv)
                         const uint32_t lo = std::min(total, r * per), hi = std::min(total, lo + per);
                         if (lo >= hi) return;
                         init_hip((int)((device + r) % (uint32_t)std::max(1, visible)));
-                        auto sr = create_source(pos[0], hints), sd = create_source(pos[1], hints);
-                        uint32_t b = std::min(batch, hi - lo);
-                        TurboMetrics tmx(w, h, metrics, b, pipeline && hi - lo > b);
-                        if (full_sums) tmx.set_full_sums(true);
-                        for (auto &t : tune) if (t.first < 100) tmx.debug_set_param(t.first, t.second);
-                        Options o = opts;
-                        o.decode_start = lo;
-                        o.frames = hi; // absolute decode index at which this shard stops (lib.rs:396-398)
-                        uint32_t dc = 0;
-                        tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { sh.scores.push_back(fs); }, &dc);
-                        sh.decoded = dc - lo;
-                    } catch (const NoFramesSelected &) { // a shard in which `every` selects no frame is empty, not an error (any other exception is one)
+                        score_block(w, h, lo, hi, sh.blk);
                     } catch (const std::exception &e) { sh.err = e.what(); }
                 });
             for (auto &t : th) t.join();
@@ -296,23 +397,10 @@ int main(int argc, char **argv)
             std::vector<FrameScores> all;
             uint32_t decoded = 0;
             for (const Shard &sh : shards) {
-                for (const FrameScores &fs : sh.scores) { output_single_score(output, fs, std::cout); all.push_back(fs); }
-                decoded += sh.decoded;
+                for (const FrameScores &fs : sh.blk.scores) { output_single_score(output, fs, std::cout); all.push_back(fs); }
+                decoded += sh.blk.decoded;
             }
-            MetricsResults results;
-            try { results = aggregate_scores(all, metrics); }
-            catch (const std::exception &e) { std::cout.flush(); log_line(L_ERROR, kTarget, std::string("Computation failed : ") + e.what()); return EXIT_FAILURE; }
-            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start);
-            const long long dms = ms.count() > 0 ? ms.count() : 1;
-            const unsigned long long fps = (unsigned long long)results.frame_count * 1000ull / (unsigned long long)dms;
-            char perf_s[64];
-            snprintf(perf_s, sizeof perf_s, "%.3f", (double)w * (double)h * (double)results.frame_count / (double)dms / 1000.0);
-            log_line(L_INFO, kTarget, "Processed: " + std::to_string(results.frame_count) + " (decoded: ~" + std::to_string(decoded + opts.skip) +
-                                          ") frame pairs in " + format_duration(ms) + " (" + std::to_string(fps) + " fps) (Mpx/s: " + perf_s + ") on " +
-                                          std::to_string(want) + " devices");
-            output_results(output, results, std::cout);
-            std::cout.flush();
-            return EXIT_SUCCESS;
+            return report(all, decoded, w, h, start, std::to_string(want) + " devices");
         }
     }
 
