@@ -56,7 +56,7 @@ class FrameDesc(C.Structure):
                 ("kind", C.c_int), ("matrix", C.c_int), ("shift", C.c_int), ("pad_", C.c_int)]
 
 
-KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 5, "i420_8": 6, "i420_16": 7}
+KIND = {"nv12": 0, "p016": 1, "rgb8": 2, "rgb16": 3, "rgbf32": 4, "linear_f32": 5, "i420_8": 6, "i420_16": 7, "i420_p10": 8}
 
 
 class Emulated:
@@ -87,6 +87,13 @@ class Emulated:
                     d.p0, d.p1, d.p2 = (p.ctypes.data for p in pl)
                     d.pitch, d.pitch2 = pl[0].strides[0], pl[1].strides[0]
                     d.shift = 0 if f["bits"] == 8 else 16 - f["bits"]
+                    continue
+                if f["kind"] == "i420p10":  # the packed 10-bit upload kind: data = (Y, Cb, Cr) as uint32 word planes (synth.p10_pack_plane)
+                    pl = [np.ascontiguousarray(p, np.uint32) for p in f["data"]]; keep.extend(pl)
+                    d.kind = KIND["i420_p10"]; d.matrix = int(f.get("matrix", 0))
+                    d.p0, d.p1, d.p2 = (p.ctypes.data for p in pl)
+                    d.pitch, d.pitch2 = pl[0].strides[0], pl[1].strides[0]
+                    d.shift = 6
                     continue
                 a = np.ascontiguousarray(f["data"]); keep.append(a)
                 d.kind = KIND[f["kind"]]; d.matrix = int(f.get("matrix", 0)); d.p0 = a.ctypes.data

@@ -313,7 +313,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         std::vector<float> lin2((size_t)n * 2 * 3 * g.s[2].plane, 0.0f);
         int kind = desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
-        const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16;
+        const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16 || kind == TM_KIND_I420_P10;
         if (yuv && !(variant & 0x200)) { // the engine's choice for the 4:2:0 kinds: the side-packed row-walking kernel
             const int rpw = g_ingest_rows;
             launch_wg_lockstep(dim3((qw + 63) / 64, (qh + 4 * rpw - 1) / (4 * rpw), n), 256, [&] {
@@ -321,6 +321,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
                 case TM_KIND_NV12: tmk::k_ingest_rows<TM_KIND_NV12, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
                 case TM_KIND_P016: tmk::k_ingest_rows<TM_KIND_P016, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
                 case TM_KIND_I420_8: tmk::k_ingest_rows<TM_KIND_I420_8, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                case TM_KIND_I420_P10: tmk::k_ingest_rows<TM_KIND_I420_P10, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
                 default: tmk::k_ingest_rows<TM_KIND_I420_16, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
                 } });
         } else
@@ -330,6 +331,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             case TM_KIND_P016: tmk::k_ingest_wave<TM_KIND_P016>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             case TM_KIND_I420_8: tmk::k_ingest_wave<TM_KIND_I420_8>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             case TM_KIND_I420_16: tmk::k_ingest_wave<TM_KIND_I420_16>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
+            case TM_KIND_I420_P10: tmk::k_ingest_wave<TM_KIND_I420_P10>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             } });
         launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });

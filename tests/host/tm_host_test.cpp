@@ -97,6 +97,12 @@ int main(int argc, char **argv)
                     out.write((const char *)f.data, (std::streamsize)(f.pitch * luma_rows));
                     out.write((const char *)f.uv, (std::streamsize)(f.pitch * crows));
                     std::cout << (f.kind == HwFrame::NvDecNV12 ? "nv12 " : "p016 ") << f.pitch << " " << luma_rows << " " << crows << "\n";
+                } else if (f.kind == HwFrame::Planar420P10) {
+                    const size_t crows = (hh + 1) / 2;
+                    out.write((const char *)f.data, (std::streamsize)(f.pitch * hh));
+                    out.write((const char *)f.u, (std::streamsize)(f.pitch_uv * crows));
+                    out.write((const char *)f.v, (std::streamsize)(f.pitch_uv * crows));
+                    std::cout << "p10 " << f.bits << " " << f.pitch << " " << f.pitch_uv << " " << hh << " " << crows << "\n";
                 } else if (f.kind == HwFrame::Planar420) {
                     const size_t crows = (hh + 1) / 2;
                     out.write((const char *)f.data, (std::streamsize)(f.pitch * hh));
@@ -184,7 +190,8 @@ int main(int argc, char **argv)
             }
             sv.add_decoded(hi - lo);
             auto tr = make_rank_transport(env, "pipe");
-            tr->reduce_sum_to_root(sv.v);
+            try { tr->reduce_sum_to_root(sv.v); }
+            catch (const RankPeerLost &) { return RANK_PEER_LOST; }
             if (env.rank == 0) {
                 std::cout << "lo " << lo << " hi " << hi << " decoded " << sv.decoded() << " " << tr->name() << "\n";
                 for (const FrameScores &f : sv.frames()) printf("%a %a\n", *f.psnr, *f.ssimulacra2);

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
     L = tm.ffi.lib()
     facade, lab = declared_symbols(), declared_symbols("turbo_metrics_hip_debug.h")
     # the facade is what INTEGRATION.md binds: small, and free of variants / tuning / read-back hooks
-    assert 30 <= len(facade) <= 40, len(facade)
+    assert 30 <= len(facade) <= 43, len(facade)
     assert not [n for n in facade if "debug" in n or "variant" in n or "profiling" in n or "stage_ms" in n]
     assert not set(facade) & set(lab)
     src = open(os.path.join(ROOT, "include", "turbo_metrics_hip.h")).read()
@@ -44,6 +44,43 @@ def test_the_rust_binding_in_integration_md_is_the_facade_header():
     block = block[:block.index("\n}\n")]
     bound = sorted(set(re.findall(r"pub fn (tm_[a-z0-9_]+)\(", block)))
     assert bound == declared_symbols(), (sorted(set(declared_symbols()) - set(bound)), sorted(set(bound) - set(declared_symbols())))
+
+
+def test_the_collective_library_exports_its_header():
+    """libturbometrics_rccl.so (the ONE reduce of `turbo-metrics --ranks N`) exports exactly include/turbo_metrics_comm.h, the Rust block of
+    INTEGRATION.md section 5.1 binds the same five names, and the engine library does not depend on RCCL.  Loading only: no communicator
+    without a GPU."""
+    import subprocess
+    want = declared_symbols("turbo_metrics_comm.h")
+    assert want == ["tm_comm_destroy", "tm_comm_get_unique_id", "tm_comm_init", "tm_comm_last_error", "tm_comm_reduce_sum_f64"]
+    lib = os.path.join(ROOT, "turbo-metrics_amd", "libturbometrics_rccl.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert sorted(n for n in re.findall(r" T (\w+)", out) if n.startswith("tm_")) == want
+    L = C.CDLL(lib)
+    L.tm_comm_last_error.restype = C.c_char_p
+    assert L.tm_comm_get_unique_id(None) != 0 and b"null pointer" in L.tm_comm_last_error()
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = txt[txt.index("pub fn tm_comm_get_unique_id") - 40:]
+    assert sorted(set(re.findall(r"pub fn (tm_comm_[a-z0-9_]+)\(", block[:block.index("\n}\n")]))) == want
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "turbo-metrics_amd", "libturbometrics_hip.so")], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed  # the CLI loads it at run time, for --ranks only
+
+
+def test_p10_packer_follows_the_headers_sentence():
+    """tm_p10_pack_rows / tm_p10_row_bytes (host code of the facade) against the numpy statement of the layout in synth.py"""
+    L = tm.ffi.lib()
+    rng = np.random.default_rng(1)
+    for n in (1, 5, 127, 128, 129, 383, 384, 385, 960, 1000, 1920, 3840):
+        pl = rng.integers(0, 1024, (5, n))
+        pk = tm.synth.p10_pack_plane(pl)
+        assert pk.shape[1] * 4 == L.tm_p10_row_bytes(n) == 512 * -(-n // 384)
+        assert np.array_equal(tm.synth.p10_unpack_plane(pk, n), pl)
+        src = np.ascontiguousarray((pl | (rng.integers(0, 64, pl.shape) << 10)).astype(np.uint16))  # bits above the tenth are dropped
+        dst = np.full((5, pk.shape[1] + 3), 0xFFFFFFFF, np.uint32)
+        L.tm_p10_pack_rows(src.ctypes.data, src.strides[0], n, 5, dst.ctypes.data, dst.strides[0])
+        assert np.array_equal(dst[:, :pk.shape[1]], pk) and (dst[:, pk.shape[1]:] == 0xFFFFFFFF).all()
 
 
 def test_strerror_and_version():

@@ -15,6 +15,11 @@ def coef_table():
 
 def oracle_linear(f, w, h):
     k = f["kind"]
+    if k == "i420p10":  # the packed upload kind: unpacked by the numpy statement of the layout, then like planar 10-bit
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        planes = tuple(tm.synth.p10_unpack_plane(p, n) for p, n in zip(f["data"], (w, cw, cw)))
+        surf, pitch, coded = tm.synth.pack_biplanar(planes, w, h, 10)
+        return O.yuv420_biplanar_to_linear(surf, pitch, coded, w, h, 16, int(f.get("matrix", 0)))
     if k == "i420":  # planar: the oracle sees the same samples repacked into the reference's biplanar surface
         surf, pitch, ch = tm.synth.pack_biplanar(tuple(np.asarray(p, np.int64) for p in f["data"]), w, h, f["bits"])
         return O.yuv420_biplanar_to_linear(surf, pitch, ch, w, h, 8 if f["bits"] == 8 else 16, int(f.get("matrix", 0)))
@@ -309,10 +314,37 @@ def test_planar_i420_equals_the_repacked_biplanar_surface(w, h, bits, variant):
     check_against_oracle(em, frames, w, h, have_linear=variant == REFERENCE, have_xybt=variant == REFERENCE)
 
 
+def packed10_frames(w, h, count=2, extra_words=0):
+    frames = []
+    for n in range(count):
+        ref, dis = tm.synth.yuv420_pair(w, h, n + 5, 10)
+        frames.append(tuple(dict(kind="i420p10", data=tuple(tm.synth.p10_pack_plane(p, tm.synth.p10_row_words(p.shape[1]) + extra_words) for p in side), matrix=(n + 1) % 3)
+                            for side in (ref, dis)))
+    return frames
+
+
+@pytest.mark.parametrize("variant", [DEFAULT, TILE_INGEST, REFERENCE])
+@pytest.mark.parametrize("w,h,extra", [(70, 38, 0), (33, 67, 2), (129, 20, 0), (400, 18, 0), (770, 12, 4)])  # one run, a partial block, beyond one block, chroma beyond a block
+def test_packed_10_bit_planes_equal_the_planar_10_bit_frame(w, h, extra, variant):
+    """tm_engine_set_frame_i420p10 (round 6: 10.7 instead of 16 bits per sample over PCIe): three samples per word, runs of 128 -- the
+    row-walking kernel (a wave = one run behind one shift), the tile kernel and the reference kernel (per-lane word and shift) all give
+    the planes and sums of the same samples handed over as planar 10-bit"""
+    frames = packed10_frames(w, h, extra_words=extra)
+    em = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=variant, weights=O.weights(), full_sums=True)
+    check_against_oracle(em, frames, w, h, have_linear=variant == REFERENCE, have_xybt=variant == REFERENCE)
+    if variant == DEFAULT:  # ... and bit for bit what the 16-bit planar kind computes
+        planar = []
+        for fr in frames:
+            cw = (w + 1) // 2
+            planar.append(tuple(dict(kind="i420", bits=10, matrix=f["matrix"], data=tuple(tm.synth.p10_unpack_plane(p, n).astype(np.uint16) for p, n in zip(f["data"], (w, cw, cw)))) for f in fr))
+        em2 = E.Emulated(w, h, planar, O.srgb8_lut(), coef_table(), variant=variant, weights=O.weights(), full_sums=True)
+        assert np.array_equal(em.XYB, em2.XYB) and np.array_equal(em.SUMS, em2.SUMS) and np.array_equal(em.SSE, em2.SSE)
+
+
 def test_planar_and_biplanar_frames_in_one_launch():
     """per-frame dispatch (mixed kinds): planar 8-bit, planar 10-bit with stray high bits masked away, NV12"""
     w, h = 46, 30
-    frames = planar_frames(w, h, 8, 1) + planar_frames(w, h, 10, 1) + nv12_frames(w, h, 1)
+    frames = planar_frames(w, h, 8, 1) + planar_frames(w, h, 10, 1) + nv12_frames(w, h, 1) + packed10_frames(w, h, 1)
     dirty = tuple(dict(f, data=tuple((p | np.uint16(0xFC00)) for p in f["data"])) for f in frames[1])  # bits above the declared depth
     em = E.Emulated(w, h, frames[:1] + [dirty] + frames[2:], O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True)
     check_against_oracle(em, frames, w, h, have_linear=False, have_xybt=False)

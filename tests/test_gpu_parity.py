@@ -547,6 +547,81 @@ def test_planar_i420_is_bit_identical_with_the_repacked_biplanar_surface(bits, w
     planar.close(); packed.close()
 
 
+@pytest.mark.parametrize("w,h", [(333, 203), (70, 38), (1, 1), (129, 20), (770, 67), (1920, 1080), (3840, 2160)])
+def test_packed_10_bit_upload_kind_is_bit_identical_with_planar_10_bit(w, h):
+    """tm_engine_set_frame_i420p10 -- three 10-bit samples per 32-bit word, 10.7 instead of 16 bits per sample over PCIe --
+    against tm_engine_set_frame_i420(bits = 10) on the same samples: raw sums, SSE and scores bit for bit (the row-walking kernel, the tile
+    kernel, the reference pipeline; mixed with another kind in one launch), from pageable, page-locked and device memory, as separate
+    planes with a wider pitch and as one tight picture (one linear copy), packed by numpy (the header's sentence) and by tm_p10_pack_rows;
+    small sizes against the oracle."""
+    import torch
+    L = F.lib()
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    B = 2 if w * h > 2000 * 1000 else 3
+    pairs = [tm.synth.yuv420_pair(w, h, n + 7, 10) for n in range(B)]
+    m = tm.Metrics(ssimulacra2=True, psnr=True)
+    planar = tm.TurboMetrics(w, h, m, batch=B, full_sums=True)
+    for slot, (ref, dis) in enumerate(pairs):
+        for side, planes in enumerate((ref, dis)):
+            planar.set_frame(slot, side, tm.HwFrame.i420(*(np.ascontiguousarray(p.astype(np.uint16)) for p in planes), bits=10, matrix=tm.ColorMatrix(slot % 3)))
+    planar.compute_async(); planar.sync()
+    want = [(planar.raw_sums(s).copy(), planar.sse(s), planar.scores(s)) for s in range(B)]
+
+    def lib_pack(plane, pitch_words):  # the library's packer, from u16 rows with junk above bit 9
+        src = np.ascontiguousarray((plane.astype(np.int64) | 0xFC00).astype(np.uint16))
+        dst = np.zeros((plane.shape[0], pitch_words), np.uint32)
+        L.tm_p10_pack_rows(src.ctypes.data, src.strides[0], plane.shape[1], plane.shape[0], dst.ctypes.data, dst.strides[0])
+        return dst
+
+    def tight(planes, pinned):  # Y, Cb, Cr words back to back without row padding: goes up as one linear copy
+        flat = np.concatenate([tm.synth.p10_pack_plane(p).reshape(-1) for p in planes])
+        t = torch.from_numpy(flat.view(np.int32))
+        t = t.pin_memory() if pinned else t
+        wy, wc = tm.synth.p10_row_words(w), tm.synth.p10_row_words(cw)
+        return t[:h * wy].view(h, wy), t[h * wy:h * wy + ch * wc].view(ch, wc), t[h * wy + ch * wc:].view(ch, wc)
+
+    makers = {
+        "numpy_pageable": lambda pl, slot: [tm.synth.p10_pack_plane(p, tm.synth.p10_row_words(p.shape[1]) + 2 * slot) for p in pl],
+        "library_packer": lambda pl, slot: [lib_pack(p, tm.synth.p10_row_words(p.shape[1]) + 2) for p in pl],
+        "device": lambda pl, slot: [torch.from_numpy(tm.synth.p10_pack_plane(p, tm.synth.p10_row_words(p.shape[1]) + 4).view(np.int32)).cuda() for p in pl],
+        "tight_pinned": lambda pl, slot: tight(pl, True),
+        "tight_pageable": lambda pl, slot: tight(pl, False),
+    }
+    for name, make in makers.items():
+        for variant in ((0, F.TM_VARIANT_TILE_INGEST, F.TM_VARIANT_REFERENCE) if name == "numpy_pageable" and w * h <= 1920 * 1080 else (0,)):
+            eng = tm.TurboMetrics(w, h, m, batch=B, full_sums=True)
+            eng.set_variant(variant)
+            eng.debug_set_param(F.TM_DBG_LINEAR_UPLOAD, 1)
+            keep = []
+            for slot, (ref, dis) in enumerate(pairs):
+                for side, planes in enumerate((ref, dis)):
+                    pl = make(planes, slot); keep.append(pl)
+                    eng.set_frame(slot, side, tm.HwFrame.i420p10(pl[0], pl[1], pl[2], matrix=tm.ColorMatrix(slot % 3)))
+            eng.compute_async(); eng.sync()
+            for s in range(B):
+                assert np.array_equal(eng.raw_sums(s), want[s][0]) and eng.sse(s) == want[s][1] and eng.scores(s) == want[s][2], (name, variant, s)
+            if name == "numpy_pageable" and variant == 0 and w * h <= 640 * 360:
+                fr = tm.HwFrame.p016(*tm.synth.pack_biplanar(pairs[0][0], w, h, 10)); fd = tm.HwFrame.p016(*tm.synth.pack_biplanar(pairs[0][1], w, h, 10))
+                lin, sums = check_planes(eng, 0, fr, fd, w, h)
+                check_scores(eng, 0, lin, sums, w, h)
+            if name == "numpy_pageable" and variant == 0:  # one launch of two kinds: per-frame dispatch
+                pl = [np.ascontiguousarray(p.astype(np.uint16)) for p in pairs[1][0]]
+                eng.set_frame(1, 0, tm.HwFrame.i420(pl[0], pl[1], pl[2], bits=10, matrix=tm.ColorMatrix(1)))
+                eng.compute_async(); eng.sync()
+                for s in range(B):
+                    assert np.array_equal(eng.raw_sums(s), want[s][0]) and eng.sse(s) == want[s][1], ("mixed", s)
+            eng.close()
+    e1 = tm.TurboMetrics(w, h, m, batch=1)
+    pk = [tm.synth.p10_pack_plane(p) for p in pairs[0][0]]
+    with pytest.raises(tm.TmError) as ei:  # a pitch below one packed row
+        e1.set_frame(0, 0, tm.HwFrame.i420p10(pk[0][:, :-2] if pk[0].shape[1] > 2 else pk[0][:, :0], pk[1], pk[2]))
+    assert ei.value.code == F.TM_ERR_INVALID_ARG
+    with pytest.raises(tm.TmError) as ei:
+        e1.set_frame(0, 0, tm.HwFrame.i420p10(pk[0], pk[1], pk[2], full_range=True))
+    assert ei.value.code == F.TM_ERR_UNSUPPORTED
+    e1.close(); planar.close()
+
+
 def test_8k_pair_against_oracle():
     """7680x4320: one slot's arenas pass 2 GB (several kernels carry 32-bit lane offsets inside a plane), two slots so that the
     second one starts beyond 4 GB of the pass-1 arena"""

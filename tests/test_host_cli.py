@@ -7,6 +7,7 @@ import json
 import os
 import struct
 import subprocess
+import sys
 import zlib
 from decimal import Decimal
 
@@ -36,8 +37,11 @@ def helper():
     return HELPER
 
 
+PACK10 = "0"  # the source tests below look at 10-bit pictures as the stream's own 16-bit words; the packing tests set "1" (the product's default)
+
+
 def run(helper, *args, stdin=None):
-    r = subprocess.run([helper] + [str(a) for a in args], input=stdin, capture_output=True, text=True, check=False)
+    r = subprocess.run([helper] + [str(a) for a in args], input=stdin, capture_output=True, text=True, check=False, env=dict(os.environ, TM_PACK10=PACK10))
     if SANITIZE:  # a report of a sanitizer fails the test that provoked it, whatever the helper printed
         assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     return r.stdout
@@ -334,7 +338,7 @@ def test_y4m_pictures_reach_the_engine_as_planar_frames(helper, tmp_path, w, h, 
         outp = str(tmp_path / "pipe.bin")
         if path == p:
             write_y4m(p, [pr[0] for pr in pairs], w, h, bits)
-        r = subprocess.run([helper, "source", "-", outp] + [str(a) for a in extra], stdin=open(path, "rb"), capture_output=True, text=True)
+        r = subprocess.run([helper, "source", "-", outp] + [str(a) for a in extra], stdin=open(path, "rb"), capture_output=True, text=True, env=dict(os.environ, TM_PACK10=PACK10))
         assert r.stdout.strip().split("\n")[0].split()[1:3] == [str(w), str(h)] and len(r.stdout.strip().split("\n")) == 4, r.stdout
         assert np.array_equal(np.fromfile(outp, np.uint8), data)
 
@@ -365,6 +369,41 @@ def test_read_ahead_delivers_the_stream_in_order_through_a_small_ring(helper, tm
     for o in outs:
         assert o.strip().split("\n")[-1].startswith("ERROR: truncated picture") and len(o.strip().split("\n")) == 1 + (frames - 1) + 1, o[-300:]
     assert np.array_equal(np.fromfile(str(tmp_path / "c0.bin"), np.uint8), np.fromfile(str(tmp_path / "c1.bin"), np.uint8))
+
+
+@pytest.mark.parametrize("w,h,frames", [(46, 30, 3), (318, 258, 5), (1920, 1080, 7), (770, 300, 4)])
+def test_10_bit_pictures_are_packed_three_samples_to_a_word_on_their_way_into_the_ring(helper, tmp_path, w, h, frames, monkeypatch):
+    """round 6: a yuv420p10 stream reaches the engine as HwFrame::Planar420P10 -- the readers pack every row (tm_p10_pack_rows) while they
+    copy the picture into the page-locked ring: through the read-ahead pool (pieces of whole rows), the synchronous reader with its row
+    workers, and a pipe; unpacked by the numpy statement of the layout the samples are the stream's"""
+    monkeypatch.setattr(sys.modules[__name__], "PACK10", "1")
+    rng = np.random.default_rng(11)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    pics = [[rng.integers(0, 1024, (h, w), dtype=np.uint16), rng.integers(0, 1024, (ch, cw), dtype=np.uint16), rng.integers(0, 1024, (ch, cw), dtype=np.uint16)] for _ in range(frames)]
+    p = str(tmp_path / "v.y4m")
+    write_y4m(p, pics, w, h, 10)
+    wy, wc = tm.synth.p10_row_words(w), tm.synth.p10_row_words(cw)
+    per = (h * wy + 2 * ch * wc) * 4
+
+    def check(fr, data, skip=0):
+        assert len(fr) == frames - skip and all(f == ["p10", "10", str(wy * 4), str(wc * 4), str(h), str(ch)] for f in fr)
+        words = data.view(np.uint32)
+        for n in range(skip, frames):
+            pic = words[(n - skip) * per // 4:(n - skip + 1) * per // 4]
+            got = (tm.synth.p10_unpack_plane(pic[:h * wy].reshape(h, wy), w), tm.synth.p10_unpack_plane(pic[h * wy:h * wy + ch * wc].reshape(ch, wc), cw),
+                   tm.synth.p10_unpack_plane(pic[h * wy + ch * wc:].reshape(ch, wc), cw))
+            assert all(np.array_equal(g, pl) for g, pl in zip(got, pics[n])), n
+            assert np.array_equal(pic[:h * wy].reshape(h, wy), tm.synth.p10_pack_plane(pics[n][0]))  # absent samples and the two top bits are 0
+    for extra in (("--readahead", 1), ("--readahead", 0), ("--readahead", 1, "--lookahead", 4, "--skip", 2)):
+        head, fr, data = read_dump(helper, p, str(tmp_path / "o.bin"), *extra)
+        assert head[0] == "Y4M/I420p10/turbo-metrics-hip"
+        check(fr, data, 2 if "--skip" in extra else 0)
+    outp = str(tmp_path / "pipe.bin")
+    r = subprocess.run([helper, "source", "-", outp], stdin=open(p, "rb"), capture_output=True, text=True, env=dict(os.environ, TM_PACK10="1"))
+    check([t.split() for t in r.stdout.strip().split("\n")[1:]], np.fromfile(outp, np.uint8))
+    # 12-bit streams stay 16-bit words
+    write_y4m(p, [[pl * 4 for pl in pics[0]]], w, h, 12)
+    assert read_dump(helper, p, str(tmp_path / "o12.bin"))[1][0][0] == "i420"
 
 
 def test_y4m_rejects_what_the_reference_cannot_represent(helper, tmp_path):

@@ -360,8 +360,9 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
 }
 
 // planar 4:2:0 (TM_KIND_I420_8 / I420_16): three planes; the staged copy keeps them planar (Y rows, then Cb rows, then Cr rows)
+// packed10: TM_KIND_I420_P10 -- three 10-bit samples per 32-bit word (tm_geom.h), rows of whole 512-byte blocks
 int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const void *u, const void *v, size_t pitch_y,
-                     size_t pitch_uv, int bits, int matrix, int mem)
+                     size_t pitch_uv, int bits, int matrix, int mem, bool packed10 = false)
 {
     int rc = check_slot_side(e, slot, side);
     if (rc) return rc;
@@ -370,7 +371,9 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
     if (bits < 8 || bits > 16) return TM_ERR_INVALID_ARG;
     const size_t bps = bits == 8 ? 1 : 2;
     const size_t cw = (e->w + 1) / 2, ch = (e->h + 1) / 2;
-    const size_t row_y = (size_t)e->w * bps, row_c = cw * bps;
+    const size_t row_y = packed10 ? (size_t)tm_p10_row_words(e->w) * 4 : (size_t)e->w * bps, row_c = packed10 ? (size_t)tm_p10_row_words(cw) * 4 : cw * bps;
+    if (packed10 && (((uintptr_t)y | (uintptr_t)u | (uintptr_t)v | pitch_y | pitch_uv) & 7)) return TM_ERR_INVALID_ARG; // the kernels read word pairs
+    const int kind = packed10 ? TM_KIND_I420_P10 : (bits == 8 ? TM_KIND_I420_8 : TM_KIND_I420_16);
     if (pitch_y < row_y || pitch_uv < row_c) return TM_ERR_INVALID_ARG;
     // the kernels address a plane with 32-bit lane offsets (row * pitch through a 24-bit multiply), chroma planes included
     if (pitch_y >= ((size_t)1 << 24) || pitch_y * (size_t)e->h >= ((size_t)1 << 32) || pitch_uv >= ((size_t)1 << 24) || pitch_uv * ch >= ((size_t)1 << 32)) return TM_ERR_INVALID_ARG;
@@ -399,7 +402,7 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
             HIPCHK(hipMemcpyAsync(s, y, row_y * e->h + 2 * row_c * ch, hipMemcpyHostToDevice, us));
             if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
             d.p0 = s; d.p1 = s + row_y * e->h; d.p2 = s + row_y * e->h + row_c * ch; d.pitch = row_y; d.pitch2 = row_c;
-            d.kind = bits == 8 ? TM_KIND_I420_8 : TM_KIND_I420_16;
+            d.kind = kind;
             d.matrix = matrix;
             d.shift = bits == 8 ? 0 : 16 - bits;
             return TM_OK;
@@ -415,7 +418,7 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
         if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
         d.p0 = s; d.p1 = su; d.p2 = sv; d.pitch = sp_y; d.pitch2 = sp_c;
     }
-    d.kind = bits == 8 ? TM_KIND_I420_8 : TM_KIND_I420_16;
+    d.kind = kind;
     d.matrix = matrix;
     d.shift = bits == 8 ? 0 : 16 - bits;
     return TM_OK;
@@ -819,6 +822,45 @@ int tm_engine_set_frame_i420(tm_engine *e, uint32_t slot, int side, const void *
     return set_frame_planar(e, slot, side, y, u, v, pitch_y, pitch_uv, bits, matrix, mem);
 }
 
+int tm_engine_set_frame_i420p10(tm_engine *e, uint32_t slot, int side, const void *y, const void *u, const void *v, size_t pitch_y,
+                                size_t pitch_uv, int matrix, int transfer, int full_range, int mem)
+{
+    int rc = check_yuv_args(matrix, transfer, full_range);
+    if (rc) return rc;
+    return set_frame_planar(e, slot, side, y, u, v, pitch_y, pitch_uv, 10, matrix, mem, true);
+}
+
+size_t tm_p10_row_bytes(uint32_t n_samples) { return (size_t)tm_p10_row_words(n_samples) * 4; }
+
+// one row: word k of block b = s[384 b + k] | s[384 b + 128 + k] << 10 | s[384 b + 256 + k] << 20 (tm_geom.h); three contiguous runs in, one run
+// out: the loops below are what a vectorising compiler wants (no gather, no cross-lane step)
+static void p10_pack_row(const uint16_t *__restrict__ s, uint32_t n, uint32_t *__restrict__ d)
+{
+    uint32_t b = 0;
+    for (; (b + 1) * TM_P10_BLOCK <= n; ++b) { // whole blocks
+        const uint16_t *__restrict__ s0 = s + (size_t)b * TM_P10_BLOCK, *__restrict__ s1 = s0 + TM_P10_RUN, *__restrict__ s2 = s1 + TM_P10_RUN;
+        uint32_t *__restrict__ o = d + (size_t)b * TM_P10_RUN;
+        for (int k = 0; k < TM_P10_RUN; ++k) o[k] = ((uint32_t)s0[k] & 1023u) | (((uint32_t)s1[k] & 1023u) << 10) | (((uint32_t)s2[k] & 1023u) << 20);
+    }
+    if (b * TM_P10_BLOCK < n) { // the last, partial block: absent samples are 0
+        uint32_t *o = d + (size_t)b * TM_P10_RUN;
+        for (uint32_t k = 0; k < TM_P10_RUN; ++k) {
+            uint32_t w = 0;
+            for (uint32_t j = 0; j < 3; ++j) {
+                const uint32_t x = b * TM_P10_BLOCK + j * TM_P10_RUN + k;
+                if (x < n) w |= ((uint32_t)s[x] & 1023u) << (10 * j);
+            }
+            o[k] = w;
+        }
+    }
+}
+
+void tm_p10_pack_rows(const void *src, size_t src_pitch, uint32_t width, uint32_t rows, void *dst, size_t dst_pitch)
+{
+    for (uint32_t r = 0; r < rows; ++r)
+        p10_pack_row((const uint16_t *)((const char *)src + (size_t)r * src_pitch), width, (uint32_t *)((char *)dst + (size_t)r * dst_pitch));
+}
+
 int tm_engine_set_frame_rgb8(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
 {
     return set_frame_common(e, slot, side, TM_KIND_RGB8, rgb, nullptr, pitch, 0, mem);
@@ -1006,6 +1048,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         case TM_KIND_P016: if (rows) TM_LAUNCH_R(TM_KIND_P016); else TM_LAUNCH_W(TM_KIND_P016); break;
         case TM_KIND_I420_8: if (rows) TM_LAUNCH_R(TM_KIND_I420_8); else TM_LAUNCH_W(TM_KIND_I420_8); break;
         case TM_KIND_I420_16: if (rows) TM_LAUNCH_R(TM_KIND_I420_16); else TM_LAUNCH_W(TM_KIND_I420_16); break;
+        case TM_KIND_I420_P10: if (rows) TM_LAUNCH_R(TM_KIND_I420_P10); else TM_LAUNCH_W(TM_KIND_I420_P10); break;
         case TM_KIND_RGB8: TM_LAUNCH_W(TM_KIND_RGB8); break;
         case TM_KIND_RGB16: TM_LAUNCH_W(TM_KIND_RGB16); break;
         case TM_KIND_RGBF32: TM_LAUNCH_W(TM_KIND_RGBF32); break;

@@ -41,8 +41,17 @@ struct TmGeom {
 // I420_8 / I420_16: PLANAR 4:2:0 as files and software decoders deliver it (three planes; 16-bit samples little endian with
 // the value in the LOW `16 - shift` bits): converted exactly like NV12 / P016 -- a 16-bit sample enters as v << shift, which is
 // what an NVDEC P016 surface holds (cudarse-video/src/dec.rs:398-400)
+// I420_P10: planar 4:2:0, 10-bit, THREE samples per 32-bit word (the upload kind for host frames: 10.7 instead of 16 bits per sample
+// over PCIe).  A row of n samples is ceil(n / 384) blocks of 128 words; word k of block b holds samples 384 b + k (bits 0..9),
+// 384 b + 128 + k (bits 10..19) and 384 b + 256 + k (bits 20..29), absent samples 0 (tm_p10_* below).  Three contiguous runs of 128
+// samples per block: a host packs a row with plain vector code (three loads, two shifts, two ors), and a wave of the ingest kernel -- 128
+// luma samples, 64 chroma samples -- finds all of its samples in ONE sub-run, behind a wave-uniform shift, as the same aligned 8-byte /
+// 4-byte loads per lane the 16-bit kind uses.  The samples enter the conversion as v << 6, like I420_16 with shift 6: same bits.
 enum { TM_KIND_NONE = -1, TM_KIND_NV12 = 0, TM_KIND_P016 = 1, TM_KIND_RGB8 = 2, TM_KIND_RGB16 = 3,
-       TM_KIND_RGBF32 = 4, TM_KIND_LINEARF32 = 5, TM_KIND_I420_8 = 6, TM_KIND_I420_16 = 7 };
+       TM_KIND_RGBF32 = 4, TM_KIND_LINEARF32 = 5, TM_KIND_I420_8 = 6, TM_KIND_I420_16 = 7, TM_KIND_I420_P10 = 8 };
+#define TM_P10_RUN 128                     /* samples per contiguous run = words per block */
+#define TM_P10_BLOCK (3 * TM_P10_RUN)      /* samples per block */
+static inline unsigned long long tm_p10_row_words(unsigned long long n_samples) { return (n_samples + TM_P10_BLOCK - 1) / TM_P10_BLOCK * TM_P10_RUN; }
 
 struct TmFrameDesc {
     const void *p0;            // luma plane or packed RGB
@@ -52,7 +61,7 @@ struct TmFrameDesc {
     unsigned long long pitch2; // bytes, chroma rows of the planar kinds
     int kind;
     int matrix;
-    int shift;                 // I420_16: left shift that brings the sample to the top of 16 bits (6 for 10-bit content)
+    int shift;                 // I420_16 / I420_P10: left shift that brings the sample to the top of 16 bits (6 for 10-bit content)
     int pad_;
 };
 

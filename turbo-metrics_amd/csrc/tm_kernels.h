@@ -68,6 +68,13 @@ __device__ __forceinline__ float ld_row(const float *__restrict__ p, int row, in
 // ------------------------------------------------------------------------------------------------
 //   planar     TM_KIND_I420_8 / I420_16: the same conversion; Cb and Cr come from two planes and a 16-bit sample is first
 //              shifted to the top of its 16 bits (a P016 surface holds exactly that)
+// sample x of a TM_KIND_I420_P10 row (tm_geom.h): block x / 384, run (x % 384) / 128, word x % 128
+__device__ __forceinline__ unsigned p10_word_offset(unsigned x) { return ((x / TM_P10_BLOCK) * TM_P10_RUN + (x % TM_P10_RUN)) * 4u; }
+__device__ __forceinline__ unsigned p10_shift(unsigned x) { return 10u * ((x % TM_P10_BLOCK) / TM_P10_RUN); }
+__device__ __forceinline__ unsigned p10_sample(const char *row, unsigned x)
+{
+    return (*(const unsigned *)(row + p10_word_offset(x)) >> p10_shift(x)) & 1023u;
+}
 template <typename T, int BITS>
 __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const float *__restrict__ coef,
                                                 const double *__restrict__ tab, int qx, int qy, float (&px)[2][2][3])
@@ -75,22 +82,29 @@ __device__ __forceinline__ void ingest_yuv_quad(const TmFrameDesc &d, const floa
     const float *k = coef + (d.matrix * 2 + (BITS == 16 ? 1 : 0)) * 5;
     const int neutral = 1 << (BITS - 1);
     const unsigned ymin = 16u << (BITS - 8);
-    const bool planar = d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16;
+    const bool planar = d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16 || d.kind == TM_KIND_I420_P10;
     const int sh = planar && BITS == 16 ? d.shift : 0;
-    // all six samples of the quad are fetched before any is used: one exposed latency instead of six
-    const T *yrow0 = (const T *)((const char *)d.p0 + (size_t)(2 * qy) * d.pitch) + 2 * qx;
-    const T *yrow1 = (const T *)((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch) + 2 * qx;
-    unsigned ucb, ucr;
-    if (planar) {
-        ucb = ((const T *)((const char *)d.p1 + (size_t)qy * d.pitch2))[qx];
-        ucr = ((const T *)((const char *)d.p2 + (size_t)qy * d.pitch2))[qx];
+    unsigned ucb, ucr, y00, y01, y10, y11;
+    if (BITS == 16 && d.kind == TM_KIND_I420_P10) { // three samples per word (tm_geom.h)
+        const char *yr0 = (const char *)d.p0 + (size_t)(2 * qy) * d.pitch, *yr1 = yr0 + d.pitch;
+        y00 = p10_sample(yr0, 2 * qx); y01 = p10_sample(yr0, 2 * qx + 1); y10 = p10_sample(yr1, 2 * qx); y11 = p10_sample(yr1, 2 * qx + 1);
+        ucb = p10_sample((const char *)d.p1 + (size_t)qy * d.pitch2, qx);
+        ucr = p10_sample((const char *)d.p2 + (size_t)qy * d.pitch2, qx);
     } else {
-        const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
-        ucb = uv[0]; ucr = uv[1];
+        // all six samples of the quad are fetched before any is used: one exposed latency instead of six
+        const T *yrow0 = (const T *)((const char *)d.p0 + (size_t)(2 * qy) * d.pitch) + 2 * qx;
+        const T *yrow1 = (const T *)((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch) + 2 * qx;
+        if (planar) {
+            ucb = ((const T *)((const char *)d.p1 + (size_t)qy * d.pitch2))[qx];
+            ucr = ((const T *)((const char *)d.p2 + (size_t)qy * d.pitch2))[qx];
+        } else {
+            const T *uv = (const T *)((const char *)d.p1 + (size_t)qy * d.pitch) + 2 * qx;
+            ucb = uv[0]; ucr = uv[1];
+        }
+        y00 = yrow0[0]; y01 = yrow0[1]; y10 = yrow1[0]; y11 = yrow1[1];
     }
     ucb = (ucb << sh) & 0xFFFFu; ucr = (ucr << sh) & 0xFFFFu;
-    const unsigned yv[2][2] = {{((unsigned)yrow0[0] << sh) & 0xFFFFu, ((unsigned)yrow0[1] << sh) & 0xFFFFu},
-                               {((unsigned)yrow1[0] << sh) & 0xFFFFu, ((unsigned)yrow1[1] << sh) & 0xFFFFu}};
+    const unsigned yv[2][2] = {{(y00 << sh) & 0xFFFFu, (y01 << sh) & 0xFFFFu}, {(y10 << sh) & 0xFFFFu, (y11 << sh) & 0xFFFFu}};
     const float cb = (float)((int)ucb - neutral);
     const float cr = (float)((int)ucr - neutral);
     const float r_ = k[1] * cr;
@@ -142,6 +156,34 @@ __device__ __forceinline__ void yuv_quad_load_pairs(const TmFrameDesc &d, int qx
         if (aligned) raw[2] = sizeof(T) == 1 ? (unsigned)*(const unsigned short *)uv : *(const unsigned *)uv;
         else raw[2] = (unsigned)((const T *)uv)[0] | ((unsigned)((const T *)uv)[1] << sh);
     }
+}
+// TM_KIND_I420_P10: the same three raw words -- first | second << 16, each sample shifted to the top of its half like I420_16 with
+// shift 6 -- out of the packed rows: the two luma samples of a quad row are neighbouring words of one run (2 qx is even, a run has 128
+// words: one aligned 8-byte load), behind one shift
+__device__ __forceinline__ void yuv_quad_load_p10(const TmFrameDesc &d, int qx, int qy, unsigned (&raw)[3])
+{
+    const unsigned x = (unsigned)(2 * qx), oy = p10_word_offset(x), sy = p10_shift(x), oc = p10_word_offset((unsigned)qx), sc = p10_shift((unsigned)qx);
+    const char *y0 = (const char *)d.p0 + tm_mul24((unsigned)(2 * qy), (unsigned)d.pitch) + oy;
+    const tm_u2 a = *(const tm_u2 *)y0, b = *(const tm_u2 *)(y0 + d.pitch);
+    const unsigned coff = tm_mul24((unsigned)qy, (unsigned)d.pitch2) + oc;
+    const unsigned cb = *(const unsigned *)((const char *)d.p1 + coff), cr = *(const unsigned *)((const char *)d.p2 + coff);
+    raw[0] = ((((a.x >> sy) & 1023u) | (((a.y >> sy) & 1023u) << 16)) << 6);
+    raw[1] = ((((b.x >> sy) & 1023u) | (((b.y >> sy) & 1023u) << 16)) << 6);
+    raw[2] = ((((cb >> sc) & 1023u) | (((cr >> sc) & 1023u) << 16)) << 6);
+}
+// ... and for a wave of k_ingest_rows (64 quads from x = 128 blockIdx.x: one run of the luma rows, half a run of the chroma rows): row
+// addresses in SGPRs, the lane's byte offsets xo_y / xo_c fixed for the whole walk, both shifts wave-uniform
+__device__ __forceinline__ void yuv_row_load_p10(const TmFrameDesc &d, unsigned xo_y, unsigned xo_c, unsigned sy, unsigned sc, int qy, unsigned (&raw)[3])
+{
+    TM_GLOBAL_AS const char *y0 = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p0 + (size_t)(2 * qy) * d.pitch);
+    TM_GLOBAL_AS const char *y1 = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p0 + (size_t)(2 * qy + 1) * d.pitch);
+    TM_GLOBAL_AS const char *cbp = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p1 + (size_t)qy * d.pitch2);
+    TM_GLOBAL_AS const char *crp = (TM_GLOBAL_AS const char *)tm_uniform_ptr((const char *)d.p2 + (size_t)qy * d.pitch2);
+    const tm_u2 a = *(TM_GLOBAL_AS const tm_u2 *)(y0 + xo_y), b = *(TM_GLOBAL_AS const tm_u2 *)(y1 + xo_y);
+    const unsigned cb = *(TM_GLOBAL_AS const unsigned *)(cbp + xo_c), cr = *(TM_GLOBAL_AS const unsigned *)(crp + xo_c);
+    raw[0] = ((((a.x >> sy) & 1023u) | (((a.y >> sy) & 1023u) << 16)) << 6);
+    raw[1] = ((((b.x >> sy) & 1023u) | (((b.y >> sy) & 1023u) << 16)) << 6);
+    raw[2] = ((((cb >> sc) & 1023u) | (((cr >> sc) & 1023u) << 16)) << 6);
 }
 // The same six samples for a wave whose lanes all sit in ONE quad row (k_ingest_rows: qy is wave-uniform): the row addresses stay in
 // SGPRs and a lane contributes a 32-bit byte offset that does not change from row to row (xo_y into a luma row, xo_c into a chroma
@@ -231,7 +273,7 @@ __global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__r
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
         if (inside) {
-            if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016 || d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16) {
+            if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016 || d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16 || d.kind == TM_KIND_I420_P10) {
                 if (2 * qx + 1 < w && 2 * qy + 1 < h) {
                     if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, tab + TM_TAB_EOTF64, qx, qy, px);
                     else ingest_yuv_quad<unsigned short, 16>(d, coef, tab + TM_TAB_EOTF64, qx, qy, px);
@@ -367,14 +409,15 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
     __shared__ float keep_s[15][64];
     // YUV kinds: the samples of BOTH sides are requested before anything else (three pair loads per side), so that side 1's
     // never sit behind side 0's arithmetic
-    constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16;
+    constexpr bool YUV = KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16 || KIND == TM_KIND_I420_P10;
     constexpr bool PLANAR = KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16;
     constexpr bool YUV8 = KIND == TM_KIND_NV12 || KIND == TM_KIND_I420_8;
     const TmFrameDesc dd0 = desc[slot * 2], dd1 = desc[slot * 2 + 1];
     const bool quad_ok = X0 + 1 < w && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
     unsigned pr0[3] = {0, 0, 0}, pr1[3] = {0, 0, 0};
     if (YUV && quad_ok) {
-        if (YUV8) { yuv_quad_load_pairs<unsigned char, PLANAR>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned char, PLANAR>(dd1, X0 / 2, Y0 / 2, pr1); }
+        if (KIND == TM_KIND_I420_P10) { yuv_quad_load_p10(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_p10(dd1, X0 / 2, Y0 / 2, pr1); }
+        else if (YUV8) { yuv_quad_load_pairs<unsigned char, PLANAR>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned char, PLANAR>(dd1, X0 / 2, Y0 / 2, pr1); }
         else { yuv_quad_load_pairs<unsigned short, PLANAR>(dd0, X0 / 2, Y0 / 2, pr0); yuv_quad_load_pairs<unsigned short, PLANAR>(dd1, X0 / 2, Y0 / 2, pr1); }
     }
 #pragma unroll 1
@@ -396,7 +439,7 @@ __global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom 
                 if (YUV8) yuv_quad_convert<8>(d, raw, coef, et64, px);
                 else yuv_quad_convert<16>(d, raw, coef, et64, px);
             }
-        } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16) {
+        } else if (kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16 || kind == TM_KIND_I420_P10) {
             if (quad_ok) {
                 if (kind == TM_KIND_NV12 || kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, et64, X0 / 2, Y0 / 2, px);
                 else ingest_yuv_quad<unsigned short, 16>(d, coef, et64, X0 / 2, Y0 / 2, px);
@@ -561,8 +604,9 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
                                                     unsigned long long qplane, int qpitch, int rows_per_wave)
 {
     using namespace tmdev;
-    static_assert(KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16, "4:2:0 kinds only");
+    static_assert(KIND == TM_KIND_NV12 || KIND == TM_KIND_P016 || KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16 || KIND == TM_KIND_I420_P10, "4:2:0 kinds only");
     constexpr bool PLANAR = KIND == TM_KIND_I420_8 || KIND == TM_KIND_I420_16;
+    constexpr bool P10 = KIND == TM_KIND_I420_P10;
     constexpr bool YUV8 = KIND == TM_KIND_NV12 || KIND == TM_KIND_I420_8;
     constexpr int BITS = YUV8 ? 8 : 16;
     using T = typename std::conditional<YUV8, unsigned char, unsigned short>::type;
@@ -584,8 +628,16 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
     const float neutral = (float)(1 << (BITS - 1)), ymin = (float)(16u << (BITS - 8));
     const bool colq = X0 + 1 < w; // this lane's quads are complete along x
     unsigned prn0[3] = {0, 0, 0}, prn1[3] = {0, 0, 0};
-    const unsigned xo_y = (unsigned)(2 * qx) * (unsigned)sizeof(T), xo_c = (unsigned)qx * (unsigned)sizeof(T); // this lane's byte offsets inside a luma (CbCr) / a planar chroma row
-    if (colq && 2 * qy_begin + 1 < h) { yuv_row_load_pairs<T, PLANAR>(dd0, xo_y, xo_c, qy_begin, prn0); yuv_row_load_pairs<T, PLANAR>(dd1, xo_y, xo_c, qy_begin, prn1); }
+    // this lane's byte offsets inside a luma (CbCr) / a planar chroma row; P10: the wave's 128 luma samples are one run of the packed row, its
+    // 64 chroma samples half a run, each behind a wave-uniform shift (tm_geom.h)
+    const unsigned xo_y = P10 ? p10_word_offset((unsigned)(2 * qx)) : (unsigned)(2 * qx) * (unsigned)sizeof(T);
+    const unsigned xo_c = P10 ? p10_word_offset((unsigned)qx) : (unsigned)qx * (unsigned)sizeof(T);
+    const unsigned sy10 = __builtin_amdgcn_readfirstlane(p10_shift(blockIdx.x * 128u)), sc10 = __builtin_amdgcn_readfirstlane(p10_shift(blockIdx.x * 64u));
+    const auto load_row = [&](const TmFrameDesc &d, int qyl, unsigned (&raw)[3]) {
+        if (P10) yuv_row_load_p10(d, xo_y, xo_c, sy10, sc10, qyl, raw);
+        else yuv_row_load_pairs<T, PLANAR>(d, xo_y, xo_c, qyl, raw);
+    };
+    if (colq && 2 * qy_begin + 1 < h) { load_row(dd0, qy_begin, prn0); load_row(dd1, qy_begin, prn1); }
     // (taken before the loop for the same reason as inside it: a load still pending at the loop header would make the compiler wait
     // for everything outstanding -- the previous row's stores included -- at the top of every iteration)
 #pragma unroll
@@ -601,7 +653,7 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
         const bool quad_ok = colq && Y0 + 1 < h; // incomplete quads are not converted (cuda-colorspace/src/kernel.rs:64-65)
         unsigned pr0[3] = {prn0[0], prn0[1], prn0[2]}, pr1[3] = {prn1[0], prn1[1], prn1[2]};
         if (qy + 1 < qy_end && colq && Y0 + 3 < h) { // the next row's samples, requested before this row's arithmetic
-            yuv_row_load_pairs<T, PLANAR>(dd0, xo_y, xo_c, qy + 1, prn0); yuv_row_load_pairs<T, PLANAR>(dd1, xo_y, xo_c, qy + 1, prn1);
+            load_row(dd0, qy + 1, prn0); load_row(dd1, qy + 1, prn1);
         }
         // ---- biplanar.rs:8-70 on {ref, dis} pairs
         tm_f2 pr[4], pg[4], pb[4];

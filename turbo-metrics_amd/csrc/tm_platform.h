@@ -42,6 +42,7 @@ static inline float tm_fract_pos(float s) { return s - floorf(s); }
 
 struct alignas(16) tm_f4 { float x, y, z, w; };
 struct alignas(8) tm_g2 { float x, y; };
+struct alignas(8) tm_u2 { unsigned x, y; };
 static inline unsigned tm_mul24(unsigned a, unsigned b) { return a * b; }
 static inline float tm_swap1(float v) { return tm_shfl_xor(v, 1); }
 // {value of the even lane, value of the odd lane} of this lane's pair; `odd`: this lane is the odd one
@@ -97,6 +98,7 @@ __device__ __forceinline__ float tm_fract_pos(float s) { return __builtin_amdgcn
 
 typedef float tm_f4 __attribute__((ext_vector_type(4))); // plain vector: assignable through address_space(1)
 typedef float tm_g2 __attribute__((ext_vector_type(2)));
+typedef unsigned tm_u2 __attribute__((ext_vector_type(2)));
 
 // wave-level sum helpers; return true on the lane that ends up holding the total
 __device__ __forceinline__ bool tm_wave_sum6(double (&a)[6])

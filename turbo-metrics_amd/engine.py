@@ -97,8 +97,9 @@ class FrameScores:
 
 @dataclass
 class HwFrame:
-    """One decoded frame.  kind: 'nv12' | 'p016' | 'i420' | 'rgb8' | 'rgb16' | 'rgbf32' | 'linear_f32'.
+    """One decoded frame.  kind: 'nv12' | 'p016' | 'i420' | 'i420p10' | 'rgb8' | 'rgb16' | 'rgbf32' | 'linear_f32'.
     'i420': planar 4:2:0, `data` = (Y, Cb, Cr) arrays (uint8, or uint16 with the value in the low `bits` bits).
+    'i420p10': the same 10-bit planes PACKED three samples to a uint32 (tm_engine_set_frame_i420p10: the upload form; synth.p10_pack_plane).
     data: numpy array (host memory) or any object with .data_ptr() (device memory, e.g. a torch
     tensor on the GPU).  For the biplanar kinds `data` is the whole surface (luma rows, then the CbCr
     plane at pitch*coded_height); for RGB kinds it is (h, w, 3).
@@ -118,6 +119,10 @@ class HwFrame:
     @staticmethod
     def i420(y, u, v, bits=8, matrix=ColorMatrix.BT709, full_range=False):
         return HwFrame("i420", (y, u, v), 0, 0, matrix, full_range, bits=bits)
+
+    @staticmethod
+    def i420p10(y, u, v, matrix=ColorMatrix.BT709, full_range=False):
+        return HwFrame("i420p10", (y, u, v), 0, 0, matrix, full_range, bits=10)
 
     @staticmethod
     def nv12(surface, pitch, coded_height, matrix=ColorMatrix.BT709, full_range=False):
@@ -187,7 +192,7 @@ class TurboMetrics:
 
     # -- frames -------------------------------------------------------------------------------
     def set_frame(self, slot: int, side: int, f: HwFrame):
-        if f.kind == "i420":
+        if f.kind in ("i420", "i420p10"):
             planes = [_ptr_and_mem(p) for p in f.data]
             self._keep[(slot, side)] = [k for _, _, k in planes]
             mems = {m for _, m, _ in planes}
@@ -196,6 +201,11 @@ class TurboMetrics:
             pitch = lambda k: int(k.stride(0) * k.element_size()) if hasattr(k, "data_ptr") else int(k.strides[0])
             if pitch(planes[1][2]) != pitch(planes[2][2]):
                 raise ValueError("Cb and Cr must have the same row pitch (tm_engine_set_frame_i420 takes pitch_uv once)")
+            if f.kind == "i420p10":
+                _chk(self._L.tm_engine_set_frame_i420p10(self._h, slot, side, planes[0][0], planes[1][0], planes[2][0], pitch(planes[0][2]),
+                                                         pitch(planes[1][2]), int(f.matrix), int(f.transfer),
+                                                         int(bool(f.full_range)), mems.pop()), "tm_engine_set_frame_i420p10")
+                return
             _chk(self._L.tm_engine_set_frame_i420(self._h, slot, side, planes[0][0], planes[1][0], planes[2][0], pitch(planes[0][2]),
                                                   pitch(planes[1][2]), int(f.bits), int(f.matrix), int(f.transfer),
                                                   int(bool(f.full_range)), mems.pop()), "tm_engine_set_frame_i420")

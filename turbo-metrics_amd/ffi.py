@@ -44,6 +44,9 @@ SYMBOLS = {
     "tm_engine_set_surface_nv12": (_i, [_vp, _u32, _i, _vp, _sz, _u32, _i, _i, _i, _i]),
     "tm_engine_set_surface_p016": (_i, [_vp, _u32, _i, _vp, _sz, _u32, _i, _i, _i, _i]),
     "tm_engine_set_frame_i420": (_i, [_vp, _u32, _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _i, _i, _i]),
+    "tm_engine_set_frame_i420p10": (_i, [_vp, _u32, _i, _vp, _vp, _vp, _sz, _sz, _i, _i, _i, _i]),
+    "tm_p10_row_bytes": (_sz, [_u32]),
+    "tm_p10_pack_rows": (None, [_vp, _sz, _u32, _u32, _vp, _sz]),
     "tm_engine_set_frame_rgb8": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
     "tm_engine_set_frame_rgb16": (_i, [_vp, _u32, _i, _vp, _sz, _i]),
     "tm_engine_set_frame_rgbf32": (_i, [_vp, _u32, _i, _vp, _sz, _i]),

@@ -365,7 +365,7 @@ unsigned effective_cpus()
 
 // ---- planar 4:2:0 streams ---------------------------------------------------------------------------------------------
 struct YuvStreamSource::ReadAhead {
-    struct Piece { size_t pic, off, len; unsigned char *dst; };
+    struct Piece { size_t pic, off, len; unsigned char *dst; uint32_t rows, width; size_t dst_pitch; }; // rows > 0: `rows` rows of `width` 10-bit samples, packed into dst
     std::vector<std::thread> pool;
     std::thread dispatcher;
     std::mutex m;
@@ -387,6 +387,13 @@ YuvStreamSource::YuvStreamSource(FILE *in, bool y4m, uint32_t w, uint32_t h, int
 {
     const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
     planar_bytes_ = ((size_t)w_ * h_ + 2 * cw * ch) * bps;
+    // 10-bit pictures cross PCIe packed: 10.7 instead of 16 bits per sample (37.5 % of a yuv420p10 upload is zeros, and 4K end to end is
+    // bound by that link).  The readers pack while they copy a picture into the page-locked ring.
+    const char *pk = getenv("TM_PACK10");
+    pack10_ = bits_ == 10 && !(pk && atoi(pk) == 0);
+    row_y_ = pack10_ ? tm_p10_row_bytes(w_) : (size_t)w_ * bps;
+    row_c_ = pack10_ ? tm_p10_row_bytes((uint32_t)cw) : cw * bps;
+    slot_bytes_ = row_y_ * h_ + 2 * row_c_ * ch;
     // a regular file is read with pread(), every worker its own byte range, straight from the page cache into the page-locked
     // ring (a mapping of the file costs a minor page fault per 4 KB on first touch: 1.5 M faults for a 6-GB clip, which was what
     // bounded 4K streams)
@@ -556,11 +563,11 @@ void YuvStreamSource::alloc_ring()
     ring_.assign(n, nullptr);
     ring_pinned_.assign(n, 0);
     // slot 0 here ...
-    ring_[0] = (unsigned char *)tm_host_alloc(planar_bytes_);
+    ring_[0] = (unsigned char *)tm_host_alloc(slot_bytes_);
     ring_pinned_[0] = ring_[0] != nullptr;
     if (!ring_pinned_[0]) { // no page-locked memory at all: the whole ring is plain memory (the engine then copies synchronously)
         for (size_t i = 0; i < n; ++i) {
-            ring_[i] = (unsigned char *)calloc(1, planar_bytes_);
+            ring_[i] = (unsigned char *)calloc(1, slot_bytes_);
             if (!ring_[i]) fail("out of memory for the frame ring");
         }
         ring_ready_ = n;
@@ -572,8 +579,8 @@ void YuvStreamSource::alloc_ring()
         ring_alloc_ = std::thread([this, n] {
             bool pinned = true;
             for (size_t i = 1; i < n; ++i) {
-                unsigned char *p = pinned ? (unsigned char *)tm_host_alloc(planar_bytes_) : nullptr;
-                if (!p) { pinned = false; p = (unsigned char *)calloc(1, planar_bytes_); }
+                unsigned char *p = pinned ? (unsigned char *)tm_host_alloc(slot_bytes_) : nullptr;
+                if (!p) { pinned = false; p = (unsigned char *)calloc(1, slot_bytes_); }
                 std::lock_guard<std::mutex> g(ring_m_);
                 if (!p) { ring_failed_ = true; ring_cv_.notify_all(); return; } // out of plain memory too
                 ring_[i] = p;
@@ -645,12 +652,28 @@ void YuvStreamSource::start_readahead(unsigned threads, size_t ahead)
             if (R.quit) return;
             if (ex) { if (p < R.err_pic) { R.err_pic = p; R.err = ex; } R.cv_done.notify_all(); return; }
             if (!more) { R.eof_pic = p; R.cv_done.notify_all(); return; }
-            const size_t npieces = (planar_bytes_ + piece - 1) / piece;
             R.pic_of[slot] = p;
-            R.left[slot] = (unsigned)npieces;
-            for (size_t i = 0; i < npieces; ++i) {
-                const size_t first = i * piece, len = std::min(piece, planar_bytes_ - first);
-                R.q.push_back(ReadAhead::Piece{p, at + first, len, dst + first});
+            if (pack10_) { // whole rows of one plane per piece, ~256 KB of the stream each: the 16-bit rows pass through a reader's cache, not through memory
+                const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
+                struct Plane { size_t off, rows, width, pitch; unsigned char *dst; } planes[3] = {
+                    {at, h_, w_, row_y_, dst}, {at + (size_t)w_ * h_ * 2, ch, cw, row_c_, dst + row_y_ * h_}, {at + ((size_t)w_ * h_ + cw * ch) * 2, ch, cw, row_c_, dst + row_y_ * h_ + row_c_ * ch}};
+                unsigned n = 0;
+                for (const Plane &pl : planes) {
+                    const size_t per = std::max<size_t>(1, ((size_t)256 << 10) / (pl.width * 2));
+                    for (size_t r = 0; r < pl.rows; r += per) {
+                        const size_t k = std::min(per, pl.rows - r);
+                        R.q.push_back(ReadAhead::Piece{p, pl.off + r * pl.width * 2, k * pl.width * 2, pl.dst + r * pl.pitch, (uint32_t)k, (uint32_t)pl.width, pl.pitch});
+                        ++n;
+                    }
+                }
+                R.left[slot] = n;
+            } else {
+                const size_t npieces = (planar_bytes_ + piece - 1) / piece;
+                R.left[slot] = (unsigned)npieces;
+                for (size_t i = 0; i < npieces; ++i) {
+                    const size_t first = i * piece, len = std::min(piece, planar_bytes_ - first);
+                    R.q.push_back(ReadAhead::Piece{p, at + first, len, dst + first, 0, 0, 0});
+                }
             }
             R.cv_job.notify_all();
         }
@@ -667,7 +690,14 @@ void YuvStreamSource::start_readahead(unsigned threads, size_t ahead)
                     R.q.pop_front();
                 }
                 std::exception_ptr ex;
-                try { pread_all(fd_, pc.dst, pc.len, pc.off); } catch (...) { ex = std::current_exception(); }
+                try {
+                    if (pc.rows) { // 10-bit rows: stream -> this thread's scratch -> packed into the ring
+                        static thread_local std::vector<unsigned char> scratch;
+                        if (scratch.size() < pc.len) scratch.resize(pc.len);
+                        pread_all(fd_, scratch.data(), pc.len, pc.off);
+                        tm_p10_pack_rows(scratch.data(), (size_t)pc.width * 2, pc.width, pc.rows, pc.dst, pc.dst_pitch);
+                    } else pread_all(fd_, pc.dst, pc.len, pc.off);
+                } catch (...) { ex = std::current_exception(); }
                 std::lock_guard<std::mutex> g(R.m);
                 if (ex && pc.pic < R.err_pic) { R.err_pic = pc.pic; R.err = ex; }
                 if (--R.left[pc.pic % ring_.size()] == 0 || ex) R.cv_done.notify_all();
@@ -688,9 +718,20 @@ bool YuvStreamSource::read_picture(unsigned char *surface)
         const size_t at = file_pos_;
         file_pos_ += planar_bytes_;
         if (!surface) return true;
-        const std::function<void(size_t, size_t)> piece = [&](size_t first, size_t last) { pread_all(fd_, surface + first, last - first, at + first); };
+        unsigned char *into = surface;
+        if (pack10_) { // the 16-bit picture goes through a scratch copy, then row by row into the packed surface
+            if (planar_.size() != planar_bytes_) planar_.resize(planar_bytes_);
+            into = planar_.data();
+        }
+        const std::function<void(size_t, size_t)> piece = [&](size_t first, size_t last) { pread_all(fd_, into + first, last - first, at + first); };
         if (workers_) workers_->run(planar_bytes_, piece);
         else piece(0, planar_bytes_);
+        if (pack10_) {
+            const size_t rows = (size_t)h_ + 2 * ((h_ + 1) / 2);
+            const std::function<void(size_t, size_t)> pack = [&](size_t first, size_t last) { pack_picture(planar_.data(), surface, first, last); };
+            if (workers_) workers_->run(rows, pack);
+            else pack(0, rows);
+        }
         return true;
     }
     // a pipe: sequential reads, straight into the surface (or into a scratch picture when it is only consumed)
@@ -704,17 +745,32 @@ bool YuvStreamSource::read_picture(unsigned char *surface)
             if (read_bytes(&c, 1) != 1) fail("Y4M: truncated FRAME header");
         } while (c != '\n');
     }
-    if (!surface) {
+    unsigned char *into = surface;
+    if (!surface || pack10_) {
         if (planar_.size() != planar_bytes_) planar_.resize(planar_bytes_);
-        surface = planar_.data();
+        into = planar_.data();
     }
-    const size_t got = read_bytes(surface, planar_bytes_);
+    const size_t got = read_bytes(into, planar_bytes_);
     if (got == 0 && !y4m_) return false;
     if (got != planar_bytes_) {
         if (!y4m_) return false; // a trailing partial picture of a raw stream is ignored
         fail("truncated picture in the YUV stream");
     }
+    if (surface && pack10_) pack_picture(planar_.data(), surface, 0, (size_t)h_ + 2 * ((h_ + 1) / 2));
     return true;
+}
+
+// rows [first_row, last_row) of a 10-bit picture, counted through its Y, Cb and Cr planes: from the stream's 16-bit rows to packed rows
+void YuvStreamSource::pack_picture(const unsigned char *planar, unsigned char *surface, size_t first_row, size_t last_row) const
+{
+    const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
+    for (size_t r = first_row; r < last_row; ++r) {
+        if (r < h_) tm_p10_pack_rows(planar + r * w_ * 2, (size_t)w_ * 2, w_, 1, surface + r * row_y_, row_y_);
+        else {
+            const size_t plane = r - h_ < ch ? 0 : 1, cr = r - h_ - plane * ch;
+            tm_p10_pack_rows(planar + ((size_t)w_ * h_ + (plane * ch + cr) * cw) * 2, cw * 2, (uint32_t)cw, 1, surface + row_y_ * h_ + (plane * ch + cr) * row_c_, row_c_);
+        }
+    }
 }
 
 bool YuvStreamSource::skip_one()
@@ -751,14 +807,14 @@ bool YuvStreamSource::next_frame(HwFrame &out)
         if (!read_picture(surface)) return false;
         ring_pos_ = (ring_pos_ + 1) % ring_.size();
     }
-    const size_t bps = bits_ > 8 ? 2 : 1, cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
+    const size_t ch = (h_ + 1) / 2;
     out = HwFrame{};
-    out.kind = HwFrame::Planar420;
+    out.kind = pack10_ ? HwFrame::Planar420P10 : HwFrame::Planar420;
     out.data = surface;
-    out.u = surface + (size_t)w_ * h_ * bps;
-    out.v = surface + ((size_t)w_ * h_ + cw * ch) * bps;
-    out.pitch = (size_t)w_ * bps;
-    out.pitch_uv = cw * bps;
+    out.u = surface + row_y_ * h_;
+    out.v = surface + row_y_ * h_ + row_c_ * ch;
+    out.pitch = row_y_;
+    out.pitch_uv = row_c_;
     out.bits = bits_;
     out.pinned = ring_pinned_[slot] != 0;
     return true;

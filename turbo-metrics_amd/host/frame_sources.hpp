@@ -7,7 +7,8 @@
 //   ImageFrameSource   PNG (8/16-bit RGB, also Adam7), PPM P6 (8/16-bit), PFM "PF" (f32 RGB): like the reference,
 //                      only RGB sample layouts are accepted (img.rs:17-37 is todo!() for anything else)
 //   YuvStreamSource    YUV4MPEG2 (C420* 8-bit, C420p10 / p12 / p16) and headerless planar I420 / I420p10 with the size given on
-//                      the command line -> HwFrame::Planar420
+//                      the command line -> HwFrame::Planar420; 10-bit streams are PACKED three samples to a word while they are copied into
+//                      the page-locked ring (HwFrame::Planar420P10, tm_p10_pack_rows; TM_PACK10=0 hands them over as 16-bit words)
 #pragma once
 #include <condition_variable>
 #include <cstdio>
@@ -122,7 +123,10 @@ private:
     ColorRange cr_;
     size_t frame_count_;
     std::string codec_;
-    size_t planar_bytes_ = 0;
+    size_t planar_bytes_ = 0;                   // one picture in the STREAM
+    bool pack10_ = false;                       // 10-bit pictures are packed three samples to a word on their way into the ring
+    size_t slot_bytes_ = 0, row_y_ = 0, row_c_ = 0; // one picture in the RING (packed: rows of whole 512-byte blocks), its row pitches
+    void pack_picture(const unsigned char *planar, unsigned char *surface, size_t first_row, size_t last_row) const; // rows of Y, Cb, Cr counted through
     std::vector<unsigned char> planar_;         // pipes: scratch for a picture that is consumed but not handed out
     int fd_ = -1;                               // regular files: positioned reads (pread), split over the workers
     size_t file_size_ = 0, file_pos_ = 0;

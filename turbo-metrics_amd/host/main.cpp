@@ -333,6 +333,10 @@ int main(int argc, char **argv)
             const std::vector<FrameScores> all = sv.frames();
             for (const FrameScores &fs : all) output_single_score(output, fs, std::cout);
             return report(all, sv.decoded(), w, h, start, std::to_string(renv.world) + " ranks (" + transport->name() + ")");
+        } catch (const RankPeerLost &e) { // not this rank's failure: the launcher reports the rank that went away
+            std::cout.flush();
+            log_line(L_WARN, kTarget, "rank " + std::to_string(renv.rank) + " gives up : " + e.what());
+            return RANK_PEER_LOST;
         } catch (const std::exception &e) {
             std::cout.flush();
             log_line(L_ERROR, kTarget, "Computation failed (rank " + std::to_string(renv.rank) + ") : " + e.what());

@@ -111,7 +111,8 @@ int launch_ranks(char **argv, int world, double timeout_s, const char *self)
     int rc = 0, alive = world;
     std::vector<bool> done(world, false);
     bool told = false;
-    std::chrono::steady_clock::time_point told_at;
+    int lost_rank = -1; // a rank that exited with RANK_PEER_LOST while no other failure is known yet
+    std::chrono::steady_clock::time_point told_at, lost_at;
     while (alive > 0) {
         bool progress = false;
         for (int r = 0; r < world; ++r) {
@@ -122,17 +123,25 @@ int launch_ranks(char **argv, int world, double timeout_s, const char *self)
             done[r] = true; --alive; progress = true;
             int code = 1;
             if (got == pids[r]) code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
-            if (code != 0 && rc == 0 && !told) {
-                rc = code;
-                fprintf(stderr, "ERROR turbo_metrics_cli: rank %d of %d failed (exit code %d)\n", r, world, code);
+            // the first failure decides -- unless it is a rank that only lost its peer: the peer's own failure is looked for first
+            if (code != 0 && !told && (rc == 0 || rc == RANK_PEER_LOST)) {
+                if (code == RANK_PEER_LOST && rc == 0) { rc = code; lost_rank = r; lost_at = std::chrono::steady_clock::now(); }
+                else if (code != RANK_PEER_LOST) {
+                    rc = code; lost_rank = -1;
+                    fprintf(stderr, "ERROR turbo_metrics_cli: rank %d of %d failed (exit code %d)\n", r, world, code);
+                }
             }
+        }
+        if (lost_rank >= 0 && (alive == 0 || std::chrono::duration<double>(std::chrono::steady_clock::now() - lost_at).count() > 0.5)) {
+            fprintf(stderr, "ERROR turbo_metrics_cli: rank %d of %d failed (it lost another rank)\n", lost_rank, world);
+            lost_rank = -1;
         }
         const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc == 0 && timeout_s > 0.0 && elapsed > timeout_s) {
             rc = 124;
             fprintf(stderr, "ERROR turbo_metrics_cli: the ranks did not finish within %.0f s\n", timeout_s);
         }
-        if (rc != 0 && alive > 0 && !told) {
+        if (rc != 0 && lost_rank < 0 && alive > 0 && !told) {
             for (int r = 0; r < world; ++r) if (!done[r]) kill(pids[r], SIGTERM);
             told = true; told_at = std::chrono::steady_clock::now();
         }
@@ -150,6 +159,7 @@ static void write_all(int fd, const void *p, size_t n, const char *what)
     while (n) {
         const ssize_t k = write(fd, c, n);
         if (k < 0 && errno == EINTR) continue;
+        if (k < 0 && errno == EPIPE) throw RankPeerLost(std::string(what) + ": the other rank closed the pipe");
         if (k <= 0) throw std::runtime_error(std::string(what) + ": " + strerror(errno));
         c += k; n -= (size_t)k;
     }
@@ -160,13 +170,32 @@ static void read_all(int fd, void *p, size_t n, const char *what)
     while (n) {
         const ssize_t k = read(fd, c, n);
         if (k < 0 && errno == EINTR) continue;
-        if (k == 0) throw std::runtime_error(std::string(what) + ": the other rank closed the pipe");
+        if (k == 0) throw RankPeerLost(std::string(what) + ": the other rank closed the pipe");
         if (k < 0) throw std::runtime_error(std::string(what) + ": " + strerror(errno));
         c += k; n -= (size_t)k;
     }
 }
 
 namespace {
+
+// RCCL writes a version banner to STDOUT when a communicator is set up (seen with 2.27.7: "RCCL version : ...", five lines), and rank 0's
+// stdout is the scores and nothing else: while a call into the library runs, file descriptor 1 points at stderr.
+class StdoutToStderr {
+public:
+    StdoutToStderr()
+    {
+        fflush(stdout);
+        saved_ = dup(STDOUT_FILENO);
+        if (saved_ >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+    }
+    ~StdoutToStderr()
+    {
+        fflush(stdout);
+        if (saved_ >= 0) { dup2(saved_, STDOUT_FILENO); close(saved_); }
+    }
+private:
+    int saved_ = -1;
+};
 
 class PipeTransport : public RankTransport {
 public:
@@ -209,6 +238,7 @@ public:
         if (!get_id_ || !init_ || !reduce_ || !destroy_ || !err_) throw std::runtime_error("libturbometrics_rccl.so does not export include/turbo_metrics_comm.h");
         signal(SIGPIPE, SIG_IGN);
         // the communicator's id: made by rank 0, carried to the others over the launcher's pipes
+        StdoutToStderr quiet;
         char id[TM_COMM_ID_BYTES];
         if (env_.rank == 0) {
             if (get_id_(id)) throw std::runtime_error(std::string("tm_comm_get_unique_id: ") + err_());
@@ -218,12 +248,14 @@ public:
     }
     ~RcclTransport() override
     {
+        StdoutToStderr quiet;
         if (comm_) destroy_(comm_);
         // (the library stays loaded: RCCL's own threads may outlive the communicator)
     }
     const char *name() const override { return "rccl"; }
     void reduce_sum_to_root(std::vector<double> &v) override
     {
+        StdoutToStderr quiet;
         if (reduce_(comm_, v.data(), v.size(), 0)) throw std::runtime_error(std::string("tm_comm_reduce_sum_f64: ") + err_());
     }
 private:

@@ -18,6 +18,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,14 @@ bool rank_env(RankEnv &out);
 // first failing rank's; 124 after timeout_s > 0 seconds).  Must be called before the process has made any GPU call.
 // self: the program to start (nullptr = /proc/self/exe)
 int launch_ranks(char **argv, int world, double timeout_s = 0.0, const char *self = nullptr);
+
+// A rank that fails only because ANOTHER rank went away (its pipe was closed under the reduce) says so: the process exits with
+// RANK_PEER_LOST, and the launcher reports the rank that failed first -- with its own exit code -- when it finds one.
+constexpr int RANK_PEER_LOST = 75;
+class RankPeerLost : public std::runtime_error {
+public:
+    using std::runtime_error::runtime_error;
+};
 
 // one reduce(sum, f64) to rank 0
 class RankTransport {

@@ -237,6 +237,12 @@ void TurboMetrics::set_frame(tm_engine *e, uint32_t slot, int side, const HwFram
         chk(tm_engine_set_frame_i420(e, slot, side, f.data, f.u, f.v, f.pitch, f.pitch_uv, f.bits, matrix, transfer, full, mem), "tm_engine_set_frame_i420");
         break;
     }
+    case HwFrame::Planar420P10: {
+        const int matrix = get_color_matrix(c.first), transfer = get_transfer(c.first);
+        const int full = c.second == ColorRange::Full ? 1 : 0;
+        chk(tm_engine_set_frame_i420p10(e, slot, side, f.data, f.u, f.v, f.pitch, f.pitch_uv, matrix, transfer, full, mem), "tm_engine_set_frame_i420p10");
+        break;
+    }
     case HwFrame::Npp8: chk(tm_engine_set_frame_rgb8(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgb8"); break;
     case HwFrame::Npp16: chk(tm_engine_set_frame_rgb16(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgb16"); break;
     case HwFrame::Npp32: chk(tm_engine_set_frame_rgbf32(e, slot, side, f.data, f.pitch, mem), "tm_engine_set_frame_rgbf32"); break;

@@ -115,7 +115,9 @@ MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Me
 struct HwFrame {
     // Planar420: planar 4:2:0 as files deliver it (not a reference kind: its decoder only yields NV12 / P016) -- data = Y, u, v =
     // the chroma planes at pitch_uv, `bits` = 8, or 9..16 for little-endian u16 samples with the value in the low bits
-    enum Kind { NvDecNV12, NvDecP016, Npp8, Npp16, Npp32, Planar420 } kind = Npp8;
+    // Planar420P10: the same 10-bit planes packed three samples to a 32-bit word (tm_engine_set_frame_i420p10: the upload form; pitches in
+    // bytes of the packed rows)
+    enum Kind { NvDecNV12, NvDecP016, Npp8, Npp16, Npp32, Planar420, Planar420P10 } kind = Npp8;
     const void *data = nullptr; // luma plane or packed RGB
     const void *uv = nullptr;   // CbCr plane (NvDec kinds)
     const void *u = nullptr, *v = nullptr; // Cb, Cr planes (Planar420)

@@ -82,6 +82,37 @@ def pack_biplanar(planes, w, h, bits=8, pitch=None, coded_height=None):
     return surf.view(np.uint8).reshape(-1), pitch, coded_height
 
 
+P10_RUN = 128  # tm_geom.h TM_P10_RUN: samples per contiguous run = words per block of a TM_KIND_I420_P10 row
+
+
+def p10_row_words(n):
+    return -(-n // (3 * P10_RUN)) * P10_RUN
+
+
+def p10_pack_plane(plane, pitch_words=None):
+    """(rows, n) integers in [0, 1023] -> (rows, pitch_words) uint32 in the packed 10-bit upload layout (include/turbo_metrics_hip.h,
+    tm_engine_set_frame_i420p10): word k of block b = s[384 b + k] | s[384 b + 128 + k] << 10 | s[384 b + 256 + k] << 20, absent samples 0.
+    Written with numpy from the header's sentence, not through the library's tm_p10_pack_rows (the tests hold the two against each other)."""
+    plane = np.asarray(plane)
+    rows, n = plane.shape
+    words = p10_row_words(n)
+    pitch_words = words if pitch_words is None else pitch_words
+    pad = np.zeros((rows, words // P10_RUN, 3, P10_RUN), np.uint32)
+    pad.reshape(rows, -1)[:, :n] = plane.astype(np.uint32) & 1023
+    out = np.zeros((rows, pitch_words), np.uint32)
+    out[:, :words] = (pad[:, :, 0] | (pad[:, :, 1] << 10) | (pad[:, :, 2] << 20)).reshape(rows, words)
+    return out
+
+
+def p10_unpack_plane(words, n):
+    """inverse of p10_pack_plane: (rows, >= p10_row_words(n)) uint32 -> (rows, n) int64"""
+    words = np.asarray(words, np.uint32)
+    rows = words.shape[0]
+    w = words[:, :p10_row_words(n)].reshape(rows, -1, 1, P10_RUN)
+    s = np.concatenate([(w >> np.uint32(10 * j)) & np.uint32(1023) for j in range(3)], axis=2)
+    return s.reshape(rows, -1)[:, :n].astype(np.int64)
+
+
 def nv12_pair(w, h, n):
     ref, dis = yuv420_pair(w, h, n, 8)
     return pack_biplanar(ref, w, h, 8), pack_biplanar(dis, w, h, 8)
