@@ -486,13 +486,32 @@ def run_fixed_stream(ctx, eng, name, B, distinct, total):
             "score_mean": float(sc.mean())}
 
 
-def run_host_fed(ctx, args, name, B, steps, warmup):
+def packed10_pairs(ctx, w, h, distinct):
+    """`distinct` 10-bit pairs as page-locked PACKED pictures (tm_engine_set_frame_i420p10: three samples per 32-bit word): Y, Cb, Cr
+    word planes back to back in one tensor per frame, like the CLI's ring slots.  Returns [(ref planes, dis planes)], bytes per pair."""
+    tm, np, torch = ctx.tm, ctx.np, ctx.torch
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    wy, wc = tm.synth.p10_row_words(w), tm.synth.p10_row_words(cw)
+    out = []
+    for n in range(distinct):
+        sides = []
+        for planes in tm.synth.yuv420_pair(w, h, n, 10):
+            flat = np.concatenate([tm.synth.p10_pack_plane(p).reshape(-1) for p in planes])
+            t = torch.from_numpy(flat.view(np.int32)).pin_memory()
+            sides.append((t[:h * wy].view(h, wy), t[h * wy:h * wy + ch * wc].view(ch, wc), t[h * wy + ch * wc:].view(ch, wc)))
+        out.append(tuple(sides))
+    return out, 2 * (h * wy + 2 * ch * wc) * 4
+
+
+def run_host_fed(ctx, args, name, B, steps, warmup, packed10=False):
     """every step uploads its B pairs from page-locked host memory (TM_MEM_HOST_PINNED: asynchronous
     DMA on the engine's stream).  Two engines ping-pong, so the upload of batch k+1 overlaps the kernels of batch k -- the
-    arrangement of the CLI's compute_all.  PCIe-inclusive: reported beside `value`, never as `value`."""
+    arrangement of the CLI's compute_all.  PCIe-inclusive: reported beside `value`, never as `value`.
+    packed10: the same 10-bit pictures handed over as tm_engine_set_frame_i420p10 frames (10.7 instead of 16 bits per sample on the link)."""
     tm, torch = ctx.tm, ctx.torch
     w, h, kind, _, _ = WORKLOADS[name]
     distinct = max(1, min(args.distinct if w * h <= 1920 * 1080 else 2, B))
+    p10 = packed10_pairs(ctx, w, h, distinct) if packed10 else None
     tm.set_placement_candidates(1)
     engs = [tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B) for _ in range(2)]
     tm.set_placement_candidates(8)
@@ -505,7 +524,12 @@ def run_host_fed(ctx, args, name, B, steps, warmup):
         if busy[k & 1]:
             e.sync()
             n_scores += len(e.scores_batch(B))
-        ctx.fill_slots(e, name, distinct, k * B, B, pinned=True)
+        if p10 is not None:
+            for slot in range(B):
+                fr, fd = p10[0][(k * B + slot) % distinct]
+                e.set_pair(slot, tm.HwFrame.i420p10(*fr), tm.HwFrame.i420p10(*fd))
+        else:
+            ctx.fill_slots(e, name, distinct, k * B, B, pinned=True)
         e.compute_async(B)
         busy[k & 1] = True
 
@@ -527,8 +551,8 @@ def run_host_fed(ctx, args, name, B, steps, warmup):
     dt = ctx.max_over_ranks(time.perf_counter() - t0)
     for e in engs:
         e.close()
-    in_bytes = w * h * 3 // 2 * (1 if kind == "nv12" else 2) * 2
-    return {"config": "SURVEY 8d config 2 (ii): pinned host -> H2D every pair, two engines ping-pong", "workload": name,
+    in_bytes = p10[1] if p10 is not None else w * h * 3 // 2 * (1 if kind == "nv12" else 2) * 2
+    return {"config": "SURVEY 8d config 2 (ii): pinned host -> H2D every pair, two engines ping-pong" + (", 10-bit samples packed three to a word (tm_engine_set_frame_i420p10)" if packed10 else ""), "workload": name,
             "value": ctx.world * B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3, "pairs_per_step_per_gpu": B,
             "h2d_GBs_per_gpu": B * steps * in_bytes / dt / 1e9, "note": "PCIe-inclusive; includes the Python loop's 2 x B set_frame calls per step"}
 
@@ -662,7 +686,10 @@ def run_cli_end_to_end(ctx):
             for label, extra in (("tmpfs_just_written", []), ("default", []), ("batch16", ["--batch", "16"]),
                                  # the reference's own loop -- one blocking compute_one per pair -- and the same loop on
                                  # compute_one_deferred + collect (two pairs in flight): what a reference-style caller gets end to end
-                                 ("loop_reference", ["--loop", "reference"]), ("loop_deferred", ["--loop", "deferred"])):
+                                 ("loop_reference", ["--loop", "reference"]), ("loop_deferred", ["--loop", "deferred"])) + (
+                                 # 10-bit clips: the readers pack three samples to a word on the way into the page-locked ring (default since
+                                 # round 6); TM_PACK10=0 hands the 16-bit words over as before
+                                 (("words16", ["TM_PACK10=0"]),) if bits == 10 else ()):
                 # `default` is the STEADY rate with the clip in the page cache: the passes right after the clip was written run at a
                 # third to a half of the later ones, and for how many passes differs from box to box and run to run (1-2 of 5 in
                 # tools-free probes: [2970, 4063, 7529, 7492, 7566]) -- the leg repeats until two consecutive passes agree within
@@ -670,7 +697,9 @@ def run_cli_end_to_end(ctx):
                 passes = []
                 for attempt in range(6 if label == "default" else 1):
                     t0 = time.perf_counter()
-                    r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + extra, capture_output=True, text=True, timeout=300)
+                    env_extra = dict(a.split("=", 1) for a in extra if "=" in a and not a.startswith("-"))
+                    r = subprocess.run([cli, paths[0], paths[1], "-m", "ssimulacra2", "--output", "json-lines"] + [a for a in extra if a.startswith("-") or "=" not in a],
+                                       capture_output=True, text=True, timeout=300, env=dict(os.environ, **env_extra))
                     wall = time.perf_counter() - t0
                     m = re.search(r"Processed: (\d+) .*?\((\d+) fps\)", r.stderr)
                     passes.append(int(m.group(2)) if m else None)
@@ -810,7 +839,7 @@ def compact_line(d):
             sm["_batch_curve_in_flight"] = "[pairs per launch, launches in flight (2_api: via compute_one_deferred/collect), pairs/s]"
     cli = d.get("cli_end_to_end")
     if cli:
-        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("default", "batch16", "loop_reference", "loop_deferred") if isinstance(v.get(lab), dict)}
+        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("default", "batch16", "loop_reference", "loop_deferred", "words16") if isinstance(v.get(lab), dict)}
                                 if isinstance(v, dict) and "error" not in v else (v.get("error", "")[:60] if isinstance(v, dict) else None)
                                 for tag, v in cli.items() if tag != "note"}
     pl = d.get("pipeline")
@@ -910,6 +939,9 @@ def run_rank(args):
                 got = leg("host_fed_" + wl, lambda: run_host_fed(ctx, args, wl, 32 if wl == "1080p_nv12" else 8, max(ks, 40), min(kw, 2)))
                 if got is not None:
                     host_fed[wl] = got
+            got = leg("host_fed_4k_p10", lambda: run_host_fed(ctx, args, "4k_p016", 8, max(ks, 40), min(kw, 2), packed10=True))
+            if got is not None:
+                host_fed["4k_p10"] = got
     batch_curve = None
     if extras and ctx.world == 1 and head_name == "1080p_nv12":
         batch_curve = leg("batch_curve", lambda: run_batch_curve(ctx, args, head_name, B, res))

@@ -46,7 +46,9 @@ int tm_engine_get_stage_ms(tm_engine *e, double ms[TM_STAGE_COUNT], uint64_t *n_
  * the TM_PLANE_PASS1_T read-back of such a job then returns what an earlier launch left there.
  * Every combination produces the same bits.  TM_ERR_INVALID_ARG for any other value. */
 enum { TM_VARIANT_DEFAULT = 0, TM_VARIANT_REFERENCE = 1, TM_VARIANT_WIDE_ROWS = 0x100, TM_VARIANT_TILE_INGEST = 0x200, TM_VARIANT_SPLIT_ROWS = 0x400,
-       TM_VARIANT_WHOLE_ROWS = 0x800, TM_VARIANT_TWO_PASS_EDGE = 0x1000, TM_VARIANT_FUSED_EDGE = 0x4000 };
+       TM_VARIANT_WHOLE_ROWS = 0x800, TM_VARIANT_TWO_PASS_EDGE = 0x1000, TM_VARIANT_UPPER_KERNEL = 0x2000, TM_VARIANT_FUSED_EDGE = 0x4000 };
+/* TM_VARIANT_UPPER_KERNEL: pyramid levels 2..5 of the 4:2:0 kinds by the second kernel (k_ingest_upper_rd, through the LIN2 arena: the
+ * arrangement up to round 5, and still that of the tile kernel) instead of the row-walking kernel's own epilogue. */
 int tm_engine_set_variant(tm_engine *e, int variant);
 
 /* ---- test hooks: read back intermediate planes of one slot (blocking) ------------------ */

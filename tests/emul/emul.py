@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _ASAN = os.environ.get("TM_EMUL_ASAN") == "1"
 _LIB = os.path.join(_HERE, "libtm_emul_asan.so" if _ASAN else "libtm_emul.so")
 _SRCS = [os.path.join(_HERE, "tm_emul.cpp"), os.path.join(_HERE, "hip_emul.h")] + [
-    os.path.join(_ROOT, "turbo-metrics_amd", "csrc", f) for f in ("tm_platform.h", "tm_kernels.h", "tm_ssim_kernels.h", "tm_device_math.h", "tm_geom.h", "tm_math_tables.inc")]
+    os.path.join(_ROOT, "turbo-metrics_amd", "csrc", f) for f in ("tm_platform.h", "tm_kernels.h", "tm_reference_kernels.h", "tm_ssim_kernels.h", "tm_device_math.h", "tm_geom.h", "tm_math_tables.inc")]
 
 
 def build():

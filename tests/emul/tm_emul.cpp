@@ -180,6 +180,7 @@ float tm_shfl_xor(float v, int mask)
 }
 
 #include "../../turbo-metrics_amd/csrc/tm_kernels.h"
+#include "../../turbo-metrics_amd/csrc/tm_reference_kernels.h"
 #include "../../turbo-metrics_amd/csrc/tm_ssim_kernels.h"
 
 // a whole workgroup of `nthreads` lanes; __syncthreads() is a real barrier
@@ -314,8 +315,19 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
         int kind = desc[0].kind;
         for (int i = 1; i < 2 * n; ++i) if (desc[i].kind != kind) kind = -1;
         const bool yuv = kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16 || kind == TM_KIND_I420_P10;
+        bool folded = false;
         if (yuv && !(variant & 0x200)) { // the engine's choice for the 4:2:0 kinds: the side-packed row-walking kernel
             const int rpw = g_ingest_rows;
+            folded = !(variant & 0x2000) && (rpw == 4 || rpw == 8); // TM_VARIANT_UPPER_KERNEL / other row counts: levels 2..5 by k_ingest_upper_rd
+            if (folded) launch_wg_lockstep(dim3((qw + 63) / 64, (qh + 4 * rpw - 1) / (4 * rpw), n), 256, [&] {
+                switch (kind) {
+                case TM_KIND_NV12: tmk::k_ingest_rows<TM_KIND_NV12, true, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                case TM_KIND_P016: tmk::k_ingest_rows<TM_KIND_P016, true, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                case TM_KIND_I420_8: tmk::k_ingest_rows<TM_KIND_I420_8, true, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                case TM_KIND_I420_P10: tmk::k_ingest_rows<TM_KIND_I420_P10, true, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                default: tmk::k_ingest_rows<TM_KIND_I420_16, true, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
+                } });
+            else
             launch_wg_lockstep(dim3((qw + 63) / 64, (qh + 4 * rpw - 1) / (4 * rpw), n), 256, [&] {
                 switch (kind) {
                 case TM_KIND_NV12: tmk::k_ingest_rows<TM_KIND_NV12, true>(tmk::tm_ingest_geom(g), desc, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch, rpw); break;
@@ -334,7 +346,7 @@ void emul_pipeline(int w, int h, int n, const TmFrameDesc *desc, const float *lu
             case TM_KIND_I420_P10: tmk::k_ingest_wave<TM_KIND_I420_P10>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             default: tmk::k_ingest_wave<-1>(g, desc, lut, coef, tab, XYB, lin2.data(), SSE, want_sse, QU8, qplane, qpitch); break;
             } });
-        launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
+        if (!folded) launch_wg_lockstep(dim3((g.s[2].w + 31) / 32, (g.s[2].h + 31) / 32, n), 256, [&] { tmk::k_ingest_upper_rd(g, lin2.data(), XYB); });
         const int vb = jobs.vstart[jobs.nfull], hb = jobs.hstart[jobs.nfull]; // the two passes run jobs [0, nfull)
         // 0x10000: the column pass with every role-wave as a workgroup of its own (launches of a pair or two)
         if (variant & 0x10000) launch_wave_lockstep(dim3(n, vb, 5), [&] { tmk::k_blur_v_jobs<32, 16, 0, true>(g, jobs, XYB, V); });

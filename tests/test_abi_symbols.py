@@ -36,6 +36,61 @@ def test_header_symbols_are_exported_and_bound():
     assert sorted(tm.ffi.SYMBOLS) == names
 
 
+def exported(lib):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    return sorted(m.group(2) for m in re.finditer(r" ([A-Za-z]) (\S+)", out) if m.group(1) in "TDBRW" and not m.group(2).startswith(("_init", "_fini", "__bss", "_edata", "_end")))
+
+
+def device_code(lib, tmp):
+    """{kernel: its disassembly, addresses stripped} of the gfx950 code object inside a library"""
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+    subprocess.check_call([llvm + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    subprocess.check_call([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    txt = subprocess.run([llvm + "llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", co], capture_output=True, text=True, check=True).stdout
+    kernels, name = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]* ?<(\S+)>:$", line.strip())
+        if m:
+            name = m.group(1); kernels[name] = []
+        elif name and line.strip():
+            kernels[name].append(re.sub(r"\s*//.*$", "", line.strip()))
+    for k, ins in kernels.items():  # what follows the last s_endpgm is alignment padding up to the next symbol
+        ends = [i for i, t in enumerate(ins) if t.startswith("s_endpgm")]
+        kernels[k] = ins[:ends[-1] + 1] if ends else ins
+    return kernels
+
+
+def test_the_ship_library_is_the_facade_and_shares_its_kernels_with_the_laboratory_build(tmp_path):
+    """`make ship` -> libturbometrics_hip.so exports exactly the entry points of include/turbo_metrics_hip.h (ship.map), no
+    tm_engine_debug_*, no variants, no fault-injection or read-back hooks, and carries none of the straight-line reference kernels; `make
+    lab` -> lab/libturbometrics_hip_lab.so (what the tests load) has both headers.  Every kernel the ship library carries is in the
+    laboratory build too, instruction for instruction -- what the GPU tier verifies is what ships."""
+    ship, lab = tm.ffi.SHIP_LIB_PATH, tm.ffi.LIB_PATH
+    facade, labsyms = declared_symbols(), declared_symbols("turbo_metrics_hip_debug.h")
+    assert exported(ship) == facade
+    assert [n for n in exported(lab) if n.startswith("tm_")] == sorted(facade + labsyms)  # (the laboratory build has no export map: kernel stubs show too)
+    mp = open(os.path.join(ROOT, "turbo-metrics_amd", "csrc", "ship.map")).read()
+    assert sorted(re.findall(r"^\s+(tm_[a-z0-9_]+);", mp, flags=re.M)) == facade
+    d1, d2 = tmp_path / "ship", tmp_path / "lab"
+    d1.mkdir(); d2.mkdir()
+    ks, kl = device_code(ship, str(d1)), device_code(lab, str(d2))
+    names = lambda d: sorted(n for n in d if n.startswith("_ZN3tmk"))
+    assert names(ks) and set(names(ks)) < set(names(kl))
+    only_lab = sorted(set(names(kl)) - set(names(ks)))
+    assert all(any(k in n for k in ("8k_ingestE", "11k_downscale", "5k_xyb", "8k_blur_vE", "13k_blur_h_jobsE")) for n in only_lab), only_lab  # the reference pipeline, nothing else
+    assert len(only_lab) == 5
+    for n in names(ks):
+        assert ks[n] == kl[n], n
+        assert len(ks[n]) > 10
+    # the C client of the header links against the ship library (test_header_is_plain_c_and_host_entry_points_work) and so does the CLI
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "turbo-metrics_amd", "bin", "turbo-metrics")], capture_output=True, text=True, check=True).stdout
+    assert "libturbometrics_hip.so" in needed and "_lab" not in needed
+
+
 def test_the_rust_binding_in_integration_md_is_the_facade_header():
     """INTEGRATION.md section 2 shows the `extern "C"` block a maintainer adds on the reference's side: exactly the entry points of
     include/turbo_metrics_hip.h -- none missing, none of the laboratory header's"""
@@ -153,10 +208,11 @@ def test_ssim_host_functions_match_oracle():
 
 def test_header_is_plain_c_and_host_entry_points_work(tmp_path):
     import subprocess
-    exe = str(tmp_path / "abi_c_check")
-    lib_dir = os.path.join(ROOT, "turbo-metrics_amd")
-    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "host", "abi_c_check.c"),
-                           "-L" + lib_dir, "-lturbometrics_hip", "-Wl,-rpath," + lib_dir])
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
-    assert out.stdout.startswith("abi ok: turbo-metrics-hip")
+    for flags, lib_dir, name in (([], os.path.join(ROOT, "turbo-metrics_amd"), "turbometrics_hip"),                       # the facade header against the ship library
+                                 (["-DTM_ABI_CHECK_LAB"], os.path.join(ROOT, "turbo-metrics_amd", "lab"), "turbometrics_hip_lab")):  # both headers against the laboratory build
+        exe = str(tmp_path / ("abi_c_check" + ("_lab" if flags else "")))
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror"] + flags + ["-o", exe, os.path.join(ROOT, "tests", "host", "abi_c_check.c"),
+                               "-L" + lib_dir, "-l" + name, "-Wl,-rpath," + lib_dir])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+        assert out.stdout.startswith("abi ok: turbo-metrics-hip")

@@ -231,7 +231,7 @@ def p016_frames(w, h, count=2):
     return frames
 
 
-@pytest.mark.parametrize("rows", [2, 6, 16])
+@pytest.mark.parametrize("rows", [2, 4, 6, 8, 16])  # 4 and 8: pyramid levels 2..5 in the kernel's own epilogue (FOLD); the others through k_ingest_upper_rd
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (1, 1), (2, 5), (129, 20), (257, 131), (130, 7)])
 def test_row_walking_ingest_matches_oracle_and_the_tile_kernel(w, h, rows):
     """k_ingest_rows (what a launch of one 4:2:0 kind gets: a lane = one quad of BOTH frames, a wave = 64 quads x `rows` quad rows,
@@ -246,6 +246,23 @@ def test_row_walking_ingest_matches_oracle_and_the_tile_kernel(w, h, rows):
         assert np.array_equal(em.SUMS, old.SUMS)
         if ssimw is not None:
             assert np.array_equal(em.QU8, old.QU8)
+
+
+UPPER_KERNEL = 0x2000
+
+
+@pytest.mark.parametrize("rows", [4, 8])
+@pytest.mark.parametrize("w,h", [(300, 261), (513, 130), (127, 65), (64, 64), (31, 33), (260, 17)])
+def test_pyramid_levels_2_to_5_from_the_ingest_kernels_epilogue_equal_the_second_kernels(w, h, rows):
+    """round 6: k_ingest_rows<.., FOLD> finishes levels 2..5 from an LDS tile of its workgroup's level-2 linear pixels --
+    several workgroups in x and y, partial tiles on both edges, odd sizes at every level: the whole XYB arena, the SSE and the sums are the
+    bits of the LIN2 + k_ingest_upper_rd arrangement (TM_VARIANT_UPPER_KERNEL), for 8-bit, 16-bit and the packed 10-bit kind"""
+    for frames in (nv12_frames(w, h), p016_frames(w, h, 1), packed10_frames(w, h, 1)):
+        new = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=DEFAULT, weights=O.weights(), full_sums=True, ingest_rows=rows)
+        old = E.Emulated(w, h, frames, O.srgb8_lut(), coef_table(), variant=UPPER_KERNEL, weights=O.weights(), full_sums=True, ingest_rows=rows)
+        assert np.array_equal(new.XYB.view(np.uint32), old.XYB.view(np.uint32)) and np.array_equal(new.SSE, old.SSE) and np.array_equal(new.SUMS, old.SUMS)
+    if w * h < 40000:
+        check_against_oracle(new, frames, w, h, have_linear=False, have_xybt=False)
 
 
 @pytest.mark.parametrize("w,h", [(70, 38), (33, 67), (1, 1), (2, 5), (129, 20), (257, 131), (16, 200), (12, 64)])

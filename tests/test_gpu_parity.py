@@ -143,7 +143,10 @@ def test_row_walking_ingest_equals_the_tile_ingest_and_the_oracle(kind, w, h):
     eng.set_variant(F.TM_VARIANT_TILE_INGEST)
     tile = snapshot()
     eng.set_variant(F.TM_VARIANT_DEFAULT)
-    for rows in (0, 2, 6, 32):
+    # rows 0 (chosen per launch), 4, 8: pyramid levels 2..5 in the kernel's own epilogue (round 6); other counts and TM_VARIANT_UPPER_KERNEL: by
+    # k_ingest_upper_rd, like the tile kernel
+    for rows, variant in ((0, 0), (2, 0), (4, 0), (6, 0), (8, 0), (32, 0), (0, F.TM_VARIANT_UPPER_KERNEL), (8, F.TM_VARIANT_UPPER_KERNEL)):
+        eng.set_variant(variant)
         assert F.lib().tm_engine_debug_set_ingest_rows(eng._h, rows) == 0
         got = snapshot()
         assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got[0], tile[0])), rows
@@ -151,6 +154,9 @@ def test_row_walking_ingest_equals_the_tile_ingest_and_the_oracle(kind, w, h):
         if want_ssim:
             assert all(np.array_equal(a, b) for a, b in zip(got[3], tile[3])), rows
     assert F.lib().tm_engine_debug_set_ingest_rows(eng._h, 3) != 0  # odd
+    eng.set_variant(F.TM_VARIANT_DEFAULT)
+    assert F.lib().tm_engine_debug_set_ingest_rows(eng._h, 0) == 0
+    eng.compute_async(); eng.sync()
     if kind != "i420_10":  # (the planar kinds are checked against the repacked surface elsewhere)
         for slot, (fr, fd) in enumerate(frames):
             lin, sums = check_planes(eng, slot, fr, fd, w, h, scales=range(3))
@@ -613,9 +619,10 @@ def test_packed_10_bit_upload_kind_is_bit_identical_with_planar_10_bit(w, h):
             eng.close()
     e1 = tm.TurboMetrics(w, h, m, batch=1)
     pk = [tm.synth.p10_pack_plane(p) for p in pairs[0][0]]
-    with pytest.raises(tm.TmError) as ei:  # a pitch below one packed row
-        e1.set_frame(0, 0, tm.HwFrame.i420p10(pk[0][:, :-2] if pk[0].shape[1] > 2 else pk[0][:, :0], pk[1], pk[2]))
-    assert ei.value.code == F.TM_ERR_INVALID_ARG
+    if h > 1:  # (a one-row array has no pitch to speak of)
+        with pytest.raises(tm.TmError) as ei:  # a pitch below one packed row
+            e1.set_frame(0, 0, tm.HwFrame.i420p10(np.ascontiguousarray(pk[0][:, :-2]), pk[1], pk[2]))
+        assert ei.value.code == F.TM_ERR_INVALID_ARG
     with pytest.raises(tm.TmError) as ei:
         e1.set_frame(0, 0, tm.HwFrame.i420p10(pk[0], pk[1], pk[2], full_range=True))
     assert ei.value.code == F.TM_ERR_UNSUPPORTED

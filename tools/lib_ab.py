@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""GPU box: A/B of two builds of libturbometrics_hip.so (the shipped one against a lab build from `make -C turbo-metrics_amd/csrc ab
+"""GPU box: A/B of two laboratory builds of the engine library (the committed one, lab/libturbometrics_hip_lab.so, against a build from `make -C turbo-metrics_amd/csrc ab
 EXPFLAGS=... EXPNAME=...`).  Each arm runs in a process of its own (TM_HIP_LIB), the arms alternate A B A B ..., every run = one
 engine, bench.py's pairs per step (bench.WORKLOADS: 128 1080p NV12 / 48 4K P016; --batch B overrides), 32 distinct pairs, 400 ms of
 settling, 60 timed steps with stage events.
 Reports per arm: step ms, pairs/s, stage ms [ingest, col, row, edge, finish] and the scores' checksum (the arms must agree).
 
-    python tools/lib_ab.py A=turbo-metrics_amd/libturbometrics_hip.so B=build_exp/libtm_x.so [--rounds 3] [--workload 4k_p016] [--batch B]
+    python tools/lib_ab.py A=turbo-metrics_amd/lab/libturbometrics_hip_lab.so B=build_exp/libtm_x.so [--rounds 3] [--workload 4k_p016] [--batch B]
+An arm may name an engine variant of the same library instead of another build: B=turbo-metrics_amd/lab/libturbometrics_hip_lab.so@0x2000
+(tm_engine_set_variant: here TM_VARIANT_UPPER_KERNEL).
 """
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,6 +27,7 @@ with ThreadPoolExecutor(8) as ex:
     host = list(ex.map(lambda n: gen(w, h, n), range(ND)))
 pairs = [((torch.from_numpy(rs).cuda(), rp, rch), (torch.from_numpy(ds).cuda(), dp, dch)) for (rs, rp, rch), (ds, dp, dch) in host]
 eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True), batch=B)
+eng.set_variant(%(variant)d)
 for slot in range(B):
     (rt, rp, rch), (dt, dp, dch) = pairs[slot %% ND]
     eng.set_pair(slot, mk(rt, rp, rch), mk(dt, dp, dch))
@@ -53,8 +56,9 @@ def main():
     res = {name: [] for name, _ in arms}
     for r in range(rounds):
         for name, lib in arms:
+            lib, _, variant = lib.partition("@")
             env = dict(os.environ, TM_HIP_LIB=os.path.join(ROOT, lib))
-            p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "wl": wl, "batch": batch}], capture_output=True, text=True, env=env, timeout=600)
+            p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "wl": wl, "batch": batch, "variant": int(variant or "0", 0)}], capture_output=True, text=True, env=env, timeout=600)
             if p.returncode != 0:
                 print(name, "FAILED", p.stderr[-800:])
                 continue

@@ -26,6 +26,14 @@
 #include "tm_geom.h"
 #include "tm_kernels.h"
 #include "tm_ssim_kernels.h"
+// Two builds of this file (csrc/Makefile).  `ship` (-DTM_SHIP; libturbometrics_hip.so, what the CLI and a binder link): the entry points
+// of include/turbo_metrics_hip.h and nothing else are exported (ship.map), the laboratory's functions are not reachable and are dropped by
+// the linker, and the straight-line reference pipeline is not compiled in.  `lab` (lab/libturbometrics_hip_lab.so, what tests/, tools/ and
+// bench.py load): everything of both headers.  The kernels the two builds share are the same device code, instruction for instruction
+// (tests/test_abi_symbols.py compares them).
+#ifndef TM_SHIP
+#include "tm_reference_kernels.h"
+#endif
 #include "tm_tables.inc"
 #include "tm_math_tables.inc"
 
@@ -834,7 +842,7 @@ size_t tm_p10_row_bytes(uint32_t n_samples) { return (size_t)tm_p10_row_words(n_
 
 // one row: word k of block b = s[384 b + k] | s[384 b + 128 + k] << 10 | s[384 b + 256 + k] << 20 (tm_geom.h); three contiguous runs in, one run
 // out: the loops below are what a vectorising compiler wants (no gather, no cross-lane step)
-static void p10_pack_row(const uint16_t *__restrict__ s, uint32_t n, uint32_t *__restrict__ d)
+static inline __attribute__((always_inline)) void p10_pack_row_body(const uint16_t *__restrict__ s, uint32_t n, uint32_t *__restrict__ d)
 {
     uint32_t b = 0;
     for (; (b + 1) * TM_P10_BLOCK <= n; ++b) { // whole blocks
@@ -855,10 +863,15 @@ static void p10_pack_row(const uint16_t *__restrict__ s, uint32_t n, uint32_t *_
     }
 }
 
+// the same loops compiled for the baseline x86-64 (SSE2: four words per step) and for AVX2 (eight), chosen once per process
+static void p10_pack_row_sse2(const uint16_t *s, uint32_t n, uint32_t *d) { p10_pack_row_body(s, n, d); }
+__attribute__((target("avx2"))) static void p10_pack_row_avx2(const uint16_t *s, uint32_t n, uint32_t *d) { p10_pack_row_body(s, n, d); }
+
 void tm_p10_pack_rows(const void *src, size_t src_pitch, uint32_t width, uint32_t rows, void *dst, size_t dst_pitch)
 {
+    static void (*const pack)(const uint16_t *, uint32_t, uint32_t *) = __builtin_cpu_supports("avx2") ? p10_pack_row_avx2 : p10_pack_row_sse2;
     for (uint32_t r = 0; r < rows; ++r)
-        p10_pack_row((const uint16_t *)((const char *)src + (size_t)r * src_pitch), width, (uint32_t *)((char *)dst + (size_t)r * dst_pitch));
+        pack((const uint16_t *)((const char *)src + (size_t)r * src_pitch), width, (uint32_t *)((char *)dst + (size_t)r * dst_pitch));
 }
 
 int tm_engine_set_frame_rgb8(tm_engine *e, uint32_t slot, int side, const void *rgb, size_t pitch, int mem)
@@ -954,7 +967,7 @@ int tm_engine_set_profiling(tm_engine *e, int on)
 
 int tm_engine_set_variant(tm_engine *e, int variant)
 {
-    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST | TM_VARIANT_SPLIT_ROWS | TM_VARIANT_WHOLE_ROWS | TM_VARIANT_TWO_PASS_EDGE | TM_VARIANT_FUSED_EDGE))) return TM_ERR_INVALID_ARG;
+    if (!e || (variant & ~(TM_VARIANT_REFERENCE | TM_VARIANT_WIDE_ROWS | TM_VARIANT_TILE_INGEST | TM_VARIANT_SPLIT_ROWS | TM_VARIANT_WHOLE_ROWS | TM_VARIANT_TWO_PASS_EDGE | TM_VARIANT_FUSED_EDGE | TM_VARIANT_UPPER_KERNEL))) return TM_ERR_INVALID_ARG;
     if ((variant & TM_VARIANT_TWO_PASS_EDGE) && (variant & TM_VARIANT_FUSED_EDGE)) return TM_ERR_INVALID_ARG;
     const bool ref = (variant & TM_VARIANT_REFERENCE) != 0;
     // the reference pipeline is SSIMULACRA2 (+ PSNR) only: its ingest kernel neither writes the u8 planes of SSIM / MS-SSIM nor runs without the XYB arenas
@@ -1008,15 +1021,21 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
     const TmFrameDesc *h_desc = e->h_desc, *d_desc = e->d_desc;
     const bool ssimu2 = (e->mask & TM_METRIC_SSIMULACRA2) != 0;
     float *XYB = e->XYB, *XYBT = e->XYBT, *V = e->V, *LIN = e->LIN, *LIN2 = e->LIN2;
+    (void)XYBT; (void)LIN; // (the reference pipeline's arenas: unused in the ship build)
     double *PART = e->PART, *SUMS = e->SUMS;
     unsigned long long *SSE = e->SSE;
     unsigned char *QU8 = e->QU8;
+#ifdef TM_SHIP
+    const bool reference = false; // (no way to select it: tm_engine_set_variant is not part of the ship library)
+#else
     const bool reference = (e->variant & TM_VARIANT_REFERENCE) != 0;
+#endif
     const bool chained = e->chain_peer != nullptr && !e->use_graph;
     if (chained) HIPCHK(hipStreamWaitEvent(st, e->chain_peer->ev_col_done, 0)); // (an event never recorded counts as complete)
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     // ---- stage INGEST: frames -> linear RGB -> XYB pyramid
     if (reference) { // separate straight-line kernels, linear pyramid in HBM, two plain XYB pyramids [side][scale][channel]
+#ifndef TM_SHIP
         const int qw = ((int)e->w + 1) / 2, qh = ((int)e->h + 1) / 2;
         dim3 grid((unsigned)((qw + 63) / 64), (unsigned)((qh + 3) / 4), (unsigned)n), block(64, 4, 1);
         hipLaunchKernelGGL(tmk::k_ingest, grid, block, 0, st, g, d_desc, e->d_lut, e->d_coef, e->d_powtab, LIN, SSE, want_sse);
@@ -1024,6 +1043,7 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             hipLaunchKernelGGL(tmk::k_downscale, grid2(g.s[s].w, g.s[s].h, n * 6), dim3(64), 0, st, g, s, LIN);
         for (int s = 0; s < TM_SCALES; ++s)
             hipLaunchKernelGGL(tmk::k_xyb, grid2(g.s[s].w, g.s[s].h, n * 2), dim3(64), 0, st, g, s, LIN, XYB);
+#endif
     } else {
         dim3 grid((unsigned)((e->w + 31) / 32), (unsigned)((e->h + 7) / 8), (unsigned)n);
         int kind = h_desc[0].kind; // one format for the whole launch (the normal case) -> specialised kernel
@@ -1037,12 +1057,18 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
             rpw = 8;
             while (rpw > 2 && (long long)((qw + 63) / 64) * ((qh + rpw - 1) / rpw) * n < 16384) rpw /= 2;
         }
+        const bool rows = !(e->variant & TM_VARIANT_TILE_INGEST);
+        const bool yuv420 = kind == TM_KIND_NV12 || kind == TM_KIND_P016 || kind == TM_KIND_I420_8 || kind == TM_KIND_I420_16 || kind == TM_KIND_I420_P10;
+        // levels 2..5 in the row-walking kernel's own epilogue (a workgroup = 128 x 16 rpw pixels = whole level-5 pixels for rpw 4 or 8); the
+        // tile kernel, other values of the test hook and TM_VARIANT_UPPER_KERNEL go through LIN2 and k_ingest_upper_rd
+        const bool fold = ssimu2 && rows && yuv420 && !(e->variant & TM_VARIANT_UPPER_KERNEL) && (e->ingest_rows <= 0 || e->ingest_rows == 4 || e->ingest_rows == 8);
+        if (fold && rpw < 4) rpw = 4;
         dim3 rgrid((unsigned)((qw + 63) / 64), (unsigned)((qh + 4 * rpw - 1) / (4 * rpw)), (unsigned)n);
         const tmk::TmIngestGeom ig = tmk::tm_ingest_geom(g);
         const bool quant = want_sse || QU8 != nullptr;
-#define TM_LAUNCH_R(K) do { if (quant) hipLaunchKernelGGL((tmk::k_ingest_rows<K, true>), rgrid, dim3(256), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); \
-                        else hipLaunchKernelGGL((tmk::k_ingest_rows<K, false>), rgrid, dim3(256), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw); } while (0)
-        const bool rows = !(e->variant & TM_VARIANT_TILE_INGEST);
+#define TM_LAUNCH_RF(K, Q, F) hipLaunchKernelGGL((tmk::k_ingest_rows<K, Q, F>), rgrid, dim3(256), 0, st, ig, d_desc, e->d_coef, e->d_powtab, XYB, LIN2, SSE, want_sse, QU8, e->sg.qplane, e->sg.pitch[0], rpw)
+#define TM_LAUNCH_R(K) do { if (quant) { if (fold) TM_LAUNCH_RF(K, true, true); else TM_LAUNCH_RF(K, true, false); } \
+                        else { if (fold) TM_LAUNCH_RF(K, false, true); else TM_LAUNCH_RF(K, false, false); } } while (0)
         switch (kind) {
         case TM_KIND_NV12: if (rows) TM_LAUNCH_R(TM_KIND_NV12); else TM_LAUNCH_W(TM_KIND_NV12); break;
         case TM_KIND_P016: if (rows) TM_LAUNCH_R(TM_KIND_P016); else TM_LAUNCH_W(TM_KIND_P016); break;
@@ -1056,9 +1082,10 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         default: TM_LAUNCH_W(-1); break;
         }
 #undef TM_LAUNCH_R
+#undef TM_LAUNCH_RF
 #undef TM_LAUNCH_W
-        // levels 2..5
-        if (ssimu2) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
+        // levels 2..5 (when the ingest kernel has not produced them itself)
+        if (ssimu2 && !fold) hipLaunchKernelGGL(tmk::k_ingest_upper_rd, dim3((unsigned)((g.s[2].w + 31) / 32), (unsigned)((g.s[2].h + 31) / 32), (unsigned)n), dim3(256), 0, st, g, LIN2, XYB);
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     // ---- SSIM / MS-SSIM on the u8 planes the ingest kernel wrote (tm_ssim_kernels.h)
@@ -1122,16 +1149,22 @@ static int launch_batch(tm_engine *e, hipStream_t st, int n, int want_sse, hipEv
         if (beside) { HIPCHK(hipEventRecord(e->ev_fork, st)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); }
         if (beside && e->ef_beside == 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_V: column pass, all scales / channels / slots in one launch
+#ifndef TM_SHIP
         if (reference) hipLaunchKernelGGL(tmk::k_blur_v, dim3((unsigned)g.vblk[TM_SCALES], 3, (unsigned)n), dim3(64), 0, st, g, XYB, XYBT, V);
+        else
+#endif
         // few column blocks (a pair or two per launch): every role-wave as a workgroup of its own, a SIMD each (tm_kernels.h)
-        else if (vgrid.y && 5ll * n * vgrid.y <= e->solo_col_below) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 0, true>), dim3(vgrid.x, vgrid.y, 5), dim3(64), 0, st, g, jobs, XYB, V);
+        if (vgrid.y && 5ll * n * vgrid.y <= e->solo_col_below) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16, 0, true>), dim3(vgrid.x, vgrid.y, 5), dim3(64), 0, st, g, jobs, XYB, V);
         else if (vgrid.y) hipLaunchKernelGGL((tmk::k_blur_v_jobs<32, 16>), vgrid, dim3(320), 0, st, g, jobs, XYB, V);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         if (!e->use_graph) HIPCHK(hipEventRecord(e->ev_col_done, st));
         if (beside && e->ef_beside != 1) { int rc = launch_fused(e->stream2); if (rc) return rc; }
         // ---- stage BLUR_H: row pass + error maps + reductions
+#ifndef TM_SHIP
         if (reference) hipLaunchKernelGGL(tmk::k_blur_h_jobs, dim3((unsigned)jobs.hstart[TM_MAX_JOBS], 1, (unsigned)n), dim3(64), 0, st, g, jobs, XYBT, V, PART);
-        else if (!hgrid.y) {}
+        else
+#endif
+        if (!hgrid.y) {}
         // few row blocks (small launches): eight waves per block -- what one CU can issue for one row block, not the chip, bounds this pass then
         // (faster than the one-wave pass up to 32 1080p pairs beside the fused kernel = 2 432 row blocks of FULL jobs -- 13.2 k vs 13.0 k pairs/s --,
         // slower at 48 = 3 648 blocks: 13.6 k vs 13.75 k; profiles/r04e_split8_threshold.log)

@@ -6,8 +6,8 @@
 //              over the ref/dis-interleaved XYB pyramid, job-table driven, slot-major grids (x = slot); larger launches send the
 //              edge-only jobs through k_blur_edge_fused + k_finish_edge (one kernel, no pass-1 planes) beside the two passes
 //   reference  k_ingest + k_downscale + k_xyb -> k_blur_v -> k_blur_h_jobs -> k_finish_jobs: straight-line, LDS-free kernels
-//              whose only job is to be obviously correct (engine variant TM_VARIANT_REFERENCE); the GPU tier checks that the
-//              two pipelines produce identical bits on the device, and both against the CPU oracle.
+//              whose only job is to be obviously correct (engine variant TM_VARIANT_REFERENCE): tm_reference_kernels.h, laboratory
+//              build only; the GPU tier checks that the two pipelines produce identical bits on the device, and both against the CPU oracle.
 //
 // Launch geometry (64-lane wavefront == 1 workgroup unless noted):
 //   k_ingest_rows     grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/(4 rows_per_wave)), slots)  block 256  four waves, each 64 quads x rows_per_wave quad rows of both sides
@@ -19,11 +19,6 @@
 //   k_finish_jobs     grid (slots)                                   block 128
 //   k_blur_edge_fused<4, grouped>  grid (tickets = slots * edge jobs * ceil(bands of 32 rows / 4), or fewer: persistent)  block 256   four waves = four adjacent bands of one (slot, job) per ticket
 //   k_finish_edge     grid (slots * edge jobs)                       block 64
-//   k_ingest          grid (ceil(ceil(w/2)/64), ceil(ceil(h/2)/4), slots)   block (64,4)
-//   k_downscale       grid (ceil(dw/64), dh, slots*2*3)              block 64
-//   k_xyb             grid (ceil(w/64), h, slots*2)                  block 64
-//   k_blur_v          grid (vblk[6], 3, slots)                       block 64    lane = image column, all 6 scales in one launch
-//   k_blur_h_jobs     grid (jobs.hstart[n], 1, slots)                block 64
 //
 // Arithmetic follows the reference kernels operation for operation (cited per function); the
 // file must be compiled with -ffp-contract=off so that only the explicit fmaf calls fuse.
@@ -248,91 +243,6 @@ __device__ __forceinline__ void yuv_quad_convert(const TmFrameDesc &d, const uns
         px[q >> 1][q & 1][0] = tmdev::clamp01(tmdev::bt709_eotf(luma + r_, tab));
         px[q >> 1][q & 1][1] = tmdev::clamp01(tmdev::bt709_eotf(luma + g_, tab));
         px[q >> 1][q & 1][2] = tmdev::clamp01(tmdev::bt709_eotf(luma + b_, tab));
-    }
-}
-
-__global__ void __launch_bounds__(256) k_ingest(TmGeom g, const TmFrameDesc *__restrict__ desc,
-                                                const float *__restrict__ lut, const float *__restrict__ coef,
-                                                const double *__restrict__ tab, float *__restrict__ LIN,
-                                                unsigned long long *__restrict__ SSE, int want_sse)
-{
-    const int qx = blockIdx.x * 64 + threadIdx.x;
-    const int qy = blockIdx.y * 4 + threadIdx.y;
-    const int slot = blockIdx.z;
-    const int w = g.s[0].w, h = g.s[0].h, pitch = g.s[0].pitch;
-    const bool inside = 2 * qx < w && 2 * qy < h;
-    int q[2][2][2][3];
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const TmFrameDesc d = desc[slot * 2 + side];
-        float px[2][2][3];
-#pragma unroll
-        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < 2; ++ix)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) px[iy][ix][c] = 0.0f;
-        if (inside) {
-            if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_P016 || d.kind == TM_KIND_I420_8 || d.kind == TM_KIND_I420_16 || d.kind == TM_KIND_I420_P10) {
-                if (2 * qx + 1 < w && 2 * qy + 1 < h) {
-                    if (d.kind == TM_KIND_NV12 || d.kind == TM_KIND_I420_8) ingest_yuv_quad<unsigned char, 8>(d, coef, tab + TM_TAB_EOTF64, qx, qy, px);
-                    else ingest_yuv_quad<unsigned short, 16>(d, coef, tab + TM_TAB_EOTF64, qx, qy, px);
-                }
-            } else {
-#pragma unroll
-                for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                    for (int ix = 0; ix < 2; ++ix) {
-                        const int x = 2 * qx + ix, y = 2 * qy + iy;
-                        if (x < w && y < h) {
-                            const char *row = (const char *)d.p0 + (size_t)y * d.pitch;
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                float v;
-                                if (d.kind == TM_KIND_RGB8) v = lut[((const unsigned char *)row)[3 * x + c]];
-                                else if (d.kind == TM_KIND_RGB16)
-                                    v = tmdev::srgb_inverse_oetf((float)((const unsigned short *)row)[3 * x + c] / 65535.0f, tab);
-                                else if (d.kind == TM_KIND_RGBF32)
-                                    v = tmdev::srgb_inverse_oetf(((const float *)row)[3 * x + c], tab);
-                                else v = ((const float *)row)[3 * x + c];
-                                px[iy][ix][c] = v;
-                            }
-                        }
-                    }
-            }
-            float *base = LIN + (size_t)(slot * 2 + side) * g.pyr;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int iy = 0; iy < 2; ++iy) {
-                    const int y = 2 * qy + iy;
-                    if (y < h) {
-                        float *o = base + c * g.s[0].plane + (size_t)y * pitch + 2 * qx;
-                        if (2 * qx + 1 < w) *(float2 *)o = make_float2(px[iy][0][c], px[iy][1][c]);
-                        else o[0] = px[iy][0][c];
-                    }
-                }
-        }
-#pragma unroll
-        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-            for (int ix = 0; ix < 2; ++ix)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) q[side][iy][ix][c] = (int)rintf(px[iy][ix][c] * 255.0f);
-    }
-    if (want_sse) {
-        unsigned sse[3] = {0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix) {
-                    const int dlt = q[0][iy][ix][c] - q[1][iy][ix][c];
-                    sse[c] += (unsigned)(dlt * dlt);
-                }
-        if (tm_wave_sum_u32x3(sse))
-            for (int c = 0; c < 3; ++c) atomicAdd(&SSE[(size_t)slot * TM_SSE_BINS * 3 + c], (unsigned long long)sse[c]);
     }
 }
 
@@ -578,12 +488,22 @@ struct TmIngestGeom {
     int w, h, w1, h1, w2, h2;
     int pitch0, pitch1, pitch2;
     unsigned long long plane0, plane1, plane2, off1, pyr;
+    // levels 2..5 (the FOLD epilogue): sizes, pitches, plane sizes and offsets inside a pyramid
+    int wu[4], hu[4], pitchu[4];
+    unsigned long long planeu[4], offu[4];
 };
 __host__ __device__ inline TmIngestGeom tm_ingest_geom(const TmGeom &g)
 {
-    return TmIngestGeom{g.s[0].w, g.s[0].h, g.s[1].w, g.s[1].h, g.s[2].w, g.s[2].h, g.s[0].pitch, g.s[1].pitch, g.s[2].pitch,
-                        g.s[0].plane, g.s[1].plane, g.s[2].plane, g.s[1].off, g.pyr};
+    TmIngestGeom o{g.s[0].w, g.s[0].h, g.s[1].w, g.s[1].h, g.s[2].w, g.s[2].h, g.s[0].pitch, g.s[1].pitch, g.s[2].pitch,
+                   g.s[0].plane, g.s[1].plane, g.s[2].plane, g.s[1].off, g.pyr, {}, {}, {}, {}, {}};
+    for (int k = 0; k < 4; ++k) { o.wu[k] = g.s[2 + k].w; o.hu[k] = g.s[2 + k].h; o.pitchu[k] = g.s[2 + k].pitch; o.planeu[k] = g.s[2 + k].plane; o.offu[k] = g.s[2 + k].off; }
+    return o;
 }
+// FOLD (round 6): levels 2..5 of the pyramid are finished by the workgroup that produced their level-2 linear pixels -- the four waves of
+// a workgroup cover 128 x 16 rows_per_wave pixels, a whole number of level-5 pixels when rows_per_wave is 4 or 8 -- out of an LDS tile
+// instead of the LIN2 arena and a second kernel (k_ingest_upper_rd: 3 MB written and read per 1080p pair, a launch, and a kernel of 2 040
+// small workgroups at its own latency floor).  Same operations on the same values: same bits.
+#define TM_FOLD_ROWS2 16 /* level-2 rows of the tile at rows_per_wave = 8 */
 
 // QUANT: the launch wants the integer SSE (PSNR) and / or the u8 planes (SSIM, MS-SSIM); the SSIMULACRA2-only instantiation carries
 // none of that code
@@ -597,7 +517,7 @@ __host__ __device__ inline TmIngestGeom tm_ingest_geom(const TmGeom &g)
 #ifndef TM_ROWS_WAVES
 #define TM_ROWS_WAVES 5
 #endif
-template <int KIND, bool QUANT>
+template <int KIND, bool QUANT, bool FOLD = false>
 __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAVES) k_ingest_rows(TmIngestGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ coef,
                                                     const double *__restrict__ gtab, float *__restrict__ XYB, float *__restrict__ LIN2,
                                                     unsigned long long *__restrict__ SSE, int want_sse, unsigned char *__restrict__ QU8,
@@ -611,6 +531,11 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
     constexpr int BITS = YUV8 ? 8 : 16;
     using T = typename std::conditional<YUV8, unsigned char, unsigned short>::type;
     __shared__ __attribute__((aligned(32))) double et64[TM_EOTF64_STRIDE * TM_EOTF64_SEGS]; // the transfer-function table (tm_device_math.h bt709_power2), 16.4 KB per four waves
+    // FOLD: {ref, dis} linear pixels of level 2 (32 columns x up to 16 rows per workgroup: 12.7 KB, filled while the waves walk); those of
+    // levels 3 and 4 (3.3 + 0.9 KB) take the table's place once every wave is done with it -- 29.1 KB per workgroup: five per CU
+    __shared__ tm_f2 l2t[FOLD ? 3 * TM_FOLD_ROWS2 * 33 : 1];
+    tm_f2 *const l3t = (tm_f2 *)et64, *const l4t = l3t + 3 * (TM_FOLD_ROWS2 / 2) * 17;
+    static_assert((3 * (TM_FOLD_ROWS2 / 2) * 17 + 3 * (TM_FOLD_ROWS2 / 4) * 9) * sizeof(tm_f2) <= TM_EOTF64_STRIDE * TM_EOTF64_SEGS * sizeof(double), "fold tiles fit the table");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // four independent waves share one staging of the table
     const int slot = blockIdx.z;
@@ -769,7 +694,9 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
             for (int c = 0; c < 3; ++c) {
                 const tm_f2 v00 = lower ? up[c] : l1[c], v10 = l1[c];
                 const tm_f2 v = ds4_sides(v00, tm_swap1(v00), v10, tm_swap1(v10), ok2x, ok2y);
-                if (st) {
+                if (FOLD) {
+                    if (st) l2t[(c * TM_FOLD_ROWS2 + (YL - (int)blockIdx.y * 2 * rows_per_wave)) * 33 + (lane >> 1)] = v;
+                } else if (st) {
                     const size_t o = (size_t)c * g.plane2 + tm_mul24((unsigned)YL, (unsigned)g.pitch2) + (unsigned)XL;
                     LIN2[(size_t)(slot * 2 + 0) * 3 * g.plane2 + o] = v.x;
                     LIN2[(size_t)(slot * 2 + 1) * 3 * g.plane2 + o] = v.y;
@@ -785,6 +712,77 @@ __global__ void __launch_bounds__(256) TM_WAVES_PER_SIMD(QUANT ? 4 : TM_ROWS_WAV
             const unsigned bin = (blockIdx.x + (blockIdx.y * 4 + wave) * 29) % TM_SSE_BINS;
 #pragma unroll
             for (int c = 0; c < 3; ++c) atomicAdd(&SSE[((size_t)slot * TM_SSE_BINS + bin) * 3 + c], (unsigned long long)sse3[c]);
+        }
+    }
+    if (!FOLD || xi == nullptr) return; // (wave- and workgroup-uniform)
+    // ---- levels 2..5 of this workgroup's tile: 32 x R2 pixels of level 2 (R2 = 2 rows_per_wave = 8 or 16), what k_ingest_upper_rd does for
+    // the tile kernel (downscale.rs:5-35, xyb.rs:42-79), on {ref, dis} pairs.  Pixels beyond the image read as 0 and are never stored.
+    TM_LDS_BARRIER(); // the four waves' level-2 pixels are in the tile
+    const int tid = threadIdx.x;
+    const int R2 = 2 * rows_per_wave, x2_0 = blockIdx.x * 32, y2_0 = blockIdx.y * R2;
+    if (tid < 8 * R2) { // one lane per 2 x 2 quad of level 2: its four pixels and their level-3 parent
+        const int qx2 = tid & 15, qy2 = tid >> 4, X2 = x2_0 + 2 * qx2, Y2 = y2_0 + 2 * qy2;
+        tm_f2 lr[5], lg[5], lb[5], xa[5], xb[5], xc[5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = X2 + (k & 1) < g.wu[0] && Y2 + (k >> 1) < g.hu[0];
+            const int o = (2 * qy2 + (k >> 1)) * 33 + 2 * qx2 + (k & 1);
+            const tm_f2 a = l2t[o], b = l2t[TM_FOLD_ROWS2 * 33 + o], c = l2t[2 * TM_FOLD_ROWS2 * 33 + o];
+            lr[k] = in ? a : f2_splat(0.0f); lg[k] = in ? b : f2_splat(0.0f); lb[k] = in ? c : f2_splat(0.0f);
+        }
+        const bool okx = X2 + 1 < g.wu[0], oky = Y2 + 1 < g.hu[0];
+        lr[4] = ds4_sides(lr[0], lr[1], lr[2], lr[3], okx, oky);
+        lg[4] = ds4_sides(lg[0], lg[1], lg[2], lg[3], okx, oky);
+        lb[4] = ds4_sides(lb[0], lb[1], lb[2], lb[3], okx, oky);
+        l3t[qy2 * 17 + qx2] = lr[4]; l3t[(TM_FOLD_ROWS2 / 2) * 17 + qy2 * 17 + qx2] = lg[4]; l3t[2 * (TM_FOLD_ROWS2 / 2) * 17 + qy2 * 17 + qx2] = lb[4];
+        linear_to_xyb_sides<5>(lr, lg, lb, xa, xb, xc);
+        const tm_f2 *xv[3] = {xa, xb, xc};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy)
+                if (X2 < g.wu[0] && Y2 + iy < g.hu[0]) // X2 is even and the pitch a multiple of 64 floats: the pair of pixels stays inside the row
+                    *(tm_f4 *)(xi + 2 * (g.offu[0] + c * g.planeu[0] + (size_t)(Y2 + iy) * g.pitchu[0] + X2)) =
+                        tm_make_f4(xv[c][2 * iy].x, xv[c][2 * iy].y, xv[c][2 * iy + 1].x, xv[c][2 * iy + 1].y);
+            if (X2 / 2 < g.wu[1] && Y2 / 2 < g.hu[1])
+                *(tm_g2 *)(xi + 2 * (g.offu[1] + c * g.planeu[1] + (size_t)(Y2 / 2) * g.pitchu[1] + X2 / 2)) = tm_g2{xv[c][4].x, xv[c][4].y};
+        }
+    }
+    TM_LDS_BARRIER();
+    if (tid < 2 * R2) { // level 4: 8 x R2 / 4 pixels
+        const int ox = tid & 7, oy = tid >> 3, XL = (x2_0 >> 2) + ox, YL = (y2_0 >> 2) + oy;
+        const bool okx = 2 * XL + 1 < g.wu[1], oky = 2 * YL + 1 < g.hu[1];
+        tm_f2 v[3][1], xa[1], xb[1], xc[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const tm_f2 *t = l3t + c * (TM_FOLD_ROWS2 / 2) * 17 + (2 * oy) * 17 + 2 * ox;
+            v[c][0] = ds4_sides(t[0], t[1], t[17], t[18], okx, oky);
+            l4t[c * (TM_FOLD_ROWS2 / 4) * 9 + oy * 9 + ox] = v[c][0];
+        }
+        if (XL < g.wu[2] && YL < g.hu[2]) {
+            linear_to_xyb_sides<1>(v[0], v[1], v[2], xa, xb, xc);
+            const size_t o = g.offu[2] + (size_t)YL * g.pitchu[2] + XL;
+            *(tm_g2 *)(xi + 2 * o) = tm_g2{xa[0].x, xa[0].y};
+            *(tm_g2 *)(xi + 2 * (o + g.planeu[2])) = tm_g2{xb[0].x, xb[0].y};
+            *(tm_g2 *)(xi + 2 * (o + 2 * g.planeu[2])) = tm_g2{xc[0].x, xc[0].y};
+        }
+    }
+    TM_LDS_BARRIER();
+    if (tid < R2 / 2) { // level 5: 4 x R2 / 8 pixels
+        const int ox = tid & 3, oy = tid >> 2, XL = (x2_0 >> 3) + ox, YL = (y2_0 >> 3) + oy;
+        const bool okx = 2 * XL + 1 < g.wu[2], oky = 2 * YL + 1 < g.hu[2];
+        tm_f2 v[3][1], xa[1], xb[1], xc[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const tm_f2 *t = l4t + c * (TM_FOLD_ROWS2 / 4) * 9 + (2 * oy) * 9 + 2 * ox;
+            v[c][0] = ds4_sides(t[0], t[1], t[9], t[10], okx, oky);
+        }
+        if (XL < g.wu[3] && YL < g.hu[3]) {
+            linear_to_xyb_sides<1>(v[0], v[1], v[2], xa, xb, xc);
+            const size_t o = g.offu[3] + (size_t)YL * g.pitchu[3] + XL;
+            *(tm_g2 *)(xi + 2 * o) = tm_g2{xa[0].x, xa[0].y};
+            *(tm_g2 *)(xi + 2 * (o + g.planeu[3])) = tm_g2{xb[0].x, xb[0].y};
+            *(tm_g2 *)(xi + 2 * (o + 2 * g.planeu[3])) = tm_g2{xc[0].x, xc[0].y};
         }
     }
 }
@@ -889,121 +887,6 @@ __global__ void __launch_bounds__(256) k_ingest_upper_rd(TmGeom g, const float *
             }
         }
         TM_LDS_BARRIER(); // lin3 / lin4 are reused by the next side
-    }
-}
-
-// downscale_by_2, ssimulacra2-cuda-kernel/src/downscale.rs:5-35, one plane per blockIdx.z
-__global__ void __launch_bounds__(64) k_downscale(TmGeom g, int s, float *__restrict__ LIN)
-{
-    const TmScaleGeom src = g.s[s - 1], dst = g.s[s];
-    const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y;
-    if (ox >= dst.w) return;
-    const int img = blockIdx.z / 3, c = blockIdx.z % 3;
-    const float *sp = LIN + (size_t)img * g.pyr + src.off + c * src.plane;
-    float *dp = LIN + (size_t)img * g.pyr + dst.off + c * dst.plane;
-    float sum = 0.0f;
-#pragma unroll
-    for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-        for (int ix = 0; ix < 2; ++ix) {
-            const int x = min(ox * 2 + ix, src.w - 1);
-            const int y = min(oy * 2 + iy, src.h - 1);
-            sum += sp[(size_t)y * src.pitch + x];
-        }
-    dp[(size_t)oy * dst.pitch + ox] = sum * 0.25f;
-}
-
-// linear_to_xyb, ssimulacra2-cuda-kernel/src/xyb.rs:42-102 (planar in, planar out)
-__global__ void __launch_bounds__(64) k_xyb(TmGeom g, int s, const float *__restrict__ LIN, float *__restrict__ XYB)
-{
-    const TmScaleGeom sg = g.s[s];
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y;
-    if (x >= sg.w) return;
-    const size_t o = (size_t)blockIdx.z * g.pyr + sg.off + (size_t)y * sg.pitch + x;
-    float X, Y, B;
-    tmdev::linear_to_xyb(LIN[o], LIN[o + sg.plane], LIN[o + 2 * sg.plane], X, Y, B);
-    XYB[o] = X;
-    XYB[o + sg.plane] = Y;
-    XYB[o + 2 * sg.plane] = B;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Column pass ("pass 1"): blur_plane_pass_fused down the columns of the five planes
-// ref^2, dis^2, ref*dis, ref, dis  (ssimulacra2-cuda-kernel/src/blur.rs:34-137; which planes:
-// ssimulacra2-cuda/src/lib.rs:299-335).  The three products (nppiMul, lib.rs:299-317) are formed in
-// registers -- a rounded f32 multiply each, exactly what NPP stores -- so they never exist in HBM.
-// One lane owns one column: 15 IIR sections (30 state registers) + a 20-row register window per
-// input that is both the reference's 11-deep ring (blur.rs:25) and a 10-row load prefetch.
-// Outputs are written TRANSPOSED (the reference's nppiTranspose, lib.rs:342-361,383-390): four
-// consecutive rows of one column are 16 contiguous bytes there, so each lane stores one float4 per
-// plane every four steps.  The row pass then reads everything row-contiguous.
-// Step t reads row t (zero outside the image) and emits row t-4, t = 0 .. h+3 (blur.rs:95-136).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_blur_v(TmGeom g, const float *__restrict__ XYB, float *__restrict__ XYBT,
-                                               float *__restrict__ V)
-{
-    int b = blockIdx.x, s = 0;
-#pragma unroll
-    for (int i = 1; i < TM_SCALES; ++i)
-        if (b >= g.vblk[i]) s = i;
-    const TmScaleGeom sg = g.s[s];
-    const int x = (b - g.vblk[s]) * 64 + threadIdx.x;
-    if (x >= sg.w) return;
-    const int c = blockIdx.y, slot = blockIdx.z;
-    const int h = sg.h, pitch = sg.pitch;
-    const float *ref = XYB + (size_t)(slot * 2 + 0) * g.pyr + sg.off + c * sg.plane + x;
-    const float *dis = XYB + (size_t)(slot * 2 + 1) * g.pyr + sg.off + c * sg.plane + x;
-    const size_t to = sg.off_t + c * sg.plane_t + (size_t)x * sg.pitch_t;
-    float *reft = XYBT + (size_t)(slot * 2 + 0) * g.pyr_t + to;
-    float *dist = XYBT + (size_t)(slot * 2 + 1) * g.pyr_t + to;
-    float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to;
-    float *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to;
-    float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
-    float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
-    float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
-
-    float wr[20], wd[20];
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        wr[j] = ld_row(ref, j, h, pitch);
-        wd[j] = ld_row(dis, j, h, pitch);
-        wr[j + 10] = 0.0f;
-        wd[j + 10] = 0.0f;
-    }
-    tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
-    float a0[4], a1[4], a2[4], a3[4], a4[4], ar[4], ad[4];
-    const int T = h + 4;
-    for (int t0 = 0; t0 < T; t0 += 20) {
-#pragma unroll
-        for (int j = 0; j < 20; ++j) {
-            const int t = t0 + j;
-            const float r = wr[j], d = wd[j];
-            const float rold = wr[(j + 10) % 20], dold = wd[(j + 10) % 20];
-            wr[(j + 10) % 20] = ld_row(ref, t + 10, h, pitch);
-            wd[(j + 10) % 20] = ld_row(dis, t + 10, h, pitch);
-            a0[j & 3] = tmdev::iir_step(f0, rold * rold + r * r);
-            a1[j & 3] = tmdev::iir_step(f1, dold * dold + d * d);
-            a2[j & 3] = tmdev::iir_step(f2, rold * dold + r * d);
-            a3[j & 3] = tmdev::iir_step(f3, rold + r);
-            a4[j & 3] = tmdev::iir_step(f4, dold + d);
-            ar[j & 3] = r;
-            ad[j & 3] = d;
-            if ((j & 3) == 3) {
-                const int y0 = t - 7; // output rows y0..y0+3 (row t-4 is the newest)
-                if (y0 >= 0 && y0 < h) {
-                    *(float4 *)(v0 + y0) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-                    *(float4 *)(v1 + y0) = make_float4(a1[0], a1[1], a1[2], a1[3]);
-                    *(float4 *)(v2 + y0) = make_float4(a2[0], a2[1], a2[2], a2[3]);
-                    *(float4 *)(v3 + y0) = make_float4(a3[0], a3[1], a3[2], a3[3]);
-                    *(float4 *)(v4 + y0) = make_float4(a4[0], a4[1], a4[2], a4[3]);
-                }
-                const int r0 = t - 3; // input rows r0..r0+3, transposed copies for the edge terms
-                if (r0 < h) {
-                    *(float4 *)(reft + r0) = make_float4(ar[0], ar[1], ar[2], ar[3]);
-                    *(float4 *)(dist + r0) = make_float4(ad[0], ad[1], ad[2], ad[3]);
-                }
-            }
-        }
     }
 }
 
@@ -1184,115 +1067,6 @@ __global__ void __launch_bounds__(SOLO ? 64 : 320, 4) k_blur_v_jobs(TmGeom g, Tm
     } else {
         const unsigned xp = (unsigned)min(x0 + 32 * half + (lane >> 1), sg.w - 1) * 8u + (unsigned)(lane & 1) * 4u;
         blur_v_role<R, W, false>(tile, in, xp, vdst, sg.h, 2 * sg.pitch, sg.pitch_t, role == 0, (unsigned)g.pyr_t);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Row pass ("pass 2") fused with the error maps and the reductions: the reference's second
-// blur_plane_pass_fused on the transposed images (lib.rs:368-379), compute_error_maps
-// (error_maps.rs:5-60) and the six nppiSum / two nppiSqr per map (lib.rs:417-447) in one kernel.
-// One lane owns one image ROW and walks x = 0..w-1 through the transposed planes (coalesced: lanes
-// are consecutive y).  The blurred planes and the three maps never reach HBM; each lane keeps
-// Sum(x) and Sum((x^2)^2) (squares rounded to f32, accumulation in f64, as NPP's Npp64f sums) and
-// the wave total goes to PART; k_finish_jobs adds the partials of a job in a fixed order.
-//
-// Job driven: one wave = one 64-row block of one job.  FULL runs all five recurrences; EDGE runs only the
-// mu1 / mu2 recurrences and the edge half of compute_error_maps, reading 4 planes instead of 7 (its freed
-// registers go into a deeper load window: WN = 16 -> rows t+1 .. t+6 in flight).
-// WN = window slots of the pass-1 planes (rows t-10 .. t+WN-11), WS = slots of the ref/dis windows
-// (rows t-4 .. t+WN-11 need WN-6 slots; WS must divide WN).  PART[slot][row block over all jobs][6].
-// grid (jobs.hstart[n], 1, slots), block 64.
-// ------------------------------------------------------------------------------------------------
-template <bool FULL, int WN, int WS>
-__device__ __forceinline__ void blur_h_job(const float *__restrict__ reft, const float *__restrict__ dist,
-                                           const float *__restrict__ v0, const float *__restrict__ v1,
-                                           const float *__restrict__ v2, const float *__restrict__ v3,
-                                           const float *__restrict__ v4, int w, int pt, bool valid, double (&acc)[6])
-{
-    static_assert(WN % WS == 0 && WS >= WN - 6, "window sizes");
-    constexpr int P = WN - 10; // load distance in rows
-    constexpr int NF = FULL ? WN : 1;
-    float w0[NF], w1[NF], w2[NF], w3[WN], w4[WN], ws[WS], wq[WS];
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        w3[j] = j < P ? ld_row(v3, j, w, pt) : 0.0f;
-        w4[j] = j < P ? ld_row(v4, j, w, pt) : 0.0f;
-        if (FULL) {
-            w0[j] = j < P ? ld_row(v0, j, w, pt) : 0.0f;
-            w1[j] = j < P ? ld_row(v1, j, w, pt) : 0.0f;
-            w2[j] = j < P ? ld_row(v2, j, w, pt) : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < WS; ++j) {
-        ws[j] = j < P ? ld_row(reft, j, w, pt) : 0.0f;
-        wq[j] = j < P ? ld_row(dist, j, w, pt) : 0.0f;
-    }
-    tmdev::Iir f0 = {0, 0, 0, 0, 0, 0}, f1 = f0, f2 = f0, f3 = f0, f4 = f0;
-    const int T = w + 4;
-    for (int t0 = 0; t0 < T; t0 += WN) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int t = t0 + j; // row t lives in slot j, row t-10 in slot (j+P) % WN, which row t+P then takes over
-            float s11 = 0.0f, s22 = 0.0f, s12 = 0.0f;
-            if (FULL) {
-                s11 = tmdev::iir_step(f0, w0[(j + P) % NF] + w0[j % NF]);
-                s22 = tmdev::iir_step(f1, w1[(j + P) % NF] + w1[j % NF]);
-                s12 = tmdev::iir_step(f2, w2[(j + P) % NF] + w2[j % NF]);
-            }
-            const float mu1 = tmdev::iir_step(f3, w3[(j + P) % WN] + w3[j]);
-            const float mu2 = tmdev::iir_step(f4, w4[(j + P) % WN] + w4[j]);
-            const float src = ws[(j + WS - 4) % WS], dsv = wq[(j + WS - 4) % WS]; // row t-4
-            if (FULL) {
-                w0[(j + P) % NF] = ld_row(v0, t + P, w, pt);
-                w1[(j + P) % NF] = ld_row(v1, t + P, w, pt);
-                w2[(j + P) % NF] = ld_row(v2, t + P, w, pt);
-            }
-            w3[(j + P) % WN] = ld_row(v3, t + P, w, pt);
-            w4[(j + P) % WN] = ld_row(v4, t + P, w, pt);
-            ws[(j + P) % WS] = ld_row(reft, t + P, w, pt);
-            wq[(j + P) % WS] = ld_row(dist, t + P, w, pt);
-            if (t >= 4 && t < T) {
-                float ssim = 0.0f, art, det;
-                if (FULL) tmdev::error_maps(src, dsv, mu1, mu2, s11, s22, s12, ssim, art, det);
-                else tmdev::edge_maps(src, dsv, mu1, mu2, art, det);
-                if (valid) {
-                    float q;
-                    if (FULL) { acc[0] += (double)ssim; q = ssim * ssim; q = q * q; acc[3] += (double)q; }
-                    acc[1] += (double)art;  q = art * art;   q = q * q; acc[4] += (double)q;
-                    acc[2] += (double)det;  q = det * det;   q = q * q; acc[5] += (double)q;
-                }
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(64) k_blur_h_jobs(TmGeom g, TmJobs jobs, const float *__restrict__ XYBT,
-                                                    const float *__restrict__ V, double *__restrict__ PART)
-{
-    const int b = blockIdx.x;
-    const int j = tm_find_job(jobs.hstart, b);
-    const int s = jobs.scale[j], c = jobs.chan[j], mode = jobs.mode[j];
-    const TmScaleGeom sg = g.s[s];
-    const int y = (b - jobs.hstart[j]) * 64 + threadIdx.x;
-    const bool valid = y < sg.h;
-    const int yy = valid ? y : sg.h - 1;
-    const int slot = blockIdx.z;
-    const size_t to = sg.off_t + c * sg.plane_t + yy;
-    const float *reft = XYBT + (size_t)(slot * 2 + 0) * g.pyr_t + to;
-    const float *dist = XYBT + (size_t)(slot * 2 + 1) * g.pyr_t + to;
-    const float *v0 = V + (size_t)(slot * 5 + 0) * g.pyr_t + to;
-    const float *v1 = V + (size_t)(slot * 5 + 1) * g.pyr_t + to;
-    const float *v2 = V + (size_t)(slot * 5 + 2) * g.pyr_t + to;
-    const float *v3 = V + (size_t)(slot * 5 + 3) * g.pyr_t + to;
-    const float *v4 = V + (size_t)(slot * 5 + 4) * g.pyr_t + to;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (mode == TM_MODE_FULL) blur_h_job<true, 12, 6>(reft, dist, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
-    else blur_h_job<false, 16, 16>(reft, dist, v0, v1, v2, v3, v4, sg.w, sg.pitch_t, valid, acc);
-    if (tm_wave_sum6(acc)) {
-        double *o = PART + ((size_t)slot * jobs.hstart[TM_MAX_JOBS] + b) * 6;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = acc[k];
     }
 }
 

@@ -1,10 +1,13 @@
 """ctypes binding of the C ABI (include/turbo_metrics_hip.h + the laboratory half, include/turbo_metrics_hip_debug.h).  Loads the in-tree
-libturbometrics_hip.so; raises loudly if it is missing -- there is no fallback."""
+LABORATORY build, lab/libturbometrics_hip_lab.so -- the engine of libturbometrics_hip.so (the ship build: facade only, what the CLI links)
+plus kernel variants, stage timers, plane read-back and fault injection, which tests/, tools/ and bench.py's roofline measurement need; the
+kernels the two builds share are the same device code (tests/test_abi_symbols.py).  Raises loudly if it is missing -- there is no fallback."""
 import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TM_HIP_LIB") or os.path.join(_HERE, "libturbometrics_hip.so")  # override: experiment builds only
+LIB_PATH = os.environ.get("TM_HIP_LIB") or os.path.join(_HERE, "lab", "libturbometrics_hip_lab.so")  # override: experiment builds only
+SHIP_LIB_PATH = os.path.join(_HERE, "libturbometrics_hip.so")
 
 TM_OK, TM_ERR_INVALID_ARG, TM_ERR_UNSUPPORTED, TM_ERR_HIP, TM_ERR_OOM, TM_ERR_STATE = range(6)
 TM_METRIC_PSNR, TM_METRIC_SSIM, TM_METRIC_MSSSIM, TM_METRIC_SSIMULACRA2 = 1, 2, 4, 8
@@ -16,7 +19,7 @@ TM_MEM_HOST, TM_MEM_DEVICE, TM_MEM_HOST_PINNED = 0, 1, 2
 TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_SSIM, TM_STAGE_EDGE, TM_STAGE_COUNT = 0, 1, 2, 3, 4, 5
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
 TM_VARIANT_DEFAULT, TM_VARIANT_REFERENCE, TM_VARIANT_WIDE_ROWS, TM_VARIANT_TILE_INGEST, TM_VARIANT_SPLIT_ROWS, TM_VARIANT_WHOLE_ROWS = 0, 1, 0x100, 0x200, 0x400, 0x800
-TM_VARIANT_TWO_PASS_EDGE, TM_VARIANT_FUSED_EDGE = 0x1000, 0x4000
+TM_VARIANT_TWO_PASS_EDGE, TM_VARIANT_UPPER_KERNEL, TM_VARIANT_FUSED_EDGE = 0x1000, 0x2000, 0x4000
 TM_DBG_FUSED_EDGE_FROM, TM_DBG_EF_WAVES, TM_DBG_EF_PERSIST_WGS, TM_DBG_PASS_PRIO, TM_DBG_SPLIT_ROWS_BELOW, TM_DBG_SOLO_COL_BELOW, TM_DBG_EF_FAULT, TM_DBG_LINEAR_UPLOAD, TM_DBG_UPLOAD_STREAMS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 

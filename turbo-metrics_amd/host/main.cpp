@@ -49,7 +49,7 @@ void usage(std::ostream &os)
           "      --skip-dis <SKIP_DIS>  Index of the first distorted frame, additive with `skip` [default: 0]\n"
           "      --frames <FRAMES>      Amount of frames to compute [default: 0]\n"
           "      --output <OUTPUT>      stdout format [possible values: default, json, json-lines, csv]\n"
-          "      --batch <N>            frame pairs per GPU launch [default: by picture size, 16 at 1080p, 4 at 4K]\n"
+          "      --batch <N>            frame pairs per GPU launch [default: by picture size, 16 at 1080p, 8 at 4K]\n"
           "      --device <N>           GPU ordinal [default: 0]\n"
           "      --devices <N>          shard the frame pairs of two regular files over N GPUs (0 = all visible) [default: 1]\n"
           "      --ranks <N>            the same shards as N processes, one per GPU, scores gathered by ONE RCCL reduce to rank 0\n"
@@ -97,7 +97,8 @@ void log_source(const char *target, const FrameSource &src)
 
 } // namespace
 
-// --batch not given: about 32 Mpx per launch, 2 .. 32 pairs (16 at 1080p, 4 at 4K, 32 at 720p and below).  Host-fed streams are
+// --batch not given: at most 72 Mpx per launch, 2 .. 16 pairs (16 at 1080p and below, 8 at 4K; round 6: with 10-bit pictures packed on the
+// link the 4K loop is no longer bound by PCIe alone -- 4 pairs per launch 1 246 pairs/s, 16: 1 333, profiles/r06b_bench.json).  Host-fed streams are
 // bound by the file reads and PCIe long before the engine (1080p: ~7.5 k pairs/s over PCIe against 12.7 k pairs/s of the engine at 16
 // pairs per launch; 4K: 1.1 k against 3.0 k at 4), and since round 4 the page-locked frame rings no longer grow with the batch
 // (upload fences), so the batch only has to be large enough for the kernels and small enough for the engines' memory
@@ -105,8 +106,8 @@ void log_source(const char *target, const FrameSource &src)
 static uint32_t auto_batch(uint32_t w, uint32_t h)
 {
     const double mpx = (double)w * (double)h / 1e6;
-    uint32_t b = 32;
-    while (b > 2 && (double)b * mpx > 36.0) b /= 2;
+    uint32_t b = 16;
+    while (b > 2 && (double)b * mpx > 72.0) b /= 2;
     return b;
 }
 

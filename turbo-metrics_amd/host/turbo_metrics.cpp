@@ -1,7 +1,7 @@
 // turbo_metrics.cpp -- see turbo_metrics.hpp.  Host orchestration only: frame selection, batching over the engine's
 // slots, ping-pong pipelining of two engines; every number comes out of libturbometrics_hip.so.
 #include "turbo_metrics.hpp"
-#include "../../include/turbo_metrics_hip_debug.h" // tm_engine_debug_set_param: only behind TurboMetrics::debug_set_param (the CLI's --tune)
+#include <dlfcn.h>
 #include <chrono>
 #include <fstream>
 #include <sched.h>
@@ -200,12 +200,23 @@ size_t TurboMetrics::mem_usage() const
     return tm_engine_mem_usage(eng_[0]) + (eng_[1] ? tm_engine_mem_usage(eng_[1]) : 0);
 }
 
+// tm_engine_debug_set_param is a function of the LABORATORY build (include/turbo_metrics_hip_debug.h): the ship library this file links
+// does not export it.  A measurement run puts the laboratory build in front (LD_PRELOAD=turbo-metrics_amd/lab/libturbometrics_hip_lab.so,
+// tools/cli_ab.sh); the CLI's --tune says so otherwise.
+using debug_set_param_fn = int (*)(tm_engine *, int, long long);
+static debug_set_param_fn lab_set_param()
+{
+    static const debug_set_param_fn fn = (debug_set_param_fn)dlsym(RTLD_DEFAULT, "tm_engine_debug_set_param");
+    return fn;
+}
+
 void TurboMetrics::debug_set_param(int param, long long value)
 {
+    if (!lab_set_param()) throw std::runtime_error("tuning values belong to the laboratory build: run with LD_PRELOAD=<...>/turbo-metrics_amd/lab/libturbometrics_hip_lab.so");
     retire_deferred(); // a setting never changes under a pair in flight: its scores are collected first
     debug_params_.emplace_back(param, value);
     for (tm_engine *e : eng_)
-        if (e) chk(tm_engine_debug_set_param(e, param, value), "tm_engine_debug_set_param");
+        if (e) chk(lab_set_param()(e, param, value), "tm_engine_debug_set_param");
 }
 
 void TurboMetrics::set_full_sums(bool on)
@@ -290,7 +301,7 @@ uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo
         chk(tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), 1), "tm_engine_create (second engine of compute_one_deferred)");
         (void)tm_engine_set_linear_upload(eng_[1], 1);
         if (full_sums_) chk(tm_engine_set_full_sums(eng_[1], 1), "tm_engine_set_full_sums");
-        for (const auto &kv : debug_params_) (void)tm_engine_debug_set_param(eng_[1], kv.first, kv.second);
+        for (const auto &kv : debug_params_) (void)lab_set_param()(eng_[1], kv.first, kv.second); // (only ever non-empty with the laboratory build loaded)
     }
     const uint64_t ticket = def_next_++;
     const int i = (int)(ticket & 1);
