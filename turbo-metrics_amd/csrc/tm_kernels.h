@@ -293,8 +293,10 @@ __device__ __forceinline__ void ingest_px_rgb(const TmFrameDesc &d, int kind, co
 // away and the sample loads of both sides are issued back to back; KIND = -1: per-frame dispatch.
 // grid (ceil(w/32), ceil(h/8), slots), block 64.
 // ------------------------------------------------------------------------------------------------
+// (KIND = -1 carries every format's code: held to the 96 registers of five waves per SIMD it spilled 18 of them -- 76 bytes of scratch per lane;
+// the mixed launch is the rare path and runs at four waves per SIMD instead)
 template <int KIND>
-__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(5) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
+__global__ void __launch_bounds__(64) TM_WAVES_PER_SIMD(KIND < 0 ? 4 : 5) k_ingest_wave(TmGeom g, const TmFrameDesc *__restrict__ desc, const float *__restrict__ lut,
                                                     const float *__restrict__ coef, const double *__restrict__ gtab,
                                                     float *__restrict__ XYB, float *__restrict__ LIN2,
                                                     unsigned long long *__restrict__ SSE, int want_sse,
