@@ -57,6 +57,14 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         if rc != rc0 or out != out0:
             bad += 1
             print(f"MISMATCH case {case} {w}x{h} {bits}-bit {n} frames {sel}: --devices 2 rc {rc} vs {rc0}\n{err[-300:]}", flush=True)
+        # round 6: one process per device + ONE reduce of the score vector (here: ranks sharing the box's GPU, over the launcher's pipes) and
+        # 10-bit pictures handed over as 16-bit words instead of packed three to a word
+        for name, extra, env in (("ranks", ["--ranks", int(rng.integers(2, 4))], {"TM_SHARE_DEVICE": "1", "TM_RANK_TRANSPORT": "pipe", "TM_RANK_TIMEOUT_S": "300"}),
+                                 ("words16", [], {"TM_PACK10": "0"})):
+            rc, out, err = run(base + extra, env=env)
+            if rc != rc0 or out != out0:
+                bad += 1
+                print(f"MISMATCH case {case} {w}x{h} {bits}-bit {n} frames {sel}: {name} rc {rc} vs {rc0}\n{err[-300:]}", flush=True)
         rc, out, err = run(["-", pd] + mets + sel + ["--output", "json-lines"], stdin=open(pr, "rb").read())
         if rc != rc0 or out != out0:
             bad += 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE (may use the oracle).  GPU box: ONE long-lived engine under a random sequence of state changes -- kernel variant, hipGraph replay on / off, pruned / full
-sums, channel mode, profiling, slots per launch, frames of other KINDS (NV12, P016, planar 8 / 10 bit, RGB8 / 16 / f32) and memory kinds
+sums, channel mode, profiling, slots per launch, frames of other KINDS (NV12, P016, planar 8 / 10 bit, packed 10 bit, RGB8 / 16 / f32) and memory kinds
 in random slots -- every launch checked against what a fresh one-pair engine computes for the same frames (raw sums where a weight
 reads them, SSE, SSIM sums).  State that leaks from one launch into the next shows up here.  usage: engine_state_soak.py [launches] [w h]"""
 import os, sys, time
@@ -20,14 +20,20 @@ one.set_full_sums(True)
 
 # a pool of frame pairs of every kind, each with its expected results from the one-pair engine
 pool = []
-for n in range(14):
-    kind = ["nv12", "p016", "i420_8", "i420_10", "rgb8", "rgb16", "rgbf32"][n % 7]
+for n in range(16):
+    kind = ["nv12", "p016", "i420_8", "i420_10", "rgb8", "rgb16", "rgbf32", "i420_p10"][n % 8]
     if kind in ("nv12", "p016"):
         (rs, rp, rch), (ds, dp, dch) = (tm.synth.nv12_pair if kind == "nv12" else tm.synth.p016_pair)(w, h, n)
         mk = tm.HwFrame.nv12 if kind == "nv12" else tm.HwFrame.p016
         host = (mk(rs, rp, rch), mk(ds, dp, dch))
         dev = (mk(torch.from_numpy(rs).cuda(), rp, rch), mk(torch.from_numpy(ds).cuda(), dp, dch))
         pin = (mk(torch.from_numpy(np.asarray(rs).copy()).pin_memory(), rp, rch), mk(torch.from_numpy(np.asarray(ds).copy()).pin_memory(), dp, dch))
+    elif kind == "i420_p10":  # 10-bit planes packed three samples to a word (round 6)
+        pr = tm.synth.yuv420_pair(w, h, n, 10)
+        mkp = lambda planes, f: tm.HwFrame.i420p10(*[f(tm.synth.p10_pack_plane(p).view(np.int32)) for p in planes])
+        host = (mkp(pr[0], lambda a: a.view(np.uint32)), mkp(pr[1], lambda a: a.view(np.uint32)))
+        dev = (mkp(pr[0], lambda a: torch.from_numpy(a).cuda()), mkp(pr[1], lambda a: torch.from_numpy(a).cuda()))
+        pin = (mkp(pr[0], lambda a: torch.from_numpy(a).pin_memory()), mkp(pr[1], lambda a: torch.from_numpy(a).pin_memory()))
     elif kind.startswith("i420"):
         bits = 8 if kind == "i420_8" else 10
         pr = tm.synth.yuv420_pair(w, h, n, bits)
@@ -55,7 +61,7 @@ slots = [None] * B
 full = False
 state = {"variant": 0, "graph": False, "full": False, "first": False, "prof": False}
 VARS = [0, F.TM_VARIANT_FUSED_EDGE, F.TM_VARIANT_TWO_PASS_EDGE, F.TM_VARIANT_SPLIT_ROWS, F.TM_VARIANT_WHOLE_ROWS, F.TM_VARIANT_TILE_INGEST,
-        F.TM_VARIANT_TILE_INGEST | F.TM_VARIANT_FUSED_EDGE, F.TM_VARIANT_WIDE_ROWS]
+        F.TM_VARIANT_TILE_INGEST | F.TM_VARIANT_FUSED_EDGE, F.TM_VARIANT_WIDE_ROWS, F.TM_VARIANT_UPPER_KERNEL, F.TM_VARIANT_UPPER_KERNEL | F.TM_VARIANT_FUSED_EDGE]
 t0, bad = time.time(), 0
 for k in range(launches):
     for _ in range(int(rng.integers(0, 4))):  # a few random state changes

@@ -43,8 +43,21 @@ for case in range(cases):
             mkb = tm.HwFrame.nv12 if bits == 8 else tm.HwFrame.p016
             base.set_frame(slot, side, mkb(torch.from_numpy(sb).cuda(), pit, ch))
             mem = str(rng.choice(["device", "pinned", "host"]))
-            how = str(rng.choice(["surface", "i420", "i420_tight"]))
-            if how == "surface":
+            how = str(rng.choice(["surface", "i420", "i420_tight"] + (["p10", "p10_tight"] if bits == 10 else [])))
+            if how in ("p10", "p10_tight"):  # round 6: the same 10-bit planes packed three samples to a word, rows padded or the whole picture tight
+                cw, chh = (w + 1) // 2, (h + 1) // 2
+                wy, wc = tm.synth.p10_row_words(w), tm.synth.p10_row_words(cw)
+                if how == "p10_tight":
+                    flat = np.concatenate([tm.synth.p10_pack_plane(p).ravel() for p in (Y, Cb, Cr)]).view(np.int32)
+                    buf = place(flat, mem); keep.append(buf)
+                    cut = (lambda a, r, c: a.reshape(r, c)) if mem == "host" else (lambda a, r, c: a.view(r, c))
+                    y, u, v = cut(buf[: h * wy], h, wy), cut(buf[h * wy: h * wy + chh * wc], chh, wc), cut(buf[h * wy + chh * wc:], chh, wc)
+                else:
+                    pad_c = 2 * int(rng.integers(0, 20))
+                    pk = lambda p, pad: (lambda t: t[:, : t.shape[1] - pad] if pad else t)(place(tm.synth.p10_pack_plane(p, tm.synth.p10_row_words(p.shape[1]) + pad).view(np.int32), mem))
+                    y, u, v = pk(Y, 2 * int(rng.integers(0, 20))), pk(Cb, pad_c), pk(Cr, pad_c)
+                fr = tm.HwFrame.i420p10(y, u, v)
+            elif how == "surface":
                 bps = 1 if bits == 8 else 2
                 pitch = (max(w, 2 * ((w + 1) // 2)) + int(rng.integers(0, 150))) * bps
                 coded = h + int(rng.integers(0, 40))

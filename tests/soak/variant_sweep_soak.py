@@ -15,7 +15,8 @@ tm.set_placement_candidates(1)
 rng = np.random.default_rng(20261003)
 edges = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025]
 VARIANTS = [("fused", F.TM_VARIANT_FUSED_EDGE), ("two_pass", F.TM_VARIANT_TWO_PASS_EDGE), ("split_rows", F.TM_VARIANT_SPLIT_ROWS | F.TM_VARIANT_FUSED_EDGE),
-            ("whole_rows", F.TM_VARIANT_WHOLE_ROWS | F.TM_VARIANT_TWO_PASS_EDGE), ("tile_ingest", F.TM_VARIANT_TILE_INGEST), ("reference", F.TM_VARIANT_REFERENCE)]
+            ("whole_rows", F.TM_VARIANT_WHOLE_ROWS | F.TM_VARIANT_TWO_PASS_EDGE), ("tile_ingest", F.TM_VARIANT_TILE_INGEST), ("reference", F.TM_VARIANT_REFERENCE),
+            ("upper_kernel", F.TM_VARIANT_UPPER_KERNEL)]  # round 6: pyramid levels 2..5 by k_ingest_upper_rd instead of the ingest kernel's own epilogue
 t0, bad = time.time(), 0
 for case in range(cases):
     w = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, max_side))

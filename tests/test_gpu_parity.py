@@ -908,20 +908,24 @@ def test_random_sweep_of_sizes_kinds_and_metric_masks(seed):
     edges = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 117, 118, 119, 127, 128, 129, 191, 192, 193, 202, 203, 255, 256, 257, 383, 384, 385]
     w = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 420))
     h = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 420))
-    kind = str(rng.choice(["nv12", "p016", "rgb8", "rgb16", "rgbf32"]))
+    kind = str(rng.choice(["nv12", "p016", "rgb8", "rgb16", "rgbf32", "p10"]))  # p10 (round 6): 10-bit planes packed three samples to a word
     matrix = tm.ColorMatrix(int(rng.integers(0, 3)))
     want_ms = w >= 176 and h >= 176 and rng.random() < 0.7
     want_ssim = w >= 11 and h >= 11 and rng.random() < 0.7
     m = tm.Metrics(ssimulacra2=True, psnr=bool(rng.random() < 0.7), ssim=want_ssim, msssim=want_ms)
     full = bool(rng.random() < 0.4)
     B = int(rng.integers(1, 4))
-    frames = []
+    frames, packed = [], []
     for slot in range(B):
         n = int(rng.integers(0, 50))
         if kind == "nv12":
             frames.append(nv12_frames(w, h, n, matrix))
         elif kind == "p016":
             frames.append(p016_frames(w, h, n))
+        elif kind == "p10":
+            ref, dis = tm.synth.yuv420_pair(w, h, n, 10)
+            packed.append(tuple(tm.HwFrame.i420p10(*(tm.synth.p10_pack_plane(p) for p in side), matrix=matrix) for side in (ref, dis)))
+            frames.append(tuple(tm.HwFrame.p016(*tm.synth.pack_biplanar(side, w, h, 10), matrix) for side in (ref, dis)))  # what the oracle sees
         else:
             r8 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
             d8 = np.clip(r8.astype(np.int32) + rng.integers(-9, 10, r8.shape), 0, 255).astype(np.uint8)
@@ -932,7 +936,7 @@ def test_random_sweep_of_sizes_kinds_and_metric_masks(seed):
             else:
                 frames.append((tm.HwFrame.rgb(r8.astype(np.float32) / 255), tm.HwFrame.rgb(d8.astype(np.float32) / 255)))
     eng = tm.TurboMetrics(w, h, m, batch=B, full_sums=full)
-    for slot, (fr, fd) in enumerate(frames):
+    for slot, (fr, fd) in enumerate(packed or frames):
         eng.set_pair(slot, fr, fd)
     eng.compute_async()
     eng.sync()
