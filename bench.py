@@ -349,7 +349,7 @@ def run_workload(ctx, args, name, mets, B, steps, warmup, settle_ms, compare, ke
     # without SSIMULACRA2 the ingest kernel writes no pyramid (only the u8 planes when SSIM / MS-SSIM ask for them) and the
     # blur kernels are not launched at all
     ingest_bytes = (in_bytes + (24 * spx if has_s2 else 0) + (6 * w * h if has_ssim else 0)) * B
-    ingest_name = "k_ingest_rows" if kind in ("nv12", "p016") else "k_ingest_wave"  # stage time: + k_ingest_upper_rd (levels 2-5, ~0.1 ms)
+    ingest_name = "k_ingest_rows" if kind in ("nv12", "p016") else "k_ingest_wave"  # (since round 6 the 4:2:0 kernel finishes all six levels itself)
     per_kernel = {ingest_name: roof(stage_ms[F.TM_STAGE_INGEST], ingest_bytes)}
     if has_s2:
         per_kernel["k_blur_v_jobs"] = roof(stage_ms[F.TM_STAGE_BLUR_V], job_bytes * B)

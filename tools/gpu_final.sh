@@ -5,7 +5,7 @@
 # workloads + fixed stream + host-fed + cpu baseline), the 2-rank bench over gloo, rocprofv3 kernel stats (SSIMULACRA2 alone
 # and fused, 1080p and 4K), SQ counters.  Outputs -> gpurun_out/<TAG>_*; tools/collect_profiles.sh copies what is judged.
 set -u
-TAG=${1:-r02z}
+TAG=${1:-r06z}
 bash tools/pmc_traffic.sh $TAG 1080p_nv12 > /dev/null
 bash tools/pmc_traffic.sh $TAG 1080p_nv12 --full-sums > /dev/null
 bash tools/pmc_traffic.sh $TAG 4k_p016 > /dev/null
@@ -28,4 +28,8 @@ timeout 300 python tools/cli_bench.py --size 1080p 2>&1 | grep -v amdgpu.ids > g
 timeout 300 python tools/cli_bench.py --size 4k 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_cli_4k.log
 (bash tools/cli_ab.sh 1080p 3 "" "--tune 7=0" "--tune 7=0 --tune 8=1"; bash tools/cli_ab.sh 4k 3 "" "--tune 7=0" "--tune 7=0 --tune 8=1") 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_cli_ab.log
 (timeout 300 python3 tools/host_fed_ab.py 1080p 2; timeout 300 python3 tools/host_fed_ab.py 4k 2) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_host_fed_ab.log
+# round 6: the write ceiling of the part, the ingest fold A/B on this tree (laboratory library, TM_VARIANT_UPPER_KERNEL = round 5's arrangement)
+timeout 300 tools/microbench/wr_ceiling > gpurun_out/${TAG}_wr_ceiling.log 2>&1
+LIB=turbo-metrics_amd/lab/libturbometrics_hip_lab.so
+(for B in 128 64 1; do echo "== batch $B"; timeout 900 python tools/lib_ab.py fold=$LIB upper=$LIB@0x2000 --rounds 3 --batch $B 2>&1 | tail -9; done; echo "== 4k"; timeout 900 python tools/lib_ab.py fold=$LIB upper=$LIB@0x2000 --rounds 2 --workload 4k_p016 2>&1 | tail -7) > gpurun_out/${TAG}_fold_ab.log 2>&1
 ls gpurun_out | grep $TAG | head -60
