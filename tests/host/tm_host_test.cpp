@@ -174,7 +174,7 @@ int main(int argc, char **argv)
             const uint32_t total = (uint32_t)atoi(argv[3]), every = (uint32_t)atoi(argv[4]);
             const int fail_rank = argc > 5 ? atoi(argv[5]) : -1, hang_rank = argc > 6 ? atoi(argv[6]) : -1;
             RankEnv env;
-            if (!rank_env(env)) return launch_ranks(argv, world, 60.0);
+            if (!rank_env(env)) { if (getenv("TM_TEST_PRINT_PID")) { printf("launcher %d\n", (int)getpid()); fflush(stdout); } return launch_ranks(argv, world, 60.0); }
             if (env.rank == fail_rank) return 3;
             if (env.rank == hang_rank) { for (;;) std::this_thread::sleep_for(std::chrono::seconds(1)); }
             Metrics m; m.psnr = true; m.ssimulacra2 = true;

@@ -468,6 +468,18 @@ def test_rank_launcher_ends_the_job_when_a_rank_fails(helper):
     # rank 0 gone: the others' writes fail instead of blocking
     r = subprocess.run([helper, "ranks", "3", "200000", "0", "0"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3
+    # a signal to the launcher stops its ranks (one of them blocked for good): nothing is left behind
+    import signal
+    p = subprocess.Popen([helper, "ranks", "3", "23", "0", "-1", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, TM_TEST_PRINT_PID="1"))
+    assert p.stdout.readline().startswith("launcher ")
+    time.sleep(0.5)
+    kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+    assert len(kids) >= 1  # (the rank that hangs is still there; the others may have finished or wait in the reduce)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    assert p.returncode == 128 + signal.SIGTERM and "stopping the ranks" in err
+    time.sleep(0.2)
+    assert not [k for k in kids if os.path.exists(f"/proc/{k}") and "Z" not in open(f"/proc/{k}/stat").read().split()[2]]
 
 
 # ---- the command line on the device ------------------------------------------------------------------------------------

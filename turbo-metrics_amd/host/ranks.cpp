@@ -64,9 +64,19 @@ static std::string fd_list(const std::vector<int> &v)
     return s;
 }
 
+// a signal that asks the launcher to stop (SIGTERM, SIGINT, SIGHUP) stops the ranks: they are this process's children and nobody else's
+static volatile sig_atomic_t g_launcher_signal = 0;
+static void launcher_signal(int sig) { g_launcher_signal = sig; }
+
 int launch_ranks(char **argv, int world, double timeout_s, const char *self)
 {
     if (world < 1) return 2;
+    for (int sig : {SIGTERM, SIGINT, SIGHUP}) {
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = launcher_signal;
+        sigaction(sig, &sa, nullptr);
+    }
     // up[r] : rank r -> rank 0 (the vector, pipe transport); down[r] : rank 0 -> rank r (the communicator id, RCCL transport)
     std::vector<int> up_r(world, -1), up_w(world, -1), down_r(world, -1), down_w(world, -1);
     for (int r = 1; r < world; ++r) {
@@ -99,6 +109,7 @@ int launch_ranks(char **argv, int world, double timeout_s, const char *self)
                 const int nul = open("/dev/null", O_WRONLY);
                 if (nul >= 0) { dup2(nul, STDOUT_FILENO); close(nul); }
             }
+            for (int sig : {SIGTERM, SIGINT, SIGHUP}) signal(sig, SIG_DFL); // (the launcher's handlers are not the ranks')
             execv(self ? self : "/proc/self/exe", argv);
             perror("turbo-metrics: exec");
             _exit(127);
@@ -137,6 +148,10 @@ int launch_ranks(char **argv, int world, double timeout_s, const char *self)
             lost_rank = -1;
         }
         const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc == 0 && g_launcher_signal) {
+            rc = 128 + (int)g_launcher_signal;
+            fprintf(stderr, "ERROR turbo_metrics_cli: signal %d: stopping the ranks\n", (int)g_launcher_signal);
+        }
         if (rc == 0 && timeout_s > 0.0 && elapsed > timeout_s) {
             rc = 124;
             fprintf(stderr, "ERROR turbo_metrics_cli: the ranks did not finish within %.0f s\n", timeout_s);
