@@ -22,10 +22,18 @@ for case in range(cases):
     w = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, max_side))
     h = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, max_side))
     B = int(rng.integers(1, 5))
-    p016 = rng.random() < 0.3
+    r = rng.random()
+    p016, p10 = r < 0.3, r >= 0.8  # (p10, round 6: 10-bit planes packed three samples to a word)
     gen, mk = (tm.synth.p016_pair, tm.HwFrame.p016) if p016 else (tm.synth.nv12_pair, tm.HwFrame.nv12)
     eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True), batch=B)
+    keep = []
     for slot in range(B):
+        if p10:
+            ref, dis = tm.synth.yuv420_pair(w, h, int(rng.integers(0, 1000)), 10)
+            fr = [tm.HwFrame.i420p10(*(torch.from_numpy(tm.synth.p10_pack_plane(p).view(np.int32)).cuda() for p in side)) for side in (ref, dis)]
+            keep.append(fr)
+            eng.set_pair(slot, fr[0], fr[1])
+            continue
         (rs, rp, rch), (ds, dp, dch) = gen(w, h, int(rng.integers(0, 1000)))
         eng.set_pair(slot, mk(torch.from_numpy(rs).cuda(), rp, rch), mk(torch.from_numpy(ds).cuda(), dp, dch))
     eng.compute_async(B); eng.sync()
@@ -36,7 +44,7 @@ for case in range(cases):
         for i in range(B):
             if not (np.array_equal(eng.raw_sums(i), want[i][0]) and eng.sse(i) == want[i][1]):
                 bad += 1
-                print(f"MISMATCH case {case}: {w}x{h} batch {B} {'p016' if p016 else 'nv12'} variant {name} slot {i}", flush=True)
+                print(f"MISMATCH case {case}: {w}x{h} batch {B} {'p016' if p016 else 'p10' if p10 else 'nv12'} variant {name} slot {i}", flush=True)
     eng.close()
 print(f"variant sweep: {cases} random cases x {len(VARIANTS)} variants against the default configuration, mismatches {bad}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
