@@ -58,6 +58,9 @@ for i in range(N):
     if k == 0: note("set_frame_nv12", L.tm_engine_set_frame_nv12(hnd, slot, side, p0, p1, pt, matrix, transfer, full, mem))
     elif k == 1: note("set_frame_p016", L.tm_engine_set_frame_p016(hnd, slot, side, p0, p1, pt, matrix, transfer, full, mem))
     elif k == 2: note("set_surface_nv12", L.tm_engine_set_surface_nv12(hnd, slot, side, p0, pt, int(rng.choice([0, h - 1, h, h + 8, 2 ** 31])) if mem == 1 else h, matrix, transfer, full, mem))
+    elif k == 3 and rng.random() < 0.4:  # round 6: the packed 10-bit kind (pointers and pitches must be multiples of 8, a row is whole 512-byte blocks)
+        note("set_frame_i420p10", L.tm_engine_set_frame_i420p10(hnd, slot, side, p0, p1, p2, pitch() if mem == 1 else int(rng.choice([512, 512, 520, 256, 1024])),
+                                                                pitch() if mem == 1 else int(rng.choice([512, 512, 516, 0])), matrix, transfer, full, mem))
     elif k == 3: note("set_frame_i420", L.tm_engine_set_frame_i420(hnd, slot, side, p0, p1, p2, pt, pitch() if mem == 1 else w, int(rng.choice([0, 7, 8, 10, 16, 17, -3])), matrix, transfer, full, mem))
     elif k == 4: note("set_frame_rgb8", L.tm_engine_set_frame_rgb8(hnd, slot, side, p0, pt if mem == 1 else w * 3, mem))
     elif k == 5: note("set_frame_rgbf32", L.tm_engine_set_frame_rgbf32(hnd, slot, side, p0, pt if mem == 1 else w * 12, mem))

@@ -78,5 +78,5 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
             if abs(first - want) > 1e-9:
                 bad += 1
                 print(f"ORACLE MISMATCH case {case} {w}x{h} {bits}-bit: {first} vs {want}", flush=True)
-print(f"cli sweep: {cases} random clips x 9 host arrangements, mismatches {bad}, {time.time() - t0:.0f} s")
+print(f"cli sweep: {cases} random clips x 11 host arrangements, mismatches {bad}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
