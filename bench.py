@@ -689,7 +689,10 @@ def run_cli_end_to_end(ctx):
                                  ("loop_reference", ["--loop", "reference"]), ("loop_deferred", ["--loop", "deferred"])) + (
                                  # 10-bit clips: the readers pack three samples to a word on the way into the page-locked ring (default since
                                  # round 6); TM_PACK10=0 hands the 16-bit words over as before
-                                 (("words16", ["TM_PACK10=0"]),) if bits == 10 else ()):
+                                 (("words16", ["TM_PACK10=0"]),) if bits == 10 else
+                                 # the product's own multi-GPU arrangement with ONE rank: launcher, rank process, a one-rank RCCL communicator and the
+                                 # ncclReduce of the score vector inside the CLI's clock (round 6; N > 1 needs N GPUs)
+                                 (("ranks1_rccl", ["--ranks", "1", "TM_RANK_TRANSPORT=rccl", "TM_RANK_TIMEOUT_S=280"]),)):
                 # `default` is the STEADY rate with the clip in the page cache: the passes right after the clip was written run at a
                 # third to a half of the later ones, and for how many passes differs from box to box and run to run (1-2 of 5 in
                 # tools-free probes: [2970, 4063, 7529, 7492, 7566]) -- the leg repeats until two consecutive passes agree within
@@ -839,7 +842,7 @@ def compact_line(d):
             sm["_batch_curve_in_flight"] = "[pairs per launch, launches in flight (2_api: via compute_one_deferred/collect), pairs/s]"
     cli = d.get("cli_end_to_end")
     if cli:
-        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("default", "batch16", "loop_reference", "loop_deferred", "words16") if isinstance(v.get(lab), dict)}
+        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("default", "batch16", "loop_reference", "loop_deferred", "words16", "ranks1_rccl") if isinstance(v.get(lab), dict)}
                                 if isinstance(v, dict) and "error" not in v else (v.get("error", "")[:60] if isinstance(v, dict) else None)
                                 for tag, v in cli.items() if tag != "note"}
     pl = d.get("pipeline")
