@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <string>
 #include <thread>
@@ -264,8 +265,10 @@ int main(int argc, char **argv)
     // engines, the reference's selection loop (lib.rs:385-404) with decode_start = lo.  Shared by --devices (a thread per device) and
     // --ranks (a process per device).
     struct Block { std::vector<FrameScores> scores; uint32_t decoded = 0; };
-    const auto score_block = [&](uint32_t w, uint32_t h, uint32_t lo, uint32_t hi, Block &out) {
-        if (lo >= hi) return;
+    // ready (optional): called once the block's engines exist and its sources have page-locked their rings -- where the one-device run starts its
+    // clock (main.rs:252: after the decoders and the engine exist)
+    const auto score_block = [&](uint32_t w, uint32_t h, uint32_t lo, uint32_t hi, Block &out, const std::function<void()> &ready = nullptr) {
+        if (lo >= hi) { if (ready) ready(); return; }
         auto sr = create_source(pos[0], hints), sd = create_source(pos[1], hints);
         const uint32_t b = std::min(batch, hi - lo);
         TurboMetrics tmx(w, h, metrics, b, pipeline && hi - lo > b);
@@ -274,6 +277,7 @@ int main(int argc, char **argv)
         Options o = opts;
         o.decode_start = lo;
         o.frames = hi; // absolute decode index at which this block stops (lib.rs:396-398)
+        if (ready) { TurboMetrics::prepare_sources(*sr, *sd, o); ready(); }
         uint32_t dc = lo;
         try { tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { out.scores.push_back(fs); }, &dc); }
         catch (const NoFramesSelected &) { dc = hi; } // a block in which `every` selects no frame is empty, not an error (any other exception is one)
@@ -315,11 +319,13 @@ int main(int argc, char **argv)
         try {
             std::unique_ptr<RankTransport> transport = make_rank_transport(renv); // (RCCL: the communicator is set up while nothing else runs)
             if (root) log_line(L_DEBUG, kTarget, std::string("ranks: ") + std::to_string(renv.world) + " over " + transport->name());
-            const auto start = std::chrono::steady_clock::now();
+            auto start = std::chrono::steady_clock::now();
             uint32_t lo = 0, hi = 0;
             shard_range(total, (uint32_t)renv.rank, (uint32_t)renv.world, lo, hi);
             Block blk;
-            score_block(w, h, lo, hi, blk);
+            // rank 0's clock starts where the one-device run's does: engines created, rings page-locked (the other ranks set up at the same time; the
+            // figure then covers rank 0's block, the wait for the slowest rank and the reduce)
+            score_block(w, h, lo, hi, blk, [&] { start = std::chrono::steady_clock::now(); });
             ScoreVector sv(metrics, total);
             size_t k = 0;
             for (uint32_t dc = lo; dc < hi && k < blk.scores.size(); ++dc) {
