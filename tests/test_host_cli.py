@@ -624,6 +624,11 @@ def test_cli_ranks_one_process_per_device_and_one_reduce_with_identical_output(t
     rccl = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--batch", 4, "--ranks", 1, env={"TM_RANK_TRANSPORT": "rccl", "TM_RANK_TIMEOUT_S": "300"})
     assert rccl[0] == 0, rccl[2]
     assert rccl[1] == one[1] and "on 1 ranks (rccl)" in rccl[2]
+    # no silent fallback to pipes when the collective library cannot be loaded
+    rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--ranks", 1, env={"TM_RANK_TRANSPORT": "rccl", "TM_RCCL_LIB": str(tmp_path / "nowhere.so"), "TM_RANK_TIMEOUT_S": "120"})
+    assert rc != 0 and "needs libturbometrics_rccl.so" in err and out == ""
+    rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--ranks", 1, env={"TM_RANK_TRANSPORT": "carrier-pigeon", "TM_RANK_TIMEOUT_S": "120"})
+    assert rc != 0 and "possible values: rccl, pipe" in err
     # without sharing, more ranks than GPUs is an error of every rank and of the launcher
     import torch
     rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--ranks", torch.cuda.device_count() + 1, env={"TM_RANK_TRANSPORT": "pipe", "TM_RANK_TIMEOUT_S": "120"})
