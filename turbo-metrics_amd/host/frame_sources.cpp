@@ -554,7 +554,10 @@ void YuvStreamSource::alloc_ring()
     // profiles/r04h_read_probe.log) -> a third of the CPUs left after main thread, dispatchers, ring helper and the HIP runtime
     // (streams: how many sources this process reads at the same time -- two, or two per device with `--devices N`)
     const unsigned streams = g_concurrent_streams.load();
-    const unsigned want = env ? (unsigned)std::max(1, atoi(env)) : std::min(by_size, std::max(1u, (cpus > 4 ? cpus - 4 : 1) / (streams + 1)));
+    // (round 6, 10-bit streams packed on the way in: a reader now also packs what it reads, and writes a third less -- on the same 16-CPU box
+    // 4 / 6 / 8 threads per stream = 1.13-1.38 / 1.41-1.51 / 1.41-1.51 k pairs/s of 4K, from 6 on the loop waits for the uploads instead of the
+    // sources: profiles/r06h_pack_piece_ab.log -> half of the CPUs left after the helpers, per stream)
+    const unsigned want = env ? (unsigned)std::max(1, atoi(env)) : std::min(by_size, std::max(1u, (cpus > 4 ? cpus - 4 : 1) / (pack10_ ? streams : streams + 1)));
     const bool ra = readahead_ && fd_ >= 0 && h_ >= 64;
     // read-ahead: enough pictures in flight to keep `want` readers busy with pieces of ~2 MB, at most 256 MB of them
     const size_t pieces = std::max<size_t>(1, (planar_bytes_ + ((size_t)2 << 20) - 1) / ((size_t)2 << 20));
@@ -653,13 +656,16 @@ void YuvStreamSource::start_readahead(unsigned threads, size_t ahead)
             if (ex) { if (p < R.err_pic) { R.err_pic = p; R.err = ex; } R.cv_done.notify_all(); return; }
             if (!more) { R.eof_pic = p; R.cv_done.notify_all(); return; }
             R.pic_of[slot] = p;
-            if (pack10_) { // whole rows of one plane per piece, ~256 KB of the stream each: the 16-bit rows pass through a reader's cache, not through memory
+            if (pack10_) { // whole rows of one plane per piece, ~1 MB of the stream each: the 16-bit rows pass through a reader's caches, not through memory
                 const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
                 struct Plane { size_t off, rows, width, pitch; unsigned char *dst; } planes[3] = {
                     {at, h_, w_, row_y_, dst}, {at + (size_t)w_ * h_ * 2, ch, cw, row_c_, dst + row_y_ * h_}, {at + ((size_t)w_ * h_ + cw * ch) * 2, ch, cw, row_c_, dst + row_y_ * h_ + row_c_ * ch}};
                 unsigned n = 0;
                 for (const Plane &pl : planes) {
-                    const size_t per = std::max<size_t>(1, ((size_t)256 << 10) / (pl.width * 2));
+                    // (pieces of 64 KB / 128 KB / 256 KB / 512 KB / 1 MB / 2 MB: 1.09 / 1.2 / 1.1-1.4 / 1.3 / 1.3-1.4 / 1.25-1.4 k pairs/s of 4K with four readers per
+                    // stream -- small pieces pay for the queue, large ones leave the cache: 1 MB; TM_PACK_PIECE_KB overrides for a measurement)
+                    static const size_t piece_kb = [] { const char *e = getenv("TM_PACK_PIECE_KB"); const int v = e ? atoi(e) : 0; return (size_t)(v >= 16 && v <= 8192 ? v : 1024); }();
+                    const size_t per = std::max<size_t>(1, (piece_kb << 10) / (pl.width * 2));
                     for (size_t r = 0; r < pl.rows; r += per) {
                         const size_t k = std::min(per, pl.rows - r);
                         R.q.push_back(ReadAhead::Piece{p, pl.off + r * pl.width * 2, k * pl.width * 2, pl.dst + r * pl.pitch, (uint32_t)k, (uint32_t)pl.width, pl.pitch});
