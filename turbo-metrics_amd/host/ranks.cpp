@@ -260,6 +260,10 @@ public:
             for (int r = 1; r < env_.world; ++r) write_all(env_.down[r - 1], id, sizeof id, "communicator id: write");
         } else read_all(env_.down[0], id, sizeof id, "communicator id: read");
         if (init_(&comm_, env_.world, env_.rank, id)) throw std::runtime_error(std::string("tm_comm_init: ") + err_());
+        // the first collective of a communicator pays for RCCL's lazy set-up (channels, kernels: ~0.1 s): an 8-byte reduce HERE, while the ranks are
+        // still setting up, so that the one reduce of the scores costs what a reduce costs
+        double warm = 0.0;
+        if (reduce_(comm_, &warm, 1, 0)) throw std::runtime_error(std::string("tm_comm_reduce_sum_f64 (warm-up): ") + err_());
     }
     ~RcclTransport() override
     {

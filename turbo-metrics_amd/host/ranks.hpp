@@ -11,7 +11,7 @@
 //   rank r     binds to device r (and that device's NUMA node: init_hip), scores its block, and takes part in the one reduce.
 //   transport  "rccl" (default for N > 1): libturbometrics_rccl.so (include/turbo_metrics_comm.h) is loaded at run time -- a
 //              single-device run never pays for loading RCCL --, the communicator's unique id travels from rank 0 to the others over the
-//              launcher's pipes, then ncclReduce(sum, ncclDouble, root 0).  "pipe" (TM_RANK_TRANSPORT=pipe; the CPU test tier, and
+//              launcher's pipes, an 8-byte reduce warms the communicator up during set-up, then ONE ncclReduce(sum, ncclDouble, root 0) carries the scores.  "pipe" (TM_RANK_TRANSPORT=pipe; the CPU test tier, and
 //              ranks that share one device, which RCCL refuses): every rank writes its vector to rank 0, which adds them in rank order.
 //              Either way every entry is non-zero on at most one rank and is added to zeros: rank 0 holds the single-device values
 //              bit for bit.
