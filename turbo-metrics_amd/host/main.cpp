@@ -267,7 +267,9 @@ int main(int argc, char **argv)
     struct Block { std::vector<FrameScores> scores; uint32_t decoded = 0; };
     // ready (optional): called once the block's engines exist and its sources have page-locked their rings -- where the one-device run starts its
     // clock (main.rs:252: after the decoders and the engine exist)
-    const auto score_block = [&](uint32_t w, uint32_t h, uint32_t lo, uint32_t hi, Block &out, const std::function<void()> &ready = nullptr) {
+    // each: sees every FrameScores of the block as it arrives (rank 0 prints its own block while the others compute)
+    const auto score_block = [&](uint32_t w, uint32_t h, uint32_t lo, uint32_t hi, Block &out, const std::function<void()> &ready = nullptr,
+                                 const std::function<void(const FrameScores &)> &each = nullptr) {
         if (lo >= hi) { if (ready) ready(); return; }
         auto sr = create_source(pos[0], hints), sd = create_source(pos[1], hints);
         const uint32_t b = std::min(batch, hi - lo);
@@ -279,7 +281,7 @@ int main(int argc, char **argv)
         o.frames = hi; // absolute decode index at which this block stops (lib.rs:396-398)
         if (ready) { TurboMetrics::prepare_sources(*sr, *sd, o); ready(); }
         uint32_t dc = lo;
-        try { tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { out.scores.push_back(fs); }, &dc); }
+        try { tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { out.scores.push_back(fs); if (each) each(fs); }, &dc); }
         catch (const NoFramesSelected &) { dc = hi; } // a block in which `every` selects no frame is empty, not an error (any other exception is one)
         out.decoded = dc - lo;
     };
@@ -325,7 +327,10 @@ int main(int argc, char **argv)
             Block blk;
             // rank 0's clock starts where the one-device run's does: engines created, rings page-locked (the other ranks set up at the same time; the
             // figure then covers rank 0's block, the wait for the slowest rank and the reduce)
-            score_block(w, h, lo, hi, blk, [&] { start = std::chrono::steady_clock::now(); });
+            // rank 0 holds the FIRST block: its lines go out as they are computed, like the one-device run's; the other blocks' follow the reduce
+            if (root) output_prepare(output, metrics, std::cout);
+            score_block(w, h, lo, hi, blk, [&] { start = std::chrono::steady_clock::now(); },
+                        root ? std::function<void(const FrameScores &)>([&](const FrameScores &fs) { output_single_score(output, fs, std::cout); }) : nullptr);
             ScoreVector sv(metrics, total);
             size_t k = 0;
             for (uint32_t dc = lo; dc < hi && k < blk.scores.size(); ++dc) {
@@ -336,9 +341,8 @@ int main(int argc, char **argv)
             sv.add_decoded(blk.decoded);
             transport->reduce_sum_to_root(sv.v); // the ONE collective of the path
             if (!root) return EXIT_SUCCESS;
-            output_prepare(output, metrics, std::cout);
             const std::vector<FrameScores> all = sv.frames();
-            for (const FrameScores &fs : all) output_single_score(output, fs, std::cout);
+            for (size_t i = blk.scores.size(); i < all.size(); ++i) output_single_score(output, all[i], std::cout); // (rank 0's own are out already)
             return report(all, sv.decoded(), w, h, start, std::to_string(renv.world) + " ranks (" + transport->name() + ")");
         } catch (const RankPeerLost &e) { // not this rank's failure: the launcher reports the rank that went away
             std::cout.flush();
