@@ -199,8 +199,25 @@ class Ctx:
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max(1, min(8, distinct, self.cpu_share))) as ex:  # numpy releases the GIL in the heavy parts
                     host = self._surfaces[(name, distinct, "host")] = list(ex.map(lambda n: gen(w, h, n), range(distinct)))
-            put = (lambda a: self.torch.from_numpy(a).pin_memory()) if pinned else (lambda a: self.torch.from_numpy(a).cuda())
-            self._surfaces[key] = [((put(rs), rp, rch), (put(ds), dp, dch)) for (rs, rp, rch), (ds, dp, dch) in host]
+            if pinned:
+                # a decoder's surface pool: the page-locked surfaces of a side lie back to back -- what the engine copies of one (coded_height
+                # luma rows + ceil(h / 2) CbCr rows) ends where the next begins, so two frames of 1080p can share a DMA (tm_engine.hip, queue_copy)
+                (rs0, rp0, rch0) = host[0][0]
+                frame = rp0 * (rch0 + (h + 1) // 2)
+                pools = [self.torch.empty(frame * distinct + len(rs0), dtype=self.torch.uint8).pin_memory() for _ in range(2)]
+                out = []
+                for k, ((rs, rp, rch), (ds, dp, dch)) in enumerate(host):
+                    views = []
+                    for side, surf in enumerate((rs, ds)):
+                        v = pools[side][k * frame:k * frame + len(surf)]
+                        v[:frame].copy_(self.torch.from_numpy(surf[:frame]))  # (what lies behind the CbCr rows of a surface is never read)
+                        views.append(v)
+                    out.append(((views[0], rp, rch), (views[1], dp, dch)))
+                self._surfaces[key] = out
+                self._pools = getattr(self, "_pools", []) + pools
+            else:
+                put = lambda a: self.torch.from_numpy(a).cuda()
+                self._surfaces[key] = [((put(rs), rp, rch), (put(ds), dp, dch)) for (rs, rp, rch), (ds, dp, dch) in host]
             self.torch.cuda.synchronize()
         return self._surfaces[key]
 

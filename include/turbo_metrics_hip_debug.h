@@ -90,10 +90,13 @@ int tm_engine_debug_set_edge_epoch(tm_engine *e, uint32_t epoch);
  *                              behind Cb) goes up as one linear copy; 0 (default): as 2-D copies into padded rows like every other layout
  *   TM_DBG_UPLOAD_STREAMS      2 (default): page-locked frames of the distorted side go up on a second stream (one per device, shared by its
  *                              engines) beside those of the reference side; 1: every frame on the engine's own stream
+ *   TM_DBG_UPLOAD_MERGE        bytes up to which two page-locked frames that lie back to back in the caller's memory (and therefore in the
+ *                              engine's staging arena) go up as ONE DMA (8 MiB: pairs of 1080p frames; 0: every frame its own copy, at once)
  *   TM_DBG_EF_FAULT            fault injection: 2 = the fused kernel does not publish the column state between groups of bands -- the next
  *                              group's wait times out, tm_engine_sync returns TM_ERR_HIP and the results of that launch are not
  *                              available; 1 = do not wait at all (wrong sums, no error); 0 = off.  The engine stays usable. */
-enum { TM_DBG_FUSED_EDGE_FROM = 0, TM_DBG_EF_WAVES = 1, TM_DBG_EF_PERSIST_WGS = 2, TM_DBG_PASS_PRIO = 3, TM_DBG_SPLIT_ROWS_BELOW = 4, TM_DBG_SOLO_COL_BELOW = 5, TM_DBG_EF_FAULT = 6, TM_DBG_LINEAR_UPLOAD = 7, TM_DBG_UPLOAD_STREAMS = 8 };
+enum { TM_DBG_FUSED_EDGE_FROM = 0, TM_DBG_EF_WAVES = 1, TM_DBG_EF_PERSIST_WGS = 2, TM_DBG_PASS_PRIO = 3, TM_DBG_SPLIT_ROWS_BELOW = 4, TM_DBG_SOLO_COL_BELOW = 5, TM_DBG_EF_FAULT = 6, TM_DBG_LINEAR_UPLOAD = 7, TM_DBG_UPLOAD_STREAMS = 8,
+       TM_DBG_UPLOAD_MERGE = 9 };
 int tm_engine_debug_set_param(tm_engine *e, int param, long long value);
 /* measurement hook (tools/pipeline_probe.py): two engines on one device that take turns can be CHAINED -- from now on this engine's
  * ingest stage waits for `peer`'s last column pass and its column pass for `peer`'s last row pass, so that with both engines kept

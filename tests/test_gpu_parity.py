@@ -629,6 +629,97 @@ def test_packed_10_bit_upload_kind_is_bit_identical_with_planar_10_bit(w, h):
     e1.close(); planar.close()
 
 
+@pytest.mark.parametrize("form", ["nv12_surfaces", "i420_tight", "p10_tight"])
+def test_back_to_back_page_locked_frames_share_a_dma_and_nothing_changes(form):
+    """round 6 (second half): page-locked frames that lie back to back in the caller's memory -- a decoder's surface pool, the
+    CLI's ring -- land back to back in the engine's staging arena, and two of them go up as ONE DMA (a copy is held back until the next one
+    of its stream is known; fences, launches and syncs flush).  Same sums as device-resident frames whatever the hand-over order: in slot order
+    (pairs merge), in reverse (nothing merges), a slot handed over twice, a pageable frame behind a held page-locked one, fences in between,
+    merging off (TM_DBG_UPLOAD_MERGE 0), one upload stream."""
+    import torch
+    w, h, B = 640, 360, 6
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    m = tm.Metrics(ssimulacra2=True, psnr=True)
+    pairs = [tm.synth.yuv420_pair(w, h, n + 11, 10 if form == "p10_tight" else 8) for n in range(B + 1)]
+    base = tm.TurboMetrics(w, h, m, batch=B, full_sums=True)
+
+    def dev_frame(planes):
+        if form == "p10_tight":
+            return tm.HwFrame.i420(*(torch.from_numpy(np.ascontiguousarray(p.astype(np.uint16))).cuda() for p in planes), bits=10)
+        return tm.HwFrame.i420(*(torch.from_numpy(np.ascontiguousarray(p.astype(np.uint8))).cuda() for p in planes), bits=8)
+    keep = []
+    for slot in range(B):
+        fr = [dev_frame(pairs[slot][side]) for side in range(2)]; keep.append(fr)
+        base.set_pair(slot, fr[0], fr[1])
+    base.compute_async(); base.sync()
+    want = [(base.raw_sums(s).copy(), base.sse(s)) for s in range(B)]
+    other = tm.TurboMetrics(w, h, m, batch=1, full_sums=True)
+    fr7 = [dev_frame(pairs[B][side]) for side in range(2)]
+    other.compute_one(fr7[0], fr7[1])
+    want7 = (other.raw_sums(0).copy(), other.sse(0))
+
+    # one page-locked pool per side, frames back to back
+    if form == "nv12_surfaces":
+        surf = [[tm.synth.pack_biplanar(pairs[n][side], w, h, 8, coded_height=h) for n in range(B + 1)] for side in range(2)]
+        nbytes = len(surf[0][0][0])
+        mk = lambda side, n, t: tm.HwFrame.nv12(t, surf[side][n][1], surf[side][n][2])
+        blob = lambda side, n: surf[side][n][0]
+    elif form == "i420_tight":
+        blob = lambda side, n: np.concatenate([p.astype(np.uint8).ravel() for p in pairs[n][side]])
+        nbytes = w * h + 2 * cw * ch
+        mk = lambda side, n, t: tm.HwFrame.i420(t[:w * h].view(h, w), t[w * h:w * h + cw * ch].view(ch, cw), t[w * h + cw * ch:].view(ch, cw), bits=8)
+    else:
+        wy, wc = tm.synth.p10_row_words(w), tm.synth.p10_row_words(cw)
+        blob = lambda side, n: np.concatenate([tm.synth.p10_pack_plane(p).ravel() for p in pairs[n][side]]).view(np.uint8)
+        nbytes = (h * wy + 2 * ch * wc) * 4
+        def mk(side, n, t):
+            t32 = t.view(torch.int32)
+            return tm.HwFrame.i420p10(t32[:h * wy].view(h, wy), t32[h * wy:h * wy + ch * wc].view(ch, wc), t32[h * wy + ch * wc:].view(ch, wc))
+    pools = [torch.empty(nbytes * (B + 1), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    for side in range(2):
+        for n in range(B + 1):
+            pools[side][n * nbytes:(n + 1) * nbytes].copy_(torch.from_numpy(np.ascontiguousarray(blob(side, n))))
+    frame = lambda side, n: mk(side, n, pools[side][n * nbytes:(n + 1) * nbytes])
+
+    def check(eng, expect):
+        eng.compute_async(); eng.sync()
+        for s in range(B):
+            assert np.array_equal(eng.raw_sums(s), expect[s][0]) and eng.sse(s) == expect[s][1], (form, s)
+    for merge, streams in ((8 << 20, 2), (0, 2), (8 << 20, 1), (1 << 30, 2)):
+        eng = tm.TurboMetrics(w, h, m, batch=B, full_sums=True)
+        eng.debug_set_param(F.TM_DBG_LINEAR_UPLOAD, 1)
+        eng.debug_set_param(F.TM_DBG_UPLOAD_MERGE, merge)
+        eng.debug_set_param(F.TM_DBG_UPLOAD_STREAMS, streams)
+        for slot in range(B):  # in slot order: neighbours share a DMA
+            eng.set_pair(slot, frame(0, slot), frame(1, slot))
+        check(eng, want)
+        for slot in reversed(range(B)):  # in reverse: nothing to merge, every copy is held once and flushed by the next
+            eng.set_pair(slot, frame(0, slot), frame(1, slot))
+            if slot == 3:
+                tok = eng.upload_fence()
+                assert eng.upload_done(tok, block=True)
+        check(eng, want)
+        # slot 2 handed over twice (the wrong picture first), slot 4's distorted side replaced from pageable memory behind a held page-locked copy
+        for slot in range(B):
+            if slot == 2:
+                eng.set_pair(2, frame(0, B), frame(1, B))
+            eng.set_pair(slot, frame(0, slot), frame(1, slot))
+            if slot == 4:
+                eng.set_frame(4, F.TM_SIDE_DIS, frame(1, B))
+                pageable = mk(1, 4, torch.from_numpy(np.ascontiguousarray(blob(1, 4)).copy()))
+                eng.set_frame(4, F.TM_SIDE_DIS, pageable)
+        check(eng, want)
+        # every slot the seventh pair, fences after each hand-over
+        toks = []
+        for slot in range(B):
+            eng.set_pair(slot, frame(0, B), frame(1, B))
+            toks.append(eng.upload_fence())
+        assert all(eng.upload_done(t, block=True) for t in toks)
+        check(eng, [want7] * B)
+        eng.close()
+    base.close(); other.close()
+
+
 def test_8k_pair_against_oracle():
     """7680x4320: one slot's arenas pass 2 GB (several kernels carry 32-bit lane offsets inside a plane), two slots so that the
     second one starts beyond 4 GB of the pass-1 arena"""

@@ -207,8 +207,19 @@ struct tm_engine {
     bool stage_busy = false;          // a launch may still be reading the staging surfaces: up_stream waits for ev_stage_free first
     int upload_streams = 2;           // TM_DBG_UPLOAD_STREAMS
     uint64_t up_next = 0;             // tokens handed out so far (token t lives in up_ev[t % size] until token t + size is taken)
-    std::vector<void *> staging;      // [slot*2+side], lazily allocated
+    std::vector<void *> staging;      // [slot*2+side], lazily allocated: a slot of the side's arena (below) or an allocation of its own
     std::vector<size_t> staging_size;
+    std::vector<char> staging_own;    // [slot*2+side]: 1 = its own hipMalloc (a frame that does not fit the arena's slots)
+    // Round 6: the staging surfaces of a side are ONE allocation, slot after slot at the size of the first frame handed over, so that page-locked
+    // frames that lie back to back in the caller's memory (a decoder's surface pool, the CLI's frame ring) land back to back here too -- and two
+    // of them go up as ONE DMA (pend: a copy is held back until the next one of its stream is known).  Beside the kernels 3-MB copies on the
+    // two upload streams reach 48 GB/s, 6-MB ones 52-56, 25-MB ones 56-57 (profiles/r06j_dma_size_probe.log).
+    char *stage_arena[2] = {nullptr, nullptr};
+    size_t stage_stride[2] = {0, 0};
+    struct PendingCopy { char *dst; const char *src; size_t dpitch, spitch, row_bytes, rows; bool linear; };
+    PendingCopy pend[2] = {};          // [0] engine's stream, [1] second upload stream
+    bool has_pend[2] = {false, false};
+    size_t merge_limit = (size_t)8 << 20; // bytes up to which two copies are merged (1080p pairs of frames: yes; 4K frames go up one by one)
     size_t mem_bytes = 0;
     bool profiling = false, ev_pending = false;
     hipEvent_t ev[7] = {}; // 0..4: start | ingest | column pass | row pass | finisher + SSIM stage, on the engine's stream; 5, 6: around the fused EDGE kernel, on the stream it runs on
@@ -254,12 +265,63 @@ int check_slot_side(const tm_engine *e, uint32_t slot, int side)
     return TM_OK;
 }
 
-// copy `rows` rows of `row_bytes` from host memory (pitch `src_pitch`) into the staging surface
-int stage_rows(tm_engine *e, hipStream_t st, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, size_t rows)
+int submit_copy(tm_engine *e, int si, const tm_engine::PendingCopy &c)
+{
+    hipStream_t st = si ? e->up_stream : e->stream;
+    if (c.linear) HIPCHK(hipMemcpyAsync(c.dst, c.src, c.row_bytes, hipMemcpyHostToDevice, st));
+    else HIPCHK(hipMemcpy2DAsync(c.dst, c.dpitch, c.src, c.spitch, c.row_bytes, c.rows, hipMemcpyHostToDevice, st));
+    return TM_OK;
+}
+
+// the copy that is held back on stream si (if any) goes out
+int flush_pending(tm_engine *e, int si)
+{
+    if (!e->has_pend[si]) return TM_OK;
+    e->has_pend[si] = false;
+    return submit_copy(e, si, e->pend[si]);
+}
+int flush_pending(tm_engine *e)
+{
+    int rc = flush_pending(e, 0);
+    const int rc2 = flush_pending(e, 1);
+    return rc ? rc : rc2;
+}
+
+// A page-locked copy for stream si: merged with the one held back when the two are one run of bytes (or of rows) on both ends -- then the pair
+// goes out as ONE DMA --, otherwise the held one goes out and this one is held.  Never more than one copy is held per stream, and every
+// fence, launch and sync flushes: the caller's "bytes stay untouched until the fence is done / tm_engine_sync returns" does not change.
+int queue_copy(tm_engine *e, int si, const tm_engine::PendingCopy &c)
+{
+    const size_t bytes = c.linear ? c.row_bytes : c.row_bytes * c.rows;
+    if (e->has_pend[si]) {
+        tm_engine::PendingCopy &p = e->pend[si];
+        const size_t pbytes = p.linear ? p.row_bytes : p.row_bytes * p.rows;
+        const bool run = p.linear == c.linear && pbytes + bytes <= e->merge_limit &&
+                         (c.linear ? c.src == p.src + p.row_bytes && c.dst == p.dst + p.row_bytes
+                                   : c.row_bytes == p.row_bytes && c.spitch == p.spitch && c.dpitch == p.dpitch && c.src == p.src + p.spitch * p.rows && c.dst == p.dst + p.dpitch * p.rows);
+        if (run) {
+            if (c.linear) p.row_bytes += c.row_bytes; else p.rows += c.rows;
+            return flush_pending(e, si); // (pairs: what the link gains from three and more is within its spread)
+        }
+        const int rc = flush_pending(e, si);
+        if (rc) return rc;
+    }
+    if (2 * bytes > e->merge_limit) return submit_copy(e, si, c); // too large to share a DMA with a second one of its size
+    e->pend[si] = c;
+    e->has_pend[si] = true;
+    return TM_OK;
+}
+
+// copy `rows` rows of `row_bytes` from host memory (pitch `src_pitch`) into the staging surface; a page-locked source may be held back for a
+// moment (queue_copy), anything else goes out now, behind whatever was held on its stream
+int stage_rows(tm_engine *e, hipStream_t st, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, size_t rows, bool pinned = false)
 {
     if (rows == 0 || row_bytes == 0) return TM_OK;
-    HIPCHK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, st));
-    return TM_OK;
+    const int si = st == e->up_stream && e->up_stream ? 1 : 0;
+    const tm_engine::PendingCopy c{(char *)dst, (const char *)src, dst_pitch, src_pitch, row_bytes, rows, false};
+    if (pinned) return queue_copy(e, si, c);
+    const int rc = flush_pending(e, si);
+    return rc ? rc : submit_copy(e, si, c);
 }
 
 // the stream a host frame goes up on: the engine's own, or -- page-locked frames of the distorted side -- the device's second upload
@@ -272,6 +334,7 @@ int upload_stream(tm_engine *e, int side, int mem, hipStream_t *out)
         // a distorted-side copy on the engine's own stream after page-locked ones on the second stream: same staging surface, two
         // streams -- the engine's stream waits for the second one first (what tm_engine_compute_async would do later anyway)
         if (side == TM_SIDE_DIS && mem != TM_MEM_DEVICE && e->up_pending) {
+            { const int rc = flush_pending(e, 1); if (rc) return rc; } // (a copy still held back belongs in front of the join)
             HIPCHK(hipEventRecord(e->ev_up_join, e->up_stream));
             HIPCHK(hipStreamWaitEvent(e->stream, e->ev_up_join, 0));
             e->up_pending = false;
@@ -290,17 +353,33 @@ int upload_stream(tm_engine *e, int side, int mem, hipStream_t *out)
 int ensure_staging(tm_engine *e, size_t idx, size_t bytes)
 {
     if (e->staging_size[idx] >= bytes) return TM_OK;
+    const int side = (int)(idx & 1);
+    const size_t stride = (bytes + 255) / 256 * 256;
+    // the side's arena: made for the first frame handed over, slots of exactly that frame's size (capped: a rarely used 4K engine of 128 slots
+    // does not get 3 GB of staging it may never fill -- its frames are large copies anyway)
+    if (!e->stage_arena[side] && (size_t)e->cap * stride <= ((size_t)2 << 30)) {
+        hipError_t r = hipMalloc((void **)&e->stage_arena[side], (size_t)e->cap * stride);
+        if (r == hipSuccess) { e->stage_stride[side] = stride; e->mem_bytes += (size_t)e->cap * stride; }
+        else { (void)hipGetLastError(); e->stage_arena[side] = nullptr; } // (the slot gets an allocation of its own below, or fails there)
+    }
+    if (e->stage_arena[side] && e->stage_stride[side] >= bytes && !e->staging_own[idx]) {
+        e->staging[idx] = e->stage_arena[side] + (idx >> 1) * e->stage_stride[side];
+        e->staging_size[idx] = e->stage_stride[side];
+        return TM_OK;
+    }
+    // a frame that does not fit the arena's slots (another kind, another pitch): an allocation of its own, grown when needed
+    int rc = flush_pending(e);
+    if (rc) return rc;
     if (e->staging[idx]) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->up_pending) HIPCHK(hipStreamSynchronize(e->up_stream));
-        HIPCHK(hipFree(e->staging[idx]));
-        e->mem_bytes -= e->staging_size[idx];
-        e->staging[idx] = nullptr; e->staging_size[idx] = 0;
+        if (e->staging_own[idx]) { HIPCHK(hipFree(e->staging[idx])); e->mem_bytes -= e->staging_size[idx]; }
+        e->staging[idx] = nullptr; e->staging_size[idx] = 0; e->staging_own[idx] = 0;
     }
     hipError_t r = hipMalloc(&e->staging[idx], bytes);
     if (r == hipErrorOutOfMemory) return TM_ERR_OOM;
     if (r != hipSuccess) return hip_fail(r, "hipMalloc(staging)");
-    e->staging_size[idx] = bytes; e->mem_bytes += bytes;
+    e->staging_size[idx] = bytes; e->staging_own[idx] = 1; e->mem_bytes += bytes;
     return TM_OK;
 }
 
@@ -336,6 +415,7 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         if (rc) return rc;
         hipStream_t us;
         if ((rc = upload_stream(e, side, mem, &us))) return rc;
+        const bool pinned = mem == TM_MEM_HOST_PINNED;
         char *s = (char *)e->staging[idx];
         const size_t uv_bytes = yuv ? (size_t)((e->w + 1) / 2) * 2 * bps : 0, uv_row = uv_bytes <= pitch ? uv_bytes : pitch;
         // ONE 2-D copy of all rows instead of two (the per-copy cost is what limits small frames: docs/LABBOOK.md section 5, host-fed) in
@@ -346,14 +426,14 @@ int set_frame_common(tm_engine *e, uint32_t slot, int side, int kind, const void
         const size_t gap = yuv && (const char *)p1 >= (const char *)p0 ? (size_t)((const char *)p1 - (const char *)p0) : 0;
         const size_t luma_rows = coded_rows ? coded_rows : (yuv && gap == pitch * (size_t)e->h ? (size_t)e->h : 0);
         if (luma_rows >= e->h) {
-            rc = stage_rows(e, us, s, spitch, p0, pitch, row_bytes > uv_row ? row_bytes : uv_row, luma_rows + chroma_rows);
+            rc = stage_rows(e, us, s, spitch, p0, pitch, row_bytes > uv_row ? row_bytes : uv_row, luma_rows + chroma_rows, pinned);
             if (rc) return rc;
             d.p1 = s + spitch * luma_rows;
         } else {
-            rc = stage_rows(e, us, s, spitch, p0, pitch, row_bytes, e->h);
+            rc = stage_rows(e, us, s, spitch, p0, pitch, row_bytes, e->h, pinned);
             if (rc) return rc;
             if (yuv) {
-                rc = stage_rows(e, us, s + spitch * e->h, spitch, p1, pitch, uv_row, chroma_rows);
+                rc = stage_rows(e, us, s + spitch * e->h, spitch, p1, pitch, uv_row, chroma_rows, pinned);
                 if (rc) return rc;
                 d.p1 = s + spitch * e->h;
             } else d.p1 = nullptr;
@@ -395,19 +475,29 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
     } else {
         const size_t idx = slot * 2 + side;
         const size_t sp_y = (row_y + 255) / 256 * 256, sp_c = (row_c + 255) / 256 * 256;
-        rc = ensure_staging(e, idx, sp_y * e->h + 2 * sp_c * ch);
+        // (a tight picture that goes up as ONE linear copy gets a slot of exactly its size: pictures back to back in the caller's ring then are back
+        // to back here, and two of them share a DMA)
+        const bool tight = pitch_y == row_y && pitch_uv == row_c && (const char *)u == (const char *)y + row_y * e->h && (const char *)v == (const char *)u + row_c * ch &&
+                           row_c % 4 == 0 && !e->dbg_no_linear_upload;
+        rc = ensure_staging(e, idx, tight ? row_y * e->h + 2 * row_c * ch : sp_y * e->h + 2 * sp_c * ch);
         if (rc) return rc;
         hipStream_t us;
         if ((rc = upload_stream(e, side, mem, &us))) return rc;
+        const bool pinned = mem == TM_MEM_HOST_PINNED;
         char *s = (char *)e->staging[idx];
         // a TIGHT picture (rows without padding, Cb behind Y, Cr behind Cb: a picture of a Y4M / raw planar file as it lies in the file)
         // can go up as ONE linear copy and be read with its own pitches (TM_DBG_LINEAR_UPLOAD = 1).  Which way is faster depends on how the
         // caller submits: pictures handed over one by one as they arrive, with a fence per pair (the CLI) -- linear 7.1-7.7 k pairs/s of 1080p
         // against 5.3-6.1 k with the 2-D copies; a whole batch queued at once (bench.py's host_fed loop) -- 2-D 6.6 k against 5.3 k linear
         // (tools/cli_ab.sh, tools/host_fed_ab.py).  The CLI's host layer switches it on; the default is the 2-D path.
-        if (pitch_y == row_y && pitch_uv == row_c && (const char *)u == (const char *)y + row_y * e->h && (const char *)v == (const char *)u + row_c * ch &&
-            row_c % 4 == 0 && !e->dbg_no_linear_upload) {
-            HIPCHK(hipMemcpyAsync(s, y, row_y * e->h + 2 * row_c * ch, hipMemcpyHostToDevice, us));
+        if (tight) {
+            {
+                const int si = us == e->up_stream && e->up_stream ? 1 : 0;
+                const tm_engine::PendingCopy c{s, (const char *)y, 0, 0, row_y * e->h + 2 * row_c * ch, 1, true};
+                if (pinned) rc = queue_copy(e, si, c);
+                else if (!(rc = flush_pending(e, si))) rc = submit_copy(e, si, c);
+                if (rc) return rc;
+            }
             if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
             d.p0 = s; d.p1 = s + row_y * e->h; d.p2 = s + row_y * e->h + row_c * ch; d.pitch = row_y; d.pitch2 = row_c;
             d.kind = kind;
@@ -416,12 +506,12 @@ int set_frame_planar(tm_engine *e, uint32_t slot, int side, const void *y, const
             return TM_OK;
         }
         char *su = s + sp_y * e->h, *sv = su + sp_c * ch;
-        if ((rc = stage_rows(e, us, s, sp_y, y, pitch_y, row_y, e->h))) return rc;
+        if ((rc = stage_rows(e, us, s, sp_y, y, pitch_y, row_y, e->h, pinned))) return rc;
         if ((const char *)v == (const char *)u + pitch_uv * ch) { // Cr follows Cb (a picture of a planar file): one copy for both
-            if ((rc = stage_rows(e, us, su, sp_c, u, pitch_uv, row_c, 2 * ch))) return rc;
+            if ((rc = stage_rows(e, us, su, sp_c, u, pitch_uv, row_c, 2 * ch, pinned))) return rc;
         } else {
-            if ((rc = stage_rows(e, us, su, sp_c, u, pitch_uv, row_c, ch))) return rc;
-            if ((rc = stage_rows(e, us, sv, sp_c, v, pitch_uv, row_c, ch))) return rc;
+            if ((rc = stage_rows(e, us, su, sp_c, u, pitch_uv, row_c, ch, pinned))) return rc;
+            if ((rc = stage_rows(e, us, sv, sp_c, v, pitch_uv, row_c, ch, pinned))) return rc;
         }
         if (mem == TM_MEM_HOST) HIPCHK(hipStreamSynchronize(e->stream));
         d.p0 = s; d.p1 = su; d.p2 = sv; d.pitch = sp_y; d.pitch2 = sp_c;
@@ -729,6 +819,7 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     for (size_t i = 0; i < B * 2; ++i) { e->h_desc[i] = TmFrameDesc{nullptr, nullptr, nullptr, 0, 0, TM_KIND_NONE, 0, 0, 0}; }
     e->staging.assign(B * 2, nullptr);
     e->staging_size.assign(B * 2, 0);
+    e->staging_own.assign(B * 2, 0);
     for (int i = 0; i < 7; ++i)
         if ((he = hipEventCreate(&e->ev[i])) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
     {
@@ -755,7 +846,8 @@ void tm_engine_destroy(tm_engine *e)
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream); // (copies into the staging surfaces that no launch has waited for)
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
-    for (void *p : e->staging) if (p) (void)hipFree(p);
+    for (size_t i = 0; i < e->staging.size(); ++i) if (e->staging[i] && e->staging_own[i]) (void)hipFree(e->staging[i]);
+    for (char *a : e->stage_arena) if (a) (void)hipFree(a);
     (void)hipFree(e->LIN); (void)hipFree(e->LIN2); (void)hipFree(e->XYB); (void)hipFree(e->XYBT); (void)hipFree(e->V_alloc);
     (void)hipFree(e->QU8); (void)hipFree(e->SPYR); (void)hipFree(e->SPART); (void)hipFree(e->SSUMS);
     if (e->h_ssums) (void)hipHostFree(e->h_ssums);
@@ -913,6 +1005,7 @@ int tm_engine_upload_fence(tm_engine *e, uint64_t *token)
         e->up_ev2.swap(b);
         e->up_tok2.assign(TM_UPLOAD_FENCES, UINT64_MAX);
     }
+    { const int rc = flush_pending(e); if (rc) return rc; } // a fence covers every upload handed over so far: also the one still held back
     const size_t i = e->up_next % TM_UPLOAD_FENCES;
     HIPCHK(hipEventRecord(e->up_ev[i], e->stream));
     if (e->up_since_fence) { // the copies of this fence that went up on the second upload stream
@@ -1199,6 +1292,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
         int rc = tm_engine_sync(e);
         if (rc) return rc;
     }
+    { const int rc = flush_pending(e); if (rc) return rc; }
     hipStream_t st = e->stream;
     const int n = (int)n_slots;
     bool fused_launch = false;
@@ -1290,6 +1384,7 @@ int tm_engine_sync(tm_engine *e)
 {
     if (!e) return TM_ERR_INVALID_ARG;
     TM_BIND(e);
+    { const int rc = flush_pending(e); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->up_pending) { // frames handed over since the last launch: "valid until tm_engine_sync" holds for them too
         HIPCHK(hipStreamSynchronize(e->up_stream));
@@ -1532,6 +1627,7 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
 {
     if (!e) return TM_ERR_INVALID_ARG;
     if (e->in_flight) { int rc = tm_engine_sync(e); if (rc && param != TM_DBG_EF_FAULT) return rc; }
+    if (param == TM_DBG_UPLOAD_STREAMS || param == TM_DBG_UPLOAD_MERGE) { TM_BIND(e); const int rc = flush_pending(e); if (rc) return rc; }
     switch (param) {
     case TM_DBG_FUSED_EDGE_FROM: if (value < 0) return TM_ERR_INVALID_ARG; e->fused_edge_from = value; break;
     case TM_DBG_EF_WAVES: if (value != 1 && value != 4 && value != 5) return TM_ERR_INVALID_ARG; e->ef_waves = (int)value; break;
@@ -1542,6 +1638,7 @@ int tm_engine_debug_set_param(tm_engine *e, int param, long long value)
     case TM_DBG_SOLO_COL_BELOW: if (value < 0) return TM_ERR_INVALID_ARG; e->solo_col_below = value; break;
     case TM_DBG_UPLOAD_STREAMS: if (value < 1 || value > 2) return TM_ERR_INVALID_ARG; if (e->up_pending) { HIPCHK(hipStreamSynchronize(e->up_stream)); e->up_pending = false; } e->upload_streams = (int)value; break;
     case TM_DBG_LINEAR_UPLOAD: if (value < 0 || value > 1) return TM_ERR_INVALID_ARG; e->dbg_no_linear_upload = value ? 0 : 1; break;
+    case TM_DBG_UPLOAD_MERGE: if (value < 0 || value > ((long long)1 << 32)) return TM_ERR_INVALID_ARG; e->merge_limit = (size_t)value; break;
     default: return TM_ERR_INVALID_ARG;
     }
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; e->gkey = -1; } // captured launches hold the old values

@@ -20,7 +20,7 @@ TM_STAGE_INGEST, TM_STAGE_BLUR_V, TM_STAGE_BLUR_H, TM_STAGE_SSIM, TM_STAGE_EDGE,
 TM_PLANE_LINEAR, TM_PLANE_XYB, TM_PLANE_XYB_T, TM_PLANE_PASS1_T = 0, 1, 2, 3
 TM_VARIANT_DEFAULT, TM_VARIANT_REFERENCE, TM_VARIANT_WIDE_ROWS, TM_VARIANT_TILE_INGEST, TM_VARIANT_SPLIT_ROWS, TM_VARIANT_WHOLE_ROWS = 0, 1, 0x100, 0x200, 0x400, 0x800
 TM_VARIANT_TWO_PASS_EDGE, TM_VARIANT_UPPER_KERNEL, TM_VARIANT_FUSED_EDGE = 0x1000, 0x2000, 0x4000
-TM_DBG_FUSED_EDGE_FROM, TM_DBG_EF_WAVES, TM_DBG_EF_PERSIST_WGS, TM_DBG_PASS_PRIO, TM_DBG_SPLIT_ROWS_BELOW, TM_DBG_SOLO_COL_BELOW, TM_DBG_EF_FAULT, TM_DBG_LINEAR_UPLOAD, TM_DBG_UPLOAD_STREAMS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+TM_DBG_FUSED_EDGE_FROM, TM_DBG_EF_WAVES, TM_DBG_EF_PERSIST_WGS, TM_DBG_PASS_PRIO, TM_DBG_SPLIT_ROWS_BELOW, TM_DBG_SOLO_COL_BELOW, TM_DBG_EF_FAULT, TM_DBG_LINEAR_UPLOAD, TM_DBG_UPLOAD_STREAMS, TM_DBG_UPLOAD_MERGE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 class FrameScoresC(C.Structure):
