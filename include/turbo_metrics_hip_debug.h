@@ -91,7 +91,7 @@ int tm_engine_debug_set_edge_epoch(tm_engine *e, uint32_t epoch);
  *   TM_DBG_UPLOAD_STREAMS      2 (default): page-locked frames of the distorted side go up on a second stream (one per device, shared by its
  *                              engines) beside those of the reference side; 1: every frame on the engine's own stream
  *   TM_DBG_UPLOAD_MERGE        bytes up to which two page-locked frames that lie back to back in the caller's memory (and therefore in the
- *                              engine's staging arena) go up as ONE DMA (8 MiB: pairs of 1080p frames; 0: every frame its own copy, at once)
+ *                              engine's staging arena) go up as ONE DMA (14 MiB: up to four 1080p frames; 0: every frame its own copy, at once)
  *   TM_DBG_EF_FAULT            fault injection: 2 = the fused kernel does not publish the column state between groups of bands -- the next
  *                              group's wait times out, tm_engine_sync returns TM_ERR_HIP and the results of that launch are not
  *                              available; 1 = do not wait at all (wrong sums, no error); 0 = off.  The engine stays usable. */

@@ -685,7 +685,7 @@ def test_back_to_back_page_locked_frames_share_a_dma_and_nothing_changes(form):
         eng.compute_async(); eng.sync()
         for s in range(B):
             assert np.array_equal(eng.raw_sums(s), expect[s][0]) and eng.sse(s) == expect[s][1], (form, s)
-    for merge, streams in ((8 << 20, 2), (0, 2), (8 << 20, 1), (1 << 30, 2)):
+    for merge, streams in ((14 << 20, 2), (0, 2), (7 << 20, 1), (1 << 30, 2)):
         eng = tm.TurboMetrics(w, h, m, batch=B, full_sums=True)
         eng.debug_set_param(F.TM_DBG_LINEAR_UPLOAD, 1)
         eng.debug_set_param(F.TM_DBG_UPLOAD_MERGE, merge)

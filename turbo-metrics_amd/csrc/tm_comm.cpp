@@ -50,9 +50,11 @@ int tm_comm_init(tm_comm **out, int n_ranks, int rank, const void *id128)
     c->rank = rank; c->n_ranks = n_ranks;
     ncclUniqueId id;
     memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    // (no stream of its own while the communicator idles: the runtime maps streams onto a handful of hardware queues, and one more stream in
+    // the process put the engine's second upload stream on a shared queue -- the CLI's uploads ran at half their rate with the communicator
+    // merely existing, profiles/r06l_ranks_time.log.  The reduce makes its stream and gives it back.)
     hipError_t he = hipGetDevice(&c->device);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (he != hipSuccess) { const int rc = fail_hip(he, "hipStreamCreate"); tm_comm_destroy(c); return rc; }
+    if (he != hipSuccess) { const int rc = fail_hip(he, "hipGetDevice"); tm_comm_destroy(c); return rc; }
     const ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, id, rank);
     if (r != ncclSuccess) { const int rc = fail_nccl(r, "ncclCommInitRank"); c->comm = nullptr; tm_comm_destroy(c); return rc; }
     *out = c;
@@ -72,11 +74,19 @@ int tm_comm_reduce_sum_f64(tm_comm *c, double *v, size_t n, int root)
         HIPCHK(hipMalloc((void **)&c->d_recv, n * sizeof(double)));
         c->cap = n;
     }
-    HIPCHK(hipMemcpyAsync(c->d_send, v, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(ncclReduce(c->d_send, c->d_recv, n, ncclDouble, ncclSum, root, c->comm, c->stream));
-    if (c->rank == root) HIPCHK(hipMemcpyAsync(v, c->d_recv, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    int rc = 0;
+    do {
+        hipError_t he = hipMemcpyAsync(c->d_send, v, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (he != hipSuccess) { rc = fail_hip(he, "hipMemcpyAsync"); break; }
+        const ncclResult_t nr = ncclReduce(c->d_send, c->d_recv, n, ncclDouble, ncclSum, root, c->comm, c->stream);
+        if (nr != ncclSuccess) { rc = fail_nccl(nr, "ncclReduce"); break; }
+        if (c->rank == root && (he = hipMemcpyAsync(v, c->d_recv, n * sizeof(double), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { rc = fail_hip(he, "hipMemcpyAsync"); break; }
+        if ((he = hipStreamSynchronize(c->stream)) != hipSuccess) rc = fail_hip(he, "hipStreamSynchronize");
+    } while (0);
+    (void)hipStreamDestroy(c->stream);
+    c->stream = nullptr;
+    return rc;
 }
 
 void tm_comm_destroy(tm_comm *c)

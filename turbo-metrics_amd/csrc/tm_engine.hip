@@ -219,7 +219,7 @@ struct tm_engine {
     struct PendingCopy { char *dst; const char *src; size_t dpitch, spitch, row_bytes, rows; bool linear; };
     PendingCopy pend[2] = {};          // [0] engine's stream, [1] second upload stream
     bool has_pend[2] = {false, false};
-    size_t merge_limit = (size_t)8 << 20; // bytes up to which two copies are merged (1080p pairs of frames: yes; 4K frames go up one by one)
+    size_t merge_limit = (size_t)14 << 20; // bytes up to which copies are merged (1080p: up to four frames; 4K frames go up one by one)
     size_t mem_bytes = 0;
     bool profiling = false, ev_pending = false;
     hipEvent_t ev[7] = {}; // 0..4: start | ingest | column pass | row pass | finisher + SSIM stage, on the engine's stream; 5, 6: around the fused EDGE kernel, on the stream it runs on
@@ -301,7 +301,9 @@ int queue_copy(tm_engine *e, int si, const tm_engine::PendingCopy &c)
                                    : c.row_bytes == p.row_bytes && c.spitch == p.spitch && c.dpitch == p.dpitch && c.src == p.src + p.spitch * p.rows && c.dst == p.dst + p.dpitch * p.rows);
         if (run) {
             if (c.linear) p.row_bytes += c.row_bytes; else p.rows += c.rows;
-            return flush_pending(e, si); // (pairs: what the link gains from three and more is within its spread)
+            // held on while one more frame of this size would still fit (1080p: up to four frames = 13 MB per DMA; beside the kernels 3 / 6 / 12 / 25 MB
+            // copies reach 48 / 52-56 / 54-56 / 56-57 GB/s)
+            return pbytes + 2 * bytes <= e->merge_limit ? TM_OK : flush_pending(e, si);
         }
         const int rc = flush_pending(e, si);
         if (rc) return rc;

@@ -268,9 +268,10 @@ int main(int argc, char **argv)
     // ready (optional): called once the block's engines exist and its sources have page-locked their rings -- where the one-device run starts its
     // clock (main.rs:252: after the decoders and the engine exist)
     // each: sees every FrameScores of the block as it arrives (rank 0 prints its own block while the others compute)
+    // computed (optional): called when the block's last score is there, before its engines and rings are given back
     const auto score_block = [&](uint32_t w, uint32_t h, uint32_t lo, uint32_t hi, Block &out, const std::function<void()> &ready = nullptr,
-                                 const std::function<void(const FrameScores &)> &each = nullptr) {
-        if (lo >= hi) { if (ready) ready(); return; }
+                                 const std::function<void(const FrameScores &)> &each = nullptr, const std::function<void()> &computed = nullptr) {
+        if (lo >= hi) { if (ready) ready(); if (computed) computed(); return; }
         auto sr = create_source(pos[0], hints), sd = create_source(pos[1], hints);
         const uint32_t b = std::min(batch, hi - lo);
         TurboMetrics tmx(w, h, metrics, b, pipeline && hi - lo > b);
@@ -284,6 +285,14 @@ int main(int argc, char **argv)
         try { tmx.compute_all(*sr, *sd, o, [&](const FrameScores &fs) { out.scores.push_back(fs); if (each) each(fs); }, &dc); }
         catch (const NoFramesSelected &) { dc = hi; } // a block in which `every` selects no frame is empty, not an error (any other exception is one)
         out.decoded = dc - lo;
+        if (computed) computed();
+        if (g_level >= L_DEBUG) {
+            const TurboMetrics::LoopTiming &t = tmx.loop_timing();
+            char b[256];
+            snprintf(b, sizeof b, "block [%u, %u): %.0f ms waiting for an upload slot, %.0f ms for the sources, %.0f ms handing frames to the engine, %.0f ms submitting, %.0f ms waiting for results + output",
+                     lo, hi, t.wait_upload * 1e3, t.wait_frames * 1e3, t.set_frames * 1e3, t.submit * 1e3, t.drain * 1e3);
+            log_line(L_DEBUG, kTarget, b);
+        }
     };
     // what the one-device run prints behind the last per-frame line
     const auto report = [&](const std::vector<FrameScores> &all, uint32_t decoded, uint32_t w, uint32_t h, std::chrono::steady_clock::time_point start, const std::string &where) -> int {
@@ -329,8 +338,12 @@ int main(int argc, char **argv)
             // figure then covers rank 0's block, the wait for the slowest rank and the reduce)
             // rank 0 holds the FIRST block: its lines go out as they are computed, like the one-device run's; the other blocks' follow the reduce
             if (root) output_prepare(output, metrics, std::cout);
+            // (the clock is stopped while the block's engines and page-locked rings are freed: the one-device run frees its own after its report)
+            auto computed_at = start;
             score_block(w, h, lo, hi, blk, [&] { start = std::chrono::steady_clock::now(); },
-                        root ? std::function<void(const FrameScores &)>([&](const FrameScores &fs) { output_single_score(output, fs, std::cout); }) : nullptr);
+                        root ? std::function<void(const FrameScores &)>([&](const FrameScores &fs) { output_single_score(output, fs, std::cout); }) : nullptr,
+                        [&] { computed_at = std::chrono::steady_clock::now(); });
+            start += std::chrono::steady_clock::now() - computed_at;
             ScoreVector sv(metrics, total);
             size_t k = 0;
             for (uint32_t dc = lo; dc < hi && k < blk.scores.size(); ++dc) {
