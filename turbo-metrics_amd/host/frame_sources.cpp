@@ -474,11 +474,13 @@ YuvStreamSource::~YuvStreamSource()
     if (ring_alloc_.joinable()) ring_alloc_.join();
     workers_.reset();
     if (in_ && in_ != stdin) fclose(in_);
-    for (size_t i = 0; i < ring_.size(); ++i) {
-        if (!ring_[i]) continue;
-        if (ring_pinned_[i]) tm_host_free(ring_[i]);
-        else free(ring_[i]);
-    }
+    if (ring_block_) tm_host_free(ring_block_);
+    else
+        for (size_t i = 0; i < ring_.size(); ++i) {
+            if (!ring_[i]) continue;
+            if (ring_pinned_[i]) tm_host_free(ring_[i]);
+            else free(ring_[i]);
+        }
 }
 
 void YuvStreamSource::stop_readahead()
@@ -565,6 +567,15 @@ void YuvStreamSource::alloc_ring()
     const size_t n = lookahead_ + 1 + ahead;
     ring_.assign(n, nullptr);
     ring_pinned_.assign(n, 0);
+    // the whole ring in one page-locked piece when the pictures are small (1080p: 25 MB, ~10 ms of page-locking; larger rings -- 4K -- are built
+    // slot by slot on a helper thread while the first pictures are read: their pictures are a DMA each anyway)
+    if (n * slot_bytes_ <= ((size_t)64 << 20) && (ring_block_ = (unsigned char *)tm_host_alloc(n * slot_bytes_)) != nullptr) {
+        for (size_t i = 0; i < n; ++i) { ring_[i] = ring_block_ + i * slot_bytes_; ring_pinned_[i] = 1; }
+        ring_ready_ = n;
+        reader_threads_ = want;
+        ahead_ = ahead;
+        return;
+    }
     // slot 0 here ...
     ring_[0] = (unsigned char *)tm_host_alloc(slot_bytes_);
     ring_pinned_[0] = ring_[0] != nullptr;

@@ -136,6 +136,8 @@ private:
     // pictures are being read and computed (page-locking runs at ~3 GB/s: 0.28 s for the two rings of a 4K 10-bit pair at batch 8)
     std::vector<unsigned char *> ring_;
     std::vector<char> ring_pinned_;  // per slot: page-locked (tm_host_alloc) or plain memory (when page-locking fails: ring_failed_)
+    unsigned char *ring_block_ = nullptr; // the whole ring as ONE page-locked allocation, slot after slot (round 6): pictures that follow each other in
+                                          // the stream lie back to back, and the engine sends two to four of them up as one DMA (tm_engine.hip, queue_copy)
     size_t ring_pos_ = 0, lookahead_ = 1;
     size_t ring_ready_ = 0;          // slots usable so far (guarded by ring_m_)
     bool ring_failed_ = false;       // a page-locked allocation failed: the remaining slots come from pageable memory
