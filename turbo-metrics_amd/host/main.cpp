@@ -456,8 +456,9 @@ int main(int argc, char **argv)
     // allocates when it is created (its clock, main.rs:252, starts after decoders and engine exist too)
     {   // --tune 100=<pairs in flight> / 101=<pairs per fence>: host-side upload tuning (the rest goes to the engines)
         size_t in_flight = 4, fence_every = 1;
-        for (auto &t : tune) { if (t.first == 100) in_flight = (size_t)t.second; if (t.first == 101) fence_every = (size_t)t.second; }
-        TurboMetrics::set_upload_tuning(in_flight, fence_every);
+        bool given = false;
+        for (auto &t : tune) { if (t.first == 100) { in_flight = (size_t)t.second; given = true; } if (t.first == 101) { fence_every = (size_t)t.second; given = true; } }
+        if (given) TurboMetrics::set_upload_tuning(in_flight, fence_every); // (default: by picture size, TurboMetrics::prepare_sources)
     }
     try { TurboMetrics::prepare_sources(*source_ref, *source_dis, opts); }
     catch (const std::exception &e) { log_line(L_ERROR, kTarget, std::string("Could not initialize the sources : ") + e.what()); return EXIT_FAILURE; }

@@ -366,16 +366,26 @@ MetricsResults aggregate_scores(const std::vector<FrameScores> &frames, const Me
 // (Up to 16 pairs in flight with a fence per 4 was measured too -- TurboMetrics::set_upload_tuning, `--tune 100=16 --tune 101=4`: the loop
 // then waits for the readers instead of the uploads and ends within the run-to-run spread of the default, 7.06 k vs 6.69 k pairs/s on one
 // box, 5.87 k vs 6.04 k on another; profiles/r04y_cli_ab2.log, r04y_cli_ab3.log -- the small ring kept.)
+// (Round 6: the engine sends page-locked pictures that lie back to back in the source's ring up as ONE DMA, up to 14 MB of them, and every fence
+// flushes what it holds back: pictures of up to 1080p 8-bit get a fence per 4 pairs with 8 pairs in flight -- 7.84-7.92 k -> 8.08-8.21 k pairs/s,
+// profiles/r06o_cli_fence_ab.log --; larger ones are a DMA each and keep the small ring.)
 static size_t UPLOADS_IN_FLIGHT = 4; // pairs whose uploads may be in flight behind the one being read (the sources' lookahead)
 static size_t FENCE_EVERY = 1;       // pairs per fence
+static bool UPLOAD_TUNING_SET = false;
 void TurboMetrics::set_upload_tuning(size_t in_flight, size_t fence_every)
 {
     FENCE_EVERY = std::max<size_t>(1, fence_every);
     UPLOADS_IN_FLIGHT = std::max(std::max<size_t>(in_flight ? 1 : 4, in_flight), FENCE_EVERY);
+    UPLOAD_TUNING_SET = true;
 }
 
 void TurboMetrics::prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts)
 {
+    if (!UPLOAD_TUNING_SET) {
+        const bool small = (size_t)frames_ref.width() * frames_ref.height() <= (size_t)1920 * 1088 * 2; // pictures of which several fit one DMA
+        UPLOADS_IN_FLIGHT = small ? 8 : 4;
+        FENCE_EVERY = small ? 4 : 1;
+    }
     for (FrameSource *s : {&frames_ref, &frames_dis}) {
         s->set_lookahead(UPLOADS_IN_FLIGHT);
         s->set_readahead(opts.every <= 1); // dropped pictures are consumed without being read: no reading ahead then
