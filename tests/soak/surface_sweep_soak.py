@@ -32,6 +32,15 @@ for case in range(cases):
     eng.debug_set_param(F.TM_DBG_LINEAR_UPLOAD, eng_lin)
     eng.debug_set_param(F.TM_DBG_UPLOAD_STREAMS, eng_str)
     keep, desc = [], []
+    # round 6: in a quarter of the cases the page-locked pictures of a side lie back to back in ONE pool, slot after slot (a ring, a surface pool):
+    # the engine then sends neighbours up as one DMA (merge limit drawn too: off, pairs, everything)
+    pooled = rng.random() < 0.25
+    pools = None
+    if pooled:
+        eng.debug_set_param(F.TM_DBG_UPLOAD_MERGE, int(rng.choice([0, 1 << 20, 14 << 20, 1 << 30])))
+        bps_ = 1 if bits == 8 else 2
+        nb = (w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2)) * bps_
+        pools = [torch.empty(nb * B + 64, dtype=torch.uint8).pin_memory() for _ in range(2)]
     for slot in range(B):
         planes = tm.synth.yuv420_pair(w, h, int(rng.integers(0, 500)), bits if bits != 16 else 10)
         for side in range(2):
@@ -44,6 +53,8 @@ for case in range(cases):
             base.set_frame(slot, side, mkb(torch.from_numpy(sb).cuda(), pit, ch))
             mem = str(rng.choice(["device", "pinned", "host"]))
             how = str(rng.choice(["surface", "i420", "i420_tight"] + (["p10", "p10_tight"] if bits == 10 else [])))
+            if pooled and rng.random() < 0.85:  # (now and then a frame of another form in between: it breaks the run, nothing else)
+                mem, how = "pinned", "i420_tight"
             if how in ("p10", "p10_tight"):  # round 6: the same 10-bit planes packed three samples to a word, rows padded or the whole picture tight
                 cw, chh = (w + 1) // 2, (h + 1) // 2
                 wy, wc = tm.synth.p10_row_words(w), tm.synth.p10_row_words(cw)
@@ -67,7 +78,12 @@ for case in range(cases):
                 dt = np.uint8 if bits == 8 else np.uint16
                 if how == "i420_tight":  # one allocation: Y rows, then Cb rows, then Cr rows, no padding
                     flat = np.concatenate([Y.astype(dt).ravel(), Cb.astype(dt).ravel(), Cr.astype(dt).ravel()])
-                    buf = place(flat, mem)
+                    if pooled and mem == "pinned":
+                        raw = pools[side][slot * nb:(slot + 1) * nb]
+                        raw.copy_(torch.from_numpy(flat.view(np.uint8)))
+                        buf = raw if bits == 8 else raw.view(torch.int16)
+                    else:
+                        buf = place(flat, mem)
                     cw, chh = (w + 1) // 2, (h + 1) // 2
                     if mem == "host":
                         y, u, v = buf[: w * h].reshape(h, w), buf[w * h: w * h + cw * chh].reshape(chh, cw), buf[w * h + cw * chh:].reshape(chh, cw)
