@@ -720,6 +720,34 @@ def test_back_to_back_page_locked_frames_share_a_dma_and_nothing_changes(form):
     base.close(); other.close()
 
 
+def test_small_repeating_launches_replay_a_graph_by_themselves_with_the_same_bits():
+    """round 6: launches of up to four pairs that come four times in a row replay a captured hipGraph by default (the reference's compute_one loop:
+    +3-4 %); a change of shape, of a setting or of the frames' kind goes back to direct launches and captures again -- the sums never change.
+    tm_engine_set_graph(e, 0) keeps every launch direct."""
+    w, h = 416, 240
+    m = tm.Metrics(ssimulacra2=True, psnr=True)
+    eng = tm.TurboMetrics(w, h, m, batch=4, full_sums=True)
+    ref = tm.TurboMetrics(w, h, m, batch=4, full_sums=True)
+    ref.set_graph(False)
+    frames = [nv12_frames(w, h, 30 + i) for i in range(6)] + [p016_frames(w, h, 40 + i) for i in range(2)]
+    rng = np.random.default_rng(5)
+    n, picks = 1, [0]
+    for step in range(120):
+        if step % 9 == 0:  # a new shape every nine launches: the first four of each run go out directly
+            n = int(rng.integers(1, 5))
+        if step % 9 == 5:
+            eng.set_full_sums(bool(step % 2)); ref.set_full_sums(bool(step % 2))
+        kind16 = step % 27 >= 18
+        picks = [int(rng.integers(6, 8)) if kind16 else int(rng.integers(0, 6)) for _ in range(n)]
+        for e in (eng, ref):
+            for slot, k in enumerate(picks):
+                e.set_pair(slot, *frames[k])
+            e.compute_async(n); e.sync()
+        for slot in range(n):
+            assert np.array_equal(eng.raw_sums(slot), ref.raw_sums(slot)) and eng.sse(slot) == ref.sse(slot), (step, n, slot)
+    eng.close(); ref.close()
+
+
 def test_8k_pair_against_oracle():
     """7680x4320: one slot's arenas pass 2 GB (several kernels carry 32-bit lane offsets inside a plane), two slots so that the
     second one starts beyond 4 GB of the pass-1 arena"""
