@@ -748,6 +748,35 @@ def test_small_repeating_launches_replay_a_graph_by_themselves_with_the_same_bit
     eng.close(); ref.close()
 
 
+def test_a_captured_launch_keeps_its_bits_when_engines_are_created_after_the_capture():
+    """round 6: the HIP 7.0 runtime PyTorch bundles (the one this process runs on: conftest imports torch first) replayed the SSE reset --
+    then a memset node -- with stale arguments once ANOTHER engine had been created after the capture: PSNR garbage, every other sum right
+    (profiles/r06x_graph_memset.log).  The reset is a kernel now; replays before and after new engines come and go give the direct
+    launch's bits, with the replay forced and with the default mode."""
+    w, h = 640, 360
+    m = tm.Metrics(ssimulacra2=True, psnr=True, ssim=True)
+    frames = [nv12_frames(w, h, i) for i in range(3)]
+    ref = tm.TurboMetrics(w, h, m, batch=1)
+    ref.set_graph(False)
+    want = [ref.compute_one(*f) for f in frames]
+    for forced in (True, False):
+        eng = tm.TurboMetrics(w, h, m, batch=1)
+        if forced:
+            eng.set_graph(True)
+        assert [eng.compute_one(*frames[k % 3]) for k in range(6)] == want * 2  # captured by now in either mode
+        others = []
+        for k in range(6):
+            others.append(tm.TurboMetrics(w + 64 * k, h, m, batch=1 + k % 2))
+            assert eng.compute_one(*frames[k % 3]) == want[k % 3], (forced, k)
+            if k % 2:
+                others.pop(0).close()
+                assert eng.compute_one(*frames[k % 3]) == want[k % 3], (forced, k)
+        for o in others:
+            o.close()
+        eng.close()
+    ref.close()
+
+
 def test_8k_pair_against_oracle():
     """7680x4320: one slot's arenas pass 2 GB (several kernels carry 32-bit lane offsets inside a plane), two slots so that the
     second one starts beyond 4 GB of the pass-1 arena"""

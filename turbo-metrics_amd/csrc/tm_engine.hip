@@ -1311,7 +1311,7 @@ int tm_engine_compute_async(tm_engine *e, uint32_t n_slots)
     // everything one batch enqueues: descriptor upload, accumulator reset, the kernels, result download
     auto enqueue_all = [&]() -> int {
         HIPCHK(hipMemcpyAsync(e->d_desc, e->h_desc, (size_t)n * 2 * sizeof(TmFrameDesc), hipMemcpyHostToDevice, st));
-        if (want_sse) HIPCHK(hipMemsetAsync(e->SSE, 0, (size_t)n * TM_SSE_BINS * 3 * sizeof(unsigned long long), st));
+        if (want_sse) hipLaunchKernelGGL(tmk::k_zero_u64, dim3(((unsigned)n * TM_SSE_BINS * 3 + 255) / 256), dim3(256), 0, st, e->SSE, (unsigned)n * TM_SSE_BINS * 3);
         {
             int rc = launch_batch(e, st, n, want_sse, e->profiling ? e->ev : nullptr);
             if (rc) return rc;

@@ -1740,6 +1740,14 @@ __global__ void __launch_bounds__(64) k_finish_edge(TmEdgeArgs A, const double *
     }
 }
 
+// the accumulator reset of a launch as a kernel: a memset node in a captured sequence is not safe on every HIP runtime this library
+// meets (the 7.0 runtime PyTorch bundles replayed it with stale arguments once a second engine existed: profiles/r06x_graph_memset.log)
+__global__ void __launch_bounds__(256) k_zero_u64(unsigned long long *__restrict__ p, unsigned n)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 // fixed-order sum of the per-wave partials of each job -> SUMS[slot][scale*18 + kind*3 + channel]; sums that no
 // job produces (weight 0.0 in the reference's table) are written as 0
 __global__ void __launch_bounds__(128) k_finish_jobs(TmJobs jobs, const double *__restrict__ PART, double *__restrict__ SUMS)
