@@ -577,6 +577,7 @@ def run_host_fed(ctx, args, name, B, steps, warmup, packed10=False):
 def run_batch_curve(ctx, args, name, head_B, head_res):
     """the headline workload at the reference's own call granularity and up: compute_one is ONE pair per call
     (crates/turbo-metrics/src/lib.rs:268-360).  Per batch size: a fresh engine, ~60 ms of settling, ~0.25 s timed."""
+    import subprocess
     tm, torch = ctx.tm, ctx.torch
     w, h, kind, _, _ = WORKLOADS[name]
     out = []
@@ -641,21 +642,30 @@ def run_batch_curve(ctx, args, name, head_B, head_res):
                 pairs_hw = [(mk(rt, rp, rch), mk(dt_, dp, dch)) for (rt, rp, rch), (dt_, dp, dch) in sf]
                 blocking = [eng.compute_one(a, b).ssimulacra2 for a, b in pairs_hw]
 
-                def deferred(steps):
-                    got, last = [], None
+                def deferred(steps, depth):
+                    got, tickets = [], []
                     for i in range(steps):
-                        t = eng.compute_one_deferred(*pairs_hw[i % len(pairs_hw)])
-                        if last is not None:
-                            got.append(eng.collect(last).ssimulacra2)
-                        last = t
-                    got.append(eng.collect(last).ssimulacra2)
+                        tickets.append(eng.compute_one_deferred(*pairs_hw[i % len(pairs_hw)]))
+                        if len(tickets) >= depth:  # pair k is collected after pair k + depth - 1 went in
+                            got.append(eng.collect(tickets.pop(0)).ssimulacra2)
+                    got.extend(eng.collect(t).ssimulacra2 for t in tickets)
                     return got
-                deferred(max(8, k // 10))
+                deferred(max(8, k // 10), 2)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                got = deferred(k)
+                got = deferred(k, 2)
                 fl["2_api"] = k / (time.perf_counter() - t0)
                 same = same and got[:len(blocking)] == blocking
+                # set_deferred_depth(4): four engines taking turns.  In a process of its own, like a caller's: the runtime hands its four
+                # hardware queues out by the order in which streams were created and freed, and this process has created and freed
+                # dozens of engines by now (in-process the same loop measured 4.9 k, a fresh process 8.3 k: profiles/r06y5_deferred_depth.log)
+                if name == "1080p_nv12":
+                    try:
+                        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "deferred_depth_probe.py"), "--one", "4", str(w), str(h)],
+                                           capture_output=True, text=True, timeout=300)
+                        fl["4_api"] = float(json.loads(r.stdout.strip().splitlines()[-1])["pairs_per_s"])
+                    except Exception as ex:  # noqa: BLE001 -- a leg of the side record, never the line
+                        out[-1]["in_flight_4_api_error"] = repr(ex)[:200]
             out[-1]["in_flight"] = fl
             out[-1]["in_flight_scores_identical"] = same
             for e in extra:
@@ -703,7 +713,8 @@ def run_cli_end_to_end(ctx):
             for label, extra in (("tmpfs_just_written", []), ("default", []), ("batch16", ["--batch", "16"]),
                                  # the reference's own loop -- one blocking compute_one per pair -- and the same loop on
                                  # compute_one_deferred + collect (two pairs in flight): what a reference-style caller gets end to end
-                                 ("loop_reference", ["--loop", "reference"]), ("loop_deferred", ["--loop", "deferred"])) + (
+                                 ("loop_reference", ["--loop", "reference"]), ("loop_deferred", ["--loop", "deferred"]),
+                                 ("loop_deferred4", ["--loop", "deferred", "--in-flight", "4"])) + (
                                  # 10-bit clips: the readers pack three samples to a word on the way into the page-locked ring (default since
                                  # round 6); TM_PACK10=0 hands the 16-bit words over as before
                                  (("words16", ["TM_PACK10=0"]),) if bits == 10 else
@@ -856,10 +867,10 @@ def compact_line(d):
         fl = [[p["batch"], n, _r(v, 0)] for p in bc.get("points", []) for n, v in sorted((p.get("in_flight") or {}).items())]
         if fl:
             sm["batch_curve_in_flight"] = fl
-            sm["_batch_curve_in_flight"] = "[pairs per launch, launches in flight (2_api: via compute_one_deferred/collect), pairs/s]"
+            sm["_batch_curve_in_flight"] = "[pairs per launch, launches in flight (2_api / 4_api: via compute_one_deferred/collect at that depth), pairs/s]"
     cli = d.get("cli_end_to_end")
     if cli:
-        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("default", "batch16", "loop_reference", "loop_deferred", "words16", "ranks1_rccl") if isinstance(v.get(lab), dict)}
+        sm["cli_end_to_end"] = {tag: {lab: v[lab].get("pairs_per_s") for lab in ("default", "batch16", "loop_reference", "loop_deferred", "loop_deferred4", "words16", "ranks1_rccl") if isinstance(v.get(lab), dict)}
                                 if isinstance(v, dict) and "error" not in v else (v.get("error", "")[:60] if isinstance(v, dict) else None)
                                 for tag, v in cli.items() if tag != "note"}
     pl = d.get("pipeline")

@@ -33,6 +33,19 @@ for w, h, share in ((640, 360, 0.5), (1920, 1080, 0.5)):
             bad += eng.collect(last[0]) != want[last[1]]
         last = (t, n)
     bad += eng.collect(last[0]) != want[last[1]]
+    # round 6: three to eight pairs in flight (set_deferred_depth), the depth changed every few hundred submissions with pairs in flight
+    tickets, depth = [], 2
+    for k in range(steps // 2):
+        if k % 300 == 0:
+            depth = int(rng.integers(2, 9))
+            eng.set_deferred_depth(depth)
+        n, m = int(rng.integers(6)), (0 if k % 7 else int(rng.integers(3)))
+        tickets.append((eng.compute_one_deferred(*kinds[n][m]), n))
+        while len(tickets) >= depth + (3 if k % 300 < 3 else 0):  # (right after a change: older tickets stay uncollected for a few calls)
+            t, i = tickets.pop(0)
+            bad += eng.collect(t) != want[i]
+    for t, i in tickets:
+        bad += eng.collect(t) != want[i]
     dt = time.time() - t0
     print(f"{w}x{h}: {steps} deferred submissions, {steps / dt:.0f} pairs/s, mismatches {bad}", flush=True)
     assert bad == 0

@@ -748,6 +748,45 @@ def test_small_repeating_launches_replay_a_graph_by_themselves_with_the_same_bit
     eng.close(); ref.close()
 
 
+def test_deferred_depth_three_to_eight_pairs_in_flight_with_compute_ones_scores():
+    """round 6: set_deferred_depth(d) -- d one-pair launches in flight on d engines (each created when its turn first comes), pair k
+    collected after pair k + d - 1 went in; the depth changes between runs with pairs still in flight (they are finished and stay
+    collectable), engines beyond the new depth are freed.  FrameScores are compute_one's, bit for bit, at every depth."""
+    w, h = 416, 240
+    eng = tm.TurboMetrics(w, h, tm.Metrics(ssimulacra2=True, psnr=True, ssim=True), batch=1)
+    eng.set_full_sums(True)  # (a setting made before the further engines exist: they start with it)
+    frames = [nv12_frames(w, h, 50 + i) for i in range(7)]
+    want = [eng.compute_one(fr, fd) for fr, fd in frames]
+    mem_one = eng.mem_usage()
+    stale = []
+    for depth in (3, 8, 2, 5, 4):
+        eng.set_deferred_depth(depth)
+        got, tickets = [], []
+        for k in range(3 * depth + 4):
+            tickets.append((eng.compute_one_deferred(*frames[k % 7]), k % 7))
+            if len(tickets) >= depth:
+                t, i = tickets.pop(0)
+                got.append((eng.collect(t), i))
+        assert all(s == want[i] for s, i in got), depth
+        assert len(tickets) == depth - 1
+        stale.append(tickets)  # left in flight across the change of depth
+    for tickets in stale:
+        for t, i in reversed(tickets):
+            assert eng.collect(t) == want[i]
+    with pytest.raises(tm.TmError):
+        eng.collect(stale[0][0][0])
+    for bad in (0, 1, 9):
+        with pytest.raises(tm.TmError):
+            eng.set_deferred_depth(bad)
+    eng.set_channel_mode(True)  # a setting reaches every engine of the turn
+    first = eng.compute_one(*frames[0])
+    assert first != want[0]
+    ts = [eng.compute_one_deferred(*frames[0]) for _ in range(4)]
+    assert [eng.collect(t) for t in ts] == [first] * 4
+    assert eng.mem_usage() == mem_one  # (mem_usage is the engine's own; the further engines are the mirror's)
+    eng.close()
+
+
 def test_a_captured_launch_keeps_its_bits_when_engines_are_created_after_the_capture():
     """round 6: the HIP 7.0 runtime PyTorch bundles (the one this process runs on: conftest imports torch first) replayed the SSE reset --
     then a memset node -- with stale arguments once ANOTHER engine had been created after the capture: PSNR garbage, every other sum right

@@ -562,6 +562,10 @@ def test_cli_y4m_stream_frame_selection_batching_and_pipeline(tmp_path, bits):
     rc, out1, _ = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines")
     rc2, out2, _ = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--loop", "deferred")
     assert rc == 0 and rc2 == 0 and out1 == out2                 # byte-identical stdout
+    for depth in (3, 4, 8):                                      # more pairs in flight than the clip has frames, too
+        rc2, out2, err2 = cli(pr, pd, "-m", "ssimulacra2", "-m", "psnr", "--output", "json-lines", "--loop", "deferred", "--in-flight", depth)
+        assert rc2 == 0 and out2 == out1, (depth, err2)
+        assert scores("--loop", "deferred", "--in-flight", depth, "--every", 3)[0] == [base[i] for i in (0, 3, 6, 9)]
     # explicit BT.709 metadata overrides the fallback
     rc, out, err = cli(pr, pd, "-m", "ssimulacra2", "--output", "json", "--color-primaries", 1, "--matrix-coefficients", 1, "--transfer-characteristics", 1)
     assert rc == 0 and "mc=BT709" in err and json.loads(out)["ssimulacra2"]["scores"] != base
@@ -663,6 +667,9 @@ def test_cli_error_paths(tmp_path):
     assert rc == 2 and "possible values: psnr, ssim, msssim, ssimulacra2" in err
     rc, _, err = cli(p1)
     assert rc == 2
+    for bad in ("1", "9", "x"):
+        rc, _, err = cli(p1, p1, "-m", "ssimulacra2", "--loop", "deferred", "--in-flight", bad)
+        assert rc == 2 and "--in-flight <N>" in err
     y = str(tmp_path / "f.y4m")
     write_y4m(y, [tm.synth.yuv420_pair(48, 32, 0, 8)[0]], 48, 32, 8, " XCOLORRANGE=FULL")
     rc, _, err = cli(y, y, "-m", "ssimulacra2")

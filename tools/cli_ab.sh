@@ -16,9 +16,9 @@ for side, s in enumerate(("ref", "dis")):
         for i in range(frames):
             f.write(blobs[i % 4])
 PY
-# a variant's words of the form TM_...=value go into the environment, the others onto the command line; a variant that uses --tune runs with
+# a variant's words of the form TM_...=value (GPU_...=, HIP_...=) go into the environment, the others onto the command line; a variant that uses --tune runs with
 # the laboratory build of the engine library in front of the ship library the CLI links (tuning values are laboratory functions)
-run() { local envs=() args=(); for t in $1; do if [[ $t == TM_*=* ]]; then envs+=("$t"); else args+=("$t"); fi; done; if [[ $1 == *--tune* ]]; then envs+=("LD_PRELOAD=$PWD/turbo-metrics_amd/lab/libturbometrics_hip_lab.so"); fi; set -- "${args[*]}"; env RUST_LOG=debug "${envs[@]}" turbo-metrics_amd/bin/turbo-metrics /dev/shm/tm_cli_${size}_ref.y4m /dev/shm/tm_cli_${size}_dis.y4m -m ssimulacra2 --output json-lines $1 2>&1 >/dev/null | grep -E "Processed|main thread" | sed -e 's/.*Processed: [0-9]* (decoded: ~[0-9]*) frame pairs in //' -e 's/.*main thread: /   /' | tr '\n' ' '; echo; }
+run() { local envs=() args=(); for t in $1; do if [[ $t == TM_*=* || $t == GPU_*=* || $t == HIP_*=* ]]; then envs+=("$t"); else args+=("$t"); fi; done; if [[ $1 == *--tune* ]]; then envs+=("LD_PRELOAD=$PWD/turbo-metrics_amd/lab/libturbometrics_hip_lab.so"); fi; set -- "${args[*]}"; env RUST_LOG=debug "${envs[@]}" turbo-metrics_amd/bin/turbo-metrics /dev/shm/tm_cli_${size}_ref.y4m /dev/shm/tm_cli_${size}_dis.y4m -m ssimulacra2 --output json-lines $1 2>&1 >/dev/null | grep -E "Processed|main thread" | sed -e 's/.*Processed: [0-9]* (decoded: ~[0-9]*) frame pairs in //' -e 's/.*main thread: /   /' | tr '\n' ' '; echo; }
 run "" > /dev/null   # first pass over the fresh files
 for r in $(seq "$rounds"); do
   for v in "$@"; do printf '%-40s | ' "[$v]"; run "$v"; done

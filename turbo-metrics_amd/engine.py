@@ -173,7 +173,8 @@ class TurboMetrics:
         d = getattr(self, "_def", None)
         if d is not None:
             self._def = None
-            d["peer"].close()
+            for p in d["peers"]:
+                p.close()
         if getattr(self, "_h", None):
             self._L.tm_engine_destroy(self._h)
             self._h = None
@@ -294,13 +295,14 @@ class TurboMetrics:
         return [int(x) for x in v]
 
     def _peer_follows(self, name, *args):
-        """settings are the ENGINE's, and compute_one_deferred runs every other pair on a second engine: it follows (those set before
-        it existed are replayed when it is created)"""
+        """settings are the ENGINE's, and compute_one_deferred runs the pairs on further engines in turn: they follow (those set before
+        they existed are replayed when they are created)"""
         self._settings = getattr(self, "_settings", {})
         self._settings[name] = args
         d = getattr(self, "_def", None)
         if d is not None:
-            getattr(d["peer"], name)(*args)
+            for p in d["peers"]:
+                getattr(p, name)(*args)
 
     def set_channel_mode(self, first_channel_only: bool):
         """PSNR / SSIM / MS-SSIM from channel 0 only instead of pooled / averaged over R, G, B (see the header)"""
@@ -312,11 +314,29 @@ class TurboMetrics:
         """finish the pairs in flight for compute_one_deferred and keep their scores for collect()"""
         d = getattr(self, "_def", None)
         if d is not None:
-            for i, e in enumerate((self, d["peer"])):  # (no reference to self inside _def: an engine dropped without close() must
-                if d["pending"][i] is not None:            # not wait for the cyclic collector with two engines' worth of HBM)
+            for i, e in enumerate([self] + d["peers"]):  # (no reference to self inside _def: an engine dropped without close() must
+                if d["pending"][i] is not None:          # not wait for the cyclic collector with several engines' worth of HBM)
                     e.sync()
                     d["done"][d["pending"][i]] = e.scores(0)
                     d["pending"][i] = None
+
+    MAX_DEFERRED_DEPTH = 8
+
+    def set_deferred_depth(self, depth: int):
+        """pairs in flight at most for compute_one_deferred (default 2; == TurboMetrics::set_deferred_depth, host/turbo_metrics.hpp):
+        one pair leaves most of the chip idle, three / four in flight reach 6.8 k / 8.3 k pairs/s of 1080p with frames in HBM -- for a
+        caller that collects pair k after submitting pair k + depth - 1.  Pairs in flight are finished first (their scores stay
+        collectable); engines beyond the new depth are freed."""
+        if not 2 <= int(depth) <= self.MAX_DEFERRED_DEPTH:
+            raise TmError(ffi.TM_ERR_INVALID_ARG, "set_deferred_depth: 2 ... 8 pairs in flight")
+        self._retire_deferred()
+        self._def_depth = int(depth)
+        d = getattr(self, "_def", None)
+        if d is not None:
+            for p in d["peers"][self._def_depth - 1:]:
+                p.close()
+            del d["peers"][self._def_depth - 1:]
+            d["pending"] = [None] * self._def_depth
 
     def compute_one(self, fref: HwFrame, fdis: HwFrame) -> FrameScores:
         """== TurboMetrics::compute_one: convert, compute, block, return FrameScores."""
@@ -328,21 +348,25 @@ class TurboMetrics:
 
     def compute_one_deferred(self, fref: HwFrame, fdis: HwFrame) -> int:
         """compute_one without its blocking stream sync (lib.rs:352): hand the pair over, launch, return a ticket at once;
-        collect(ticket) blocks until THAT pair's scores are there.  Two launches may be in flight -- two engines taking turns, the
-        second one created at the first call (host/turbo_metrics.hpp: the same two methods on the C++ side).  A third submission
-        first finishes the oldest pair and keeps its scores until collected.  Scores are bit-identical with compute_one's."""
+        collect(ticket) blocks until THAT pair's scores are there.  Two launches may be in flight (set_deferred_depth: up to eight) --
+        as many engines taking turns, each created when its turn first comes (host/turbo_metrics.hpp: the same methods on the C++
+        side).  One submission more first finishes the oldest pair and keeps its scores until collected.  Scores are bit-identical
+        with compute_one's."""
         if self.batch != 1:
             raise ValueError("compute_one_deferred is the one-pair-per-call path: create the engine with batch=1")
+        depth = getattr(self, "_def_depth", 2)
         if getattr(self, "_def", None) is None:
-            peer = TurboMetrics(self.width, self.height, self._metrics, batch=1)
-            for name, args in getattr(self, "_settings", {}).items():  # channel mode, full sums, variant, graph: as set on this engine
-                getattr(peer, name)(*args)
-            self._def = {"peer": peer, "pending": [None, None], "done": {}, "next": 0}
+            self._def = {"peers": [], "pending": [None] * depth, "done": {}, "next": 0}
         d = self._def
         ticket = d["next"]
         d["next"] += 1
-        i = ticket & 1
-        e = (self, d["peer"])[i]
+        i = ticket % depth
+        while i > len(d["peers"]):  # the engines the launches take turns on are created when their turn first comes
+            peer = TurboMetrics(self.width, self.height, self._metrics, batch=1)
+            for name, args in getattr(self, "_settings", {}).items():  # channel mode, full sums, variant, graph: as set on this engine
+                getattr(peer, name)(*args)
+            d["peers"].append(peer)
+        e = self if i == 0 else d["peers"][i - 1]
         if d["pending"][i] is not None:
             e.sync()
             d["done"][d["pending"][i]] = e.scores(0)
@@ -354,9 +378,9 @@ class TurboMetrics:
     def collect(self, ticket: int) -> FrameScores:
         d = getattr(self, "_def", None)
         if d is not None:
-            for i in range(2):
+            for i in range(len(d["pending"])):
                 if d["pending"][i] == ticket:
-                    e = (self, d["peer"])[i]
+                    e = self if i == 0 else d["peers"][i - 1]
                     d["pending"][i] = None
                     e.sync()
                     return e.scores(0)

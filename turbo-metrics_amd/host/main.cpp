@@ -6,6 +6,7 @@
 // --transfer-characteristics, --full-range).
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -57,7 +58,8 @@ void usage(std::ostream &os)
           "                             (TM_RANK_TRANSPORT=pipe: over pipes instead; TM_RANK_TIMEOUT_S: give up after that many seconds)\n"
           "      --no-pipeline          do not overlap reading/upload of the next batch with the current one\n"
           "      --loop <MODE>          batched (default: compute_all), reference (the reference's loop: one blocking compute_one per pair),\n"
-          "                             deferred (that loop with compute_one_deferred + collect: two pairs in flight)\n"
+          "                             deferred (that loop with compute_one_deferred + collect: --in-flight pairs in flight)\n"
+          "      --in-flight <N>        pairs in flight with --loop deferred, 2 ... 8: pair k is collected after pair k + N - 1 went in [default: 2]\n"
           "      --full-sums            compute all 108 SSIMULACRA2 sums, also the zero-weighted ones\n"
           "      --width <W> --height <H> [--bits 8|10|12|16]   headerless planar 4:2:0 input\n"
           "      --color-primaries <N> --matrix-coefficients <N> --transfer-characteristics <N>   H.273 codes (1, 5, 6; 2 = by height)\n"
@@ -124,7 +126,7 @@ int main(int argc, char **argv)
     Options opts;
     Output output = Output::Default;
     SourceHints hints;
-    uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1, ranks = 0 /* 0: not asked for */;
+    uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1, ranks = 0 /* 0: not asked for */, in_flight_pairs = 2;
     bool pipeline = true, full_sums = false;
     enum class Loop { Batched, Reference, Deferred } loop = Loop::Batched;
     std::vector<std::pair<int, long long>> tune;
@@ -176,6 +178,7 @@ int main(int argc, char **argv)
         else if (a == "--devices") { if (!u32(devices)) return bad("invalid value for '--devices <N>'"); }
         else if (a == "--ranks") { if (!u32(ranks) || ranks == 0 || ranks > 64) return bad("invalid value for '--ranks <N>'"); }
         else if (a == "--no-pipeline") pipeline = false;
+        else if (a == "--in-flight") { if (!u32(in_flight_pairs) || in_flight_pairs < 2 || in_flight_pairs > TurboMetrics::MAX_DEFERRED_DEPTH) return bad("invalid value for '--in-flight <N>'\n  [2 ... 8]"); }
         else if (a == "--loop") {
             std::string s;
             if (!value(s)) return bad("a value is required for '--loop <MODE>'");
@@ -460,7 +463,7 @@ int main(int argc, char **argv)
         for (auto &t : tune) { if (t.first == 100) { in_flight = (size_t)t.second; given = true; } if (t.first == 101) { fence_every = (size_t)t.second; given = true; } }
         if (given) TurboMetrics::set_upload_tuning(in_flight, fence_every); // (default: by picture size, TurboMetrics::prepare_sources)
     }
-    try { TurboMetrics::prepare_sources(*source_ref, *source_dis, opts); }
+    try { TurboMetrics::prepare_sources(*source_ref, *source_dis, opts, loop == Loop::Deferred ? in_flight_pairs : 0); }
     catch (const std::exception &e) { log_line(L_ERROR, kTarget, std::string("Could not initialize the sources : ") + e.what()); return EXIT_FAILURE; }
     log_line(L_DEBUG, kTarget, "Initialized, now processing ...");
 
@@ -481,7 +484,8 @@ int main(int argc, char **argv)
             source_ref->skip_frames(opts.skip_ref + opts.skip);
             source_dis->skip_frames(opts.skip_dis + opts.skip);
             HwFrame fref, fdis;
-            uint64_t last = 0;
+            std::deque<uint64_t> tickets; // --loop deferred: pairs in flight, oldest first
+            if (loop == Loop::Deferred) turbo->set_deferred_depth(in_flight_pairs);
             while (source_ref->next_frame(fref) && source_dis->next_frame(fdis)) {
                 if (opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0) { decode_count += 1; continue; }
                 if (opts.frames > 0 && decode_count >= opts.frames) break;
@@ -489,12 +493,11 @@ int main(int argc, char **argv)
                 if (loop == Loop::Reference) {
                     emit(turbo->compute_one(fref, cref, fdis, cdis));
                 } else {
-                    const uint64_t ticket = turbo->compute_one_deferred(fref, cref, fdis, cdis);
-                    if (last) emit(turbo->collect(last));
-                    last = ticket;
+                    tickets.push_back(turbo->compute_one_deferred(fref, cref, fdis, cdis));
+                    if (tickets.size() >= in_flight_pairs) { emit(turbo->collect(tickets.front())); tickets.pop_front(); }
                 }
             }
-            if (last) emit(turbo->collect(last));
+            for (uint64_t t : tickets) emit(turbo->collect(t));
             results = aggregate_scores(all, metrics);
         }
     } catch (const std::exception &e) {

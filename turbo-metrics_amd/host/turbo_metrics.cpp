@@ -197,7 +197,10 @@ TurboMetrics::~TurboMetrics()
 
 size_t TurboMetrics::mem_usage() const
 {
-    return tm_engine_mem_usage(eng_[0]) + (eng_[1] ? tm_engine_mem_usage(eng_[1]) : 0);
+    size_t total = 0;
+    for (tm_engine *e : eng_)
+        if (e) total += tm_engine_mem_usage(e);
+    return total;
 }
 
 // tm_engine_debug_set_param is a function of the LABORATORY build (include/turbo_metrics_hip_debug.h): the ship library this file links
@@ -272,9 +275,20 @@ FrameScores TurboMetrics::scores_of(tm_engine *e, uint32_t slot)
     return r;
 }
 
+void TurboMetrics::set_deferred_depth(uint32_t depth)
+{
+    if (depth < 2 || depth > MAX_DEFERRED_DEPTH) throw TmError(TM_ERR_INVALID_ARG, "set_deferred_depth: 2 ... 8 pairs in flight");
+    retire_deferred();
+    for (size_t i = std::max<size_t>(2, depth); i < eng_.size(); ++i)
+        if (eng_[i]) tm_engine_destroy(eng_[i]);
+    eng_.resize(std::max<size_t>(2, depth), nullptr);
+    def_pending_.assign(depth, 0);
+    def_depth_ = depth;
+}
+
 void TurboMetrics::retire_deferred()
 {
-    for (int i = 0; i < 2; ++i)
+    for (size_t i = 0; i < def_pending_.size(); ++i)
         if (def_pending_[i]) {
             chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
             def_done_.emplace_back(def_pending_[i], scores_of(eng_[i], 0));
@@ -297,15 +311,15 @@ uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo
     // the one-pair-per-call path, as in the Python mirror: on a batched object the lazily created second engine would cost a whole
     // batch of device memory for one-pair launches
     if (batch_ != 1) throw TmError(TM_ERR_INVALID_ARG, "compute_one_deferred: create the TurboMetrics object with batch = 1");
-    if (!eng_[1]) { // the second engine the two launches take turns on
-        chk(tm_engine_create(&eng_[1], w_, h_, metrics_.mask(), 1), "tm_engine_create (second engine of compute_one_deferred)");
-        (void)tm_engine_set_linear_upload(eng_[1], 1);
-        if (full_sums_) chk(tm_engine_set_full_sums(eng_[1], 1), "tm_engine_set_full_sums");
-        for (const auto &kv : debug_params_) (void)lab_set_param()(eng_[1], kv.first, kv.second); // (only ever non-empty with the laboratory build loaded)
-    }
     const uint64_t ticket = def_next_++;
-    const int i = (int)(ticket & 1);
-    if (def_pending_[i]) { // two pairs are in flight already: the older one (on this engine) is finished first
+    const size_t i = (size_t)(ticket % def_depth_);
+    if (!eng_[i]) { // the engines the launches take turns on are created when their turn first comes
+        chk(tm_engine_create(&eng_[i], w_, h_, metrics_.mask(), 1), "tm_engine_create (further engine of compute_one_deferred)");
+        (void)tm_engine_set_linear_upload(eng_[i], 1);
+        if (full_sums_) chk(tm_engine_set_full_sums(eng_[i], 1), "tm_engine_set_full_sums");
+        for (const auto &kv : debug_params_) (void)lab_set_param()(eng_[i], kv.first, kv.second); // (only ever non-empty with the laboratory build loaded)
+    }
+    if (def_pending_[i]) { // `depth` pairs are in flight already: the oldest one (on this engine) is finished first
         chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
         def_done_.emplace_back(def_pending_[i], scores_of(eng_[i], 0));
         def_pending_[i] = 0;
@@ -319,7 +333,7 @@ uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo
 
 FrameScores TurboMetrics::collect(uint64_t ticket)
 {
-    for (int i = 0; i < 2; ++i)
+    for (size_t i = 0; i < def_pending_.size(); ++i)
         if (ticket && def_pending_[i] == ticket) {
             def_pending_[i] = 0;
             chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
@@ -379,7 +393,7 @@ void TurboMetrics::set_upload_tuning(size_t in_flight, size_t fence_every)
     UPLOAD_TUNING_SET = true;
 }
 
-void TurboMetrics::prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts)
+void TurboMetrics::prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts, size_t min_lookahead)
 {
     if (!UPLOAD_TUNING_SET) {
         const bool small = (size_t)frames_ref.width() * frames_ref.height() <= (size_t)1920 * 1088 * 2; // pictures of which several fit one DMA
@@ -387,7 +401,7 @@ void TurboMetrics::prepare_sources(FrameSource &frames_ref, FrameSource &frames_
         FENCE_EVERY = small ? 4 : 1;
     }
     for (FrameSource *s : {&frames_ref, &frames_dis}) {
-        s->set_lookahead(UPLOADS_IN_FLIGHT);
+        s->set_lookahead(std::max(UPLOADS_IN_FLIGHT, min_lookahead));
         s->set_readahead(opts.every <= 1); // dropped pictures are consumed without being read: no reading ahead then
         s->prepare();
     }

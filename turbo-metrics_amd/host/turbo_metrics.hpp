@@ -221,7 +221,9 @@ public:
     // collect(ticket) blocks until THAT pair's scores are there.  Two launches may be in flight (two engines taking turns -- the
     // second one is created at the first call, the cost of one more engine in device memory): a caller that collects pair k after
     // submitting pair k+1 keeps the device busy while it fetches / decodes the next frames, which is worth 1.6 x at one 1080p pair
-    // per call (2.9 k -> 4.8 k pairs/s).  A third submission first finishes the oldest pair and keeps its scores until collected.
+    // per call (3.0 k -> 5.0 k pairs/s).  A third submission first finishes the oldest pair and keeps its scores until collected.
+    // set_deferred_depth(d), 2 <= d <= 8: d launches in flight on d engines (one pair leaves most of the chip idle: three / four
+    // in flight reach 6.8 k / 8.3 k pairs/s with frames in HBM) for a caller that collects pair k after submitting pair k + d - 1.
     // Frames: host memory is read before the call returns unless `pinned` (then until collect(ticket)); device memory until collect.
     // Needs an object created with batch = 1 (throws TmError(TM_ERR_INVALID_ARG) otherwise, like the Python mirror): the second engine has one slot.
     // A setting changed while pairs are in flight (set_full_sums, debug_set_param) first finishes them and keeps their scores for collect.
@@ -229,6 +231,11 @@ public:
     // may be called in between (they first finish what is in flight and keep those scores for collect).
     uint64_t compute_one_deferred(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis);
     FrameScores collect(uint64_t ticket);
+    // pairs in flight at most (default 2); pairs in flight are finished first and keep their scores for collect, engines beyond the new
+    // depth are freed.  Throws TmError(TM_ERR_INVALID_ARG) outside 2 ... MAX_DEFERRED_DEPTH.
+    static constexpr uint32_t MAX_DEFERRED_DEPTH = 8;
+    void set_deferred_depth(uint32_t depth);
+    uint32_t deferred_depth() const { return def_depth_; }
 
     // == compute_all (lib.rs:362-433) with the frame selection of Options; `on_frame` (optional) sees every FrameScores
     // in stream order (the CLI's output_single_score).  Returns the number of frames decoded (for the CLI's log line).
@@ -236,7 +243,8 @@ public:
                                const std::function<void(const FrameScores &)> &on_frame = nullptr, uint32_t *decode_count = nullptr);
     // what compute_all asks of its sources (how long a frame must stay valid, whether they may read ahead) + FrameSource::prepare():
     // a caller that times compute_all like the reference's CLI (clock started after the decoders exist) calls this first
-    static void prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts);
+    // min_lookahead: a caller that keeps frames longer than compute_all does (compute_one_deferred with d pairs in flight: d - 1 further calls)
+    static void prepare_sources(FrameSource &frames_ref, FrameSource &frames_dis, const Options &opts, size_t min_lookahead = 0);
 
 private:
     void set_frame(tm_engine *e, uint32_t slot, int side, const HwFrame &f, const ColorInfo &c);
@@ -244,10 +252,11 @@ private:
     void retire_deferred(); // finish the pairs that are in flight for compute_one_deferred and keep their scores for collect()
     uint32_t w_, h_, batch_;
     Metrics metrics_;
-    tm_engine *eng_[2] = {nullptr, nullptr};
+    std::vector<tm_engine *> eng_{nullptr, nullptr}; // [0], [1]: compute_all's two; compute_one_deferred takes turns on [0 .. depth)
     LoopTiming timing_;
     // compute_one_deferred: the ticket in flight on each engine (0 = none), finished-but-uncollected scores, next ticket
-    uint64_t def_pending_[2] = {0, 0};
+    uint32_t def_depth_ = 2;
+    std::vector<uint64_t> def_pending_{0, 0};
     std::vector<std::pair<uint64_t, FrameScores>> def_done_;
     uint64_t def_next_ = 1;
     bool full_sums_ = false;                                  // settings replayed on an engine that is created later
