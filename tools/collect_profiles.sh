@@ -17,6 +17,6 @@ cp gpurun_out/${T}_bench.json gpurun_out/${T}_bench_detail.json gpurun_out/${T}_
 cp gpurun_out/${T}_sq_summary.txt profiles/${T}_sq_counters_1080p_b128.txt
 cp gpurun_out/${T}_fused_sq_summary.txt profiles/${T}_sq_counters_1080p_b128_fused.txt
 cp gpurun_out/${T}_b1_sq_summary.txt profiles/${T}_sq_counters_1080p_b1.txt
-for f in small_launch_probe pipeline_probe soak_create_destroy cli_1080p cli_4k cli_ab host_fed_ab wr_ceiling fold_ab; do cp gpurun_out/${T}_$f.log profiles/; done
+for f in small_launch_probe deferred_depth pipeline_probe soak_create_destroy cli_1080p cli_4k cli_ab host_fed_ab wr_ceiling fold_ab; do cp gpurun_out/${T}_$f.log profiles/; done
 python3 tools/trace_timeline.py "$(ls -t gpurun_out/${T}_prof/runc/*_kernel_trace.csv | head -1)" 2 > profiles/${T}_timeline_1080p_b128.txt
 ls profiles | grep ${T}

@@ -23,6 +23,7 @@ bash tools/pmc_sq.sh ${TAG}_b1 --batch 1 --settle-ms 30 > /dev/null 2>&1     # o
 # round 4: small launches, two batches in flight, the CLI and its reader alone, create / destroy soak (no torch in that process)
 timeout 400 python tools/small_launch_probe.py 1,2,4,8,16,32 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_small_launch_probe.log
 for a in "1080p_nv12 64 60" "1080p_nv12 32 100" "4k_p016 24 40" "1080p_nv12 64 40 psnr,msssim,ssimulacra2"; do timeout 300 python tools/pipeline_probe.py $a 2>&1 | tail -1; done > gpurun_out/${TAG}_pipeline_probe.log
+timeout 600 python tools/deferred_depth_probe.py 1,2,3,4,6,8 > gpurun_out/${TAG}_deferred_depth.log 2>&1
 timeout 300 python tests/soak/create_destroy_soak.py 200 > gpurun_out/${TAG}_soak_create_destroy.log 2>&1
 timeout 300 python tools/cli_bench.py --size 1080p 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_cli_1080p.log
 timeout 300 python tools/cli_bench.py --size 4k 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_cli_4k.log
