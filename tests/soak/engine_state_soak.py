@@ -59,20 +59,28 @@ wmask = (O.weights().reshape(3, 6, 6) != 0.0).transpose(1, 2, 0)
 
 slots = [None] * B
 full = False
-state = {"variant": 0, "graph": False, "full": False, "first": False, "prof": False}
+state = {"variant": 0, "graph": None, "full": False, "first": False, "prof": False}
 VARS = [0, F.TM_VARIANT_FUSED_EDGE, F.TM_VARIANT_TWO_PASS_EDGE, F.TM_VARIANT_SPLIT_ROWS, F.TM_VARIANT_WHOLE_ROWS, F.TM_VARIANT_TILE_INGEST,
         F.TM_VARIANT_TILE_INGEST | F.TM_VARIANT_FUSED_EDGE, F.TM_VARIANT_WIDE_ROWS, F.TM_VARIANT_UPPER_KERNEL, F.TM_VARIANT_UPPER_KERNEL | F.TM_VARIANT_FUSED_EDGE]
 t0, bad = time.time(), 0
+hold, n = 0, 1
 for k in range(launches):
-    for _ in range(int(rng.integers(0, 4))):  # a few random state changes
+    # runs of launches of one shape with no state change in between (round 6: from the fourth one on such launches of up to four pairs
+    # replay a captured graph in the default mode -- with other frames in the slots, and captured again after every change)
+    if hold == 0 and rng.random() < 0.1:
+        hold = int(rng.integers(4, 14))
+    for _ in range(0 if hold else int(rng.integers(0, 4))):  # a few random state changes
         op = int(rng.integers(0, 6))
         if op == 0: state["variant"] = int(rng.choice(VARS)); eng.set_variant(state["variant"])
-        elif op == 1: state["graph"] = bool(rng.integers(0, 2)); eng.set_graph(state["graph"])
+        elif op == 1: state["graph"] = [None, None, True, False][int(rng.integers(0, 4))]; eng.set_graph(state["graph"])  # None: the default (repeating small launches replay)
         elif op == 2: state["full"] = bool(rng.integers(0, 2)); eng.set_full_sums(state["full"])
         elif op == 3: state["first"] = bool(rng.integers(0, 2)); eng.set_channel_mode(state["first"])
         elif op == 4: state["prof"] = bool(rng.integers(0, 2)); eng.set_profiling(state["prof"])
         else: eng.debug_set_param(F.TM_DBG_UPLOAD_STREAMS, int(rng.integers(1, 3)))
-    n = int(rng.integers(1, B + 1))
+    if hold:
+        hold -= 1
+    else:
+        n = int(rng.integers(1, B + 1))
     for slot in range(B):  # some slots get other frames (always the first n if never set)
         if slots[slot] is None or rng.random() < 0.4:
             p = int(rng.integers(0, len(pool)))

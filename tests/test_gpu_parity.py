@@ -729,6 +729,7 @@ def test_small_repeating_launches_replay_a_graph_by_themselves_with_the_same_bit
     eng = tm.TurboMetrics(w, h, m, batch=4, full_sums=True)
     ref = tm.TurboMetrics(w, h, m, batch=4, full_sums=True)
     ref.set_graph(False)
+    eng.set_graph(True); eng.set_graph(None)  # (forced, then the default again)
     frames = [nv12_frames(w, h, 30 + i) for i in range(6)] + [p016_frames(w, h, 40 + i) for i in range(2)]
     rng = np.random.default_rng(5)
     n, picks = 1, [0]

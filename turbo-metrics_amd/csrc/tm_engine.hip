@@ -1085,8 +1085,9 @@ int tm_engine_set_variant(tm_engine *e, int variant)
 int tm_engine_set_graph(tm_engine *e, int on)
 {
     if (!e) return TM_ERR_INVALID_ARG;
-    e->graph_mode = on ? 1 : 0;
-    e->use_graph = on != 0;
+    e->graph_mode = on < 0 ? -1 : on ? 1 : 0; // (negative: back to the default, the engine decides per launch)
+    e->use_graph = on > 0;
+    e->auto_key = -1; e->auto_seen = 0;
     return TM_OK;
 }
 

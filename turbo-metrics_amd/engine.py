@@ -463,9 +463,11 @@ class TurboMetrics:
     def debug_set_edge_epoch(self, epoch: int):
         _chk(self._L.tm_engine_debug_set_edge_epoch(self._h, int(epoch)), "tm_engine_debug_set_edge_epoch")
 
-    def set_graph(self, on: bool):
+    def set_graph(self, on: Optional[bool]):
+        """True / False: always / never replay the launch sequence from a captured hipGraph; None: the default (small launches that
+        repeat replay by themselves)"""
         self._retire_deferred()
-        _chk(self._L.tm_engine_set_graph(self._h, int(bool(on))), "tm_engine_set_graph")
+        _chk(self._L.tm_engine_set_graph(self._h, -1 if on is None else int(bool(on))), "tm_engine_set_graph")
         self._peer_follows("set_graph", on)
 
     def set_variant(self, v: int):
