@@ -749,6 +749,41 @@ def test_small_repeating_launches_replay_a_graph_by_themselves_with_the_same_bit
     eng.close(); ref.close()
 
 
+def test_engine_streams_get_hardware_queues_of_their_own_behind_other_peoples_streams(capfd):
+    """round 6: the runtime binds a stream to one of its four hardware queues when the stream is created, and kernels of two streams on
+    one queue run one after the other.  With an RCCL communicator (or any other owner of streams) created BEFORE the engine, the side
+    stream used to land on the engine's own queue: the fused kernel ran behind the column pass and the headline lost 20 %
+    (profiles/r06y9_dist_first.log).  The library now times where a new stream landed and asks for another one when that queue is taken:
+    behind six foreign streams the engine, the side stream, the upload stream and a second engine still sit on four different queues."""
+    torch = pytest.importorskip("torch")
+    import re
+    foreign = [torch.cuda.Stream() for _ in range(6)]
+    for st in foreign:
+        with torch.cuda.stream(st):
+            torch.zeros(8, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    F.lib().tm_set_debug_log(1)
+    try:
+        a = tm.TurboMetrics(1920, 1080, tm.Metrics(ssimulacra2=True), batch=8)
+        b = tm.TurboMetrics(1920, 1080, tm.Metrics(ssimulacra2=True), batch=8)
+    finally:
+        F.lib().tm_set_debug_log(0)
+    err = capfd.readouterr().err
+    rows = re.findall(r"stream for (an engine|a small engine|the fused kernel|uploads) on hardware queue (-?\d+) of (\d+) \(cost (\d+)", err)
+    assert [r[0] for r in rows].count("an engine") == 2, err
+    assert all(int(r[2]) >= 4 for r in rows), err            # the four queues of the default runtime were found
+    assert all(int(r[3]) == 0 for r in rows), err            # nobody shares a queue ...
+    queues = [int(r[1]) for r in rows]
+    assert len(set(queues)) == len(queues) and min(queues) >= 0, err  # ... (engine, [side, upload when this test made them], second engine)
+    fr, fd = nv12_frames(1920, 1080, 1)
+    for slot in range(8):
+        a.set_pair(slot, fr, fd); b.set_pair(slot, fd, fr)
+    a.compute_async(8); b.compute_async(8); a.sync(); b.sync()
+    one = tm.TurboMetrics(1920, 1080, tm.Metrics(ssimulacra2=True), batch=1)
+    assert a.scores(7) == one.compute_one(fr, fd) and b.scores(0) == one.compute_one(fd, fr)
+    a.close(); b.close(); one.close()
+
+
 def test_deferred_depth_three_to_eight_pairs_in_flight_with_compute_ones_scores():
     """round 6: set_deferred_depth(d) -- d one-pair launches in flight on d engines (each created when its turn first comes), pair k
     collected after pair k + d - 1 went in; the depth changes between runs with pairs still in flight (they are finished and stay
@@ -761,7 +796,7 @@ def test_deferred_depth_three_to_eight_pairs_in_flight_with_compute_ones_scores(
     mem_one = eng.mem_usage()
     stale = []
     for depth in (3, 8, 2, 5, 4):
-        eng.set_deferred_depth(depth)
+        eng.set_deferred_depth(depth, create_now=depth in (8, 5))
         got, tickets = [], []
         for k in range(3 * depth + 4):
             tickets.append((eng.compute_one_deferred(*frames[k % 7]), k % 7))

@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         def run(k):
             return [eng.compute_one(*frames[i % 4]).ssimulacra2 for i in range(k)]
     else:
-        eng.set_deferred_depth(depth)
+        eng.set_deferred_depth(depth, create_now=True)
 
         def run(k):
             got, tickets = [], []

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -52,18 +53,148 @@ int hip_fail(hipError_t e, const char *what)
         if (e_ != hipSuccess) return hip_fail(e_, #call);   \
     } while (0)
 
-// The second stream (the fused EDGE kernel beside the two blur passes) is ONE per device and process, shared by all engines:
-// the runtime maps streams onto a handful of hardware queues (4 by default), and a second stream per engine put the upload
-// stream of one engine of a ping-pong pair on the queue of the other engine's kernels -- host-fed 4K 1 080 -> 930 pairs/s.
-// Engines that compute at the same time take turns on it (each launch is ordered by its own fork / join events).
+// ---- streams and the hardware queues behind them -----------------------------------------------------------------------------------
+// The runtime binds a stream to one of a handful of hardware queues (four by default) WHEN THE STREAM IS CREATED -- the least-used
+// queue, the most recently opened one first --, and kernels of two streams on one queue run one after the other
+// (tools/microbench/queue_map.hip, profiles/r06y6_queue_map.log).  An engine needs three streams that run beside each other: its own,
+// the side stream of the fused EDGE kernel and the second upload stream.  Created first in a process they get a queue each; created
+// behind somebody else's streams -- an RCCL communicator, a decoder -- they may not: with the process group of `bench.py --gpus N`
+// initialised before the engine, the side stream sat on the engine's own queue, the fused kernel ran behind the column pass instead of
+// beside it, and the headline went from 14.6 k to 11.7 k pairs/s (profiles/r06y9_dist_first.log).  So the library finds out where a
+// stream landed and asks for another one when that place is taken:
+//   lanes      per device, one ANCHOR stream per hardware queue the runtime hands out, found once by creating streams and timing pairs
+//              of 150-us one-wave spin kernels on them (two streams of one queue take twice as long as two of different queues)
+//   lane_of    the anchor a new stream serialises with = its queue
+//   pick       candidate streams are created (each lands on the next least-used queue) until one sits on the cheapest queue there is:
+//              sharing a queue with another engine's stream costs most, then with the upload stream, then with the side stream
+//              (which only engines of more than four slots ever use)
+// The side stream and the second upload stream are ONE each per device and process, shared by all engines (a stream of each per
+// engine would use the queues up: host-fed 4K 1 080 -> 930 pairs/s in round 4); engines that compute at the same time take turns
+// on them (each launch is ordered by its own fork / join events).  Copies that follow each other on one stream leave the link idle
+// between them (3-MB copies with a fence per pair: 40 GB/s on one stream, 48-52 on two; profiles/r04y_dma_depth_probe.log): page-locked
+// frames of the distorted side go up on the upload stream while those of the reference side go up on the engine's own.
+// TM_QUEUE_LANES=0 in the environment: streams are taken as they come (measurements).
+std::atomic<int> g_debug_log{0}; // tm_set_debug_log: diagnostics on stderr (what the placement search measured, where the streams landed)
+__global__ void __launch_bounds__(64) k_lane_spin(long long ticks, int *sink)
+{
+    const long long t0 = wall_clock64(); // (constant 100 MHz)
+    while (wall_clock64() - t0 < ticks) { }
+    if (sink && threadIdx.x == 1000) *sink = 1;
+}
+
 std::mutex g_side_mutex;
+struct Lanes {
+    bool probed = false, off = false;
+    std::vector<hipStream_t> anchor; // one stream per hardware queue seen
+    std::vector<int> engines;        // engine streams per lane
+    int side = -1, up = -1;          // lanes of the two shared streams (-1: none / unknown)
+};
+Lanes g_lanes[64];
 hipStream_t g_side_stream[64] = {};
 int g_side_users[64] = {};
+hipStream_t g_up_stream[64] = {};
+int g_up_users[64] = {};
+constexpr long long LANE_TICKS = 15000; // 150 us
+constexpr double LANE_SERIAL_S = 1.6 * 150e-6;
+
+// do kernels on a and b run one after the other?  (a serial pair cannot look parallel; a parallel pair on a busy device can look serial: confirmed twice)
+bool lanes_serialise(hipStream_t a, hipStream_t b)
+{
+    for (int rep = 0; rep < 2; ++rep) {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, a, LANE_TICKS, (int *)nullptr);
+        hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, b, LANE_TICKS, (int *)nullptr);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < LANE_SERIAL_S) return false;
+    }
+    return true;
+}
+
+// (g_side_mutex held)  the queues this process gets streams on, one anchor each
+void lanes_probe(int device)
+{
+    Lanes &L = g_lanes[device];
+    if (L.probed) return;
+    L.probed = true;
+    const char *env = getenv("TM_QUEUE_LANES");
+    if (env && atoi(env) == 0) { L.off = true; return; }
+    hipStream_t warm = nullptr;
+    if (hipStreamCreateWithFlags(&warm, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); L.off = true; return; }
+    hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, warm, 100, (int *)nullptr); // the first launch loads the code object
+    if (hipStreamSynchronize(warm) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(warm); L.off = true; return; }
+    std::vector<hipStream_t> extra;
+    L.anchor.push_back(warm);
+    for (int i = 0, repeats = 0; i < 12 && repeats < 2 && L.anchor.size() < 8; ++i) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        bool seen = false;
+        for (hipStream_t a : L.anchor) if (lanes_serialise(s, a)) { seen = true; break; }
+        if (seen) { extra.push_back(s); ++repeats; } // (kept alive until the end: the next stream then goes to another queue)
+        else { L.anchor.push_back(s); repeats = 0; }
+    }
+    for (hipStream_t s : extra) (void)hipStreamDestroy(s);
+    L.engines.assign(L.anchor.size(), 0);
+    if (L.anchor.size() < 2) L.off = true; // one queue: nothing to choose
+}
+int lane_of(Lanes &L, hipStream_t s)
+{
+    for (size_t i = 0; i < L.anchor.size(); ++i) if (lanes_serialise(s, L.anchor[i])) return (int)i;
+    return -1; // a queue no anchor sits on (the runtime opened another one): nothing known shares it
+}
+enum LaneRole { LANE_ENGINE_SMALL, LANE_ENGINE, LANE_SIDE, LANE_UP };
+int lane_cost(const Lanes &L, int lane, LaneRole role)
+{
+    if (lane < 0) return 0;
+    int c = 8 * L.engines[(size_t)lane];
+    if (role != LANE_UP && lane == L.up) c += 4;
+    if (role != LANE_SIDE && lane == L.side) c += role == LANE_ENGINE_SMALL ? 1 : 4;
+    return c;
+}
+// (g_side_mutex held)  a new stream for `role`, on the cheapest queue of up to six tries
+hipStream_t lanes_pick(int device, LaneRole role, int *lane_out)
+{
+    *lane_out = -1;
+    if (device < 0 || device >= 64) return nullptr;
+    lanes_probe(device);
+    Lanes &L = g_lanes[device];
+    hipStream_t best = nullptr;
+    int best_cost = 1 << 30, best_lane = -1, reachable = 1 << 30; // reachable: the cheapest lane there is -- no candidate can do better
+    for (size_t l = 0; l < L.anchor.size(); ++l) reachable = std::min(reachable, lane_cost(L, (int)l, role));
+    std::vector<hipStream_t> rejected;
+    for (int t = 0; t < (L.off ? 1 : (int)L.anchor.size() + 2); ++t) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        const int lane = L.off ? -1 : lane_of(L, s);
+        const int cost = L.off ? 0 : lane_cost(L, lane, role);
+        if (cost < best_cost) { if (best) rejected.push_back(best); best = s; best_cost = cost; best_lane = lane; }
+        else rejected.push_back(s);
+        if (best_cost <= reachable) break;
+    }
+    if (g_debug_log.load()) fprintf(stderr, "[tm] device %d: stream for %s on hardware queue %d of %zu (cost %d, %zu candidate(s) given back)\n", device,
+                                    role == LANE_SIDE ? "the fused kernel" : role == LANE_UP ? "uploads" : role == LANE_ENGINE ? "an engine" : "a small engine", best_lane, L.anchor.size(), best ? best_cost : -1, rejected.size());
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    *lane_out = best_lane;
+    return best;
+}
+hipStream_t engine_stream_acquire(int device, bool small, int *lane_out)
+{
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    hipStream_t s = lanes_pick(device, small ? LANE_ENGINE_SMALL : LANE_ENGINE, lane_out);
+    if (s && *lane_out >= 0) ++g_lanes[device].engines[(size_t)*lane_out];
+    return s;
+}
+void engine_stream_release(int device, hipStream_t s, int lane)
+{
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    if (device >= 0 && device < 64 && lane >= 0 && (size_t)lane < g_lanes[device].engines.size() && g_lanes[device].engines[(size_t)lane] > 0) --g_lanes[device].engines[(size_t)lane];
+    if (s) (void)hipStreamDestroy(s);
+}
 hipStream_t side_stream_acquire(int device)
 {
     std::lock_guard<std::mutex> lock(g_side_mutex);
     if (device < 0 || device >= 64) return nullptr;
-    if (!g_side_stream[device] && hipStreamCreateWithFlags(&g_side_stream[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_side_stream[device] = nullptr; return nullptr; }
+    if (!g_side_stream[device] && !(g_side_stream[device] = lanes_pick(device, LANE_SIDE, &g_lanes[device].side))) return nullptr;
     ++g_side_users[device];
     return g_side_stream[device];
 }
@@ -71,20 +202,13 @@ void side_stream_release(int device)
 {
     std::lock_guard<std::mutex> lock(g_side_mutex);
     if (device < 0 || device >= 64 || g_side_users[device] <= 0) return;
-    if (--g_side_users[device] == 0 && g_side_stream[device]) { (void)hipStreamSynchronize(g_side_stream[device]); (void)hipStreamDestroy(g_side_stream[device]); g_side_stream[device] = nullptr; }
+    if (--g_side_users[device] == 0 && g_side_stream[device]) { (void)hipStreamSynchronize(g_side_stream[device]); (void)hipStreamDestroy(g_side_stream[device]); g_side_stream[device] = nullptr; g_lanes[device].side = -1; }
 }
-
-// The same for a second UPLOAD stream: page-locked frames of the distorted side go up on it while those of the reference side go up
-// on the engine's own stream -- copies that follow each other on one stream leave the link idle between them (3-MB copies with a
-// fence per pair: 40 GB/s on one stream, 48-52 on two; tools/microbench/dma_depth_probe.hip, profiles/r04y_dma_depth_probe.log).
-// One per device for the same reason as above: two engines + the side stream + this one = the four hardware queues.
-hipStream_t g_up_stream[64] = {};
-int g_up_users[64] = {};
 hipStream_t up_stream_acquire(int device)
 {
     std::lock_guard<std::mutex> lock(g_side_mutex);
     if (device < 0 || device >= 64) return nullptr;
-    if (!g_up_stream[device] && hipStreamCreateWithFlags(&g_up_stream[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_up_stream[device] = nullptr; return nullptr; }
+    if (!g_up_stream[device] && !(g_up_stream[device] = lanes_pick(device, LANE_UP, &g_lanes[device].up))) return nullptr;
     ++g_up_users[device];
     return g_up_stream[device];
 }
@@ -92,7 +216,7 @@ void up_stream_release(int device)
 {
     std::lock_guard<std::mutex> lock(g_side_mutex);
     if (device < 0 || device >= 64 || g_up_users[device] <= 0) return;
-    if (--g_up_users[device] == 0 && g_up_stream[device]) { (void)hipStreamSynchronize(g_up_stream[device]); (void)hipStreamDestroy(g_up_stream[device]); g_up_stream[device] = nullptr; }
+    if (--g_up_users[device] == 0 && g_up_stream[device]) { (void)hipStreamSynchronize(g_up_stream[device]); (void)hipStreamDestroy(g_up_stream[device]); g_up_stream[device] = nullptr; g_lanes[device].up = -1; }
 }
 
 // engines alive in this process (tm_engine_debug_chain keeps a raw pointer to a peer: destroying the peer must unhook it)
@@ -178,6 +302,7 @@ struct tm_engine {
     int graph_mode = -1;            // tm_engine_set_graph: 1 always, 0 never; -1 (default) = by itself for small launches that repeat (below)
     long long auto_key = -1;        // ... the launch shape seen last and how often in a row
     int auto_seen = 0;
+    int lane = -1;                  // the hardware queue its stream sits on (g_lanes)
     hipGraphExec_t gexec = nullptr;
     long long gkey = -1;
     TmSsimGeom sg{};               // SSIM / MS-SSIM (only when the mask asks for them)
@@ -675,7 +800,6 @@ int tm_init(int device)
 
 #define TM_V_SLACK ((size_t)4 << 20) /* bytes allocated beyond the pass-1 arena so that its start can be moved */
 static std::atomic<int> g_placement_candidates{-1}; // -1: not set -> environment or default
-static std::atomic<int> g_debug_log{0};             // tm_set_debug_log: diagnostics on stderr (what the placement search measured)
 
 void tm_set_debug_log(int on) { g_debug_log.store(on); }
 
@@ -777,9 +901,9 @@ int tm_engine_create(tm_engine **out, uint32_t width, uint32_t height, uint32_t 
     // the kernels' code object is loaded HERE, not by the first launch (the reference loads its PTX modules in Ssimulacra2::new:
     // cuModuleLoadData, ssimulacra2-cuda/src/kernel.rs): asking for a kernel's attributes makes the runtime load the module of this library
     { hipFuncAttributes fa; if (hipFuncGetAttributes(&fa, (const void *)tmk::k_finish_jobs) != hipSuccess) (void)hipGetLastError(); }
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    (void)he;
-    if (he != hipSuccess) return fail(hip_fail(he, "hipStreamCreate"));
+    hipError_t he = hipSuccess;
+    // (from six pairs of 1080p per launch on the edge-only planes take the fused kernel, i.e. the side stream: use_fused_edge)
+    if (!(e->stream = engine_stream_acquire(e->device, (unsigned long long)batch_capacity * height < 6ull * 1080ull, &e->lane))) return fail(hip_fail(hipErrorOutOfMemory, "hipStreamCreate"));
     if (!(e->stream2 = side_stream_acquire(e->device))) return fail(hip_fail(hipErrorOutOfMemory, "hipStreamCreate (side stream)"));
     if (!(e->up_stream = up_stream_acquire(e->device))) return fail(hip_fail(hipErrorOutOfMemory, "hipStreamCreate (upload stream)"));
     if ((he = hipEventCreateWithFlags(&e->ev_up_join, hipEventDisableTiming)) != hipSuccess || (he = hipEventCreateWithFlags(&e->ev_stage_free, hipEventDisableTiming)) != hipSuccess) return fail(hip_fail(he, "hipEventCreate"));
@@ -874,7 +998,7 @@ void tm_engine_destroy(tm_engine *e)
     if (e->ev_col_done) (void)hipEventDestroy(e->ev_col_done);
     if (e->ev_row_done) (void)hipEventDestroy(e->ev_row_done);
     if (e->stream2) side_stream_release(e->device);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->stream) engine_stream_release(e->device, e->stream, e->lane);
     delete e;
 }
 

@@ -322,11 +322,12 @@ class TurboMetrics:
 
     MAX_DEFERRED_DEPTH = 8
 
-    def set_deferred_depth(self, depth: int):
+    def set_deferred_depth(self, depth: int, create_now: bool = False):
         """pairs in flight at most for compute_one_deferred (default 2; == TurboMetrics::set_deferred_depth, host/turbo_metrics.hpp):
         one pair leaves most of the chip idle, three / four in flight reach 6.8 k / 8.3 k pairs/s of 1080p with frames in HBM -- for a
         caller that collects pair k after submitting pair k + depth - 1.  Pairs in flight are finished first (their scores stay
-        collectable); engines beyond the new depth are freed."""
+        collectable); engines beyond the new depth are freed; create_now: the engines of the turn are created by this call
+        instead of when their turn first comes."""
         if not 2 <= int(depth) <= self.MAX_DEFERRED_DEPTH:
             raise TmError(ffi.TM_ERR_INVALID_ARG, "set_deferred_depth: 2 ... 8 pairs in flight")
         self._retire_deferred()
@@ -337,6 +338,20 @@ class TurboMetrics:
                 p.close()
             del d["peers"][self._def_depth - 1:]
             d["pending"] = [None] * self._def_depth
+        if create_now:
+            if self.batch != 1:
+                raise ValueError("compute_one_deferred is the one-pair-per-call path: create the engine with batch=1")
+            if getattr(self, "_def", None) is None:
+                self._def = {"peers": [], "pending": [None] * self._def_depth, "done": {}, "next": 0}
+            self._grow_peers(self._def_depth - 1)
+
+    def _grow_peers(self, n: int):
+        d = self._def
+        while len(d["peers"]) < n:
+            peer = TurboMetrics(self.width, self.height, self._metrics, batch=1)
+            for name, args in getattr(self, "_settings", {}).items():  # channel mode, full sums, variant, graph: as set on this engine
+                getattr(peer, name)(*args)
+            d["peers"].append(peer)
 
     def compute_one(self, fref: HwFrame, fdis: HwFrame) -> FrameScores:
         """== TurboMetrics::compute_one: convert, compute, block, return FrameScores."""
@@ -361,11 +376,7 @@ class TurboMetrics:
         ticket = d["next"]
         d["next"] += 1
         i = ticket % depth
-        while i > len(d["peers"]):  # the engines the launches take turns on are created when their turn first comes
-            peer = TurboMetrics(self.width, self.height, self._metrics, batch=1)
-            for name, args in getattr(self, "_settings", {}).items():  # channel mode, full sums, variant, graph: as set on this engine
-                getattr(peer, name)(*args)
-            d["peers"].append(peer)
+        self._grow_peers(i)  # the engines the launches take turns on are created when their turn first comes (or by set_deferred_depth)
         e = self if i == 0 else d["peers"][i - 1]
         if d["pending"][i] is not None:
             e.sync()

@@ -4,6 +4,8 @@
 // Additions (no counterpart in the reference, all optional): --batch, --device, --devices, --ranks, --no-pipeline, --full-sums, and the
 // description of headerless YUV input (--width, --height, --bits, --color-primaries, --matrix-coefficients,
 // --transfer-characteristics, --full-range).
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <deque>
@@ -259,6 +261,8 @@ int main(int argc, char **argv)
     }
     try {
         init_hip((int)device);
+        if (g_level >= L_TRACE) // the engine library's own diagnostics (placement search, hardware queues): a function of the laboratory build
+            if (auto fn = (void (*)(int))dlsym(RTLD_DEFAULT, "tm_set_debug_log")) fn(1);
     } catch (const std::exception &e) {
         log_line(L_ERROR, kTarget, std::string("Could not initialize the GPU : ") + e.what());
         return EXIT_FAILURE;
@@ -331,8 +335,11 @@ int main(int argc, char **argv)
         source_ref.reset(); source_dis.reset();
         if (known < 20000) tm_set_placement_candidates(1);
         try {
-            std::unique_ptr<RankTransport> transport = make_rank_transport(renv); // (RCCL: the communicator is set up while nothing else runs)
-            if (root) log_line(L_DEBUG, kTarget, std::string("ranks: ") + std::to_string(renv.world) + " over " + transport->name());
+            // The transport is made AFTER the block's engines (inside `ready`, which every rank reaches exactly once): the runtime binds a stream to
+            // one of its four hardware queues when the stream is created, and a communicator that exists first -- RCCL creates streams of its own --
+            // takes the queues the engine's side and upload streams would have had to themselves (profiles/r06y6_queue_map.log; `--ranks 1` over
+            // RCCL then ran at 0.83 x the one-device rate, profiles/r06y8_ranks_order.log).
+            std::unique_ptr<RankTransport> transport;
             auto start = std::chrono::steady_clock::now();
             uint32_t lo = 0, hi = 0;
             shard_range(total, (uint32_t)renv.rank, (uint32_t)renv.world, lo, hi);
@@ -343,7 +350,12 @@ int main(int argc, char **argv)
             if (root) output_prepare(output, metrics, std::cout);
             // (the clock is stopped while the block's engines and page-locked rings are freed: the one-device run frees its own after its report)
             auto computed_at = start;
-            score_block(w, h, lo, hi, blk, [&] { start = std::chrono::steady_clock::now(); },
+            score_block(w, h, lo, hi, blk,
+                        [&] {
+                            transport = make_rank_transport(renv);
+                            if (root) log_line(L_DEBUG, kTarget, std::string("ranks: ") + std::to_string(renv.world) + " over " + transport->name());
+                            start = std::chrono::steady_clock::now();
+                        },
                         root ? std::function<void(const FrameScores &)>([&](const FrameScores &fs) { output_single_score(output, fs, std::cout); }) : nullptr,
                         [&] { computed_at = std::chrono::steady_clock::now(); });
             start += std::chrono::steady_clock::now() - computed_at;
@@ -448,6 +460,9 @@ int main(int argc, char **argv)
         turbo = std::make_unique<TurboMetrics>(source_ref->width(), source_ref->height(), metrics, batch, pipeline);
         if (full_sums) turbo->set_full_sums(true);
         for (auto &t : tune) if (t.first < 100) turbo->debug_set_param(t.first, t.second);
+        // --loop deferred: every engine of the turn exists before the clock starts (the reference allocates everything up front too,
+        // ssimulacra2-cuda/src/lib.rs:21)
+        if (loop == Loop::Deferred) turbo->set_deferred_depth(in_flight_pairs, true);
     } catch (const std::exception &e) {
         log_line(L_ERROR, kTarget, std::string("Could not initialize engine : ") + e.what());
         return EXIT_FAILURE;
@@ -485,7 +500,6 @@ int main(int argc, char **argv)
             source_dis->skip_frames(opts.skip_dis + opts.skip);
             HwFrame fref, fdis;
             std::deque<uint64_t> tickets; // --loop deferred: pairs in flight, oldest first
-            if (loop == Loop::Deferred) turbo->set_deferred_depth(in_flight_pairs);
             while (source_ref->next_frame(fref) && source_dis->next_frame(fdis)) {
                 if (opts.every > 1 && decode_count != 0 && decode_count % opts.every != 0) { decode_count += 1; continue; }
                 if (opts.frames > 0 && decode_count >= opts.frames) break;

@@ -275,7 +275,16 @@ FrameScores TurboMetrics::scores_of(tm_engine *e, uint32_t slot)
     return r;
 }
 
-void TurboMetrics::set_deferred_depth(uint32_t depth)
+void TurboMetrics::create_deferred_engine(size_t i)
+{
+    if (eng_[i]) return;
+    chk(tm_engine_create(&eng_[i], w_, h_, metrics_.mask(), 1), "tm_engine_create (further engine of compute_one_deferred)");
+    (void)tm_engine_set_linear_upload(eng_[i], 1);
+    if (full_sums_) chk(tm_engine_set_full_sums(eng_[i], 1), "tm_engine_set_full_sums");
+    for (const auto &kv : debug_params_) (void)lab_set_param()(eng_[i], kv.first, kv.second); // (only ever non-empty with the laboratory build loaded)
+}
+
+void TurboMetrics::set_deferred_depth(uint32_t depth, bool create_now)
 {
     if (depth < 2 || depth > MAX_DEFERRED_DEPTH) throw TmError(TM_ERR_INVALID_ARG, "set_deferred_depth: 2 ... 8 pairs in flight");
     retire_deferred();
@@ -284,6 +293,10 @@ void TurboMetrics::set_deferred_depth(uint32_t depth)
     eng_.resize(std::max<size_t>(2, depth), nullptr);
     def_pending_.assign(depth, 0);
     def_depth_ = depth;
+    if (create_now) {
+        if (batch_ != 1) throw TmError(TM_ERR_INVALID_ARG, "compute_one_deferred: create the TurboMetrics object with batch = 1");
+        for (size_t i = 1; i < depth; ++i) create_deferred_engine(i);
+    }
 }
 
 void TurboMetrics::retire_deferred()
@@ -313,12 +326,7 @@ uint64_t TurboMetrics::compute_one_deferred(const HwFrame &fref, const ColorInfo
     if (batch_ != 1) throw TmError(TM_ERR_INVALID_ARG, "compute_one_deferred: create the TurboMetrics object with batch = 1");
     const uint64_t ticket = def_next_++;
     const size_t i = (size_t)(ticket % def_depth_);
-    if (!eng_[i]) { // the engines the launches take turns on are created when their turn first comes
-        chk(tm_engine_create(&eng_[i], w_, h_, metrics_.mask(), 1), "tm_engine_create (further engine of compute_one_deferred)");
-        (void)tm_engine_set_linear_upload(eng_[i], 1);
-        if (full_sums_) chk(tm_engine_set_full_sums(eng_[i], 1), "tm_engine_set_full_sums");
-        for (const auto &kv : debug_params_) (void)lab_set_param()(eng_[i], kv.first, kv.second); // (only ever non-empty with the laboratory build loaded)
-    }
+    create_deferred_engine(i); // (the engines the launches take turns on are created when their turn first comes, unless set_deferred_depth made them)
     if (def_pending_[i]) { // `depth` pairs are in flight already: the oldest one (on this engine) is finished first
         chk(tm_engine_sync(eng_[i]), "tm_engine_sync");
         def_done_.emplace_back(def_pending_[i], scores_of(eng_[i], 0));

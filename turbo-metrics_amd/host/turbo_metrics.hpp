@@ -232,9 +232,10 @@ public:
     uint64_t compute_one_deferred(const HwFrame &fref, const ColorInfo &cref, const HwFrame &fdis, const ColorInfo &cdis);
     FrameScores collect(uint64_t ticket);
     // pairs in flight at most (default 2); pairs in flight are finished first and keep their scores for collect, engines beyond the new
-    // depth are freed.  Throws TmError(TM_ERR_INVALID_ARG) outside 2 ... MAX_DEFERRED_DEPTH.
+    // depth are freed.  create_now: the engines of the turn are created by this call instead of when their turn first comes (an engine's
+    // creation takes 1-20 ms, most beside running launches).  Throws TmError(TM_ERR_INVALID_ARG) outside 2 ... MAX_DEFERRED_DEPTH.
     static constexpr uint32_t MAX_DEFERRED_DEPTH = 8;
-    void set_deferred_depth(uint32_t depth);
+    void set_deferred_depth(uint32_t depth, bool create_now = false);
     uint32_t deferred_depth() const { return def_depth_; }
 
     // == compute_all (lib.rs:362-433) with the frame selection of Options; `on_frame` (optional) sees every FrameScores
@@ -250,6 +251,7 @@ private:
     void set_frame(tm_engine *e, uint32_t slot, int side, const HwFrame &f, const ColorInfo &c);
     FrameScores scores_of(tm_engine *e, uint32_t slot);
     void retire_deferred(); // finish the pairs that are in flight for compute_one_deferred and keep their scores for collect()
+    void create_deferred_engine(size_t i);
     uint32_t w_, h_, batch_;
     Metrics metrics_;
     std::vector<tm_engine *> eng_{nullptr, nullptr}; // [0], [1]: compute_all's two; compute_one_deferred takes turns on [0 .. depth)
