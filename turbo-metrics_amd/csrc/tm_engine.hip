@@ -63,7 +63,8 @@ int hip_fail(hipError_t e, const char *what)
 // beside it, and the headline went from 14.6 k to 11.7 k pairs/s (profiles/r06y9_dist_first.log).  So the library finds out where a
 // stream landed and asks for another one when that place is taken:
 //   lanes      per device, one ANCHOR stream per hardware queue the runtime hands out, found once by creating streams and timing pairs
-//              of 150-us one-wave spin kernels on them (two streams of one queue take twice as long as two of different queues)
+//              of 100-us one-wave spin kernels on them that stamp the device's clock at their start and end (on one queue the second
+//              kernel starts after the first one has ended; no host timing is involved)
 //   lane_of    the anchor a new stream serialises with = its queue
 //   pick       candidate streams are created (each lands on the next least-used queue) until one sits on the cheapest queue there is:
 //              sharing a queue with another engine's stream costs most, then with the upload stream, then with the side stream
@@ -75,11 +76,12 @@ int hip_fail(hipError_t e, const char *what)
 // frames of the distorted side go up on the upload stream while those of the reference side go up on the engine's own.
 // TM_QUEUE_LANES=0 in the environment: streams are taken as they come (measurements).
 std::atomic<int> g_debug_log{0}; // tm_set_debug_log: diagnostics on stderr (what the placement search measured, where the streams landed)
-__global__ void __launch_bounds__(64) k_lane_spin(long long ticks, int *sink)
+__global__ void __launch_bounds__(64) k_lane_spin(long long ticks, long long *stamp)
 {
-    const long long t0 = wall_clock64(); // (constant 100 MHz)
-    while (wall_clock64() - t0 < ticks) { }
-    if (sink && threadIdx.x == 1000) *sink = 1;
+    const long long t0 = wall_clock64(); // (the device's constant 100-MHz counter: the same clock on every CU)
+    long long t = t0;
+    while (t - t0 < ticks) t = wall_clock64();
+    if (stamp && threadIdx.x == 0) { stamp[0] = t0; stamp[1] = t; }
 }
 
 std::mutex g_side_mutex;
@@ -88,25 +90,28 @@ struct Lanes {
     std::vector<hipStream_t> anchor; // one stream per hardware queue seen
     std::vector<int> engines;        // engine streams per lane
     int side = -1, up = -1;          // lanes of the two shared streams (-1: none / unknown)
+    long long *stamp = nullptr;      // page-locked, device-visible: [start, end] of the two kernels of a test
 };
 Lanes g_lanes[64];
 hipStream_t g_side_stream[64] = {};
 int g_side_users[64] = {};
 hipStream_t g_up_stream[64] = {};
 int g_up_users[64] = {};
-constexpr long long LANE_TICKS = 15000; // 150 us
-constexpr double LANE_SERIAL_S = 1.6 * 150e-6;
+constexpr long long LANE_TICKS = 10000; // 100 us
 
-// do kernels on a and b run one after the other?  (a serial pair cannot look parallel; a parallel pair on a busy device can look serial: confirmed twice)
-bool lanes_serialise(hipStream_t a, hipStream_t b)
+// do kernels on a and b run one after the other?  Read off the DEVICE's clock: the second kernel started after the first one had ended.
+// (a serial pair cannot look parallel; a parallel pair on a busy device can look serial -- the second kernel found no room -- : confirmed twice)
+bool lanes_serialise(Lanes &L, hipStream_t a, hipStream_t b)
 {
     for (int rep = 0; rep < 2; ++rep) {
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
-        const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, a, LANE_TICKS, (int *)nullptr);
-        hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, b, LANE_TICKS, (int *)nullptr);
+        L.stamp[0] = L.stamp[1] = L.stamp[2] = L.stamp[3] = 0;
+        hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, a, LANE_TICKS, L.stamp);
+        hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, b, LANE_TICKS, L.stamp + 2);
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < LANE_SERIAL_S) return false;
+        const volatile long long *t = L.stamp;
+        if (t[1] == 0 || t[3] == 0) return false;             // (a stamp did not arrive: no verdict)
+        if (!(t[2] >= t[1] || t[0] >= t[3])) return false;    // the two ran at the same time for a while
     }
     return true;
 }
@@ -120,26 +125,31 @@ void lanes_probe(int device)
     const char *env = getenv("TM_QUEUE_LANES");
     if (env && atoi(env) == 0) { L.off = true; return; }
     hipStream_t warm = nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (hipHostMalloc((void **)&L.stamp, 4 * sizeof(long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); L.stamp = nullptr; L.off = true; return; }
     if (hipStreamCreateWithFlags(&warm, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); L.off = true; return; }
-    hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, warm, 100, (int *)nullptr); // the first launch loads the code object
+    hipLaunchKernelGGL(k_lane_spin, dim3(1), dim3(64), 0, warm, 100, (long long *)nullptr); // the first launch loads the code object
     if (hipStreamSynchronize(warm) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(warm); L.off = true; return; }
     std::vector<hipStream_t> extra;
+    const auto t_warm = std::chrono::steady_clock::now();
     L.anchor.push_back(warm);
     for (int i = 0, repeats = 0; i < 12 && repeats < 2 && L.anchor.size() < 8; ++i) {
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
         bool seen = false;
-        for (hipStream_t a : L.anchor) if (lanes_serialise(s, a)) { seen = true; break; }
+        for (hipStream_t a : L.anchor) if (lanes_serialise(L, s, a)) { seen = true; break; }
         if (seen) { extra.push_back(s); ++repeats; } // (kept alive until the end: the next stream then goes to another queue)
         else { L.anchor.push_back(s); repeats = 0; }
     }
     for (hipStream_t s : extra) (void)hipStreamDestroy(s);
     L.engines.assign(L.anchor.size(), 0);
+    if (g_debug_log.load()) fprintf(stderr, "[tm] device %d: %zu hardware queues found in %.1f ms (+ %.1f ms for the first stream and launch of the process)\n", device, L.anchor.size(),
+                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_warm).count(), std::chrono::duration<double, std::milli>(t_warm - t_begin).count());
     if (L.anchor.size() < 2) L.off = true; // one queue: nothing to choose
 }
 int lane_of(Lanes &L, hipStream_t s)
 {
-    for (size_t i = 0; i < L.anchor.size(); ++i) if (lanes_serialise(s, L.anchor[i])) return (int)i;
+    for (size_t i = 0; i < L.anchor.size(); ++i) if (lanes_serialise(L, s, L.anchor[i])) return (int)i;
     return -1; // a queue no anchor sits on (the runtime opened another one): nothing known shares it
 }
 enum LaneRole { LANE_ENGINE_SMALL, LANE_ENGINE, LANE_SIDE, LANE_UP };
