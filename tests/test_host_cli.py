@@ -670,6 +670,8 @@ def test_cli_error_paths(tmp_path):
     for bad in ("1", "9", "x"):
         rc, _, err = cli(p1, p1, "-m", "ssimulacra2", "--loop", "deferred", "--in-flight", bad)
         assert rc == 2 and "--in-flight <N>" in err
+    rc, out, err = cli(p1, p1, "-m", "ssim", "--output", "csv", "--in-flight", 4)
+    assert rc == 0 and "--in-flight belongs to --loop deferred" in err and out.split("\n")[:2] == ["ssim", "1"]
     y = str(tmp_path / "f.y4m")
     write_y4m(y, [tm.synth.yuv420_pair(48, 32, 0, 8)[0]], 48, 32, 8, " XCOLORRANGE=FULL")
     rc, _, err = cli(y, y, "-m", "ssimulacra2")

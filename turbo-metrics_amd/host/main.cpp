@@ -129,7 +129,7 @@ int main(int argc, char **argv)
     Output output = Output::Default;
     SourceHints hints;
     uint32_t batch = 0 /* 0: chosen from the picture size */, device = 0, devices = 1, ranks = 0 /* 0: not asked for */, in_flight_pairs = 2;
-    bool pipeline = true, full_sums = false;
+    bool pipeline = true, full_sums = false, in_flight_given = false;
     enum class Loop { Batched, Reference, Deferred } loop = Loop::Batched;
     std::vector<std::pair<int, long long>> tune;
 
@@ -180,7 +180,7 @@ int main(int argc, char **argv)
         else if (a == "--devices") { if (!u32(devices)) return bad("invalid value for '--devices <N>'"); }
         else if (a == "--ranks") { if (!u32(ranks) || ranks == 0 || ranks > 64) return bad("invalid value for '--ranks <N>'"); }
         else if (a == "--no-pipeline") pipeline = false;
-        else if (a == "--in-flight") { if (!u32(in_flight_pairs) || in_flight_pairs < 2 || in_flight_pairs > TurboMetrics::MAX_DEFERRED_DEPTH) return bad("invalid value for '--in-flight <N>'\n  [2 ... 8]"); }
+        else if (a == "--in-flight") { if (!u32(in_flight_pairs) || in_flight_pairs < 2 || in_flight_pairs > TurboMetrics::MAX_DEFERRED_DEPTH) return bad("invalid value for '--in-flight <N>'\n  [2 ... 8]"); in_flight_given = true; }
         else if (a == "--loop") {
             std::string s;
             if (!value(s)) return bad("a value is required for '--loop <MODE>'");
@@ -405,6 +405,7 @@ int main(int argc, char **argv)
             want = 1;
         }
         if (want > 1 && loop != Loop::Batched) log_line(L_WARN, kTarget, "--loop reference / deferred run on one device: --devices ignored");
+        if (in_flight_given && loop != Loop::Deferred) log_line(L_WARN, kTarget, "--in-flight belongs to --loop deferred: ignored");
         if (want > 1 && loop != Loop::Batched) want = 1;
         if (want > 1) {
             if (metrics.mask() == 0) { log_line(L_ERROR, kTarget, "Could not initialize engine : no metric selected (-m psnr|ssim|msssim|ssimulacra2)"); return EXIT_FAILURE; }
